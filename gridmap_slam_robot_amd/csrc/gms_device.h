@@ -1,0 +1,140 @@
+// gms_device.h -- device-side arithmetic helpers with the reference's (Java) numeric semantics.
+// Compiled with -ffp-contract=off: the JVM never fuses a multiply with an add.
+// Citations: J/ = java/GridMapGL/src/main/java/com/fmsz/gridmapgl/ in the reference tree.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gms_internal.h"
+
+#define GMS_WAVE 64
+
+// (int) of a double, JLS 5.1.3: truncate toward zero, saturate, NaN -> 0.
+__device__ __forceinline__ int32_t j_d2i(double d) {
+    if (d != d) return 0;
+    if (d >= 2147483647.0) return INT32_MAX;
+    if (d <= -2147483648.0) return INT32_MIN;
+    return (int32_t)d;
+}
+// Java int arithmetic wraps.
+__device__ __forceinline__ int32_t j_iadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int32_t j_isub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+
+// (float) Math.sqrt((double) s) for a float s == correctly rounded float sqrt (GridMap.java:217).
+__device__ __forceinline__ float j_sqrtf(float s) { return __builtin_sqrtf(s); }
+
+// Transform.fromRobotToWorld's trig: (double)(float) FastMath.cos((double) theta)
+// (J/math/Transform.java:15-16 via J/math/MathUtil.java:30-40).
+__device__ __forceinline__ void pose_trig(float theta, float &c, float &s) {
+    c = (float)cos((double)theta);
+    s = (float)sin((double)theta);
+}
+
+// Transform.transformX / transformY (J/math/Transform.java:23,28): double, no FMA.
+struct XformDev {
+    double c, s, px, py;
+};
+__device__ __forceinline__ double xform_x(const XformDev &t, double x, double y) { return x * t.c - y * t.s + t.px; }
+__device__ __forceinline__ double xform_y(const XformDev &t, double x, double y) { return x * t.s + y * t.c + t.py; }
+
+// ---- RayIterator (J/slam/RayIterator.java:65-130) ---------------------------------------------
+struct RayDev {
+    int32_t x, y, x_inc, y_inc, n;
+    float dx, dy, error;
+};
+
+__device__ __forceinline__ void ray_init(RayDev &r, float x0, float y0, float x1, float y1, int32_t extra) {
+    r.dx = fabsf(x1 - x0);                                   // :68
+    r.dy = fabsf(y1 - y0);                                   // :69
+    const double fx0 = floor((double)x0), fy0 = floor((double)y0);
+    r.x = j_d2i(fx0);                                        // :71
+    r.y = j_d2i(fy0);                                        // :72
+    r.n = j_iadd(1, extra);                                  // :75
+    if (r.dx == 0.0f) {                                      // :78
+        r.x_inc = 0;
+        r.error = INFINITY;
+    } else if (x1 > x0) {                                    // :81
+        r.x_inc = 1;
+        r.n = j_iadd(r.n, j_d2i(floor((double)x1) - (double)r.x));            // :83
+        r.error = (float)((fx0 + 1.0 - (double)x0) * (double)r.dy);           // :84
+    } else {
+        r.x_inc = -1;
+        r.n = j_iadd(r.n, j_isub(r.x, j_d2i(floor((double)x1))));             // :87
+        r.error = (float)(((double)x0 - fx0) * (double)r.dy);                 // :88
+    }
+    if (r.dy == 0.0f) {                                      // :91
+        r.y_inc = 0;
+        r.error = r.error - INFINITY;                        // :93
+    } else if (y1 > y0) {                                    // :94
+        r.y_inc = 1;
+        r.n = j_iadd(r.n, j_isub(j_d2i(floor((double)y1)), r.y));             // :96
+        r.error = (float)((double)r.error - (fy0 + 1.0 - (double)y0) * (double)r.dx);   // :97
+    } else {
+        r.y_inc = -1;
+        r.n = j_iadd(r.n, j_isub(r.y, j_d2i(floor((double)y1))));             // :100
+        r.error = (float)((double)r.error - ((double)y0 - fy0) * (double)r.dx);         // :101
+    }
+}
+
+__device__ __forceinline__ bool ray_has_next(const RayDev &r, int32_t W, int32_t H) {
+    return r.n > 0 && !(r.x < 0 || r.x >= W || r.y < 0 || r.y >= H);        // :108
+}
+
+__device__ __forceinline__ void ray_step(RayDev &r) {                          // :117-126
+    if (r.error > 0.0f) {
+        r.y = j_iadd(r.y, r.y_inc);
+        r.error = r.error - r.dx;
+    } else {
+        r.x = j_iadd(r.x, r.x_inc);
+        r.error = r.error + r.dy;
+    }
+    r.n = j_isub(r.n, 1);
+}
+
+// SensorModel.inverseSensorModel (J/slam/SensorModel.java:31-41) -> class 0 free, 1 prior, 2 occupied
+__device__ __forceinline__ int32_t sensor_class(float cur, float measured, int32_t hit, float half_tol) {
+    if (!hit) return cur < measured ? 0 : 1;
+    if (cur < measured - half_tol) return 0;
+    if (cur > measured + half_tol) return 1;
+    return 2;
+}
+
+// distance from the (un-shifted) ray start to the centre of cell (cx,cy), GridMap.java:215-217
+__device__ __forceinline__ float cell_distance(float sx, float sy, int32_t cx, int32_t cy) {
+    float dX = sx - ((float)cx + 0.5f);
+    float dY = sy - ((float)cy + 0.5f);
+    return j_sqrtf(dX * dX + dY * dY);
+}
+
+// GridMap.integrateObservation's per-beam locals (GridMap.java:175-188)
+__device__ __forceinline__ RayIn make_ray(const GridDev &g, const gms_beam &m, const float *pose) {
+    XformDev t;
+    float c, s;
+    pose_trig(pose[2], c, s);
+    t.c = (double)c; t.s = (double)s; t.px = (double)pose[0]; t.py = (double)pose[1];
+    RayIn r;
+    r.sx = (float)((xform_x(t, 0.0, 0.0) - g.posx) / g.res);                  // :178
+    r.sy = (float)((xform_y(t, 0.0, 0.0) - g.posy) / g.res);                  // :179
+    r.ex = (float)((xform_x(t, m.local_x, m.local_y) - g.posx) / g.res);      // :185
+    r.ey = (float)((xform_y(t, m.local_x, m.local_y) - g.posy) / g.res);      // :186
+    r.measured = (float)m.distance / g.resf;                                  // :188
+    r.hit = m.hit != 0;
+    return r;
+}
+
+// MathUtil.angleConstrain (J/math/MathUtil.java:65-72).  The Java loops do not terminate for
+// infinite or astronomically large angles; the device version gives up after 64 turns.
+__device__ __forceinline__ double angle_constrain(double a) {
+    const double PI = 3.141592653589793;
+    for (int i = 0; i < 64 && a < PI; i++) a += PI * 2;
+    for (int i = 0; i < 64 && a > PI; i++) a -= PI * 2;
+    return a;
+}
+
+// ---- wave64 helpers ------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64(double v) {   // fixed xor-butterfly shape
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GMS_WAVE);
+    return v;
+}

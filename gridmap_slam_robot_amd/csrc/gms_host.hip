@@ -1,0 +1,781 @@
+// gms_host.hip -- the C-ABI of libgridmapslam.so (include/gridmapslam.h): handle lifetime, staging,
+// stream ordering, and the launch sequences that make up each reference method.
+// There is no CPU path in this file: every compute entry point launches gfx950 kernels.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "gms_internal.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(GMS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+#define REQUIRE(cond, msg)                                     \
+    do {                                                       \
+        if (!(cond)) return fail(GMS_ERR_INVALID, "%s", msg);  \
+    } while (0)
+
+// Java (int) of a double for the host-side constructor arithmetic
+static int32_t j_d2i_host(double d) {
+    if (d != d) return 0;
+    if (d >= 2147483647.0) return INT32_MAX;
+    if (d <= -2147483648.0) return INT32_MIN;
+    return (int32_t)d;
+}
+
+extern "C" {
+
+int gms_version(void) { return GMS_VERSION_MAJOR * 1000 + GMS_VERSION_MINOR; }
+const char *gms_last_error(void) { return g_err; }
+
+int gms_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- pure host helpers ---------------------------------------------------------------------------
+double gms_log_odds(double p) { return log(p / ((double)1.0f - p)); }                    // Util.java:35-37
+double gms_inv_log_odds(double l) { return (double)1.0f - (double)1.0f / (1.0 + exp(l)); }   // Util.java:46-48
+
+int gms_generate_gaussian_kernel(double sigma, int32_t size, double *out) {             // Util.java:428-455
+    REQUIRE(out && size >= 0, "gms_generate_gaussian_kernel: bad arguments");
+    const double norm = 1.0 / (sqrt(2 * M_PI) * sigma);
+    const double coeff = 2 * sigma * sigma;
+    double total = 0;
+    for (int x = -size; x <= size; x++) {
+        const double g = norm * exp((double)(-x * x) / coeff);
+        out[x + size] = g;
+        total += g;
+    }
+    for (int i = 0; i < 2 * size + 1; i++) out[i] /= total;
+    return GMS_OK;
+}
+
+int gms_grid_size(const gms_params *p, int32_t *W, int32_t *H) {                         // GridMap.java:85
+    REQUIRE(p && W && H, "gms_grid_size: null argument");
+    *W = j_d2i_host(ceil((double)(p->width_m / p->resolution)));
+    *H = j_d2i_host(ceil((double)(p->height_m / p->resolution)));
+    return GMS_OK;
+}
+
+int gms_params_default(gms_params *p, float width_m, float height_m, float resolution, float pos_x, float pos_y) {
+    REQUIRE(p, "gms_params_default: null params");
+    memset(p, 0, sizeof(*p));
+    p->width_m = width_m; p->height_m = height_m; p->resolution = resolution;
+    p->pos_x = pos_x; p->pos_y = pos_y;
+    p->n_maps = 1;
+    p->device = 0;
+    p->l_free = gms_log_odds((double)0.30f);                  // SensorModel.java:23
+    p->l_occ = gms_log_odds((double)0.9f);                    // SensorModel.java:24
+    const double sigma = sqrt(0.05 / (double)resolution);     // GridMap.java:94
+    const int32_t size = j_d2i_host(ceil(sigma * 3));         // GridMap.java:95
+    if (size < 0 || 2 * size + 1 > GMS_MAX_TAPS)
+        return fail(GMS_ERR_INVALID, "likelihood kernel of %d taps exceeds GMS_MAX_TAPS", 2 * size + 1);
+    p->ktaps = 2 * size + 1;
+    gms_generate_gaussian_kernel(sigma, size, p->kernel);
+    p->extra_steps = 2;                                       // GridMap.java:210
+    p->hit_tolerance = 2.0f;                                  // GridMap.java:223
+    p->z_hit = 0.9;                                           // GridMap.java:259
+    p->z_random = 1 - p->z_hit;
+    p->max_range = 10.0f;                                     // SensorModel.java:20
+    p->max_beams = 0;
+    return GMS_OK;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------
+}  // extern "C"
+
+static void prof_drain(gms_map *m) {
+    for (ProfSlot &s : m->prof_pending) {
+        hipEventSynchronize(s.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            m->prof_ms[s.k] += ms;
+            m->prof_n[s.k] += 1;
+        }
+        m->prof_free.push_back(s);
+    }
+    m->prof_pending.clear();
+}
+
+void gms_prof_begin(gms_map *m, int32_t k) {
+    if (m->prof_pending.size() >= 8192) prof_drain(m);
+    ProfSlot s;
+    if (!m->prof_free.empty()) {
+        s = m->prof_free.back();
+        m->prof_free.pop_back();
+    } else {
+        hipEventCreate(&s.a);
+        hipEventCreate(&s.b);
+    }
+    s.k = k;
+    hipEventRecord(s.a, m->stream);
+    m->prof_pending.push_back(s);
+}
+
+void gms_prof_end(gms_map *m) { hipEventRecord(m->prof_pending.back().b, m->stream); }
+
+extern "C" {
+
+int gms_profile_enable(gms_map *m, int32_t on) {
+    REQUIRE(m, "null map");
+    if (!on) prof_drain(m);
+    m->prof_on = on != 0;
+    return GMS_OK;
+}
+int gms_profile_reset(gms_map *m) {
+    REQUIRE(m, "null map");
+    prof_drain(m);
+    for (int k = 0; k < GMS_K_COUNT; k++) { m->prof_ms[k] = 0; m->prof_n[k] = 0; }
+    return GMS_OK;
+}
+int gms_profile_get(gms_map *m, int32_t k, double *total_ms, int64_t *launches) {
+    REQUIRE(m && k >= 0 && k < GMS_K_COUNT, "gms_profile_get: bad arguments");
+    prof_drain(m);
+    if (total_ms) *total_ms = m->prof_ms[k];
+    if (launches) *launches = m->prof_n[k];
+    return GMS_OK;
+}
+
+// ---- GridMap --------------------------------------------------------------------------------------
+static int map_free(gms_map *m) {
+    if (!m) return GMS_OK;
+    prof_drain(m);
+    for (ProfSlot &s : m->prof_free) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    hipFree(m->d_log); hipFree(m->d_lik); hipFree(m->d_cnt); hipFree(m->d_bbox); hipFree(m->d_taps);
+    hipFree(m->d_beams); hipFree(m->d_poses); hipFree(m->d_scratch);
+    hipFree(m->d_trace_cells); hipFree(m->d_trace_cls); hipFree(m->d_trace_cnt);
+    if (m->h_beams) hipHostFree(m->h_beams);
+    if (m->h_poses) hipHostFree(m->h_poses);
+    if (m->own_stream) hipStreamDestroy(m->own_stream);
+    delete m;
+    return GMS_OK;
+}
+
+int gms_map_create(const gms_params *p, gms_map **out) {
+    REQUIRE(p && out, "gms_map_create: null argument");
+    *out = nullptr;
+    REQUIRE(p->resolution > 0.0f && p->n_maps >= 1 && p->n_maps <= 1024, "gms_map_create: bad resolution / n_maps");
+    REQUIRE(p->ktaps >= 1 && (p->ktaps & 1) && p->ktaps <= GMS_MAX_TAPS, "gms_map_create: ktaps must be odd and <= GMS_MAX_TAPS");
+    int32_t W, H;
+    gms_grid_size(p, &W, &H);
+    REQUIRE(W > 0 && H > 0 && (int64_t)W * H < (1ll << 31), "gms_map_create: grid size out of range");
+    int ndev = gms_device_count();
+    if (ndev <= 0) return fail(GMS_ERR_NO_DEVICE, "no HIP device visible: libgridmapslam has no CPU path");
+    if (p->device < 0 || p->device >= ndev) return fail(GMS_ERR_NO_DEVICE, "device %d of %d not available", p->device, ndev);
+    HIPCHK(hipSetDevice(p->device));
+
+    gms_map *m = new (std::nothrow) gms_map();
+    if (!m) return fail(GMS_ERR_NOMEM, "out of host memory");
+    m->prm = *p;
+    m->n_maps = p->n_maps;
+    m->device = p->device;
+    m->max_beams = p->max_beams > 0 ? p->max_beams : 2048;
+    GridDev &g = m->gd;
+    g.W = W; g.H = H; g.cells = (int64_t)W * H;
+    g.posx = (double)p->pos_x; g.posy = (double)p->pos_y;
+    g.res = (double)p->resolution; g.resf = p->resolution;
+    g.l_free = p->l_free; g.l_occ = p->l_occ;
+    g.extra = p->extra_steps;
+    g.half_tol = p->hit_tolerance / 2;                               // SensorModel.java:35 float arithmetic
+    g.z_hit = p->z_hit;
+    g.c_rand = p->z_random * 1.0 / (double)p->max_range;             // GridMap.java:288
+    g.inv_max = 1.0 / (double)p->max_range;                          // GridMap.java:286
+    g.ktaps = p->ktaps; g.khalf = (p->ktaps - 1) / 2;                // Util.java:384
+
+    const size_t cells = (size_t)g.cells * m->n_maps;
+    hipError_t e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete m; return fail(GMS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    m->stream = m->own_stream;
+    bool ok = true;
+    ok = ok && hipMalloc(&m->d_log, cells * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_lik, cells * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_cnt, cells * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_bbox, (size_t)m->n_maps * 4 * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_taps, GMS_MAX_TAPS * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_beams, (size_t)m->n_maps * m->max_beams * sizeof(gms_beam)) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_poses, (size_t)m->n_maps * 3 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_scratch, 64 * sizeof(double)) == hipSuccess;
+    ok = ok && hipHostMalloc(&m->h_beams, (size_t)m->n_maps * m->max_beams * sizeof(gms_beam)) == hipSuccess;
+    ok = ok && hipHostMalloc(&m->h_poses, (size_t)m->n_maps * 3 * sizeof(float) + 64 * sizeof(double)) == hipSuccess;
+    if (!ok) { map_free(m); return fail(GMS_ERR_NOMEM, "device allocation failed (%zu cells x %d maps)", (size_t)g.cells, m->n_maps); }
+    hipMemcpyAsync(m->d_taps, p->kernel, p->ktaps * sizeof(double), hipMemcpyHostToDevice, m->stream);
+    hipMemsetAsync(m->d_log, 0, cells * sizeof(double), m->stream);   // logOdds(0.5) == 0.0 (createMapData(null))
+    hipMemsetAsync(m->d_lik, 0, cells * sizeof(double), m->stream);
+    hipMemsetAsync(m->d_cnt, 0, cells * sizeof(uint32_t), m->stream);
+    hipMemsetAsync(m->d_bbox, 0, (size_t)m->n_maps * 4 * sizeof(int32_t), m->stream);
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->need_full_build = 1;
+    *out = m;
+    return GMS_OK;
+}
+
+int gms_map_destroy(gms_map *m) {
+    if (!m) return GMS_OK;
+    hipSetDevice(m->device);
+    hipStreamSynchronize(m->stream);
+    return map_free(m);
+}
+
+int gms_map_get_size(const gms_map *m, int32_t *W, int32_t *H, int32_t *n_maps) {
+    REQUIRE(m, "null map");
+    if (W) *W = m->gd.W;
+    if (H) *H = m->gd.H;
+    if (n_maps) *n_maps = m->n_maps;
+    return GMS_OK;
+}
+
+int gms_map_set_stream(gms_map *m, void *hip_stream) {
+    REQUIRE(m, "null map");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : m->own_stream;
+    return GMS_OK;
+}
+
+int gms_map_synchronize(gms_map *m) {
+    REQUIRE(m, "null map");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return GMS_OK;
+}
+
+int gms_map_reset(gms_map *m) {                                        // GridMap.java:129-132
+    REQUIRE(m, "null map");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipMemsetAsync(m->d_log, 0, (size_t)m->gd.cells * m->n_maps * sizeof(double), m->stream));
+    m->need_full_build = 1;
+    return GMS_OK;
+}
+
+static int map_xfer(gms_map *m, void *dev, void *host, bool to_device) {
+    const size_t bytes = (size_t)m->gd.cells * m->n_maps * sizeof(double);
+    HIPCHK(hipSetDevice(m->device));
+    if (to_device) HIPCHK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, m->stream));
+    else HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return GMS_OK;
+}
+
+int gms_map_upload_log(gms_map *m, const double *log_data) {
+    REQUIRE(m && log_data, "null argument");
+    m->need_full_build = 1;
+    return map_xfer(m, m->d_log, const_cast<double *>(log_data), true);
+}
+int gms_map_download_log(gms_map *m, double *log_data) {
+    REQUIRE(m && log_data, "null argument");
+    return map_xfer(m, m->d_log, log_data, false);
+}
+int gms_map_upload_likelihood(gms_map *m, const double *lik) {
+    REQUIRE(m && lik, "null argument");
+    m->need_full_build = 1;
+    return map_xfer(m, m->d_lik, const_cast<double *>(lik), true);
+}
+int gms_map_download_likelihood(gms_map *m, double *lik) {
+    REQUIRE(m && lik, "null argument");
+    return map_xfer(m, m->d_lik, lik, false);
+}
+
+int gms_map_copy(gms_map *dst, const gms_map *src) {                  // GridMap.java:106-124
+    REQUIRE(dst && src, "null argument");
+    REQUIRE(dst->gd.W == src->gd.W && dst->gd.H == src->gd.H && dst->n_maps == src->n_maps, "gms_map_copy: shape mismatch");
+    const size_t bytes = (size_t)src->gd.cells * src->n_maps * sizeof(double);
+    HIPCHK(hipStreamSynchronize(src->stream));
+    HIPCHK(hipMemcpyAsync(dst->d_log, src->d_log, bytes, hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(hipMemcpyAsync(dst->d_lik, src->d_lik, bytes, hipMemcpyDeviceToDevice, dst->stream));
+    dst->need_full_build = 1;
+    return GMS_OK;
+}
+
+int gms_map_get_raw_at(gms_map *m, int32_t mi, int32_t x, int32_t y, double *raw, double *prob) {
+    REQUIRE(m, "null map");
+    // Java would throw ArrayIndexOutOfBounds (GridMap.java:135)
+    REQUIRE(mi >= 0 && mi < m->n_maps && x >= 0 && x < m->gd.W && y >= 0 && y < m->gd.H, "gms_map_get_raw_at: index out of bounds");
+    HIPCHK(hipSetDevice(m->device));
+    gms_launch_get_raw(m, mi, x, y, m->d_scratch);
+    double *h = reinterpret_cast<double *>(m->h_poses + (size_t)m->n_maps * 3);
+    h = reinterpret_cast<double *>(((uintptr_t)h + 7) & ~(uintptr_t)7);
+    HIPCHK(hipMemcpyAsync(h, m->d_scratch, 2 * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (raw) *raw = h[0];
+    if (prob) *prob = h[1];
+    return GMS_OK;
+}
+
+// beams [n_maps][B] (host) -> d_beams [n_maps][max_beams]
+static int stage_beams(gms_map *m, const gms_beam *beams, int32_t B) {
+    REQUIRE(beams, "null beams");
+    REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
+    HIPCHK(hipSetDevice(m->device));
+    // the pinned staging buffer may still feed an earlier copy
+    HIPCHK(hipStreamSynchronize(m->stream));
+    for (int32_t mi = 0; mi < m->n_maps; mi++)
+        memcpy(m->h_beams + (size_t)mi * m->max_beams, beams + (size_t)mi * B, (size_t)B * sizeof(gms_beam));
+    if (m->n_maps == 1)
+        HIPCHK(hipMemcpyAsync(m->d_beams, m->h_beams, (size_t)B * sizeof(gms_beam), hipMemcpyHostToDevice, m->stream));
+    else
+        HIPCHK(hipMemcpyAsync(m->d_beams, m->h_beams, (size_t)m->n_maps * m->max_beams * sizeof(gms_beam),
+                              hipMemcpyHostToDevice, m->stream));
+    return GMS_OK;
+}
+
+static int stage_poses(gms_map *m, const float *poses) {
+    REQUIRE(poses, "null poses");
+    memcpy(m->h_poses, poses, (size_t)m->n_maps * 3 * sizeof(float));
+    HIPCHK(hipMemcpyAsync(m->d_poses, m->h_poses, (size_t)m->n_maps * 3 * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    return GMS_OK;
+}
+
+static int finish_likelihood(gms_map *m, int32_t dirty_only) {
+    gms_launch_likelihood(m, dirty_only);
+    HIPCHK(hipMemsetAsync(m->d_bbox, 0, (size_t)m->n_maps * 4 * sizeof(int32_t), m->stream));
+    m->need_full_build = 0;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_map_integrate(gms_map *m, const gms_beam *beams, int32_t B, const float *poses) {   // GridMap.java:173-191
+    REQUIRE(m, "null map");
+    int rc = stage_beams(m, beams, B);
+    if (rc) return rc;
+    rc = stage_poses(m, poses);
+    if (rc) return rc;
+    if (B > 0) {
+        gms_launch_raycast(m, m->d_beams, B, m->d_poses);
+        gms_launch_apply_counts(m);
+    }
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_map_integrate_at(gms_map *m, const gms_beam *beams, int32_t B, gms_pf *pf, int32_t which) {
+    REQUIRE(m && pf && pf->map == m, "gms_map_integrate_at: filter does not belong to this map");
+    REQUIRE(which == 0 || which == 1, "which must be 0 (weighted pose) or 1 (strongest particle)");
+    int rc = stage_beams(m, beams, B);
+    if (rc) return rc;
+    gms_launch_pose_from_pf(m, pf, which, m->d_poses);
+    if (B > 0) {
+        gms_launch_raycast(m, m->d_beams, B, m->d_poses);
+        gms_launch_apply_counts(m);
+    }
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_map_apply_ray(gms_map *m, float sx, float sy, float ex, float ey, float measured, int32_t hit) {
+    REQUIRE(m, "null map");
+    HIPCHK(hipSetDevice(m->device));
+    RayIn r;
+    r.sx = sx; r.sy = sy; r.ex = ex; r.ey = ey; r.measured = measured; r.hit = hit != 0;
+    gms_launch_apply_ray(m, r);
+    gms_launch_apply_counts(m);
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+static int ensure_trace(gms_map *m, size_t cells, size_t counts) {
+    const size_t need = cells * 9 + counts * 4;
+    if (need <= m->trace_cap_bytes) return GMS_OK;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    hipFree(m->d_trace_cells); hipFree(m->d_trace_cls); hipFree(m->d_trace_cnt);
+    m->d_trace_cells = nullptr; m->d_trace_cls = nullptr; m->d_trace_cnt = nullptr; m->trace_cap_bytes = 0;
+    HIPCHK(hipMalloc(&m->d_trace_cells, cells * 2 * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&m->d_trace_cls, cells));
+    HIPCHK(hipMalloc(&m->d_trace_cnt, counts * sizeof(int32_t)));
+    m->trace_cap_bytes = need;
+    return GMS_OK;
+}
+
+int gms_map_trace_ray(gms_map *m, float x0, float y0, float x1, float y1, int32_t extra, int32_t *cells_xy,
+                      int32_t cap, int32_t *n) {
+    REQUIRE(m && n && cap >= 0 && (cells_xy || cap == 0), "gms_map_trace_ray: bad arguments");
+    HIPCHK(hipSetDevice(m->device));
+    int rc = ensure_trace(m, (size_t)(cap > 0 ? cap : 1), 1);
+    if (rc) return rc;
+    gms_launch_trace_ray(m, x0, y0, x1, y1, extra, m->d_trace_cells, cap, m->d_trace_cnt);
+    HIPCHK(hipMemcpyAsync(n, m->d_trace_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    if (cap > 0)
+        HIPCHK(hipMemcpyAsync(cells_xy, m->d_trace_cells, (size_t)cap * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return GMS_OK;
+}
+
+int gms_map_trace_scan(gms_map *m, const gms_beam *beams, int32_t B, const float pose[3], int32_t *cells_xy,
+                       uint8_t *classes, int32_t cap, int32_t *counts) {
+    REQUIRE(m && pose && counts && cap > 0 && B > 0, "gms_map_trace_scan: bad arguments");
+    // only map 0's slice of the staging buffers is used
+    REQUIRE(B <= m->max_beams, "beam count exceeds gms_params.max_beams");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    memcpy(m->h_beams, beams, (size_t)B * sizeof(gms_beam));
+    memcpy(m->h_poses, pose, 3 * sizeof(float));
+    HIPCHK(hipMemcpyAsync(m->d_beams, m->h_beams, (size_t)B * sizeof(gms_beam), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_poses, m->h_poses, 3 * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    int rc = ensure_trace(m, (size_t)B * cap, (size_t)B);
+    if (rc) return rc;
+    gms_launch_trace_scan(m, m->d_beams, B, m->d_poses, cells_xy ? m->d_trace_cells : nullptr,
+                          classes ? m->d_trace_cls : nullptr, cap, m->d_trace_cnt);
+    HIPCHK(hipMemcpyAsync(counts, m->d_trace_cnt, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    if (cells_xy)
+        HIPCHK(hipMemcpyAsync(cells_xy, m->d_trace_cells, (size_t)B * cap * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    if (classes)
+        HIPCHK(hipMemcpyAsync(classes, m->d_trace_cls, (size_t)B * cap, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return GMS_OK;
+}
+
+int gms_map_build_likelihood(gms_map *m) {                              // GridMap.java:233-250
+    REQUIRE(m, "null map");
+    HIPCHK(hipSetDevice(m->device));
+    return finish_likelihood(m, 0);
+}
+
+int gms_map_update(gms_map *m, const gms_beam *beams, int32_t B, const float *poses) {
+    int rc = gms_map_integrate(m, beams, B, poses);
+    if (rc) return rc;
+    return finish_likelihood(m, m->need_full_build ? 0 : 1);
+}
+
+int gms_map_update_at(gms_map *m, const gms_beam *beams, int32_t B, gms_pf *pf, int32_t which) {
+    int rc = gms_map_integrate_at(m, beams, B, pf, which);
+    if (rc) return rc;
+    return finish_likelihood(m, m->need_full_build ? 0 : 1);
+}
+
+int gms_debug_f32(gms_map *m, int32_t op, const float *in, float *out, int64_t n) {
+    REQUIRE(m && in && out && n > 0 && op >= 0 && op <= 2, "gms_debug_f32: bad arguments");
+    HIPCHK(hipSetDevice(m->device));
+    float *d_a = nullptr, *d_o = nullptr;
+    HIPCHK(hipMalloc(&d_a, n * sizeof(float)));
+    HIPCHK(hipMalloc(&d_o, n * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(d_a, in, n * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    gms_launch_debug_f32(m, op, d_a, d_o, n);
+    HIPCHK(hipMemcpyAsync(out, d_o, n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    hipFree(d_a); hipFree(d_o);
+    return GMS_OK;
+}
+
+// ---- ParticleFilter ---------------------------------------------------------------------------------
+static int64_t nblk_of(int64_t n) { return (n + GMS_BLOCK - 1) / GMS_BLOCK; }
+static int64_t nchunks_of(int64_t n) { return (n + 63) / 64; }
+
+static void pf_free_global(gms_pf *pf) {
+    hipFree(pf->d_partials); hipFree(pf->d_partials2); hipFree(pf->d_global); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum);
+    pf->d_partials = pf->d_partials2 = nullptr; pf->d_global = nullptr; pf->d_chunk_tot = pf->d_cum = nullptr;
+}
+
+static int pf_alloc_global(gms_pf *pf) {
+    pf_free_global(pf);
+    const size_t M = pf->n_maps;
+    const size_t nblk = nblk_of(pf->n_global), nch = nchunks_of(pf->n_global);
+    HIPCHK(hipMalloc(&pf->d_partials, M * nblk * GMS_PARTIAL_STRIDE * sizeof(double)));
+    HIPCHK(hipMalloc(&pf->d_partials2, M * nblk * 5 * sizeof(double)));
+    HIPCHK(hipMalloc(&pf->d_global, M * pf->n_global * sizeof(PackedParticle)));
+    HIPCHK(hipMalloc(&pf->d_chunk_tot, M * (nch + 1) * sizeof(double)));
+    HIPCHK(hipMalloc(&pf->d_cum, M * pf->n_global * sizeof(double)));
+    return GMS_OK;
+}
+
+int gms_pf_destroy(gms_pf *pf) {
+    if (!pf) return GMS_OK;
+    hipSetDevice(pf->map->device);
+    hipStreamSynchronize(pf->map->stream);
+    hipFree(pf->d_x); hipFree(pf->d_y); hipFree(pf->d_th); hipFree(pf->d_x2); hipFree(pf->d_y2); hipFree(pf->d_th2);
+    hipFree(pf->d_w); hipFree(pf->d_w2); hipFree(pf->d_logw); hipFree(pf->d_cs); hipFree(pf->d_hitbeams);
+    hipFree(pf->d_nhit); hipFree(pf->d_stats); hipFree(pf->d_r01); hipFree(pf->d_idx);
+    pf_free_global(pf);
+    if (pf->h_stats) hipHostFree(pf->h_stats);
+    if (pf->h_stage) hipHostFree(pf->h_stage);
+    delete pf;
+    return GMS_OK;
+}
+
+int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // ParticleFilter.java:43, SLAM.java:65-77
+    REQUIRE(m && out, "gms_pf_create: null argument");
+    *out = nullptr;
+    REQUIRE(n >= 1 && n <= (1 << 24), "gms_pf_create: particle count out of range");
+    HIPCHK(hipSetDevice(m->device));
+    gms_pf *pf = new (std::nothrow) gms_pf();
+    if (!pf) return fail(GMS_ERR_NOMEM, "out of host memory");
+    pf->map = m; pf->n = n; pf->offset = 0; pf->n_global = n; pf->n_maps = m->n_maps;
+    const size_t T = (size_t)n * m->n_maps;
+    bool ok = true;
+    ok = ok && hipMalloc(&pf->d_x, T * 4) == hipSuccess && hipMalloc(&pf->d_y, T * 4) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_th, T * 4) == hipSuccess && hipMalloc(&pf->d_x2, T * 4) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_y2, T * 4) == hipSuccess && hipMalloc(&pf->d_th2, T * 4) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_w, T * 8) == hipSuccess && hipMalloc(&pf->d_w2, T * 8) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_logw, T * 8) == hipSuccess && hipMalloc(&pf->d_cs, T * 8) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_hitbeams, (size_t)m->n_maps * m->max_beams * 16) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_nhit, (size_t)m->n_maps * 4) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_stats, (size_t)m->n_maps * sizeof(PfStatsDev)) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_r01, (size_t)m->n_maps * 8) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_idx, T * 4) == hipSuccess;
+    ok = ok && hipHostMalloc(&pf->h_stats, (size_t)m->n_maps * sizeof(PfStatsDev) + (size_t)m->n_maps * 8) == hipSuccess;
+    ok = ok && hipHostMalloc(&pf->h_stage, T * 3 * sizeof(float)) == hipSuccess;
+    if (!ok || pf_alloc_global(pf) != GMS_OK) { gms_pf_destroy(pf); return fail(GMS_ERR_NOMEM, "device allocation failed for %d particles", n); }
+    hipMemsetAsync(pf->d_stats, 0, (size_t)m->n_maps * sizeof(PfStatsDev), m->stream);
+    gms_launch_pf_init(pf);
+    HIPCHK(hipGetLastError());
+    *out = pf;
+    return GMS_OK;
+}
+
+int gms_pf_set_shard(gms_pf *pf, int64_t offset, int64_t n_global) {
+    REQUIRE(pf, "null filter");
+    REQUIRE(offset >= 0 && offset % GMS_BLOCK == 0, "shard offset must be a multiple of GMS_BLOCK");
+    REQUIRE(n_global >= offset + pf->n && n_global <= (1 << 26), "shard does not fit n_global");
+    HIPCHK(hipSetDevice(pf->map->device));
+    HIPCHK(hipStreamSynchronize(pf->map->stream));
+    pf->offset = offset;
+    pf->n_global = n_global;
+    pf->have_global = 0;
+    return pf_alloc_global(pf);
+}
+
+int gms_pf_set_poses(gms_pf *pf, const float *xytheta) {
+    REQUIRE(pf && xytheta, "null argument");
+    gms_map *m = pf->map;
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    const size_t T = (size_t)pf->n * pf->n_maps;
+    float *hx = pf->h_stage, *hy = hx + T, *ht = hy + T;
+    for (size_t i = 0; i < T; i++) { hx[i] = xytheta[3 * i]; hy[i] = xytheta[3 * i + 1]; ht[i] = xytheta[3 * i + 2]; }
+    HIPCHK(hipMemcpyAsync(pf->d_x, hx, T * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(pf->d_y, hy, T * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(pf->d_th, ht, T * 4, hipMemcpyHostToDevice, m->stream));
+    pf->have_global = 0;
+    return GMS_OK;
+}
+
+int gms_pf_get_poses(gms_pf *pf, float *xytheta) {
+    REQUIRE(pf && xytheta, "null argument");
+    gms_map *m = pf->map;
+    HIPCHK(hipSetDevice(m->device));
+    const size_t T = (size_t)pf->n * pf->n_maps;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    float *hx = pf->h_stage, *hy = hx + T, *ht = hy + T;
+    HIPCHK(hipMemcpyAsync(hx, pf->d_x, T * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(hy, pf->d_y, T * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(ht, pf->d_th, T * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    for (size_t i = 0; i < T; i++) { xytheta[3 * i] = hx[i]; xytheta[3 * i + 1] = hy[i]; xytheta[3 * i + 2] = ht[i]; }
+    return GMS_OK;
+}
+
+static int pf_copy_f64(gms_pf *pf, double *dev, double *host, bool to_device) {
+    gms_map *m = pf->map;
+    HIPCHK(hipSetDevice(m->device));
+    const size_t bytes = (size_t)pf->n * pf->n_maps * sizeof(double);
+    if (to_device) HIPCHK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, m->stream));
+    else HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return GMS_OK;
+}
+
+int gms_pf_set_weights(gms_pf *pf, const double *w) {
+    REQUIRE(pf && w, "null argument");
+    pf->have_global = 0;
+    return pf_copy_f64(pf, pf->d_w, const_cast<double *>(w), true);
+}
+int gms_pf_get_weights(gms_pf *pf, double *w) {
+    REQUIRE(pf && w, "null argument");
+    return pf_copy_f64(pf, pf->d_w, w, false);
+}
+int gms_pf_get_log_weights(gms_pf *pf, double *lw) {
+    REQUIRE(pf && lw, "null argument");
+    return pf_copy_f64(pf, pf->d_logw, lw, false);
+}
+
+int gms_pf_score(gms_pf *pf, const gms_beam *beams, int32_t B) {       // GridMap.java:261-294 x N
+    REQUIRE(pf, "null filter");
+    gms_map *m = pf->map;
+    int rc = stage_beams(m, beams, B);
+    if (rc) return rc;
+    gms_launch_pf_prep(pf, m->d_beams, B);
+    gms_launch_pf_score(pf, B);
+    pf->have_global = 0;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+static void fill_stats(const gms_pf *pf, gms_pf_stats *stats) {
+    for (int32_t mi = 0; mi < pf->n_maps; mi++) {
+        const PfStatsDev &s = pf->h_stats[mi];
+        stats[mi].weight_sum = s.weight_sum;
+        stats[mi].neff = 1.0 / s.sq_sum;                                // SLAM.java:189
+        stats[mi].strongest = s.strongest;
+        stats[mi].n_zero = s.n_zero;
+        stats[mi].max_log_weight = s.max_logw;
+    }
+}
+
+static int pull_stats(gms_pf *pf) {
+    gms_map *m = pf->map;
+    HIPCHK(hipMemcpyAsync(pf->h_stats, pf->d_stats, (size_t)pf->n_maps * sizeof(PfStatsDev), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return GMS_OK;
+}
+
+int gms_pf_get_stats(gms_pf *pf, gms_pf_stats *stats) {
+    REQUIRE(pf && stats, "null argument");
+    HIPCHK(hipSetDevice(pf->map->device));
+    int rc = pull_stats(pf);
+    if (rc) return rc;
+    fill_stats(pf, stats);
+    return GMS_OK;
+}
+
+int gms_pf_normalize(gms_pf *pf, gms_pf_stats *stats) {                 // SLAM.java:87-129
+    REQUIRE(pf, "null filter");
+    if (pf->offset != 0 || pf->n_global != pf->n)
+        return fail(GMS_ERR_STATE, "sharded filter: use gms_pf_local_partials / apply_partials / import_global");
+    HIPCHK(hipSetDevice(pf->map->device));
+    gms_launch_pf_partials(pf, pf->d_partials);
+    gms_launch_pf_apply_partials(pf, pf->d_partials, pf->d_global);
+    gms_launch_pf_global_stats(pf);
+    pf->have_global = 1;
+    HIPCHK(hipGetLastError());
+    if (stats) return gms_pf_get_stats(pf, stats);
+    return GMS_OK;
+}
+
+int gms_pf_partials_len(const gms_pf *pf, int64_t *n_doubles) {
+    REQUIRE(pf && n_doubles, "null argument");
+    *n_doubles = (int64_t)pf->n_maps * nblk_of(pf->n_global) * GMS_PARTIAL_STRIDE;
+    return GMS_OK;
+}
+
+int gms_pf_local_partials(gms_pf *pf, double *dev_partials) {
+    REQUIRE(pf && dev_partials, "null argument");
+    HIPCHK(hipSetDevice(pf->map->device));
+    gms_launch_pf_partials(pf, dev_partials);
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_pf_apply_partials(gms_pf *pf, const double *dev_partials, void *dev_packed) {
+    REQUIRE(pf && dev_partials && dev_packed, "null argument");
+    HIPCHK(hipSetDevice(pf->map->device));
+    REQUIRE(dev_packed != pf->d_global, "dev_packed must be caller-owned");
+    gms_launch_pf_apply_partials(pf, dev_partials, reinterpret_cast<PackedParticle *>(dev_packed));
+    pf->have_global = 0;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_pf_pack(gms_pf *pf, void *dev_packed) {
+    REQUIRE(pf && dev_packed, "null argument");
+    HIPCHK(hipSetDevice(pf->map->device));
+    gms_launch_pf_pack(pf, reinterpret_cast<PackedParticle *>(dev_packed), pf->n);
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_pf_import_global(gms_pf *pf, const void *dev_packed_global) {
+    REQUIRE(pf && dev_packed_global, "null argument");
+    gms_map *m = pf->map;
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipMemcpyAsync(pf->d_global, dev_packed_global, (size_t)pf->n_maps * pf->n_global * sizeof(PackedParticle),
+                          hipMemcpyDeviceToDevice, m->stream));
+    gms_launch_pf_global_stats(pf);
+    pf->have_global = 1;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+// make d_global describe the current particles (stand-alone filters only)
+static int ensure_global(gms_pf *pf) {
+    if (pf->have_global) return GMS_OK;
+    if (pf->offset != 0 || pf->n_global != pf->n)
+        return fail(GMS_ERR_STATE, "sharded filter: all-gather the packed particles and call gms_pf_import_global first");
+    gms_launch_pf_pack(pf, pf->d_global, pf->n_global);
+    gms_launch_pf_global_stats(pf);
+    pf->have_global = 1;
+    return GMS_OK;
+}
+
+int gms_pf_weighted_pose(gms_pf *pf, float *out) {                      // SLAM.java:165-178
+    REQUIRE(pf && out, "null argument");
+    HIPCHK(hipSetDevice(pf->map->device));
+    int rc = ensure_global(pf);
+    if (rc) return rc;
+    rc = pull_stats(pf);
+    if (rc) return rc;
+    for (int32_t mi = 0; mi < pf->n_maps; mi++)
+        for (int k = 0; k < 3; k++) out[3 * mi + k] = pf->h_stats[mi].wpose[k];
+    return GMS_OK;
+}
+
+static int do_resample(gms_pf *pf, const double *r01, double fraction, int32_t *indices, int32_t *n_ambiguous) {
+    REQUIRE(pf && r01, "null argument");
+    gms_map *m = pf->map;
+    HIPCHK(hipSetDevice(m->device));
+    int rc = ensure_global(pf);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(m->stream));          // h_stats tail doubles as the r01 staging area
+    double *h_r = reinterpret_cast<double *>(reinterpret_cast<char *>(pf->h_stats) + (size_t)pf->n_maps * sizeof(PfStatsDev));
+    memcpy(h_r, r01, (size_t)pf->n_maps * sizeof(double));
+    HIPCHK(hipMemcpyAsync(pf->d_r01, h_r, (size_t)pf->n_maps * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    gms_launch_pf_resample(pf, fraction);
+    std::swap(pf->d_x, pf->d_x2); std::swap(pf->d_y, pf->d_y2); std::swap(pf->d_th, pf->d_th2); std::swap(pf->d_w, pf->d_w2);
+    pf->have_global = 0;
+    HIPCHK(hipGetLastError());
+    if (indices) {
+        HIPCHK(hipMemcpyAsync(indices, pf->d_idx, (size_t)pf->n * pf->n_maps * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    if (n_ambiguous) {
+        rc = pull_stats(pf);
+        if (rc) return rc;
+        for (int32_t mi = 0; mi < pf->n_maps; mi++) n_ambiguous[mi] = pf->h_stats[mi].n_ambiguous;
+    }
+    return GMS_OK;
+}
+
+int gms_pf_resample(gms_pf *pf, const double *r01, int32_t *indices, int32_t *n_ambiguous) {   // SLAM.java:133-153
+    return do_resample(pf, r01, -1.0, indices, n_ambiguous);
+}
+
+int gms_pf_resample_if(gms_pf *pf, const double *r01, double fraction) {   // GridMapApp.java:185-186
+    REQUIRE(fraction >= 0.0, "fraction must be non-negative");
+    return do_resample(pf, r01, fraction, nullptr, nullptr);
+}
+
+int gms_pf_did_resample(gms_pf *pf, int32_t *flags) {
+    REQUIRE(pf && flags, "null argument");
+    HIPCHK(hipSetDevice(pf->map->device));
+    int rc = pull_stats(pf);
+    if (rc) return rc;
+    for (int32_t mi = 0; mi < pf->n_maps; mi++) flags[mi] = pf->h_stats[mi].did_resample;
+    return GMS_OK;
+}
+
+int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B) {   // GridMap.java:319-346
+    REQUIRE(pf, "null filter");
+    gms_map *m = pf->map;
+    int rc = stage_beams(m, beams, B);
+    if (rc) return rc;
+    gms_launch_pf_prep(pf, m->d_beams, B);
+    gms_launch_pf_refine(pf, B);
+    pf->have_global = 0;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+/*
+ * gridmapslam.h -- C-ABI of the MI355X-native occupancy-grid SLAM core (libgridmapslam.so).
+ *
+ * Drop-in boundary for ONE hot path of antbern/gridmap-slam-robot's GridMapGL app: the log-odds
+ * ray-cast map update, the likelihood-field build and the particle scan matcher (score,
+ * normalise / Neff, weighted pose, systematic resample).  The reference has no FFI of its own; each
+ * entry point below replaces one public Java method and cites it.  J/ =
+ * java/GridMapGL/src/main/java/com/fmsz/gridmapgl/ in the reference tree.  The JNI / cgo-style
+ * binding a maintainer would add is shown in INTEGRATION.md; a C++ mirror of the Java classes is in
+ * include/gridmapslam.hpp.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, opaque handles, int status (GMS_OK = 0, negative =
+ *    error; text via gms_last_error()).  No exception crosses the boundary.
+ *  - The caller owns every host buffer; the library owns every device buffer.
+ *  - One host thread per handle at a time (the reference calls this path from one thread only:
+ *    J/app/DataEventHandler.java:24-26).
+ *  - All work runs on the handle's HIP stream (gms_map_set_stream).  Entry points that only take
+ *    inputs enqueue and return; entry points that fill a host buffer synchronise that stream
+ *    before returning.
+ *  - Grids are row-major `x + y*W` doubles exactly like GridMapData.logData / likelihoodData
+ *    (J/slam/GridMap.java:72-74,135), so a JNI shim can Get/SetDoubleArrayRegion them as they are.
+ *  - A handle with n_maps > 1 is a batch of independent maps (and particle sets): every per-map
+ *    argument then carries a leading [n_maps] dimension.
+ *  - There is no CPU fallback: without a HIP device gms_map_create fails with GMS_ERR_NO_DEVICE.
+ */
+#ifndef GRIDMAPSLAM_H
+#define GRIDMAPSLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+#define GMS_VERSION_MAJOR 0
+#define GMS_VERSION_MINOR 1
+
+#define GMS_MAX_TAPS 129        /* likelihood kernel taps (odd) */
+#define GMS_BLOCK 256           /* particles per reduction block; shard offsets are multiples of it */
+
+enum {
+    GMS_OK = 0,
+    GMS_ERR_INVALID = -1,       /* bad argument */
+    GMS_ERR_NO_DEVICE = -2,     /* no usable HIP device (there is no CPU path) */
+    GMS_ERR_HIP = -3,           /* a HIP runtime call failed */
+    GMS_ERR_NOMEM = -4,
+    GMS_ERR_STATE = -5          /* call order violated (e.g. resample before normalise) */
+};
+
+/* One LIDAR beam = the fields of Observation.Measurement the path reads
+ * (J/slam/Observation.java:37-41).  32 bytes. */
+typedef struct gms_beam {
+    double local_x;             /* Measurement.localX  (robot frame, metres) */
+    double local_y;             /* Measurement.localY */
+    double distance;            /* Measurement.distance (metres; SENSOR_MAX_RANGE on a miss) */
+    uint8_t hit;                /* Measurement.wasHit */
+    uint8_t pad_[7];
+} gms_beam;
+
+/* Everything the GridMap constructor and the constants it closes over decide
+ * (J/slam/GridMap.java:80-100,210,223,259; J/slam/SensorModel.java:20-25).
+ * Fill with gms_params_default() and override fields as needed. */
+typedef struct gms_params {
+    float width_m, height_m;    /* GridMap(width, height, ...) */
+    float resolution;           /* metres per cell */
+    float pos_x, pos_y;         /* lower-left corner in the world */
+    int32_t n_maps;             /* batch of independent maps (1 = the reference's single map) */
+    int32_t device;             /* HIP device ordinal */
+    double l_free, l_occ;       /* Util.logOdds(P_FREE), Util.logOdds(P_OCCUPPIED); host-supplied so
+                                   that the JVM's Math.log decides them */
+    int32_t ktaps;              /* likelihood kernel (Util.generateGaussianKernel); host-supplied so */
+    double kernel[GMS_MAX_TAPS];/* that the JVM's Math.exp decides the taps */
+    int32_t extra_steps;        /* RayIterator additionalSteps, 2 */
+    float hit_tolerance;        /* inverseSensorModel hitTolerance, 2 */
+    double z_hit, z_random;     /* 0.9, 1 - 0.9 */
+    float max_range;            /* SensorModel.SENSOR_MAX_RANGE, 10 */
+    int32_t max_beams;          /* capacity per scan (per map); 0 = 2048 */
+} gms_params;
+
+typedef struct gms_map gms_map;      /* GridMap + GridMapData (n_maps of them) */
+typedef struct gms_pf gms_pf;        /* ParticleFilter / SLAM particle set bound to a gms_map */
+
+/* Results of gms_pf_normalize, per map (SLAM.update's bookkeeping, J/slam/SLAM.java:87-129). */
+typedef struct gms_pf_stats {
+    double weight_sum;          /* sum of raw weights (SLAM.java:100) */
+    double neff;                /* calculateNeff() (SLAM.java:180-190) */
+    int32_t strongest;          /* global index of the first maximum raw weight (SLAM.java:110-115) */
+    int32_t n_zero;             /* raw weights that were exactly 0 (underflow census; not in the reference) */
+    double max_log_weight;      /* max over particles of sum(log factor); see gms_pf_score */
+} gms_pf_stats;
+
+/* ---- library ---------------------------------------------------------------------------------- */
+int gms_version(void);                         /* major*1000 + minor */
+const char *gms_last_error(void);              /* thread-local message of the last failing call */
+int gms_device_count(void);                    /* HIP devices visible; 0 when none (never throws) */
+
+/* ---- host-side helpers (pure; usable without a device) ----------------------------------------- */
+/* GridMap ctor arithmetic: fills every field with the reference's values, computing l_free/l_occ
+ * with libm log and the kernel with libm exp (J/slam/GridMap.java:80-100). */
+int gms_params_default(gms_params *p, float width_m, float height_m, float resolution, float pos_x, float pos_y);
+/* gridSize = ceil(width / resolution) in float (J/slam/GridMap.java:85). */
+int gms_grid_size(const gms_params *p, int32_t *W, int32_t *H);
+/* Util.generateGaussianKernel(sigma, size): out has 2*size+1 taps (J/app/Util.java:428-455). */
+int gms_generate_gaussian_kernel(double sigma, int32_t size, double *out);
+/* Util.logOdds / Util.invLogOdds (J/app/Util.java:35-37,46-48). */
+double gms_log_odds(double p);
+double gms_inv_log_odds(double l);
+
+/* ---- GridMap / GridMapData --------------------------------------------------------------------- */
+/* new GridMap(width,height,resolution,position) + createMapData(null)  (GridMap.java:80,106). */
+int gms_map_create(const gms_params *p, gms_map **out);
+int gms_map_destroy(gms_map *m);
+int gms_map_get_size(const gms_map *m, int32_t *W, int32_t *H, int32_t *n_maps);
+/* Run this handle's work on an existing hipStream_t (e.g. torch's current stream); NULL restores
+ * the handle's own stream. */
+int gms_map_set_stream(gms_map *m, void *hip_stream);
+int gms_map_synchronize(gms_map *m);
+/* GridMap.reset (GridMap.java:129-132): logData := logOdds(0.5) = 0 (likelihoodData is left alone,
+ * as in the reference, until the next gms_map_build_likelihood). */
+int gms_map_reset(gms_map *m);
+/* GridMapData array access (GridMap.java:72-74; read by the renderer :371-388 and serialiser).
+ * n_maps*W*H doubles. */
+int gms_map_upload_log(gms_map *m, const double *log_data);
+int gms_map_download_log(gms_map *m, double *log_data);
+int gms_map_upload_likelihood(gms_map *m, const double *lik);
+int gms_map_download_likelihood(gms_map *m, double *lik);
+/* createMapData(other): device-to-device copy of both arrays (GridMap.java:106-124). */
+int gms_map_copy(gms_map *dst, const gms_map *src);
+/* getRawAt(map,x,y) / getProbAt (GridMap.java:134-140) for map index mi. */
+int gms_map_get_raw_at(gms_map *m, int32_t mi, int32_t x, int32_t y, double *raw, double *prob);
+
+/* GridMap.integrateObservation(map, obs, pose) (GridMap.java:173-191): beams[n_maps][B],
+ * poses[n_maps][3] = x,y,theta. */
+int gms_map_integrate(gms_map *m, const gms_beam *beams, int32_t B, const float *poses);
+/* The same with the pose taken from a particle filter's device-resident weighted pose
+ * (SLAM.getWeightedPose) or strongest particle -- no host round trip.  which: 0 weighted, 1 strongest. */
+int gms_map_integrate_at(gms_map *m, const gms_beam *beams, int32_t B, gms_pf *pf, int32_t which);
+/* GridMap.applyMeasurement(map,startX,startY,endX,endY,measuredDistance,wasHit) on map 0
+ * (GridMap.java:194-228). */
+int gms_map_apply_ray(gms_map *m, float sx, float sy, float ex, float ey, float measured, int32_t hit);
+/* RayIterator(W,H).init(x0,y0,x1,y1,extra) + the hasNext/next loop, run on the device
+ * (J/slam/RayIterator.java:65-130): ordered cells x0,y0,x1,y1,...; *n = number visited (may
+ * exceed cap; only cap cells are stored). */
+int gms_map_trace_ray(gms_map *m, float x0, float y0, float x1, float y1, int32_t extra,
+                      int32_t *cells_xy, int32_t cap, int32_t *n);
+/* The cell walk of integrateObservation for map 0 without touching the map: for beam b,
+ * counts[b] cells; cells_xy/classes hold [B][cap] entries (class 0 free, 1 prior, 2 occupied:
+ * J/slam/SensorModel.java:31-41). */
+int gms_map_trace_scan(gms_map *m, const gms_beam *beams, int32_t B, const float pose[3],
+                       int32_t *cells_xy, uint8_t *classes, int32_t cap, int32_t *counts);
+/* GridMap.computeLikelihoodMap(map) (GridMap.java:233-250 + Util.java:378-426). */
+int gms_map_build_likelihood(gms_map *m);
+/* integrate + rebuild only the part of the likelihood field the scan can have changed (bit-identical
+ * to gms_map_integrate followed by gms_map_build_likelihood when the field was current before). */
+int gms_map_update(gms_map *m, const gms_beam *beams, int32_t B, const float *poses);
+/* gms_map_update with the pose taken from the filter on the device (see gms_map_integrate_at). */
+int gms_map_update_at(gms_map *m, const gms_beam *beams, int32_t B, gms_pf *pf, int32_t which);
+
+/* ---- ParticleFilter / SLAM particle set -------------------------------------------------------- */
+/* new ParticleFilter(n) (J/slam/ParticleFilter.java:43): n particles per map, weights 1/n_global,
+ * poses 0 (SLAM.reset, J/slam/SLAM.java:65-77). */
+int gms_pf_create(gms_map *m, int32_t n_particles, gms_pf **out);
+int gms_pf_destroy(gms_pf *pf);
+/* This handle holds particles [offset, offset+n) of a filter of n_global particles sharded over
+ * several GPUs (offset % GMS_BLOCK == 0).  Default: offset 0, n_global = n. */
+int gms_pf_set_shard(gms_pf *pf, int64_t offset, int64_t n_global);
+/* getParticles() pose access (ParticleFilter.java:50): [n_maps][n][3] floats x,y,theta. */
+int gms_pf_set_poses(gms_pf *pf, const float *xytheta);
+int gms_pf_get_poses(gms_pf *pf, float *xytheta);
+int gms_pf_set_weights(gms_pf *pf, const double *w);
+int gms_pf_get_weights(gms_pf *pf, double *w);
+int gms_pf_get_log_weights(gms_pf *pf, double *lw);
+/* weight[i] = GridMap.probabilityOf(map, obs, pose[i]) for every particle (GridMap.java:261-294,
+ * SLAM.java:99).  Also stores sum(log factor) per particle (underflow-free companion, not in the
+ * reference).  beams[n_maps][B]. */
+int gms_pf_score(gms_pf *pf, const gms_beam *beams, int32_t B);
+/* SLAM.update's bookkeeping: weightSum, strongest, weight /= weightSum, calculateNeff
+ * (SLAM.java:87-129,180-190) and getWeightedPose's sums (SLAM.java:165-178).  stats may be NULL
+ * (no host synchronisation then); stats[n_maps]. */
+int gms_pf_normalize(gms_pf *pf, gms_pf_stats *stats);
+int gms_pf_get_stats(gms_pf *pf, gms_pf_stats *stats);
+/* SLAM.getWeightedPose() (SLAM.java:165-178): out[n_maps][3]. */
+int gms_pf_weighted_pose(gms_pf *pf, float *out);
+/* SLAM.resample() (SLAM.java:133-153; class surface ParticleFilter.resample
+ * J/slam/ParticleFilter.java:59-82) with Math.random() passed in as r01[n_maps].
+ * Particles are replaced by copies (pose and weight).  indices (may be NULL): [n_maps][n] source
+ * index per slot; n_ambiguous (may be NULL): slots whose boundary lies within rounding distance of
+ * a cumulative weight, i.e. where a sequential and a blocked scan may legitimately disagree. */
+int gms_pf_resample(gms_pf *pf, const double *r01, int32_t *indices, int32_t *n_ambiguous);
+/* if (neff < fraction * n) resample()   (J/app/GridMapApp.java:185-186), decided on the device. */
+int gms_pf_resample_if(gms_pf *pf, const double *r01, double fraction);
+/* flags[n_maps]: whether the last gms_pf_resample / gms_pf_resample_if replaced the particles. */
+int gms_pf_did_resample(gms_pf *pf, int32_t *flags);
+/* GridMap.findBestPose(map, obs, startPose) lattice search around every particle
+ * (GridMap.java:319-346): poses are replaced by the argmax pose. */
+int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B);
+
+/* ---- multi-GPU plumbing (particles sharded over ranks; collectives stay with the caller) ------- */
+/* Number of doubles of the block-partial vector exchanged by an all-reduce(SUM):
+ * 3 per global block of GMS_BLOCK particles {sum, max, first index of max}. */
+int gms_pf_partials_len(const gms_pf *pf, int64_t *n_doubles);
+/* Phase 1 of normalise on a shard: writes this shard's block partials into dev_partials (device
+ * pointer, zero elsewhere), ready for all-reduce(SUM) -- adding zeros is exact, so the reduced
+ * vector is the same for any number of ranks. */
+int gms_pf_local_partials(gms_pf *pf, double *dev_partials);
+/* Phase 2: consumes the all-reduced partials: weightSum, strongest, weight /= weightSum; then packs
+ * this shard's {weight, x, y, theta} (24 B per particle) into dev_packed for the all-gather. */
+int gms_pf_apply_partials(gms_pf *pf, const double *dev_partials, void *dev_packed);
+/* Packs this shard's current {weight, x, y, theta} without normalising (e.g. to all-gather the
+ * population again after a resample, for getWeightedPose). */
+int gms_pf_pack(gms_pf *pf, void *dev_packed);
+/* Phase 3: consumes the all-gathered [n_global] packed particles: Neff, weighted pose, and keeps
+ * them as the source population for gms_pf_resample. */
+int gms_pf_import_global(gms_pf *pf, const void *dev_packed_global);
+
+/* ---- measurement ------------------------------------------------------------------------------- */
+enum {
+    GMS_K_RAYCAST = 0, GMS_K_APPLY = 1, GMS_K_LIKELIHOOD = 2, GMS_K_SCORE = 3, GMS_K_REDUCE = 4,
+    GMS_K_RESAMPLE = 5, GMS_K_REFINE = 6, GMS_K_COUNT = 7
+};
+/* Bracket every kernel launch of this map handle (and its filters) with HIP events on its stream. */
+int gms_profile_enable(gms_map *m, int32_t on);
+int gms_profile_reset(gms_map *m);
+/* Total device milliseconds and launch count of kernel class k since the last reset. */
+int gms_profile_get(gms_map *m, int32_t k, double *total_ms, int64_t *launches);
+
+/* ---- diagnostics ------------------------------------------------------------------------------- */
+/* The float-rounded device primitives the parity contract leans on, for tests: op 0 = (float)sqrt(a)
+ * (GridMap.java:217), 1 = (float)cos((double)a), 2 = (float)sin((double)a) (J/math/MathUtil.java:30-40). */
+int gms_debug_f32(gms_map *m, int32_t op, const float *in, float *out, int64_t n);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,412 @@
+/*
+ * gms_oracle.c -- CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY; see the
+ * header of gms_oracle.h (scope, "parity unpinned" statement, citation convention).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fPIC -shared (oracle/Makefile).
+ * x86-64 SSE2 arithmetic: float ops round to float, double ops to double, as the JVM does.
+ */
+#include "gms_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- Java primitive-conversion semantics -------------------------------------------------- */
+
+/* (int) of a double: truncate toward zero, saturate, NaN -> 0 (JLS 5.1.3). */
+static inline int32_t j_d2i(double d) {
+    if (d != d) return 0;
+    if (d >= 2147483647.0) return INT32_MAX;
+    if (d <= -2147483648.0) return INT32_MIN;
+    return (int32_t)d;
+}
+/* Java int arithmetic wraps. */
+static inline int32_t j_iadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+static inline int32_t j_isub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+static inline int32_t j_imul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+
+/* ---- J/app/Util.java ----------------------------------------------------------------------- */
+
+/* Util.java:35-37  Math.log(odds / (1.0f - odds)), all in double */
+double orc_log_odds(double p) { return log(p / ((double)1.0f - p)); }
+
+/* Util.java:46-48  (1.0f - 1.0f / (1 + Math.exp(log))) in double */
+double orc_inv_log_odds(double l) { return (double)1.0f - (double)1.0f / (1.0 + exp(l)); }
+
+/* Util.java:428-455 */
+void orc_generate_gaussian_kernel(double sigma, int size, double *out) {
+    int k_size = size * 2 + 1;                       /* :431 */
+    double norm = 1.0 / (sqrt(2 * M_PI) * sigma);    /* :436 */
+    double coeff = 2 * sigma * sigma;                /* :439  (2*sigma)*sigma */
+    double total = 0;
+    for (int x = -size; x <= size; x++) {            /* :444 */
+        double g = norm * exp((double)(-x * x) / coeff);   /* :445 int product, double divide */
+        out[x + size] = g;
+        total += g;
+    }
+    for (int i = 0; i < k_size; i++) out[i] /= total;      /* :451-453 */
+}
+
+/* ---- J/slam/GridMap.java ctor -------------------------------------------------------------- */
+
+void orc_grid_init(orc_grid *g, float width, float height, float resolution, float pos_x, float pos_y) {
+    memset(g, 0, sizeof(*g));
+    g->resolution = resolution;                                  /* :81 */
+    g->pos_x = pos_x; g->pos_y = pos_y;                          /* :82 */
+    /* :85  Math.ceil(width / resolution): float divide, widened, ceil, Number.intValue() */
+    g->W = j_d2i(ceil((double)(width / resolution)));
+    g->H = j_d2i(ceil((double)(height / resolution)));
+    /* :94-95 */
+    double sigma = sqrt(0.05 / (double)resolution);
+    int size = j_d2i(ceil(sigma * 3));
+    g->ktaps = 2 * size + 1;
+    if (g->ktaps > ORC_MAX_TAPS) { g->ktaps = 0; return; }
+    orc_generate_gaussian_kernel(sigma, size, g->kernel);
+    /* SensorModel.java:20-25: float literals widened to double */
+    g->l_free = orc_log_odds((double)0.30f);
+    g->l_prior = orc_log_odds((double)0.5f);
+    g->l_occ = orc_log_odds((double)0.9f);
+    g->extra_steps = 2;          /* GridMap.java:210 */
+    g->hit_tolerance = 2.0f;     /* GridMap.java:223 */
+    g->z_hit = 0.9;              /* GridMap.java:259 */
+    g->z_random = 1 - g->z_hit;
+    g->max_range = 10.0f;        /* SensorModel.java:20 */
+}
+
+/* ---- J/slam/RayIterator.java --------------------------------------------------------------- */
+
+typedef struct ray_it {
+    int32_t x, y, width, height, x_inc, y_inc, n;   /* :32 */
+    float dx, dy, error;                            /* :33 */
+} ray_it;
+
+/* RayIterator.init :65-104 */
+static void ray_init(ray_it *r, float x0, float y0, float x1, float y1, int32_t extra) {
+    r->dx = fabsf(x1 - x0);                          /* :68 float subtract, abs */
+    r->dy = fabsf(y1 - y0);                          /* :69 */
+    r->x = j_d2i(floor((double)x0));                 /* :71 */
+    r->y = j_d2i(floor((double)y0));                 /* :72 */
+    r->n = j_iadd(1, extra);                         /* :75 */
+    if (r->dx == 0) {                                /* :78 */
+        r->x_inc = 0;
+        r->error = INFINITY;
+    } else if (x1 > x0) {                            /* :81 */
+        r->x_inc = 1;
+        r->n = j_iadd(r->n, j_d2i(floor((double)x1) - (double)r->x));                 /* :83 */
+        r->error = (float)((floor((double)x0) + 1 - (double)x0) * (double)r->dy);     /* :84 */
+    } else {
+        r->x_inc = -1;
+        r->n = j_iadd(r->n, j_isub(r->x, j_d2i(floor((double)x1))));                  /* :87 */
+        r->error = (float)(((double)x0 - floor((double)x0)) * (double)r->dy);         /* :88 */
+    }
+    if (r->dy == 0) {                                /* :91 */
+        r->y_inc = 0;
+        r->error -= INFINITY;                        /* :93 float op; Inf-Inf = NaN */
+    } else if (y1 > y0) {                            /* :94 */
+        r->y_inc = 1;
+        r->n = j_iadd(r->n, j_isub(j_d2i(floor((double)y1)), r->y));                  /* :96 */
+        /* :97 compound assignment: (float)((double)error - product) */
+        r->error = (float)((double)r->error - (floor((double)y0) + 1 - (double)y0) * (double)r->dx);
+    } else {
+        r->y_inc = -1;
+        r->n = j_iadd(r->n, j_isub(r->y, j_d2i(floor((double)y1))));                  /* :100 */
+        r->error = (float)((double)r->error - ((double)y0 - floor((double)y0)) * (double)r->dx);  /* :101 */
+    }
+}
+
+/* RayIterator.hasNext :107-109 */
+static inline int ray_has_next(const ray_it *r) {
+    return r->n > 0 && !(r->x < 0 || r->x >= r->width || r->y < 0 || r->y >= r->height);
+}
+
+/* RayIterator.next :112-130 (cell returned through cx,cy) */
+static inline void ray_next(ray_it *r, int32_t *cx, int32_t *cy) {
+    *cx = r->x; *cy = r->y;                          /* :114 */
+    if (r->error > 0) {                              /* :117 */
+        r->y = j_iadd(r->y, r->y_inc);
+        r->error -= r->dx;                           /* float */
+    } else {
+        r->x = j_iadd(r->x, r->x_inc);
+        r->error += r->dy;
+    }
+    r->n = j_isub(r->n, 1);                          /* :126 */
+}
+
+int32_t orc_trace_ray(int32_t W, int32_t H, float x0, float y0, float x1, float y1, int32_t extra,
+                      int32_t *cells_xy, int32_t cap) {
+    ray_it r;
+    r.width = W; r.height = H;                       /* ctor :44-48 */
+    ray_init(&r, x0, y0, x1, y1, extra);
+    int32_t count = 0;
+    while (ray_has_next(&r)) {
+        int32_t cx, cy;
+        ray_next(&r, &cx, &cy);
+        if (cells_xy && count < cap) { cells_xy[2 * count] = cx; cells_xy[2 * count + 1] = cy; }
+        count++;
+    }
+    return count;
+}
+
+/* ---- J/slam/SensorModel.java:31-41 --------------------------------------------------------- */
+
+/* returns the class: 0 = P_FREE, 1 = P_PRIOR, 2 = P_OCCUPPIED */
+static inline int sensor_class(float current, float measured, int hit, float hit_tolerance) {
+    if (!hit) return current < measured ? 0 : 1;                 /* :32-33 */
+    if (current < measured - hit_tolerance / 2) return 0;        /* :35 float arithmetic */
+    if (current > measured + hit_tolerance / 2) return 1;        /* :37 */
+    return 2;                                                    /* :40 */
+}
+
+/* ---- J/slam/GridMap.java:194-228 ----------------------------------------------------------- */
+
+int32_t orc_apply_measurement(const orc_grid *g, double *log_data, float sx, float sy, float ex, float ey,
+                              float measured, int hit, int32_t *cells_xy, uint8_t *classes, int32_t cap) {
+    const double inc[3] = { g->l_free, g->l_prior, g->l_occ };
+    ray_it r;
+    r.width = g->W; r.height = g->H;                 /* static rayIterator(W,H) :98 */
+    ray_init(&r, sx + 0.5f, sy + 0.5f, ex + 0.5f, ey + 0.5f, g->extra_steps);   /* :210 */
+    int32_t count = 0;
+    while (ray_has_next(&r)) {                       /* :211 */
+        int32_t cx, cy;
+        ray_next(&r, &cx, &cy);
+        float dX = sx - ((float)cx + 0.5f);          /* :215 */
+        float dY = sy - ((float)cy + 0.5f);          /* :216 */
+        float distance = (float)sqrt((double)(dX * dX + dY * dY));   /* :217 */
+        int cls = sensor_class(distance, measured, hit, g->hit_tolerance);
+        if (log_data) log_data[j_iadd(cx, j_imul(cy, g->W))] += inc[cls];       /* :223 */
+        if (count < cap) {
+            if (cells_xy) { cells_xy[2 * count] = cx; cells_xy[2 * count + 1] = cy; }
+            if (classes) classes[count] = (uint8_t)cls;
+        }
+        count++;
+    }
+    return count;
+}
+
+/* ---- J/math/Transform.java:13-32 + J/math/MathUtil.java:30-40 ------------------------------ */
+
+void orc_pose_trig(float theta, double *cos_out, double *sin_out) {
+    /* MathUtil.cos(float) is chosen (theta is a float field): (float) FastMath.cos((double)theta),
+     * then widened back to double by the assignment in Transform.java:15-16.
+     * FastMath is restated with libm cos/sin (see header). */
+    *cos_out = (double)(float)cos((double)theta);
+    *sin_out = (double)(float)sin((double)theta);
+}
+
+typedef struct xform { double c, s, px, py; } xform;
+
+static inline xform xform_from_pose(const float pose[3]) {
+    xform t;
+    orc_pose_trig(pose[2], &t.c, &t.s);
+    t.px = (double)pose[0];
+    t.py = (double)pose[1];
+    return t;
+}
+/* Transform.java:23 / :28 */
+static inline double xform_x(const xform *t, double x, double y) { return x * t->c - y * t->s + t->px; }
+static inline double xform_y(const xform *t, double x, double y) { return x * t->s + y * t->c + t->py; }
+
+/* ---- J/slam/GridMap.java:173-191 ----------------------------------------------------------- */
+
+void orc_scan_rays(const orc_grid *g, const orc_beam *beams, int32_t B, const float pose[3], float *out6) {
+    xform t = xform_from_pose(pose);                                             /* :175 */
+    double posx = (double)g->pos_x, posy = (double)g->pos_y, res = (double)g->resolution;
+    float sx = (float)((xform_x(&t, 0, 0) - posx) / res);                        /* :178 */
+    float sy = (float)((xform_y(&t, 0, 0) - posy) / res);                        /* :179 */
+    for (int32_t b = 0; b < B; b++) {
+        const orc_beam *m = &beams[b];
+        float ex = (float)((xform_x(&t, m->local_x, m->local_y) - posx) / res);  /* :185 */
+        float ey = (float)((xform_y(&t, m->local_x, m->local_y) - posy) / res);  /* :186 */
+        float measured = (float)m->distance / g->resolution;                     /* :188 float divide */
+        float *o = out6 + 6 * (size_t)b;
+        o[0] = sx; o[1] = sy; o[2] = ex; o[3] = ey; o[4] = measured; o[5] = m->hit ? 1.0f : 0.0f;
+    }
+}
+
+int64_t orc_integrate(const orc_grid *g, double *log_data, const orc_beam *beams, int32_t B, const float pose[3]) {
+    int64_t visits = 0;
+    float ray[6];
+    for (int32_t b = 0; b < B; b++) {                /* :182 in list order */
+        orc_scan_rays(g, &beams[b], 1, pose, ray);
+        visits += orc_apply_measurement(g, log_data, ray[0], ray[1], ray[2], ray[3], ray[4],
+                                        beams[b].hit != 0, NULL, NULL, 0);
+    }
+    return visits;
+}
+
+/* ---- J/slam/GridMap.java:233-250 + J/app/Util.java:378-426 --------------------------------- */
+
+void orc_build_likelihood(const orc_grid *g, const double *log_data, double *lik, double *scratch) {
+    const int32_t W = g->W, H = g->H;
+    const size_t n = (size_t)W * (size_t)H;
+    double *prob = scratch;          /* GridMap.probData :59 */
+    double *temp = scratch + n;      /* Util.tempArray :375 */
+    const double thr = g->l_prior;   /* Util.logOdds(0.5) == 0.0 */
+    for (size_t i = 0; i < n; i++) {                 /* :238-245 */
+        if (log_data[i] > thr) prob[i] = 1;
+        else if (log_data[i] < thr) prob[i] = 0;
+        else prob[i] = 0.5;
+    }
+    const int k = (g->ktaps - 1) / 2;                /* Util.java:384 */
+    const double *kernel = g->kernel;
+    for (int32_t y = 0; y < H; y++) {                /* :387-404 horizontal */
+        size_t y_index = (size_t)y * W;
+        for (int32_t x = 0; x < W; x++) {
+            double total = 0;
+            for (int i = -k; i <= k; i++) {
+                int32_t x2 = x + i;
+                if (x2 >= 0 && x2 < W) total += kernel[i + k] * prob[y_index + x2];
+            }
+            lik[y_index + x] = total;
+        }
+    }
+    memcpy(temp, lik, n * sizeof(double));           /* :407 */
+    for (int32_t y = 0; y < H; y++) {                /* :410-425 vertical */
+        for (int32_t x = 0; x < W; x++) {
+            double total = 0;
+            for (int i = -k; i <= k; i++) {
+                int32_t y2 = y + i;
+                if (y2 >= 0 && y2 < H) total += kernel[i + k] * temp[(size_t)x + (size_t)y2 * W];
+            }
+            lik[(size_t)x + (size_t)y * W] = total;
+        }
+    }
+}
+
+/* ---- J/slam/GridMap.java:259-294 ----------------------------------------------------------- */
+
+static inline double beam_factor(const orc_grid *g, const double *lik, const xform *t, const orc_beam *m, int *used) {
+    double posx = (double)g->pos_x, posy = (double)g->pos_y, res = (double)g->resolution;
+    int32_t gx = j_d2i((xform_x(t, m->local_x, m->local_y) - posx) / res);      /* :273 */
+    int32_t gy = j_d2i((xform_y(t, m->local_x, m->local_y) - posy) / res);      /* :274 */
+    *used = 0;
+    if (!(gx < 0 || gy < 0 || gx >= g->W || gy >= g->H)) {                       /* :276 */
+        double val = lik[(size_t)gx + (size_t)gy * g->W];                        /* :277 */
+        *used = 1;
+        if (val == 0.5) return 1.0 / (double)g->max_range;                       /* :285-286 */
+        return g->z_hit * val + g->z_random * 1.0 / (double)g->max_range;        /* :288 */
+    }
+    return 1.0;
+}
+
+double orc_probability_of(const orc_grid *g, const double *lik, const orc_beam *beams, int32_t B, const float pose[3]) {
+    double product = 1;                              /* :262 */
+    xform t = xform_from_pose(pose);                 /* :265 */
+    for (int32_t b = 0; b < B; b++) {                /* :267 */
+        if (!beams[b].hit) continue;                 /* :269 */
+        int used;
+        double f = beam_factor(g, lik, &t, &beams[b], &used);
+        if (used) product *= f;
+    }
+    return product;
+}
+
+void orc_score(const orc_grid *g, const double *lik, const orc_beam *beams, int32_t B,
+               const float *poses, int32_t N, double *weights) {
+    for (int32_t i = 0; i < N; i++) weights[i] = orc_probability_of(g, lik, beams, B, poses + 3 * (size_t)i);
+}
+
+void orc_score_log(const orc_grid *g, const double *lik, const orc_beam *beams, int32_t B,
+                   const float *poses, int32_t N, double *log_weights) {
+    for (int32_t i = 0; i < N; i++) {
+        xform t = xform_from_pose(poses + 3 * (size_t)i);
+        double s = 0;
+        for (int32_t b = 0; b < B; b++) {
+            if (!beams[b].hit) continue;
+            int used;
+            double f = beam_factor(g, lik, &t, &beams[b], &used);
+            if (used) s += log(f);
+        }
+        log_weights[i] = s;
+    }
+}
+
+/* ---- J/slam/SLAM.java ---------------------------------------------------------------------- */
+
+/* :87-121 */
+double orc_normalize(double *weights, int32_t N, int32_t *strongest) {
+    double weight_sum = 0;
+    int32_t best = -1;
+    for (int32_t i = 0; i < N; i++) {
+        weight_sum += weights[i];                                    /* :100 */
+        if (best < 0) best = i;                                      /* :110-111 */
+        else if (weights[i] > weights[best]) best = i;               /* :113-114 strict */
+    }
+    for (int32_t i = 0; i < N; i++) weights[i] /= weight_sum;        /* :120-121 */
+    if (strongest) *strongest = best;
+    return weight_sum;
+}
+
+/* :180-190 */
+double orc_neff(const double *weights, int32_t N) {
+    double sum = 0;
+    for (int32_t i = 0; i < N; i++) sum += weights[i];
+    double squared_sum = 0;
+    for (int32_t i = 0; i < N; i++) squared_sum += (weights[i] / sum) * (weights[i] / sum);
+    return 1.0 / squared_sum;
+}
+
+/* J/math/MathUtil.java:65-72 */
+static inline double angle_constrain(double a) {
+    while (a < M_PI) a += M_PI * 2;
+    while (a > M_PI) a -= M_PI * 2;
+    return a;
+}
+
+/* :165-178 */
+void orc_weighted_pose(const float *poses, const double *weights, int32_t N, float out[3]) {
+    double x_sum = 0, y_sum = 0, theta_sum = 0, weight_sum = 0;
+    for (int32_t i = 0; i < N; i++) {
+        const float *p = poses + 3 * (size_t)i;
+        x_sum += (double)p[0] * weights[i];                          /* :170 */
+        y_sum += (double)p[1] * weights[i];
+        theta_sum += angle_constrain((double)p[2]) * weights[i];     /* :172 */
+        weight_sum += weights[i];
+    }
+    out[0] = (float)(x_sum / weight_sum);                            /* :176 */
+    out[1] = (float)(y_sum / weight_sum);
+    out[2] = (float)(theta_sum / weight_sum);
+}
+
+/* :133-153 */
+int32_t orc_resample_indices(const double *weights, int32_t N, double r01, int32_t *idx) {
+    int32_t clamped = 0;
+    double r = r01 * 1.0 / (double)N;                /* :136 */
+    double c = weights[0];                           /* :137 */
+    int32_t i = 0;
+    for (int32_t m = 1; m <= N; m++) {               /* :140 */
+        double U = r + (double)(m - 1) * 1.0 / (double)N;    /* :141 */
+        while (U > c) {                              /* :142 */
+            if (i >= N - 1) { clamped++; break; }    /* Java: IndexOutOfBoundsException */
+            i++;
+            c += weights[i];                         /* :144 */
+        }
+        idx[m - 1] = i;                              /* :147 */
+    }
+    return clamped;
+}
+
+/* ---- J/slam/GridMap.java:319-346 ----------------------------------------------------------- */
+
+double orc_find_best_pose(const orc_grid *g, const double *lik, const orc_beam *beams, int32_t B,
+                          const float start[3], float best[3], int32_t *n_evaluated) {
+    double max_prob = 0;                                             /* :321 */
+    best[0] = start[0]; best[1] = start[1]; best[2] = start[2];      /* :320 */
+    float x_span = 0.20f, y_span = 0.20f;
+    float theta_span = (float)(15 * (M_PI / 180.0));                 /* :324 */
+    float trans_step = 0.04f, theta_step = theta_span / 5;           /* :325 */
+    int32_t n = 0;
+    for (float dx = -x_span; dx < x_span; dx += trans_step)          /* :328 */
+        for (float dy = -y_span; dy < y_span; dy += trans_step)
+            for (float dth = -theta_span; dth < theta_span; dth += theta_step) {
+                float p[3] = { start[0] + dx, start[1] + dy, start[2] + dth };   /* :332 */
+                double prob = orc_probability_of(g, lik, beams, B, p);
+                n++;
+                if (prob > max_prob) {                               /* :334 */
+                    max_prob = prob;
+                    best[0] = p[0]; best[1] = p[1]; best[2] = p[2];
+                }
+            }
+    if (n_evaluated) *n_evaluated = n;
+    return max_prob;
+}

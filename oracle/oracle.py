@@ -1,0 +1,258 @@
+"""ctypes binding of oracle/liboracle.so (the C restatement of the reference hot path).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/gms_oracle.h.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module.  PARITY UNPINNED (no runnable reference, no
+reference fixtures): see the header of gms_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+BEAM_DTYPE = np.dtype(
+    [("local_x", "<f8"), ("local_y", "<f8"), ("distance", "<f8"), ("hit", "u1"), ("pad_", "u1", (7,))]
+)
+ORC_MAX_TAPS = 129
+
+
+class OrcGrid(C.Structure):
+    _fields_ = [
+        ("W", C.c_int32), ("H", C.c_int32),
+        ("resolution", C.c_float), ("pos_x", C.c_float), ("pos_y", C.c_float),
+        ("l_free", C.c_double), ("l_prior", C.c_double), ("l_occ", C.c_double),
+        ("ktaps", C.c_int32),
+        ("kernel", C.c_double * ORC_MAX_TAPS),
+        ("extra_steps", C.c_int32),
+        ("hit_tolerance", C.c_float),
+        ("z_hit", C.c_double), ("z_random", C.c_double),
+        ("max_range", C.c_float),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "gms_oracle.c")
+    hdr = os.path.join(_HERE, "gms_oracle.h")
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        dp = C.POINTER(C.c_double)
+        fp = C.POINTER(C.c_float)
+        ip = C.POINTER(C.c_int32)
+        gp = C.POINTER(OrcGrid)
+        vp = C.c_void_p
+        L.orc_log_odds.restype = C.c_double
+        L.orc_log_odds.argtypes = [C.c_double]
+        L.orc_inv_log_odds.restype = C.c_double
+        L.orc_inv_log_odds.argtypes = [C.c_double]
+        L.orc_generate_gaussian_kernel.restype = None
+        L.orc_generate_gaussian_kernel.argtypes = [C.c_double, C.c_int, dp]
+        L.orc_grid_init.restype = None
+        L.orc_grid_init.argtypes = [gp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.orc_trace_ray.restype = C.c_int32
+        L.orc_trace_ray.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_int32, ip, C.c_int32]
+        L.orc_apply_measurement.restype = C.c_int32
+        L.orc_apply_measurement.argtypes = [gp, dp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                            C.c_int, ip, C.POINTER(C.c_uint8), C.c_int32]
+        L.orc_scan_rays.restype = None
+        L.orc_scan_rays.argtypes = [gp, vp, C.c_int32, fp, fp]
+        L.orc_integrate.restype = C.c_int64
+        L.orc_integrate.argtypes = [gp, dp, vp, C.c_int32, fp]
+        L.orc_build_likelihood.restype = None
+        L.orc_build_likelihood.argtypes = [gp, dp, dp, dp]
+        L.orc_probability_of.restype = C.c_double
+        L.orc_probability_of.argtypes = [gp, dp, vp, C.c_int32, fp]
+        L.orc_score.restype = None
+        L.orc_score.argtypes = [gp, dp, vp, C.c_int32, fp, C.c_int32, dp]
+        L.orc_score_log.restype = None
+        L.orc_score_log.argtypes = [gp, dp, vp, C.c_int32, fp, C.c_int32, dp]
+        L.orc_normalize.restype = C.c_double
+        L.orc_normalize.argtypes = [dp, C.c_int32, ip]
+        L.orc_neff.restype = C.c_double
+        L.orc_neff.argtypes = [dp, C.c_int32]
+        L.orc_weighted_pose.restype = None
+        L.orc_weighted_pose.argtypes = [fp, dp, C.c_int32, fp]
+        L.orc_resample_indices.restype = C.c_int32
+        L.orc_resample_indices.argtypes = [dp, C.c_int32, C.c_double, ip]
+        L.orc_find_best_pose.restype = C.c_double
+        L.orc_find_best_pose.argtypes = [gp, dp, vp, C.c_int32, fp, fp, ip]
+        L.orc_pose_trig.restype = None
+        L.orc_pose_trig.argtypes = [C.c_float, dp, dp]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def make_beams(local_x, local_y, distance, hit) -> np.ndarray:
+    b = np.zeros(len(local_x), dtype=BEAM_DTYPE)
+    b["local_x"] = local_x
+    b["local_y"] = local_y
+    b["distance"] = distance
+    b["hit"] = np.asarray(hit).astype(np.uint8)
+    return b
+
+
+class Grid:
+    """GridMap geometry/constants (J/slam/GridMap.java:80-100) over the C oracle."""
+
+    def __init__(self, width: float, height: float, resolution: float, pos_x: float, pos_y: float):
+        self.g = OrcGrid()
+        lib().orc_grid_init(C.byref(self.g), width, height, resolution, pos_x, pos_y)
+        if self.g.ktaps == 0:
+            raise ValueError("likelihood kernel too wide for the oracle")
+
+    # -- geometry -----------------------------------------------------------------------------
+    @property
+    def W(self): return self.g.W
+    @property
+    def H(self): return self.g.H
+    @property
+    def resolution(self): return self.g.resolution
+    @property
+    def pos(self): return (self.g.pos_x, self.g.pos_y)
+    @property
+    def kernel(self) -> np.ndarray:
+        return np.array(self.g.kernel[: self.g.ktaps], dtype=np.float64)
+
+    def set_kernel(self, taps):
+        taps = np.asarray(taps, dtype=np.float64)
+        assert taps.size % 2 == 1 and taps.size <= ORC_MAX_TAPS
+        self.g.ktaps = taps.size
+        for i, t in enumerate(taps):
+            self.g.kernel[i] = float(t)
+
+    @property
+    def l_free(self): return self.g.l_free
+    @property
+    def l_occ(self): return self.g.l_occ
+
+    def new_log(self) -> np.ndarray:
+        return np.full(self.W * self.H, self.g.l_prior, dtype=np.float64)
+
+    # -- path functions -----------------------------------------------------------------------
+    def trace_ray(self, x0, y0, x1, y1, extra=2, cap=1 << 16) -> np.ndarray:
+        cells = np.empty((cap, 2), dtype=np.int32)
+        n = lib().orc_trace_ray(self.W, self.H, x0, y0, x1, y1, extra, _ip(cells), cap)
+        assert n <= cap
+        return cells[:n].copy()
+
+    def apply_measurement(self, log, sx, sy, ex, ey, measured, hit, cap=1 << 16):
+        cells = np.empty((cap, 2), dtype=np.int32)
+        cls = np.empty(cap, dtype=np.uint8)
+        n = lib().orc_apply_measurement(C.byref(self.g), _dp(log) if log is not None else None,
+                                        sx, sy, ex, ey, measured, int(bool(hit)), _ip(cells),
+                                        cls.ctypes.data_as(C.POINTER(C.c_uint8)), cap)
+        assert n <= cap
+        return cells[:n].copy(), cls[:n].copy()
+
+    def scan_rays(self, beams: np.ndarray, pose) -> np.ndarray:
+        pose = np.asarray(pose, dtype=np.float32)
+        out = np.empty((len(beams), 6), dtype=np.float32)
+        lib().orc_scan_rays(C.byref(self.g), beams.ctypes.data, len(beams), _fp(pose), _fp(out))
+        return out
+
+    def integrate(self, log: np.ndarray, beams: np.ndarray, pose) -> int:
+        pose = np.asarray(pose, dtype=np.float32)
+        return lib().orc_integrate(C.byref(self.g), _dp(log), beams.ctypes.data, len(beams), _fp(pose))
+
+    def build_likelihood(self, log: np.ndarray) -> np.ndarray:
+        lik = np.zeros(self.W * self.H, dtype=np.float64)
+        scratch = np.empty(2 * self.W * self.H, dtype=np.float64)
+        lib().orc_build_likelihood(C.byref(self.g), _dp(log), _dp(lik), _dp(scratch))
+        return lik
+
+    def probability_of(self, lik, beams, pose) -> float:
+        pose = np.asarray(pose, dtype=np.float32)
+        return lib().orc_probability_of(C.byref(self.g), _dp(lik), beams.ctypes.data, len(beams), _fp(pose))
+
+    def score(self, lik, beams, poses) -> np.ndarray:
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        w = np.empty(len(poses), dtype=np.float64)
+        lib().orc_score(C.byref(self.g), _dp(lik), beams.ctypes.data, len(beams), _fp(poses), len(poses), _dp(w))
+        return w
+
+    def score_log(self, lik, beams, poses) -> np.ndarray:
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        w = np.empty(len(poses), dtype=np.float64)
+        lib().orc_score_log(C.byref(self.g), _dp(lik), beams.ctypes.data, len(beams), _fp(poses), len(poses), _dp(w))
+        return w
+
+    def find_best_pose(self, lik, beams, start):
+        start = np.asarray(start, dtype=np.float32)
+        best = np.empty(3, dtype=np.float32)
+        n = C.c_int32(0)
+        p = lib().orc_find_best_pose(C.byref(self.g), _dp(lik), beams.ctypes.data, len(beams), _fp(start),
+                                     _fp(best), C.byref(n))
+        return best, p, n.value
+
+
+def normalize(weights: np.ndarray):
+    """In place; returns (weight_sum, strongest)."""
+    s = C.c_int32(-1)
+    ws = lib().orc_normalize(_dp(weights), len(weights), C.byref(s))
+    return ws, s.value
+
+
+def neff(weights: np.ndarray) -> float:
+    return lib().orc_neff(_dp(weights), len(weights))
+
+
+def weighted_pose(poses: np.ndarray, weights: np.ndarray) -> np.ndarray:
+    poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+    out = np.empty(3, dtype=np.float32)
+    lib().orc_weighted_pose(_fp(poses), _dp(weights), len(weights), _fp(out))
+    return out
+
+
+def resample_indices(weights: np.ndarray, r01: float):
+    idx = np.empty(len(weights), dtype=np.int32)
+    clamped = lib().orc_resample_indices(_dp(weights), len(weights), r01, _ip(idx))
+    return idx, clamped
+
+
+def pose_trig(theta):
+    c = C.c_double()
+    s = C.c_double()
+    lib().orc_pose_trig(np.float32(theta), C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def gaussian_kernel(sigma: float, size: int) -> np.ndarray:
+    out = np.empty(2 * size + 1, dtype=np.float64)
+    lib().orc_generate_gaussian_kernel(sigma, size, _dp(out))
+    return out
+
+
+def log_odds(p: float) -> float:
+    return lib().orc_log_odds(p)
