@@ -1,0 +1,146 @@
+"""ctypes binding of libgridmapslam.so -- the C-ABI declared in include/gridmapslam.h.
+
+The library is the product: there is no Python or CPU fallback.  Loading fails loudly when the
+shared object has not been built (`python -m gridmap_slam_robot_amd.build`), and every compute call
+fails with GMS_ERR_NO_DEVICE when no HIP device is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgridmapslam.so")
+
+GMS_MAX_TAPS = 129
+GMS_BLOCK = 256
+GMS_PARTIAL_STRIDE = 5
+PACKED_BYTES = 24
+
+GMS_OK, GMS_ERR_INVALID, GMS_ERR_NO_DEVICE, GMS_ERR_HIP, GMS_ERR_NOMEM, GMS_ERR_STATE = 0, -1, -2, -3, -4, -5
+K_RAYCAST, K_APPLY, K_LIKELIHOOD, K_SCORE, K_REDUCE, K_RESAMPLE, K_REFINE, K_COUNT = range(8)
+KERNEL_NAMES = ["raycast", "apply", "likelihood", "score", "reduce", "resample", "refine"]
+
+BEAM_DTYPE = np.dtype(
+    [("local_x", "<f8"), ("local_y", "<f8"), ("distance", "<f8"), ("hit", "u1"), ("pad_", "u1", (7,))]
+)
+PACKED_DTYPE = np.dtype([("w", "<f8"), ("x", "<f4"), ("y", "<f4"), ("theta", "<f4"), ("pad", "<u4")])
+
+
+class GmsParams(C.Structure):
+    _fields_ = [
+        ("width_m", C.c_float), ("height_m", C.c_float), ("resolution", C.c_float),
+        ("pos_x", C.c_float), ("pos_y", C.c_float),
+        ("n_maps", C.c_int32), ("device", C.c_int32),
+        ("l_free", C.c_double), ("l_occ", C.c_double),
+        ("ktaps", C.c_int32),
+        ("kernel", C.c_double * GMS_MAX_TAPS),
+        ("extra_steps", C.c_int32), ("hit_tolerance", C.c_float),
+        ("z_hit", C.c_double), ("z_random", C.c_double),
+        ("max_range", C.c_float), ("max_beams", C.c_int32),
+    ]
+
+
+class GmsPfStats(C.Structure):
+    _fields_ = [
+        ("weight_sum", C.c_double), ("neff", C.c_double),
+        ("strongest", C.c_int32), ("n_zero", C.c_int32),
+        ("max_log_weight", C.c_double),
+    ]
+
+
+class GmsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libgridmapslam error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the in-tree HIP library; raise if it is missing (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m gridmap_slam_robot_amd.build` "
+            "(hipcc, --offload-arch=gfx950). gridmap_slam_robot_amd has no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+    pp = C.POINTER(GmsParams)
+    sp = C.POINTER(GmsPfStats)
+
+    def sig(name, restype, *argtypes):
+        fn = getattr(L, name)
+        fn.restype = restype
+        fn.argtypes = list(argtypes)
+
+    sig("gms_version", C.c_int)
+    sig("gms_last_error", C.c_char_p)
+    sig("gms_device_count", C.c_int)
+    sig("gms_params_default", C.c_int, pp, f32, f32, f32, f32, f32)
+    sig("gms_grid_size", C.c_int, pp, vp, vp)
+    sig("gms_generate_gaussian_kernel", C.c_int, f64, i32, vp)
+    sig("gms_log_odds", f64, f64)
+    sig("gms_inv_log_odds", f64, f64)
+    sig("gms_map_create", C.c_int, pp, C.POINTER(vp))
+    sig("gms_map_destroy", C.c_int, vp)
+    sig("gms_map_get_size", C.c_int, vp, vp, vp, vp)
+    sig("gms_map_set_stream", C.c_int, vp, vp)
+    sig("gms_map_synchronize", C.c_int, vp)
+    sig("gms_map_reset", C.c_int, vp)
+    sig("gms_map_upload_log", C.c_int, vp, vp)
+    sig("gms_map_download_log", C.c_int, vp, vp)
+    sig("gms_map_upload_likelihood", C.c_int, vp, vp)
+    sig("gms_map_download_likelihood", C.c_int, vp, vp)
+    sig("gms_map_copy", C.c_int, vp, vp)
+    sig("gms_map_get_raw_at", C.c_int, vp, i32, i32, i32, vp, vp)
+    sig("gms_map_integrate", C.c_int, vp, vp, i32, vp)
+    sig("gms_map_integrate_at", C.c_int, vp, vp, i32, vp, i32)
+    sig("gms_map_apply_ray", C.c_int, vp, f32, f32, f32, f32, f32, i32)
+    sig("gms_map_trace_ray", C.c_int, vp, f32, f32, f32, f32, i32, vp, i32, vp)
+    sig("gms_map_trace_scan", C.c_int, vp, vp, i32, vp, vp, vp, i32, vp)
+    sig("gms_map_build_likelihood", C.c_int, vp)
+    sig("gms_map_update", C.c_int, vp, vp, i32, vp)
+    sig("gms_map_update_at", C.c_int, vp, vp, i32, vp, i32)
+    sig("gms_pf_create", C.c_int, vp, i32, C.POINTER(vp))
+    sig("gms_pf_destroy", C.c_int, vp)
+    sig("gms_pf_set_shard", C.c_int, vp, i64, i64)
+    sig("gms_pf_set_poses", C.c_int, vp, vp)
+    sig("gms_pf_get_poses", C.c_int, vp, vp)
+    sig("gms_pf_set_weights", C.c_int, vp, vp)
+    sig("gms_pf_get_weights", C.c_int, vp, vp)
+    sig("gms_pf_get_log_weights", C.c_int, vp, vp)
+    sig("gms_pf_score", C.c_int, vp, vp, i32)
+    sig("gms_pf_normalize", C.c_int, vp, sp)
+    sig("gms_pf_get_stats", C.c_int, vp, sp)
+    sig("gms_pf_weighted_pose", C.c_int, vp, vp)
+    sig("gms_pf_resample", C.c_int, vp, vp, vp, vp)
+    sig("gms_pf_resample_if", C.c_int, vp, vp, f64)
+    sig("gms_pf_did_resample", C.c_int, vp, vp)
+    sig("gms_pf_refine_poses", C.c_int, vp, vp, i32)
+    sig("gms_pf_partials_len", C.c_int, vp, vp)
+    sig("gms_pf_local_partials", C.c_int, vp, vp)
+    sig("gms_pf_apply_partials", C.c_int, vp, vp, vp)
+    sig("gms_pf_pack", C.c_int, vp, vp)
+    sig("gms_pf_import_global", C.c_int, vp, vp)
+    sig("gms_profile_enable", C.c_int, vp, i32)
+    sig("gms_profile_reset", C.c_int, vp)
+    sig("gms_profile_get", C.c_int, vp, i32, vp, vp)
+    sig("gms_debug_f32", C.c_int, vp, i32, vp, vp, i64)
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != GMS_OK:
+        raise GmsError(rc, load().gms_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a: np.ndarray) -> int:
+    return a.ctypes.data

@@ -1,0 +1,86 @@
+"""The C-ABI library builds, loads and exports every symbol include/gridmapslam.h declares; its pure
+host helpers reproduce the GridMap constructor arithmetic; and without a GPU it fails loudly
+(no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from gridmap_slam_robot_amd import _lib
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "gridmapslam.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gms_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    names = _declared()
+    assert len(names) >= 50
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in gridmapslam.h but not exported"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(names) <= exported
+    # nothing but the C-ABI leaks out
+    assert all(e.startswith("gms_") for e in exported), sorted(e for e in exported if not e.startswith("gms_"))
+
+
+def test_params_default_matches_gridmap_ctor():
+    L = _lib.load()
+    for (w, h, r, px, py) in [(6.0, 6.0, 0.05, -3.0, -3.0), (25.6, 25.6, 0.05, -12.8, -12.8),
+                              (51.2, 51.2, 0.05, -25.6, -25.6), (40.96, 40.96, 0.02, -20.48, -20.48),
+                              (3.3, 2.1, 0.07, 0.0, 1.0)]:
+        p = _lib.GmsParams()
+        _lib.check(L.gms_params_default(C.byref(p), w, h, r, px, py))
+        W, H = C.c_int32(), C.c_int32()
+        _lib.check(L.gms_grid_size(C.byref(p), C.byref(W), C.byref(H)))
+        g = orc.Grid(w, h, r, px, py)
+        assert (W.value, H.value) == (g.W, g.H)
+        assert p.ktaps == len(g.kernel)
+        assert np.array_equal(np.array(p.kernel[: p.ktaps]), g.kernel)
+        assert (p.l_free, p.l_occ) == (g.l_free, g.l_occ)
+        assert p.extra_steps == 2 and p.hit_tolerance == 2.0 and p.z_hit == 0.9 and p.z_random == 1 - 0.9
+    assert L.gms_log_odds(0.5) == 0.0
+    assert L.gms_inv_log_odds(0.0) == 0.5
+
+
+def test_sizes_of_shared_structs():
+    assert _lib.BEAM_DTYPE.itemsize == 32 and orc.BEAM_DTYPE.itemsize == 32
+    assert _lib.PACKED_DTYPE.itemsize == _lib.PACKED_BYTES
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    L = _lib.load()
+    assert L.gms_params_default(None, 1, 1, 1, 0, 0) == _lib.GMS_ERR_INVALID
+    assert b"null" in L.gms_last_error()
+    p = _lib.GmsParams()
+    _lib.check(L.gms_params_default(C.byref(p), 1.0, 1.0, 0.05, 0, 0))
+    p.ktaps = 4      # even
+    h = C.c_void_p()
+    assert L.gms_map_create(C.byref(p), C.byref(h)) == _lib.GMS_ERR_INVALID
+
+
+def test_fails_loudly_without_a_device(have_gpu):
+    if have_gpu:
+        pytest.skip("a GPU is present")
+    from gridmap_slam_robot_amd import GridMap
+    with pytest.raises(_lib.GmsError) as e:
+        GridMap(3.2, 3.2, 0.05, (-1.6, -1.6))
+    assert e.value.code == _lib.GMS_ERR_NO_DEVICE
+    assert "no CPU path" in str(e.value)
+
+
+def test_cpp_facade_compiles():
+    hpp = os.path.join(ROOT, "include", "gridmapslam.hpp")
+    if not os.path.exists(hpp):
+        pytest.skip("C++ facade not present")
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), "-x", "c++", hpp])

@@ -1,0 +1,125 @@
+"""Known-answer and property tests that pin the C oracle's RayIterator restatement.
+
+The reference holds no tests or fixtures, so these cases are derived by hand
+from J/slam/RayIterator.java:65-130: PARITY UNPINNED by the reference itself.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+@pytest.fixture(scope="module")
+def g100():
+    g = orc.Grid(5.0, 5.0, 0.05, 0.0, 0.0)
+    assert (g.W, g.H) == (100, 100)
+    return g
+
+
+def test_zero_length_ray_emits_same_cell_three_times(g100):
+    # dx == dy == 0: error = Inf - Inf = NaN, every `error > 0` is false, x += 0, n = 1 + 2
+    assert g100.trace_ray(10.5, 10.5, 10.5, 10.5).tolist() == [[10, 10]] * 3
+
+
+def test_axis_aligned_rays(g100):
+    assert g100.trace_ray(10.5, 10.5, 14.5, 10.5).tolist() == [[x, 10] for x in range(10, 17)]
+    assert g100.trace_ray(10.5, 10.5, 10.5, 7.5).tolist() == [[10, y] for y in range(10, 4, -1)]
+
+
+def test_diagonal_tie_steps_x_first(g100):
+    want = [[10, 10], [11, 10], [11, 11], [12, 11], [12, 12], [13, 12], [13, 13], [14, 13], [14, 14]]
+    assert g100.trace_ray(10.5, 10.5, 13.5, 13.5).tolist() == want
+
+
+def test_start_outside_emits_nothing(g100):
+    assert len(g100.trace_ray(-0.5, 10.5, 20.5, 10.5)) == 0
+    assert len(g100.trace_ray(10.5, 100.5, 10.5, 50.5)) == 0
+
+
+def test_ray_leaving_the_map_stops_for_good(g100):
+    cells = g100.trace_ray(95.5, 50.5, 120.5, 50.5)
+    assert cells.tolist() == [[x, 50] for x in range(95, 100)]
+
+
+def test_nan_start_touches_cell_zero_once(g100):
+    # a NaN pose makes all four coordinates NaN: x = (int)floor(NaN) = 0; dx = NaN so both axes take
+    # the `else` branch with n += 0 - 0; n = 3; the first step goes to x = -1 and the walk stops
+    nan = float("nan")
+    assert g100.trace_ray(nan, nan, nan, nan).tolist() == [[0, 0]]
+    # a finite end point makes n = 3 + (0 - 5) + (0 - 5) < 0: nothing is emitted
+    assert g100.trace_ray(nan, nan, 5.5, 5.5).tolist() == []
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_properties_four_connected_and_count(g100, seed):
+    rng = np.random.default_rng(seed)
+    for _ in range(300):
+        x0, y0, x1, y1 = rng.uniform(5, 95, 4).astype(np.float32)
+        cells = g100.trace_ray(x0, y0, x1, y1, extra=0)
+        # unclipped, extra = 0: exactly 1 + |dX| + |dY| cells, consecutive cells differ by one 4-step
+        want = 1 + abs(int(np.floor(x1)) - int(np.floor(x0))) + abs(int(np.floor(y1)) - int(np.floor(y0)))
+        assert len(cells) == want
+        d = np.abs(np.diff(cells, axis=0)).sum(axis=1)
+        assert (d == 1).all()
+        assert cells[0].tolist() == [int(np.floor(x0)), int(np.floor(y0))]
+        assert cells[-1].tolist() == [int(np.floor(x1)), int(np.floor(y1))]
+
+
+def test_constants():
+    g = orc.Grid(25.6, 25.6, 0.05, -12.8, -12.8)
+    assert (g.W, g.H) == (512, 512)
+    assert len(g.kernel) == 7
+    assert g.l_free == pytest.approx(-0.8472978036208759, abs=1e-15)
+    assert g.l_occ == pytest.approx(2.197224312426715, abs=1e-15)
+    g2 = orc.Grid(40.96, 40.96, 0.02, -20.48, -20.48)
+    assert (g2.W, g2.H) == (2048, 2048)
+    assert len(g2.kernel) == 11
+    # the 7-tap kernel sums to exactly 1.0 in tap order with glibc exp, the 11-tap one does not
+    s7 = 0.0
+    for t in g.kernel:
+        s7 += t
+    s11 = 0.0
+    for t in g2.kernel:
+        s11 += t
+    assert s7 == 1.0
+    assert s11 != 1.0 and abs(s11 - 1.0) < 1e-15
+
+
+def test_sensor_classes_along_a_hit_ray(g100):
+    log = g100.new_log()
+    cells, cls = g100.apply_measurement(log, 10.0, 10.0, 30.0, 10.0, 20.0, True)
+    assert len(cells) == 1 + 20 + 2
+    # cells nearer than measured - 1 are free, within +-1 occupied, beyond prior
+    d = np.abs(10.0 - (cells[:, 0] + 0.5))
+    assert (cls[d < 19.0] == 0).all()
+    assert (cls[(d >= 19.0) & (d <= 21.0)] == 2).all()
+    assert (cls[d > 21.0] == 1).all()
+    lg = log.reshape(100, 100)
+    assert lg[10, 10] == g100.l_free and lg[10, 30] == g100.l_occ and lg[10, 32] == 0.0
+
+
+def test_miss_ray_marks_free_then_prior(g100):
+    log = g100.new_log()
+    cells, cls = g100.apply_measurement(log, 10.0, 10.0, 30.0, 10.0, 200.0, False)
+    assert (cls == 0).all()
+    cells, cls = g100.apply_measurement(None, 10.0, 10.0, 30.0, 10.0, 5.0, False)
+    d = np.abs(10.0 - (cells[:, 0] + 0.5))
+    assert (cls[d < 5.0] == 0).all() and (cls[d >= 5.0] == 1).all()
+
+
+def test_resample_follows_slam_not_particlefilter_bug():
+    # SLAM.resample starts at i = 0 (SLAM.java:138); ParticleFilter.resample's i = 1 is a bug (ParticleFilter.java:66)
+    w = np.array([0.5, 0.25, 0.25])
+    idx, clamped = orc.resample_indices(w, 0.3)   # r = 0.1; U = 0.1, 0.4333, 0.7666
+    assert idx.tolist() == [0, 0, 2] and clamped == 0
+    idx, clamped = orc.resample_indices(np.array([0.2, 0.2, 0.2]), 0.9)   # total 0.6 < U_3: Java would throw
+    assert idx.tolist() == [1, 2, 2] and clamped == 2   # slots 2 and 3 both run off the list
+
+
+def test_find_best_pose_lattice_size():
+    g = orc.Grid(3.2, 3.2, 0.05, -1.6, -1.6)
+    lik = np.zeros(g.W * g.H)
+    beams = orc.make_beams([0.5], [0.0], [0.5], [1])
+    best, p, n = g.find_best_pose(lik, beams, np.zeros(3, dtype=np.float32))
+    # float loop counters: 11 x 11 translation steps (10 steps land on 0.19999999 < 0.2), 10 rotations
+    assert n == 11 * 11 * 10
