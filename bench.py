@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-scan evals/s of the SLAM hot path on MI355X (BASELINE.json metric).
+
+One "step" = one LIDAR scan through the whole path, inputs already resident in HBM:
+  set poses (motion-model samples are an input) -> score N particles against the likelihood field
+  -> normalise / Neff / weighted pose -> resample if neff < N/2 -> ray-cast the scan into the
+  log-odds map at the weighted pose -> rebuild the likelihood field where it changed.
+
+Workload at 1 GPU = BASELINE.json configs[2] ("C3"): 16384 particles, 720 beams, 2048x2048 grid @ 2 cm,
+the configuration the metric is quoted on.  At N GPUs the particles are sharded, 16384 per GPU (weak
+scaling; configs[3] is the 4-GPU point of that series), with an RCCL all-reduce for the weight
+normaliser and an all-gather for resampling; every rank keeps a replica of the map.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  value = total particles x steps / max-over-ranks wall time of the K
+steps.  roofline = the dominant kernel's algorithmic bytes per launch / its average launch duration
+(HIP events on the library's stream, recorded inside the timed region).  cpu_baseline = the C oracle
+(a port of the reference's Java loops; the reference itself cannot run here) on a bounded sample of
+the same workload, one host thread.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(kind: str, *, n_particles=0, n_hit=0, n_beams=0, cells=0, visits=0) -> float:
+    """SURVEY.md section 8(d) per-unit figures x the units one launch processes."""
+    if kind == "score":        # 8 B per beam-eval + (12 B pose + 8 B weight) per particle + 17 B per beam once
+        return 8.0 * n_particles * n_hit + 20.0 * n_particles + 17.0 * n_beams
+    if kind == "likelihood":   # 16 B per cell (read log-odds, write likelihood)
+        return 16.0 * cells
+    if kind == "raycast":      # 16 B per visited cell (fp64 read + write)
+        return 16.0 * visits
+    if kind == "reduce":       # 16 B per particle
+        return 16.0 * n_particles
+    if kind == "resample":     # 8 B weight + 12 B pose read + 12 B pose write
+        return 32.0 * n_particles
+    if kind == "apply":
+        return 16.0 * visits
+    return 0.0
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C3", help="C2 | C3 (per-GPU particles/beams/grid)")
+    ap.add_argument("--particles", type=int, default=0, help="override particles per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scans", type=int, default=0, help="scans of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--full-rebuild", action="store_true", help="rebuild the whole likelihood field every scan")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus N > 1 must be launched with torch.distributed.run", file=sys.stderr)
+            return 2
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from gridmap_slam_robot_amd import GridMap, ParticleFilter, _lib, synth
+    from gridmap_slam_robot_amd.distributed import HipShardOps, ShardedParticleFilter
+
+    cfg = dict(synth.CONFIGS[args.config])
+    n_local = args.particles or cfg["particles"]
+    n_global = n_local * world
+    B, ext, res = cfg["beams"], cfg["extent"], cfg["resolution"]
+    T = 64
+    dev = torch.device("cuda", local_rank)
+
+    # ---- inputs (identical on every rank: same seeds) ------------------------------------------------
+    tr = synth.make_trace(ext, res, B, T=T, seed=1234)
+    m = GridMap(ext, ext, res, (-ext / 2, -ext / 2), device=local_rank, max_beams=max(2048, B))
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    for t in range(T // 2):                      # pre-built map: likelihoods are informative
+        m.update(tr.scans[t], tr.poses[t])
+    m.synchronize()
+    log0 = m.download_log().reshape(-1).copy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+
+    n_sets = 8
+    scans_dev = torch.from_numpy(tr.scans.view(np.uint8).reshape(T, -1).copy()).to(dev)
+    pose_sets = []
+    for s in range(n_sets):
+        t = T // 2 + s
+        allp = synth.make_particles(tr.poses[t], n_global, seed=99 + s)      # sigma 0.10 m / 5 deg
+        pose_sets.append(torch.from_numpy(allp[rank * n_local:(rank + 1) * n_local].copy()).to(dev))
+    n_hit = int(tr.scans[T // 2]["hit"].sum())
+    r01 = np.random.default_rng(7).random(4096)
+
+    if world > 1:
+        ops = HipShardOps(m, n_local, rank * n_local, n_global)
+        spf = ShardedParticleFilter(n_global, ops)
+        pf = ops.pf
+    else:
+        pf = ParticleFilter(m, n_local)
+        spf = None
+
+    def step(i: int):
+        s = i % n_sets
+        t = T // 2 + s
+        beams_ptr = scans_dev[t].data_ptr()
+        pf.set_poses_dev(pose_sets[s].data_ptr())
+        pf.score_dev(beams_ptr, B)
+        if spf is None:
+            pf.normalize(fetch=False)
+            pf.resample_if(r01[i % 4096], 0.5)
+        else:
+            spf.normalize()
+            spf.resample(r01[i % 4096], 0.5)
+        if args.full_rebuild:
+            m.integrate_at_dev(beams_ptr, B, pf)
+            m.compute_likelihood_map()
+        else:
+            m.update_at_dev(beams_ptr, B, pf)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup, with every kernel class bracketed: find the dominant one -----------------------------
+    m.profile(True)
+    m.profile_reset()
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    warm = m.profile_get()
+    m.profile(False)
+    if args.warmup > 0:
+        dominant = max((k for k in warm if warm[k][1] > 0), key=lambda k: warm[k][0], default="score")
+    else:
+        dominant = "score"
+    dom_bit = 1 << _lib.KERNEL_NAMES.index(dominant)
+
+    # ---- timed region: exactly K steps, only the dominant kernel bracketed by events -------------------
+    m.profile_reset()
+    m.profile(dom_bit)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dom_ms, dom_n = m.profile_get()[dominant]
+    m.profile(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- per-kernel breakdown (second pass, all classes bracketed; informational) ----------------------
+    m.profile(True)
+    m.profile_reset()
+    nb = min(args.steps, 50)
+    for i in range(nb):
+        step(args.warmup + args.steps + i)
+    barrier()
+    prof = m.profile_get()
+    m.profile(False)
+    st = pf.stats()
+    visits = None
+    if rank == 0:
+        cells, cls, counts = m.trace_scan(tr.scans[T // 2], tr.poses[T // 2])
+        visits = int(counts.sum())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
+    steps = args.steps
+    value = n_global * steps / elapsed
+    dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
+    launches_per_step = {k: (prof[k][1] / nb if nb else 0) for k in prof}
+    alg = algorithmic_bytes(dominant, n_particles=n_local, n_hit=n_hit, n_beams=B, cells=m.W * m.H, visits=visits or 0)
+    # a class may launch several kernels per scan (reduce, resample): the figure is per scan step
+    per_launch_scale = max(1.0, launches_per_step.get(dominant, 1.0))
+    achieved = alg / per_launch_scale / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+    kernels = {}
+    for k, (ms, n) in prof.items():
+        if n:
+            kernels[k] = {"ms_per_step": round(ms / nb, 5), "launches_per_step": round(n / nb, 2)}
+    map_update_ms = sum(kernels.get(k, {}).get("ms_per_step", 0.0) for k in ("raycast", "apply", "likelihood"))
+
+    out = {
+        "metric": "particle-scan evals/sec",
+        "value": value,
+        "unit": "particle-scan evals/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.config}: {n_local} particles/GPU x {B} beams ({n_hit} hits), {m.W}x{m.H} grid @ {res} m, "
+                        f"full scan step (score+normalise+resample+ray-cast+likelihood rebuild)",
+            "particles_total": n_global, "beams": B, "grid": [m.W, m.H], "resolution_m": res,
+            "parallelism": f"particles sharded x{world}, map replicated" if world > 1 else "single GPU",
+            "likelihood_rebuild": "full" if args.full_rebuild else "dirty-rect (bit-identical to full)",
+        },
+        "beam_evals_per_s": value * n_hit,
+        "scans_per_s": steps / elapsed,
+        "map_update_ms_per_scan": map_update_ms,
+        "kernels": kernels,
+        "filter": {"neff": st["neff"], "n_zero_weights": st["n_zero"], "weight_sum": st["weight_sum"]},
+        "roofline": {
+            "kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg / per_launch_scale,
+            "avg_launch_us": dom_avg_s * 1e6 / per_launch_scale, "launches_timed": dom_n,
+        },
+    }
+
+    # ---- CPU baseline: the oracle (port of the Java loops), one thread, bounded sample ------------------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+        log = log0
+        lik = g.build_likelihood(log)
+        n_cpu = n_local
+        scans_cpu = args.cpu_scans or 16
+        P = synth.make_particles(tr.poses[T // 2], n_global, seed=99)[:n_cpu]
+        c0 = time.perf_counter()
+        done = 0
+        for i in range(scans_cpu):
+            t = T // 2 + (i % n_sets)
+            w = g.score(lik, tr.scans[t], P)
+            ws, strongest = orc.normalize(w)
+            ne = orc.neff(w) if ws > 0 else float("nan")
+            if ws > 0 and ne < n_cpu / 2:
+                orc.resample_indices(w, float(r01[i]))
+            wp = orc.weighted_pose(P, w) if ws > 0 else tr.poses[t]
+            g.integrate(log, tr.scans[t], wp)
+            lik = g.build_likelihood(log)
+            done += 1
+            if time.perf_counter() - c0 > 30.0:
+                break
+        cpu_s = time.perf_counter() - c0
+        out["cpu_baseline"] = {
+            "value": n_cpu * done / cpu_s, "unit": "particle-scan evals/s", "cores": 1, "kind": "port",
+            "sample": f"{done} scan steps of the same trace, all {n_cpu} particles "
+                      f"(C oracle, gcc -O2 -ffp-contract=off, single thread; full likelihood rebuild per scan as the reference does)",
+            "seconds": cpu_s,
+        }
+    else:
+        out["cpu_baseline"] = None
+
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

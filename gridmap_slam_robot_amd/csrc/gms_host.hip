@@ -137,7 +137,7 @@ extern "C" {
 int gms_profile_enable(gms_map *m, int32_t on) {
     REQUIRE(m, "null map");
     if (!on) prof_drain(m);
-    m->prof_on = on != 0;
+    m->prof_on = on;          // bit k brackets kernel class k
     return GMS_OK;
 }
 int gms_profile_reset(gms_map *m) {
@@ -356,7 +356,33 @@ int gms_map_integrate(gms_map *m, const gms_beam *beams, int32_t B, const float 
     rc = stage_poses(m, poses);
     if (rc) return rc;
     if (B > 0) {
-        gms_launch_raycast(m, m->d_beams, B, m->d_poses);
+        gms_launch_raycast(m, m->d_beams, B, m->max_beams, m->d_poses);
+        gms_launch_apply_counts(m);
+    }
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_map_integrate_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, const float *dev_poses) {
+    REQUIRE(m && dev_beams && dev_poses, "null argument");
+    REQUIRE(B >= 0 && B <= 16384, "beam count out of range");
+    HIPCHK(hipSetDevice(m->device));
+    if (B > 0) {
+        gms_launch_raycast(m, dev_beams, B, B, dev_poses);
+        gms_launch_apply_counts(m);
+    }
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_map_integrate_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, gms_pf *pf, int32_t which) {
+    REQUIRE(m && dev_beams && pf && pf->map == m, "gms_map_integrate_at_dev: bad arguments");
+    REQUIRE(which == 0 || which == 1, "which must be 0 (weighted pose) or 1 (strongest particle)");
+    REQUIRE(B >= 0 && B <= 16384, "beam count out of range");
+    HIPCHK(hipSetDevice(m->device));
+    gms_launch_pose_from_pf(m, pf, which, m->d_poses);
+    if (B > 0) {
+        gms_launch_raycast(m, dev_beams, B, B, m->d_poses);
         gms_launch_apply_counts(m);
     }
     HIPCHK(hipGetLastError());
@@ -370,7 +396,7 @@ int gms_map_integrate_at(gms_map *m, const gms_beam *beams, int32_t B, gms_pf *p
     if (rc) return rc;
     gms_launch_pose_from_pf(m, pf, which, m->d_poses);
     if (B > 0) {
-        gms_launch_raycast(m, m->d_beams, B, m->d_poses);
+        gms_launch_raycast(m, m->d_beams, B, m->max_beams, m->d_poses);
         gms_launch_apply_counts(m);
     }
     HIPCHK(hipGetLastError());
@@ -453,6 +479,18 @@ int gms_map_update(gms_map *m, const gms_beam *beams, int32_t B, const float *po
 
 int gms_map_update_at(gms_map *m, const gms_beam *beams, int32_t B, gms_pf *pf, int32_t which) {
     int rc = gms_map_integrate_at(m, beams, B, pf, which);
+    if (rc) return rc;
+    return finish_likelihood(m, m->need_full_build ? 0 : 1);
+}
+
+int gms_map_update_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, const float *dev_poses) {
+    int rc = gms_map_integrate_dev(m, dev_beams, B, dev_poses);
+    if (rc) return rc;
+    return finish_likelihood(m, m->need_full_build ? 0 : 1);
+}
+
+int gms_map_update_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, gms_pf *pf, int32_t which) {
+    int rc = gms_map_integrate_at_dev(m, dev_beams, B, pf, which);
     if (rc) return rc;
     return finish_likelihood(m, m->need_full_build ? 0 : 1);
 }
@@ -607,8 +645,29 @@ int gms_pf_score(gms_pf *pf, const gms_beam *beams, int32_t B) {       // GridMa
     gms_map *m = pf->map;
     int rc = stage_beams(m, beams, B);
     if (rc) return rc;
-    gms_launch_pf_prep(pf, m->d_beams, B);
+    gms_launch_pf_prep(pf, m->d_beams, B, m->max_beams);
     gms_launch_pf_score(pf, B);
+    pf->have_global = 0;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B) {
+    REQUIRE(pf && dev_beams, "null argument");
+    gms_map *m = pf->map;
+    REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
+    HIPCHK(hipSetDevice(m->device));
+    gms_launch_pf_prep(pf, dev_beams, B, B);
+    gms_launch_pf_score(pf, B);
+    pf->have_global = 0;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_pf_set_poses_dev(gms_pf *pf, const float *dev_xytheta) {
+    REQUIRE(pf && dev_xytheta, "null argument");
+    HIPCHK(hipSetDevice(pf->map->device));
+    gms_launch_pf_set_poses_aos(pf, dev_xytheta);
     pf->have_global = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
@@ -771,7 +830,7 @@ int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B) {   // Gri
     gms_map *m = pf->map;
     int rc = stage_beams(m, beams, B);
     if (rc) return rc;
-    gms_launch_pf_prep(pf, m->d_beams, B);
+    gms_launch_pf_prep(pf, m->d_beams, B, m->max_beams);
     gms_launch_pf_refine(pf, B);
     pf->have_global = 0;
     HIPCHK(hipGetLastError());

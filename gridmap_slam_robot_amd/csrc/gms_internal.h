@@ -116,7 +116,7 @@ struct gms_pf {
 };
 
 // ---- kernel launchers (gms_map_kernels.hip / gms_pf_kernels.hip) -----------------------------
-void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, const float *d_poses);
+void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses);
 void gms_launch_trace_scan(gms_map *m, const gms_beam *d_beams, int32_t B, const float *d_pose,
                            int32_t *d_cells, uint8_t *d_cls, int32_t cap, int32_t *d_counts);
 void gms_launch_trace_ray(gms_map *m, float x0, float y0, float x1, float y1, int32_t extra,
@@ -129,7 +129,8 @@ void gms_launch_get_raw(gms_map *m, int32_t mi, int32_t x, int32_t y, double *d_
 void gms_launch_debug_f32(gms_map *m, int32_t op, const float *d_a, float *d_out, int64_t n);
 
 void gms_launch_pf_init(gms_pf *pf);
-void gms_launch_pf_prep(gms_pf *pf, const gms_beam *d_beams, int32_t B);
+void gms_launch_pf_prep(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);
+void gms_launch_pf_set_poses_aos(gms_pf *pf, const float *d_xytheta);
 void gms_launch_pf_score(gms_pf *pf, int32_t B);
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials);
 void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed, int64_t stride);
@@ -145,6 +146,7 @@ void gms_prof_end(gms_map *m);
 
 struct ProfScope {
     gms_map *m;
-    ProfScope(gms_map *mm, int32_t k) : m(mm) { if (m->prof_on) gms_prof_begin(m, k); }
-    ~ProfScope() { if (m->prof_on) gms_prof_end(m); }
+    bool on;
+    ProfScope(gms_map *mm, int32_t k) : m(mm), on((mm->prof_on >> k) & 1) { if (on) gms_prof_begin(m, k); }
+    ~ProfScope() { if (on) gms_prof_end(m); }
 };

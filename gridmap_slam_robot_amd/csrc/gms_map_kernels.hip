@@ -239,10 +239,10 @@ __global__ void k_debug_f32(int32_t op, const float *__restrict__ a, float *__re
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, const float *d_poses) {
+void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses) {
     ProfScope ps(m, GMS_K_RAYCAST);
     dim3 grid((B + 63) / 64, m->n_maps);
-    hipLaunchKernelGGL(k_raycast<false>, grid, dim3(64), 0, m->stream, m->gd, d_beams, B, m->max_beams, d_poses,
+    hipLaunchKernelGGL(k_raycast<false>, grid, dim3(64), 0, m->stream, m->gd, d_beams, B, beam_stride, d_poses,
                        (const RayIn *)nullptr, m->d_cnt, m->d_bbox, (int32_t *)nullptr, (uint8_t *)nullptr, 0,
                        (int32_t *)nullptr);
 }

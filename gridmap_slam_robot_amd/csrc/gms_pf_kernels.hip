@@ -35,12 +35,12 @@ __global__ void k_pf_prep(const float *__restrict__ th, float *__restrict__ cs, 
 
 // one wave per map: order-preserving compaction of the beams with wasHit
 __global__ void __launch_bounds__(64)
-k_compact_beams(const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride, double *__restrict__ hitbeams,
-                int32_t *__restrict__ nhit) {
+k_compact_beams(const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride, int32_t out_stride,
+                double *__restrict__ hitbeams, int32_t *__restrict__ nhit) {
     const int32_t mi = blockIdx.x;
     const int32_t lane = threadIdx.x;
     const gms_beam *mb = beams + (size_t)mi * beam_stride;
-    double *out = hitbeams + (size_t)mi * beam_stride * 2;
+    double *out = hitbeams + (size_t)mi * out_stride * 2;
     int32_t base = 0;
     for (int32_t b0 = 0; b0 < B; b0 += 64) {
         const int32_t b = b0 + lane;
@@ -506,13 +506,25 @@ void gms_launch_pf_init(gms_pf *pf) {
                        pf->d_y, pf->d_th, pf->d_w, pf->d_logw, total, 1.0 / (double)pf->n_global);
 }
 
-void gms_launch_pf_prep(gms_pf *pf, const gms_beam *d_beams, int32_t B) {
+__global__ void k_set_poses_aos(const float *__restrict__ aos, float *__restrict__ x, float *__restrict__ y,
+                                float *__restrict__ th, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) { x[i] = aos[3 * i]; y[i] = aos[3 * i + 1]; th[i] = aos[3 * i + 2]; }
+}
+
+void gms_launch_pf_set_poses_aos(gms_pf *pf, const float *d_xytheta) {
+    const int64_t total = (int64_t)pf->n_maps * pf->n;
+    hipLaunchKernelGGL(k_set_poses_aos, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pf->map->stream, d_xytheta,
+                       pf->d_x, pf->d_y, pf->d_th, total);
+}
+
+void gms_launch_pf_prep(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride) {
     gms_map *m = pf->map;
     const int64_t total = (int64_t)pf->n_maps * pf->n;
     hipLaunchKernelGGL(k_pf_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, pf->d_th, pf->d_cs,
                        total);
-    hipLaunchKernelGGL(k_compact_beams, dim3(pf->n_maps), dim3(64), 0, m->stream, d_beams, B, m->max_beams,
-                       pf->d_hitbeams, pf->d_nhit);
+    hipLaunchKernelGGL(k_compact_beams, dim3(pf->n_maps), dim3(64), 0, m->stream, d_beams, B, beam_stride,
+                       m->max_beams, pf->d_hitbeams, pf->d_nhit);
 }
 
 void gms_launch_pf_score(gms_pf *pf, int32_t B) {

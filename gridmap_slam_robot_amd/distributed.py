@@ -1,0 +1,139 @@
+"""Particles sharded over the GPUs of one node: one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI) for the two exchange steps the path really has.
+
+The reference has no distributed code at all; this is the sharding BASELINE.json's
+north_star asks for.  Rank r holds the contiguous particle block [r*n, (r+1)*n) and a full replica of
+the map (the deterministic integer-count map update is run redundantly: 720 rays are cheaper than
+broadcasting 32 MiB).  Per scan:
+
+  1. all-reduce(SUM) of the block-partial vector (GMS_PARTIAL_STRIDE doubles per 256-particle block,
+     each rank's own blocks filled, zero elsewhere).  Adding zeros is exact, so every rank ends up
+     with the same partials whatever the rank count, and folds them in block order: weightSum,
+     strongest, n_zero are bit-identical for 1, 2, 4, 8 GPUs (SLAM.java:87-121).
+  2. all-gather of the packed normalised particles {w, x, y, theta} (24 B each): every rank then
+     computes Neff and the weighted pose (SLAM.java:165-190) and its own slots of the systematic
+     resample (SLAM.java:133-153) from the same global array.
+
+Both messages are small (6 KiB and 1.5 MiB at 65 536 particles): latency-bound, one RCCL call each.
+
+The collective logic is independent of where the shard kernels run: `ops` is the object that performs
+them.  The product uses HipShardOps (libgridmapslam.so, device pointers of torch CUDA tensors, the
+library running on torch's current stream).  There is no CPU implementation in this package; the gloo
+tests under tests/ inject their own stand-in to exercise the protocol.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .gridmap import GridMap, ParticleFilter
+
+
+class HipShardOps:
+    """Shard-local kernels through the C-ABI on the current CUDA(HIP) device."""
+
+    def __init__(self, grid_map: GridMap, n_local: int, offset: int, n_global: int):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipShardOps needs a HIP device (there is no CPU path)")
+        self.map = grid_map
+        self.pf = ParticleFilter(grid_map, n_local)
+        self.pf.set_shard(offset, n_global)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        grid_map.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def new_buffer(self, n_doubles: int) -> torch.Tensor:
+        return torch.zeros(n_doubles, dtype=torch.float64, device=self.device)
+
+    def partials_len(self) -> int:
+        return self.pf.partials_len()
+
+    def local_partials(self, partials: torch.Tensor):
+        self.pf.local_partials(partials.data_ptr())
+
+    def apply_partials(self, partials: torch.Tensor, packed_local: torch.Tensor):
+        self.pf.apply_partials(partials.data_ptr(), packed_local.data_ptr())
+
+    def pack(self, packed_local: torch.Tensor):
+        self.pf.pack(packed_local.data_ptr())
+
+    def import_global(self, packed_global: torch.Tensor):
+        self.pf.import_global(packed_global.data_ptr())
+
+    def resample(self, r01: float, fraction: Optional[float]):
+        if fraction is None:
+            self.pf.resample(r01)
+        else:
+            self.pf.resample_if(r01, fraction)
+
+    def stats(self) -> dict:
+        return self.pf.stats()
+
+    def weighted_pose(self) -> np.ndarray:
+        return self.pf.weighted_pose()
+
+
+class ShardedParticleFilter:
+    """ParticleFilter whose particles are split over the ranks of a process group."""
+
+    def __init__(self, n_global: int, ops, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_global = n_global
+        self.n_local, self.offset = self.shard_of(n_global, self.world, self.rank)
+        self.ops = ops
+        self.partials = ops.new_buffer(ops.partials_len())
+        self.packed_local = ops.new_buffer(3 * self.n_local)            # 24 B per particle
+        self.packed_global = ops.new_buffer(3 * n_global)
+
+    @staticmethod
+    def shard_of(n_global: int, world: int, rank: int):
+        """Contiguous equal blocks; shard boundaries must fall on GMS_BLOCK so that the reduction
+        blocks never straddle ranks."""
+        if n_global % world:
+            raise ValueError(f"{n_global} particles do not split evenly over {world} ranks")
+        n = n_global // world
+        if world > 1 and n % _lib.GMS_BLOCK:
+            raise ValueError(f"shard size {n} must be a multiple of GMS_BLOCK={_lib.GMS_BLOCK}")
+        return n, rank * n
+
+    # ------------------------------------------------------------------------------------------
+    def _all_gather(self):
+        if self.world == 1:
+            self.packed_global.copy_(self.packed_local)
+            return
+        try:
+            dist.all_gather_into_tensor(self.packed_global, self.packed_local, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            parts = list(self.packed_global.chunk(self.world))
+            dist.all_gather(parts, self.packed_local, group=self.group)
+
+    def normalize(self):
+        """SLAM.update's bookkeeping over all ranks (SLAM.java:87-129)."""
+        self.ops.local_partials(self.partials)
+        if self.world > 1:
+            dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
+        self.ops.apply_partials(self.partials, self.packed_local)
+        self._all_gather()
+        self.ops.import_global(self.packed_global)
+
+    def resample(self, r01: float, fraction: Optional[float] = None):
+        """SLAM.resample (SLAM.java:133-153); with `fraction`, only if neff < fraction*N
+        (J/app/GridMapApp.java:185-186).  Every rank must pass the same r01."""
+        self.ops.resample(r01, fraction)
+
+    def refresh_global(self):
+        """All-gather the current (e.g. resampled) particles again, for getWeightedPose after a resample."""
+        self.ops.pack(self.packed_local)
+        self._all_gather()
+        self.ops.import_global(self.packed_global)
+
+    def stats(self) -> dict:
+        return self.ops.stats()
+
+    def weighted_pose(self) -> np.ndarray:
+        return self.ops.weighted_pose()

@@ -274,8 +274,23 @@ class GridMap:
             pf.close()
 
     # -- measurement ------------------------------------------------------------------------------
-    def profile(self, on: bool):
-        check(load().gms_profile_enable(self._h, 1 if on else 0))
+    def profile(self, on=True):
+        """on: True/False, or a bitmask of kernel classes (bit k = _lib.K_*)."""
+        mask = (0x7F if on else 0) if isinstance(on, bool) else int(on)
+        check(load().gms_profile_enable(self._h, mask))
+
+    # -- device-resident inputs (raw device pointers, e.g. torch tensor .data_ptr()) -------------------
+    def update_dev(self, dev_beams: int, B: int, dev_poses: int):
+        check(load().gms_map_update_dev(self._h, C.c_void_p(dev_beams), B, C.c_void_p(dev_poses)))
+
+    def integrate_dev(self, dev_beams: int, B: int, dev_poses: int):
+        check(load().gms_map_integrate_dev(self._h, C.c_void_p(dev_beams), B, C.c_void_p(dev_poses)))
+
+    def update_at_dev(self, dev_beams: int, B: int, pf: "ParticleFilter", strongest: bool = False):
+        check(load().gms_map_update_at_dev(self._h, C.c_void_p(dev_beams), B, pf._h, 1 if strongest else 0))
+
+    def integrate_at_dev(self, dev_beams: int, B: int, pf: "ParticleFilter", strongest: bool = False):
+        check(load().gms_map_integrate_at_dev(self._h, C.c_void_p(dev_beams), B, pf._h, 1 if strongest else 0))
 
     def profile_reset(self):
         check(load().gms_profile_reset(self._h))
@@ -369,6 +384,12 @@ class ParticleFilter:
         """weight[i] = probabilityOf(map, obs, pose[i]) (SLAM.java:99)."""
         b, B = self.map._beam_args(obs)
         check(load().gms_pf_score(self._h, ptr(b), B))
+
+    def set_poses_dev(self, dev_xytheta: int):
+        check(load().gms_pf_set_poses_dev(self._h, C.c_void_p(dev_xytheta)))
+
+    def score_dev(self, dev_beams: int, B: int):
+        check(load().gms_pf_score_dev(self._h, C.c_void_p(dev_beams), B))
 
     def _stats(self, arr):
         out = [dict(weight_sum=s.weight_sum, neff=s.neff, strongest=s.strongest, n_zero=s.n_zero,

@@ -199,6 +199,17 @@ int gms_pf_did_resample(gms_pf *pf, int32_t *flags);
  * (GridMap.java:319-346): poses are replaced by the argmax pose. */
 int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B);
 
+/* ---- device-resident inputs ---------------------------------------------------------------------
+ * The same entry points for callers whose scans / poses already live in HBM (a trace staged once, a
+ * torch tensor, the output of a device-side motion model).  dev_beams is [n_maps][B] gms_beam,
+ * dev_poses [n_maps][3], dev_xytheta [n_maps][n][3]; all are read on the handle's stream. */
+int gms_map_integrate_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, const float *dev_poses);
+int gms_map_integrate_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, gms_pf *pf, int32_t which);
+int gms_map_update_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, const float *dev_poses);
+int gms_map_update_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, gms_pf *pf, int32_t which);
+int gms_pf_set_poses_dev(gms_pf *pf, const float *dev_xytheta);
+int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B);
+
 /* ---- multi-GPU plumbing (particles sharded over ranks; collectives stay with the caller) ------- */
 /* Number of doubles of the block-partial vector exchanged by an all-reduce(SUM):
  * 3 per global block of GMS_BLOCK particles {sum, max, first index of max}. */
@@ -222,8 +233,9 @@ enum {
     GMS_K_RAYCAST = 0, GMS_K_APPLY = 1, GMS_K_LIKELIHOOD = 2, GMS_K_SCORE = 3, GMS_K_REDUCE = 4,
     GMS_K_RESAMPLE = 5, GMS_K_REFINE = 6, GMS_K_COUNT = 7
 };
-/* Bracket every kernel launch of this map handle (and its filters) with HIP events on its stream. */
-int gms_profile_enable(gms_map *m, int32_t on);
+/* Bracket kernel launches of this map handle (and its filters) with HIP events on its stream:
+ * bit k of `mask` enables kernel class k (GMS_K_*); 0 turns profiling off. */
+int gms_profile_enable(gms_map *m, int32_t mask);
 int gms_profile_reset(gms_map *m);
 /* Total device milliseconds and launch count of kernel class k since the last reset. */
 int gms_profile_get(gms_map *m, int32_t k, double *total_ms, int64_t *launches);
