@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgridmapslam.so")
 
 GMS_MAX_TAPS = 129
-GMS_BLOCK = 256
-GMS_PARTIAL_STRIDE = 5
+GMS_BLOCK = 1024
+GMS_PARTIAL_STRIDE = 9
 PACKED_BYTES = 24
 
 GMS_OK, GMS_ERR_INVALID, GMS_ERR_NO_DEVICE, GMS_ERR_HIP, GMS_ERR_NOMEM, GMS_ERR_STATE = 0, -1, -2, -3, -4, -5
@@ -60,6 +60,24 @@ class GmsError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (different SONAME from /opt/rocm's
+    libamdhip64.so.7).  Two HIP runtimes in one process cannot share streams, and whichever initialises
+    second may not see the GPU.  Promote torch's copy to the global symbol scope BEFORE our library is
+    loaded, so that its hip* symbols bind to the runtime torch uses: one runtime, torch streams usable
+    through gms_map_set_stream, RCCL ordering intact.  Without torch the system runtime is used."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load() -> C.CDLL:
     """Load the in-tree HIP library; raise if it is missing (no fallback exists)."""
     global _lib
@@ -70,6 +88,7 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -m gridmap_slam_robot_amd.build` "
             "(hipcc, --offload-arch=gfx950). gridmap_slam_robot_amd has no CPU fallback."
         )
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
     pp = C.POINTER(GmsParams)
@@ -134,6 +153,7 @@ def load() -> C.CDLL:
     sig("gms_pf_local_partials", C.c_int, vp, vp)
     sig("gms_pf_apply_partials", C.c_int, vp, vp, vp)
     sig("gms_pf_pack", C.c_int, vp, vp)
+    sig("gms_pf_stats_from_partials", C.c_int, vp, vp)
     sig("gms_pf_import_global", C.c_int, vp, vp)
     sig("gms_profile_enable", C.c_int, vp, i32)
     sig("gms_profile_reset", C.c_int, vp)

@@ -37,7 +37,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    extra = os.environ.get("GMS_EXTRA_FLAGS", "").split()      # experiments only (e.g. -DRC_RAYS=4)
+    cmd = [hipcc()] + FLAGS + extra + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -17,6 +17,30 @@ __device__ __forceinline__ int32_t j_d2i(double d) {
     if (d <= -2147483648.0) return INT32_MIN;
     return (int32_t)d;
 }
+// The same conversion in one instruction: v_cvt_i32_f64 truncates toward zero, saturates and maps
+// NaN to 0 -- exactly JLS 5.1.3 (used in the scoring loop, where the three compares above cost more
+// than the conversion).
+__device__ __forceinline__ int32_t j_d2i_hw(double d) {
+    int32_t r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(d));
+    return r;
+}
+
+// (int)(d / res) without the division in the common case.  q' = d * RN(1/res) differs from the
+// correctly rounded quotient Q = RN(d / res) by at most 1.5 * 2^-52 |Q|; unless q' lies within that
+// distance of an integer, Q and q' truncate to the same int.  The guard used is absolute, 2^-19 >=
+// 4 * 2^-52 * 2^31: it covers every |q| that can land inside a map (beyond |q| ~ 2^31 both quotients
+// are outside the map, or saturate, alike) and trips for about 4e-6 of the calls.  NaN and
+// infinities never trip it and convert like Q would.
+//   j_cell_fast  branch-free: the int from q', and whether the guard tripped
+//   j_cell_exact the reference's expression, (int)(d / res)
+__device__ __forceinline__ int32_t j_cell_fast(double d, double rinv, bool &guard) {
+    const double q = d * rinv;
+    guard = guard | (fabs(q - rint(q)) <= 0x1p-19);
+    return j_d2i_hw(q);
+}
+__device__ __forceinline__ int32_t j_cell_exact(double d, double res) { return j_d2i_hw(d / res); }
+
 // Java int arithmetic wraps.
 __device__ __forceinline__ int32_t j_iadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 __device__ __forceinline__ int32_t j_isub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
@@ -90,6 +114,11 @@ __device__ __forceinline__ void ray_step(RayDev &r) {                          /
         r.error = r.error + r.dy;
     }
     r.n = j_isub(r.n, 1);
+}
+
+// probabilityOf's per-beam factor as a function of the likelihood value (GridMap.java:285-288)
+__device__ __forceinline__ double lik_factor(const GridDev &g, double val) {
+    return val == 0.5 ? g.inv_max : g.z_hit * val + g.c_rand;
 }
 
 // SensorModel.inverseSensorModel (J/slam/SensorModel.java:31-41) -> class 0 free, 1 prior, 2 occupied

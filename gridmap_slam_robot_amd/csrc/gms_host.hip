@@ -3,7 +3,9 @@
 // There is no CPU path in this file: every compute entry point launches gfx950 kernels.
 #include <math.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -159,7 +161,7 @@ static int map_free(gms_map *m) {
     if (!m) return GMS_OK;
     prof_drain(m);
     for (ProfSlot &s : m->prof_free) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
-    hipFree(m->d_log); hipFree(m->d_lik); hipFree(m->d_cnt); hipFree(m->d_bbox); hipFree(m->d_taps);
+    hipFree(m->d_log); hipFree(m->d_lik); hipFree(m->d_fac); hipFree(m->d_cnt); hipFree(m->d_bbox); hipFree(m->d_taps);
     hipFree(m->d_beams); hipFree(m->d_poses); hipFree(m->d_scratch);
     hipFree(m->d_trace_cells); hipFree(m->d_trace_cls); hipFree(m->d_trace_cnt);
     if (m->h_beams) hipHostFree(m->h_beams);
@@ -192,6 +194,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     g.W = W; g.H = H; g.cells = (int64_t)W * H;
     g.posx = (double)p->pos_x; g.posy = (double)p->pos_y;
     g.res = (double)p->resolution; g.resf = p->resolution;
+    g.rinv = 1.0 / g.res;
     g.l_free = p->l_free; g.l_occ = p->l_occ;
     g.extra = p->extra_steps;
     g.half_tol = p->hit_tolerance / 2;                               // SensorModel.java:35 float arithmetic
@@ -207,8 +210,10 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     bool ok = true;
     ok = ok && hipMalloc(&m->d_log, cells * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_lik, cells * sizeof(double)) == hipSuccess;
+    m->fac_stride = g.cells + 16;
+    ok = ok && hipMalloc(&m->d_fac, (size_t)m->fac_stride * m->n_maps * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_cnt, cells * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMalloc(&m->d_bbox, (size_t)m->n_maps * 4 * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_bbox, (size_t)m->n_maps * 8 * sizeof(int32_t)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_taps, GMS_MAX_TAPS * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_beams, (size_t)m->n_maps * m->max_beams * sizeof(gms_beam)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_poses, (size_t)m->n_maps * 3 * sizeof(float)) == hipSuccess;
@@ -220,9 +225,13 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     hipMemsetAsync(m->d_log, 0, cells * sizeof(double), m->stream);   // logOdds(0.5) == 0.0 (createMapData(null))
     hipMemsetAsync(m->d_lik, 0, cells * sizeof(double), m->stream);
     hipMemsetAsync(m->d_cnt, 0, cells * sizeof(uint32_t), m->stream);
-    hipMemsetAsync(m->d_bbox, 0, (size_t)m->n_maps * 4 * sizeof(int32_t), m->stream);
+    hipMemsetAsync(m->d_bbox, 0, (size_t)m->n_maps * 8 * sizeof(int32_t), m->stream);
+    gms_launch_factors(m);        // likelihoodData == 0 everywhere (createMapData(null))
     HIPCHK(hipStreamSynchronize(m->stream));
     m->need_full_build = 1;
+    m->score_variant = 2;
+    if (const char *v = getenv("GMS_SCORE_VARIANT")) m->score_variant = atoi(v);
+    if (const char *v = getenv("GMS_SCORE_SEGMENTS")) m->score_segments = atoi(v);
     *out = m;
     return GMS_OK;
 }
@@ -284,7 +293,11 @@ int gms_map_download_log(gms_map *m, double *log_data) {
 int gms_map_upload_likelihood(gms_map *m, const double *lik) {
     REQUIRE(m && lik, "null argument");
     m->need_full_build = 1;
-    return map_xfer(m, m->d_lik, const_cast<double *>(lik), true);
+    int rc = map_xfer(m, m->d_lik, const_cast<double *>(lik), true);
+    if (rc) return rc;
+    gms_launch_factors(m);
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
 }
 int gms_map_download_likelihood(gms_map *m, double *lik) {
     REQUIRE(m && lik, "null argument");
@@ -298,6 +311,7 @@ int gms_map_copy(gms_map *dst, const gms_map *src) {                  // GridMap
     HIPCHK(hipStreamSynchronize(src->stream));
     HIPCHK(hipMemcpyAsync(dst->d_log, src->d_log, bytes, hipMemcpyDeviceToDevice, dst->stream));
     HIPCHK(hipMemcpyAsync(dst->d_lik, src->d_lik, bytes, hipMemcpyDeviceToDevice, dst->stream));
+    gms_launch_factors(dst);
     dst->need_full_build = 1;
     return GMS_OK;
 }
@@ -341,9 +355,19 @@ static int stage_poses(gms_map *m, const float *poses) {
     return GMS_OK;
 }
 
+// device address of the filter's weighted pose (which = 0) or strongest particle's pose (1), map 0
+static const float *stats_pose_ptr(const gms_pf *pf, int32_t which) {
+    const char *base = reinterpret_cast<const char *>(pf->d_stats);
+    return reinterpret_cast<const float *>(base + (which == 0 ? offsetof(PfStatsDev, wpose) : offsetof(PfStatsDev, spose)));
+}
+
 static int finish_likelihood(gms_map *m, int32_t dirty_only) {
+    if (dirty_only && !m->bbox_dirty) return GMS_OK;     // nothing changed since the last build
     gms_launch_likelihood(m, dirty_only);
-    HIPCHK(hipMemsetAsync(m->d_bbox, 0, (size_t)m->n_maps * 4 * sizeof(int32_t), m->stream));
+    if (m->bbox_dirty) {          // the box is consumed; the other half was cleared by k_apply
+        m->bbox_cur = 1 - m->bbox_cur;
+        m->bbox_dirty = 0;
+    }
     m->need_full_build = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
@@ -356,7 +380,7 @@ int gms_map_integrate(gms_map *m, const gms_beam *beams, int32_t B, const float 
     rc = stage_poses(m, poses);
     if (rc) return rc;
     if (B > 0) {
-        gms_launch_raycast(m, m->d_beams, B, m->max_beams, m->d_poses);
+        gms_launch_raycast(m, m->d_beams, B, m->max_beams, m->d_poses, 3);
         gms_launch_apply_counts(m);
     }
     HIPCHK(hipGetLastError());
@@ -368,7 +392,7 @@ int gms_map_integrate_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, cons
     REQUIRE(B >= 0 && B <= 16384, "beam count out of range");
     HIPCHK(hipSetDevice(m->device));
     if (B > 0) {
-        gms_launch_raycast(m, dev_beams, B, B, dev_poses);
+        gms_launch_raycast(m, dev_beams, B, B, dev_poses, 3);
         gms_launch_apply_counts(m);
     }
     HIPCHK(hipGetLastError());
@@ -380,9 +404,8 @@ int gms_map_integrate_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, g
     REQUIRE(which == 0 || which == 1, "which must be 0 (weighted pose) or 1 (strongest particle)");
     REQUIRE(B >= 0 && B <= 16384, "beam count out of range");
     HIPCHK(hipSetDevice(m->device));
-    gms_launch_pose_from_pf(m, pf, which, m->d_poses);
     if (B > 0) {
-        gms_launch_raycast(m, dev_beams, B, B, m->d_poses);
+        gms_launch_raycast(m, dev_beams, B, B, stats_pose_ptr(pf, which), (int32_t)(sizeof(PfStatsDev) / sizeof(float)));
         gms_launch_apply_counts(m);
     }
     HIPCHK(hipGetLastError());
@@ -394,9 +417,8 @@ int gms_map_integrate_at(gms_map *m, const gms_beam *beams, int32_t B, gms_pf *p
     REQUIRE(which == 0 || which == 1, "which must be 0 (weighted pose) or 1 (strongest particle)");
     int rc = stage_beams(m, beams, B);
     if (rc) return rc;
-    gms_launch_pose_from_pf(m, pf, which, m->d_poses);
     if (B > 0) {
-        gms_launch_raycast(m, m->d_beams, B, m->max_beams, m->d_poses);
+        gms_launch_raycast(m, m->d_beams, B, m->max_beams, stats_pose_ptr(pf, which), (int32_t)(sizeof(PfStatsDev) / sizeof(float)));
         gms_launch_apply_counts(m);
     }
     HIPCHK(hipGetLastError());
@@ -514,8 +536,9 @@ static int64_t nblk_of(int64_t n) { return (n + GMS_BLOCK - 1) / GMS_BLOCK; }
 static int64_t nchunks_of(int64_t n) { return (n + 63) / 64; }
 
 static void pf_free_global(gms_pf *pf) {
-    hipFree(pf->d_partials); hipFree(pf->d_partials2); hipFree(pf->d_global); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum);
-    pf->d_partials = pf->d_partials2 = nullptr; pf->d_global = nullptr; pf->d_chunk_tot = pf->d_cum = nullptr;
+    hipFree(pf->d_partials); hipFree(pf->d_global); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum);
+    hipFree(pf->d_wdense);
+    pf->d_partials = nullptr; pf->d_global = nullptr; pf->d_chunk_tot = pf->d_cum = pf->d_wdense = nullptr;
 }
 
 static int pf_alloc_global(gms_pf *pf) {
@@ -523,10 +546,10 @@ static int pf_alloc_global(gms_pf *pf) {
     const size_t M = pf->n_maps;
     const size_t nblk = nblk_of(pf->n_global), nch = nchunks_of(pf->n_global);
     HIPCHK(hipMalloc(&pf->d_partials, M * nblk * GMS_PARTIAL_STRIDE * sizeof(double)));
-    HIPCHK(hipMalloc(&pf->d_partials2, M * nblk * 5 * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_global, M * pf->n_global * sizeof(PackedParticle)));
     HIPCHK(hipMalloc(&pf->d_chunk_tot, M * (nch + 1) * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_cum, M * pf->n_global * sizeof(double)));
+    HIPCHK(hipMalloc(&pf->d_wdense, M * pf->n_global * sizeof(double)));
     return GMS_OK;
 }
 
@@ -534,7 +557,7 @@ int gms_pf_destroy(gms_pf *pf) {
     if (!pf) return GMS_OK;
     hipSetDevice(pf->map->device);
     hipStreamSynchronize(pf->map->stream);
-    hipFree(pf->d_x); hipFree(pf->d_y); hipFree(pf->d_th); hipFree(pf->d_x2); hipFree(pf->d_y2); hipFree(pf->d_th2);
+    hipFree(pf->d_pose); hipFree(pf->d_pose2); hipFree(pf->d_part);
     hipFree(pf->d_w); hipFree(pf->d_w2); hipFree(pf->d_logw); hipFree(pf->d_cs); hipFree(pf->d_hitbeams);
     hipFree(pf->d_nhit); hipFree(pf->d_stats); hipFree(pf->d_r01); hipFree(pf->d_idx);
     pf_free_global(pf);
@@ -554,20 +577,19 @@ int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // Partic
     pf->map = m; pf->n = n; pf->offset = 0; pf->n_global = n; pf->n_maps = m->n_maps;
     const size_t T = (size_t)n * m->n_maps;
     bool ok = true;
-    ok = ok && hipMalloc(&pf->d_x, T * 4) == hipSuccess && hipMalloc(&pf->d_y, T * 4) == hipSuccess;
-    ok = ok && hipMalloc(&pf->d_th, T * 4) == hipSuccess && hipMalloc(&pf->d_x2, T * 4) == hipSuccess;
-    ok = ok && hipMalloc(&pf->d_y2, T * 4) == hipSuccess && hipMalloc(&pf->d_th2, T * 4) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_pose, T * 12) == hipSuccess && hipMalloc(&pf->d_pose2, T * 12) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_w, T * 8) == hipSuccess && hipMalloc(&pf->d_w2, T * 8) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_logw, T * 8) == hipSuccess && hipMalloc(&pf->d_cs, T * 8) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_hitbeams, (size_t)m->n_maps * m->max_beams * 16) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_nhit, (size_t)m->n_maps * 4) == hipSuccess;
-    ok = ok && hipMalloc(&pf->d_stats, (size_t)m->n_maps * sizeof(PfStatsDev)) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_part, T * GMS_SCORE_MAXSEG * 8) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_stats, (size_t)m->n_maps * 2 * sizeof(PfStatsDev)) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_r01, (size_t)m->n_maps * 8) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_idx, T * 4) == hipSuccess;
     ok = ok && hipHostMalloc(&pf->h_stats, (size_t)m->n_maps * sizeof(PfStatsDev) + (size_t)m->n_maps * 8) == hipSuccess;
     ok = ok && hipHostMalloc(&pf->h_stage, T * 3 * sizeof(float)) == hipSuccess;
     if (!ok || pf_alloc_global(pf) != GMS_OK) { gms_pf_destroy(pf); return fail(GMS_ERR_NOMEM, "device allocation failed for %d particles", n); }
-    hipMemsetAsync(pf->d_stats, 0, (size_t)m->n_maps * sizeof(PfStatsDev), m->stream);
+    hipMemsetAsync(pf->d_stats, 0, (size_t)m->n_maps * 2 * sizeof(PfStatsDev), m->stream);
     gms_launch_pf_init(pf);
     HIPCHK(hipGetLastError());
     *out = pf;
@@ -590,14 +612,12 @@ int gms_pf_set_poses(gms_pf *pf, const float *xytheta) {
     REQUIRE(pf && xytheta, "null argument");
     gms_map *m = pf->map;
     HIPCHK(hipSetDevice(m->device));
-    HIPCHK(hipStreamSynchronize(m->stream));
-    const size_t T = (size_t)pf->n * pf->n_maps;
-    float *hx = pf->h_stage, *hy = hx + T, *ht = hy + T;
-    for (size_t i = 0; i < T; i++) { hx[i] = xytheta[3 * i]; hy[i] = xytheta[3 * i + 1]; ht[i] = xytheta[3 * i + 2]; }
-    HIPCHK(hipMemcpyAsync(pf->d_x, hx, T * 4, hipMemcpyHostToDevice, m->stream));
-    HIPCHK(hipMemcpyAsync(pf->d_y, hy, T * 4, hipMemcpyHostToDevice, m->stream));
-    HIPCHK(hipMemcpyAsync(pf->d_th, ht, T * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));          // the pinned staging buffer may still feed an earlier copy
+    const size_t bytes = (size_t)pf->n * pf->n_maps * 3 * sizeof(float);
+    memcpy(pf->h_stage, xytheta, bytes);
+    HIPCHK(hipMemcpyAsync(pf->d_pose, pf->h_stage, bytes, hipMemcpyHostToDevice, m->stream));
     pf->have_global = 0;
+    pf->stats_current = 0;
     return GMS_OK;
 }
 
@@ -605,14 +625,10 @@ int gms_pf_get_poses(gms_pf *pf, float *xytheta) {
     REQUIRE(pf && xytheta, "null argument");
     gms_map *m = pf->map;
     HIPCHK(hipSetDevice(m->device));
-    const size_t T = (size_t)pf->n * pf->n_maps;
+    const size_t bytes = (size_t)pf->n * pf->n_maps * 3 * sizeof(float);
+    HIPCHK(hipMemcpyAsync(pf->h_stage, pf->d_pose, bytes, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
-    float *hx = pf->h_stage, *hy = hx + T, *ht = hy + T;
-    HIPCHK(hipMemcpyAsync(hx, pf->d_x, T * 4, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipMemcpyAsync(hy, pf->d_y, T * 4, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipMemcpyAsync(ht, pf->d_th, T * 4, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
-    for (size_t i = 0; i < T; i++) { xytheta[3 * i] = hx[i]; xytheta[3 * i + 1] = hy[i]; xytheta[3 * i + 2] = ht[i]; }
+    memcpy(xytheta, pf->h_stage, bytes);
     return GMS_OK;
 }
 
@@ -629,6 +645,7 @@ static int pf_copy_f64(gms_pf *pf, double *dev, double *host, bool to_device) {
 int gms_pf_set_weights(gms_pf *pf, const double *w) {
     REQUIRE(pf && w, "null argument");
     pf->have_global = 0;
+    pf->stats_current = 0;
     return pf_copy_f64(pf, pf->d_w, const_cast<double *>(w), true);
 }
 int gms_pf_get_weights(gms_pf *pf, double *w) {
@@ -648,6 +665,7 @@ int gms_pf_score(gms_pf *pf, const gms_beam *beams, int32_t B) {       // GridMa
     gms_launch_pf_prep(pf, m->d_beams, B, m->max_beams);
     gms_launch_pf_score(pf, B);
     pf->have_global = 0;
+    pf->stats_current = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
 }
@@ -660,6 +678,7 @@ int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B) {
     gms_launch_pf_prep(pf, dev_beams, B, B);
     gms_launch_pf_score(pf, B);
     pf->have_global = 0;
+    pf->stats_current = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
 }
@@ -667,8 +686,10 @@ int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B) {
 int gms_pf_set_poses_dev(gms_pf *pf, const float *dev_xytheta) {
     REQUIRE(pf && dev_xytheta, "null argument");
     HIPCHK(hipSetDevice(pf->map->device));
-    gms_launch_pf_set_poses_aos(pf, dev_xytheta);
+    HIPCHK(hipMemcpyAsync(pf->d_pose, dev_xytheta, (size_t)pf->n * pf->n_maps * 3 * sizeof(float),
+                          hipMemcpyDeviceToDevice, pf->map->stream));
     pf->have_global = 0;
+    pf->stats_current = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
 }
@@ -707,8 +728,8 @@ int gms_pf_normalize(gms_pf *pf, gms_pf_stats *stats) {                 // SLAM.
     HIPCHK(hipSetDevice(pf->map->device));
     gms_launch_pf_partials(pf, pf->d_partials);
     gms_launch_pf_apply_partials(pf, pf->d_partials, pf->d_global);
-    gms_launch_pf_global_stats(pf);
     pf->have_global = 1;
+    pf->stats_current = 1;
     HIPCHK(hipGetLastError());
     if (stats) return gms_pf_get_stats(pf, stats);
     return GMS_OK;
@@ -731,9 +752,18 @@ int gms_pf_local_partials(gms_pf *pf, double *dev_partials) {
 int gms_pf_apply_partials(gms_pf *pf, const double *dev_partials, void *dev_packed) {
     REQUIRE(pf && dev_partials && dev_packed, "null argument");
     HIPCHK(hipSetDevice(pf->map->device));
-    REQUIRE(dev_packed != pf->d_global, "dev_packed must be caller-owned");
     gms_launch_pf_apply_partials(pf, dev_partials, reinterpret_cast<PackedParticle *>(dev_packed));
     pf->have_global = 0;
+    pf->stats_current = 1;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_pf_stats_from_partials(gms_pf *pf, const double *dev_partials) {
+    REQUIRE(pf && dev_partials, "null argument");
+    HIPCHK(hipSetDevice(pf->map->device));
+    gms_launch_pf_stats_only(pf, dev_partials, pf->d_stats + pf->n_maps);
+    pf->stats_current = 2;        // current-particle statistics live in the second slot
     HIPCHK(hipGetLastError());
     return GMS_OK;
 }
@@ -741,7 +771,7 @@ int gms_pf_apply_partials(gms_pf *pf, const double *dev_partials, void *dev_pack
 int gms_pf_pack(gms_pf *pf, void *dev_packed) {
     REQUIRE(pf && dev_packed, "null argument");
     HIPCHK(hipSetDevice(pf->map->device));
-    gms_launch_pf_pack(pf, reinterpret_cast<PackedParticle *>(dev_packed), pf->n);
+    gms_launch_pf_pack(pf, reinterpret_cast<PackedParticle *>(dev_packed));
     HIPCHK(hipGetLastError());
     return GMS_OK;
 }
@@ -752,7 +782,7 @@ int gms_pf_import_global(gms_pf *pf, const void *dev_packed_global) {
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipMemcpyAsync(pf->d_global, dev_packed_global, (size_t)pf->n_maps * pf->n_global * sizeof(PackedParticle),
                           hipMemcpyDeviceToDevice, m->stream));
-    gms_launch_pf_global_stats(pf);
+    gms_launch_pf_unpack_weights(pf);
     pf->have_global = 1;
     HIPCHK(hipGetLastError());
     return GMS_OK;
@@ -763,21 +793,31 @@ static int ensure_global(gms_pf *pf) {
     if (pf->have_global) return GMS_OK;
     if (pf->offset != 0 || pf->n_global != pf->n)
         return fail(GMS_ERR_STATE, "sharded filter: all-gather the packed particles and call gms_pf_import_global first");
-    gms_launch_pf_pack(pf, pf->d_global, pf->n_global);
-    gms_launch_pf_global_stats(pf);
+    gms_launch_pf_pack(pf, pf->d_global);
     pf->have_global = 1;
     return GMS_OK;
 }
 
 int gms_pf_weighted_pose(gms_pf *pf, float *out) {                      // SLAM.java:165-178
     REQUIRE(pf && out, "null argument");
-    HIPCHK(hipSetDevice(pf->map->device));
-    int rc = ensure_global(pf);
-    if (rc) return rc;
-    rc = pull_stats(pf);
-    if (rc) return rc;
+    gms_map *m = pf->map;
+    HIPCHK(hipSetDevice(m->device));
+    if (!pf->stats_current) {
+        // the particles changed since the last normalise (resample, set_poses, ...): the reference
+        // recomputes the pose from whatever the particles are now (J/app/GridMapApp.java:192)
+        if (pf->offset != 0 || pf->n_global != pf->n)
+            return fail(GMS_ERR_STATE, "sharded filter: gms_pf_local_partials -> all-reduce -> gms_pf_stats_from_partials first");
+        gms_launch_pf_partials(pf, pf->d_partials);
+        gms_launch_pf_stats_only(pf, pf->d_partials, pf->d_stats + pf->n_maps);
+        pf->stats_current = 2;
+    }
+    const PfStatsDev *src = pf->d_stats + (pf->stats_current == 2 ? pf->n_maps : 0);
+    HIPCHK(hipStreamSynchronize(m->stream));
+    PfStatsDev *tmp = pf->h_stats;      // staging; the cached normalise statistics are re-pulled on demand
+    HIPCHK(hipMemcpyAsync(tmp, src, (size_t)pf->n_maps * sizeof(PfStatsDev), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
     for (int32_t mi = 0; mi < pf->n_maps; mi++)
-        for (int k = 0; k < 3; k++) out[3 * mi + k] = pf->h_stats[mi].wpose[k];
+        for (int k = 0; k < 3; k++) out[3 * mi + k] = tmp[mi].wpose[k];
     return GMS_OK;
 }
 
@@ -792,8 +832,9 @@ static int do_resample(gms_pf *pf, const double *r01, double fraction, int32_t *
     memcpy(h_r, r01, (size_t)pf->n_maps * sizeof(double));
     HIPCHK(hipMemcpyAsync(pf->d_r01, h_r, (size_t)pf->n_maps * sizeof(double), hipMemcpyHostToDevice, m->stream));
     gms_launch_pf_resample(pf, fraction);
-    std::swap(pf->d_x, pf->d_x2); std::swap(pf->d_y, pf->d_y2); std::swap(pf->d_th, pf->d_th2); std::swap(pf->d_w, pf->d_w2);
+    std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_w, pf->d_w2);
     pf->have_global = 0;
+    pf->stats_current = 0;
     HIPCHK(hipGetLastError());
     if (indices) {
         HIPCHK(hipMemcpyAsync(indices, pf->d_idx, (size_t)pf->n * pf->n_maps * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
@@ -833,6 +874,7 @@ int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B) {   // Gri
     gms_launch_pf_prep(pf, m->d_beams, B, m->max_beams);
     gms_launch_pf_refine(pf, B);
     pf->have_global = 0;
+    pf->stats_current = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
 }

@@ -15,6 +15,7 @@ struct GridDev {
     int64_t cells;        // W*H
     double posx, posy;    // (double) position.x / .y
     double res;           // (double) resolution
+    double rinv;          // RN(1.0 / res), for j_cell_of
     float resf;           // resolution
     double l_free, l_occ; // log-odds increments
     int32_t extra;        // RayIterator additionalSteps
@@ -47,7 +48,8 @@ struct PfStatsDev {
     int32_t n_ambiguous;
 };
 
-#define GMS_PARTIAL_STRIDE 5   // {sum, max, first-argmax index, n_zero, max_logw} per block
+#define GMS_SCORE_MAXSEG 32
+#define GMS_PARTIAL_STRIDE 9   // per block: sum w, max w, first argmax, n_zero, max logw, sum w^2, sum x*w, sum y*w, sum th*w
 
 // packed particle exchanged by the all-gather (24 B)
 struct PackedParticle {
@@ -71,12 +73,20 @@ struct gms_map {
     hipStream_t stream;
     double *d_log;        // [n_maps][H][W]
     double *d_lik;        // [n_maps][H][W]
+    double *d_fac;        // [n_maps][fac_stride]: per-cell scoring factor f(likelihood) (GridMap.java:285-288),
+                          // kept in step with d_lik; entry [cells] of each map is the neutral factor 1.0
+    int64_t fac_stride;   // cells + 16
     uint32_t *d_cnt;      // [n_maps][H][W] per-scan packed counts, zero between calls
-    int32_t *d_bbox;      // [n_maps][4] xmin,ymin,xmax,ymax of the cells the last scan changed
+    int32_t *d_bbox;      // [2][n_maps][4] encoded box of the cells changed since the last likelihood build;
+                          // double-buffered: k_apply clears the idle half, so no memset is ever queued
+    int32_t bbox_cur;     // half in use
+    int32_t bbox_dirty;   // an integrate ran since the last likelihood build
     double *d_taps;       // [ktaps]
     gms_beam *d_beams;    // [n_maps][max_beams] staging
     float *d_poses;       // [n_maps][3] staging
     double *d_scratch;    // small device scratch
+    int32_t score_variant;    // 0: wavefront per particle; 1: lane per particle (k_score_b); 2: cache-blocked (k_score_c, default)
+    int32_t score_segments;   // k_score_b beam segments per workgroup (0 = auto)
     int32_t need_full_build;  // likelihood field must be rebuilt everywhere (upload/reset/copy)
     gms_beam *h_beams;    // pinned staging
     float *h_poses;       // pinned staging
@@ -95,19 +105,21 @@ struct gms_pf {
     int64_t offset;       // global index of particle 0
     int64_t n_global;
     int32_t n_maps;
-    float *d_x, *d_y, *d_th;        // [n_maps][n] current poses
-    float *d_x2, *d_y2, *d_th2;     // resample double buffer
+    float *d_pose;                  // [n_maps][n][3] current poses x,y,theta (as at the boundary)
+    float *d_pose2;                 // resample double buffer
     double *d_w, *d_w2;             // [n_maps][n] weights
     double *d_logw, *d_logw2;       // [n_maps][n] sum(log factor)
     float *d_cs;                    // [n_maps][n][2] float-rounded cos/sin of theta
     double *d_hitbeams;             // [n_maps][max_beams][2] compacted hit beams
+    double *d_part;                 // [n_maps][GMS_SCORE_MAXSEG][n] per-segment products (k_score_c)
     int32_t *d_nhit;                // [n_maps]
     double *d_partials;             // [n_maps][nblk_global][GMS_PARTIAL_STRIDE]
-    double *d_partials2;            // second-phase partials [n_maps][nblk_global][4]
     PackedParticle *d_global;       // [n_maps][n_global] source population (own copy when unsharded)
+    double *d_wdense;               // [n_maps][n_global] its weights, dense (scan input)
     double *d_chunk_tot;            // [n_maps][nchunks] scan chunk totals / offsets
     double *d_cum;                  // [n_maps][n_global] in-chunk inclusive sums
-    PfStatsDev *d_stats;            // [n_maps]
+    PfStatsDev *d_stats;            // [2][n_maps]: [0] of the last normalise, [1] of the current particles (recomputed on demand)
+    int32_t stats_current;          // d_stats[0] still describes the current particles
     PfStatsDev *h_stats;            // pinned
     double *d_r01;                  // [n_maps]
     int32_t *d_idx;                 // [n_maps][n]
@@ -116,7 +128,8 @@ struct gms_pf {
 };
 
 // ---- kernel launchers (gms_map_kernels.hip / gms_pf_kernels.hip) -----------------------------
-void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses);
+void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
+                        int32_t pose_stride);
 void gms_launch_trace_scan(gms_map *m, const gms_beam *d_beams, int32_t B, const float *d_pose,
                            int32_t *d_cells, uint8_t *d_cls, int32_t cap, int32_t *d_counts);
 void gms_launch_trace_ray(gms_map *m, float x0, float y0, float x1, float y1, int32_t extra,
@@ -125,20 +138,20 @@ void gms_launch_apply_ray(gms_map *m, RayIn ray);
 void gms_launch_apply_counts(gms_map *m);
 void gms_launch_likelihood(gms_map *m, int32_t dirty_only);
 void gms_launch_fill(gms_map *m, double *d, double v, int64_t n);
+void gms_launch_factors(gms_map *m);   // d_fac from d_lik (after an upload / copy)
 void gms_launch_get_raw(gms_map *m, int32_t mi, int32_t x, int32_t y, double *d_out2);
 void gms_launch_debug_f32(gms_map *m, int32_t op, const float *d_a, float *d_out, int64_t n);
 
 void gms_launch_pf_init(gms_pf *pf);
 void gms_launch_pf_prep(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);
-void gms_launch_pf_set_poses_aos(gms_pf *pf, const float *d_xytheta);
 void gms_launch_pf_score(gms_pf *pf, int32_t B);
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials);
-void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed, int64_t stride);
+void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed);
 void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local);
-void gms_launch_pf_global_stats(gms_pf *pf);
+void gms_launch_pf_stats_only(gms_pf *pf, const double *d_partials, PfStatsDev *d_stats_out);
+void gms_launch_pf_unpack_weights(gms_pf *pf);
 void gms_launch_pf_resample(gms_pf *pf, double fraction /* <0: unconditional */);
 void gms_launch_pf_refine(gms_pf *pf, int32_t B);
-void gms_launch_pose_from_pf(gms_map *m, gms_pf *pf, int32_t which, float *d_poses);
 
 // profiling brackets
 void gms_prof_begin(gms_map *m, int32_t k);

@@ -23,62 +23,146 @@ __device__ __forceinline__ void bbox_decode(const int32_t *bb, int32_t W, int32_
     x0 = W - 1 - bb[0]; y0 = H - 1 - bb[1]; x1 = bb[2]; y1 = bb[3];   // [x0,x1) x [y0,y1)
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ray cast in two phases inside one workgroup of RC_RAYS rays x 64 lanes.
+//
+// The only truly serial part of RayIterator.next (J/slam/RayIterator.java:117-123) is the float
+// `error` recurrence that decides "y step or x step"; everything else (cell coordinates, distance,
+// sensor class, map update) is a function of how many y steps precede step k.
+//   phase A  one lane per ray runs just that recurrence (compare, select, add: the exact float
+//            operations of the reference, in order) and records the decisions as bit words in LDS,
+//            with the running count of y steps per word.
+//   phase B  one wavefront per ray: lane j of iteration i owns step k = 64 i + j, rebuilds
+//            (x_k, y_k) from a popcount, and does the per-cell work of GridMap.applyMeasurement
+//            (GridMap.java:215-223) in parallel.
+// hasNext (:108) stops at the first out-of-bounds cell; x and y move monotonically, so step k is
+// emitted iff cell 0 and cell k are both inside, and no walk is longer than W + H + 1 steps.
+// ---------------------------------------------------------------------------------------------
+#ifndef RC_RAYS
+#define RC_RAYS 4      // measured on MI355X at C3: 4 -> 18 us, 8 -> 20 us, 16 -> 24 us per scan
+#endif
+#define RC_THREADS (RC_RAYS * 64)
+
+struct RayMeta {
+    int32_t x0, y0, x_inc, y_inc, n_eff, hit;
+    float sx, sy, measured;
+};
+
 template <bool TRACE>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(RC_THREADS)
 k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride,
-          const float *__restrict__ poses, const RayIn *__restrict__ single, uint32_t *__restrict__ cnt,
-          int32_t *__restrict__ bbox, int32_t *__restrict__ t_cells, uint8_t *__restrict__ t_cls, int32_t cap,
-          int32_t *__restrict__ t_counts) {
+          const float *__restrict__ poses, int32_t pose_stride, const RayIn *__restrict__ single,
+          uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox, int32_t *__restrict__ t_cells,
+          uint8_t *__restrict__ t_cls, int32_t cap, int32_t *__restrict__ t_counts, int32_t nw_max) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *s_words = reinterpret_cast<uint32_t *>(smem);            // [nw_max][RC_RAYS]
+    uint32_t *s_ybase = s_words + (size_t)nw_max * RC_RAYS;            // [nw_max][RC_RAYS]
+    __shared__ RayMeta s_meta[RC_RAYS];
+
     const int32_t mi = blockIdx.y;
-    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = b < B;
+    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    RayIn ray;
-    if (single) {
-        ray = *single;
-    } else if (active) {
-        ray = make_ray(g, beams[(size_t)mi * beam_stride + b], poses + 3 * mi);
-    } else {
-        ray.sx = ray.sy = ray.ex = ray.ey = ray.measured = 0.0f;
-        ray.hit = 0;
+    // ---- phase A: wave 0, lane r = ray r of this workgroup -------------------------------------
+    if (wave == 0 && lane < RC_RAYS) {
+        const int32_t b = blockIdx.x * RC_RAYS + lane;
+        RayMeta mt;
+        mt.n_eff = 0; mt.x0 = mt.y0 = mt.x_inc = mt.y_inc = mt.hit = 0; mt.sx = mt.sy = mt.measured = 0.0f;
+        if (b < B) {
+            RayIn ray;
+            if (single) ray = *single;
+            else ray = make_ray(g, beams[(size_t)mi * beam_stride + b], poses + (size_t)pose_stride * mi);
+            RayDev r;
+            ray_init(r, ray.sx + 0.5f, ray.sy + 0.5f, ray.ex + 0.5f, ray.ey + 0.5f, g.extra);   // GridMap.java:210
+            mt.x0 = r.x; mt.y0 = r.y; mt.x_inc = r.x_inc; mt.y_inc = r.y_inc;
+            mt.sx = ray.sx; mt.sy = ray.sy; mt.measured = ray.measured; mt.hit = ray.hit;
+            const bool inb0 = !(r.x < 0 || r.x >= g.W || r.y < 0 || r.y >= g.H);
+            mt.n_eff = (inb0 && r.n > 0) ? min(r.n, g.W + g.H + 1) : 0;
+            float err = r.error;
+            const float ndx = -r.dx, dy = r.dy;
+#ifdef GMS_EXP_HALF_A
+            const int32_t nwords = (mt.n_eff + 63) >> 6;
+#else
+            const int32_t nwords = (mt.n_eff + 31) >> 5;
+#endif
+            uint32_t ycount = 0;
+            for (int32_t w = 0; w < nwords; ++w) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int32_t j = 0; j < 32; ++j) {
+                    const bool c = err > 0.0f;                 // RayIterator.java:117
+                    word |= (c ? 1u : 0u) << j;
+                    err = err + (c ? ndx : dy);                // :119 / :122 (a - b == a + (-b) exactly)
+                }
+                s_words[w * RC_RAYS + lane] = word;
+                s_ybase[w * RC_RAYS + lane] = ycount;
+                ycount += __popc(word);
+            }
+        }
+        s_meta[lane] = mt;
     }
+    __syncthreads();
 
+#ifdef GMS_EXP_NO_PHASE_B
+    if (s_meta[0].n_eff >= 0) return;
+#endif
+    // ---- phase B: wave v owns ray v ------------------------------------------------------------
+    const int32_t b = blockIdx.x * RC_RAYS + wave;
+    const RayMeta mt = s_meta[wave];
     int32_t bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;   // encoded bbox contributions
     int32_t count = 0;
-    if (active) {
-        RayDev r;
-        ray_init(r, ray.sx + 0.5f, ray.sy + 0.5f, ray.ex + 0.5f, ray.ey + 0.5f, g.extra);   // GridMap.java:210
-        uint32_t *mcnt = TRACE ? nullptr : cnt + (size_t)mi * g.cells;
-        while (ray_has_next(r, g.W, g.H)) {                                                  // :211
-            const int32_t cx = r.x, cy = r.y;
-            ray_step(r);
-            const float d = cell_distance(ray.sx, ray.sy, cx, cy);                           // :215-217
-            const int32_t cls = sensor_class(d, ray.measured, ray.hit, g.half_tol);          // :223
+    uint32_t *mcnt = TRACE ? nullptr : cnt + (size_t)mi * g.cells;
+#ifdef GMS_EXP_B_ONCE
+    for (int32_t k = lane; k < min(mt.n_eff, 64); k += 64) {
+#else
+    for (int32_t k = lane; k < mt.n_eff; k += 64) {
+#endif
+        const int32_t w = k >> 5, j = k & 31;
+        const uint32_t word = s_words[w * RC_RAYS + wave];
+        const int32_t ny = (int32_t)(s_ybase[w * RC_RAYS + wave] + __popc(word & ((1u << j) - 1u)));
+        const int32_t nx = k - ny;
+        const int32_t cx = mt.x0 + mt.x_inc * nx, cy = mt.y0 + mt.y_inc * ny;
+        const bool valid = !(cx < 0 || cx >= g.W || cy < 0 || cy >= g.H);                 // :108
+        if (valid) {
+            const float d = cell_distance(mt.sx, mt.sy, cx, cy);                          // GridMap.java:215-217
+            const int32_t cls = sensor_class(d, mt.measured, mt.hit, g.half_tol);         // :223
             if (TRACE) {
-                if (count < cap) {
-                    const size_t o = (size_t)b * cap + count;
+                if (k < cap) {
+                    const size_t o = (size_t)b * cap + k;
                     if (t_cells) { t_cells[2 * o] = cx; t_cells[2 * o + 1] = cy; }
                     if (t_cls) t_cls[o] = (uint8_t)cls;
                 }
             } else if (cls != 1) {
+#ifndef GMS_EXP_NO_ATOMIC
                 atomicAdd(&mcnt[(size_t)cy * g.W + cx], cls == 0 ? 1u : 0x10000u);
+#endif
                 bx0 = max(bx0, g.W - 1 - cx); by0 = max(by0, g.H - 1 - cy);
                 bx1 = max(bx1, cx + 1);       by1 = max(by1, cy + 1);
             }
-            count++;
         }
+        count += __popcll(__ballot(valid));
     }
     if (TRACE) {
-        if (active && t_counts) t_counts[b] = count;
+        if (lane == 0 && b < B && t_counts) t_counts[b] = count;
     } else {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             bx0 = max(bx0, __shfl_xor(bx0, o, GMS_WAVE)); by0 = max(by0, __shfl_xor(by0, o, GMS_WAVE));
             bx1 = max(bx1, __shfl_xor(bx1, o, GMS_WAVE)); by1 = max(by1, __shfl_xor(by1, o, GMS_WAVE));
         }
-        if ((threadIdx.x & 63) == 0 && bx1 > 0) {
+        // workgroup-level max in LDS, then at most four global atomics per workgroup, and only where they
+        // would raise the box (same-address global atomics serialise in L2: ~10 ns each)
+        __shared__ int32_t s_bb[4];
+        if (threadIdx.x < 4) s_bb[threadIdx.x] = 0;
+        __syncthreads();
+        if (lane == 0 && bx1 > 0) {
+            atomicMax(&s_bb[0], bx0); atomicMax(&s_bb[1], by0); atomicMax(&s_bb[2], bx1); atomicMax(&s_bb[3], by1);
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
             int32_t *bb = bbox + 4 * mi;
-            atomicMax(&bb[0], bx0); atomicMax(&bb[1], by0); atomicMax(&bb[2], bx1); atomicMax(&bb[3], by1);
+            const int32_t v = s_bb[threadIdx.x];
+            if (v > 0 && v > __hip_atomic_load(&bb[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&bb[threadIdx.x], v);
         }
     }
 }
@@ -102,8 +186,10 @@ __global__ void k_trace_ray(int32_t W, int32_t H, float x0, float y0, float x1, 
 #define APPLY_TW 256
 #define APPLY_TH 4
 __global__ void __launch_bounds__(256)
-k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox) {
+k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
+        int32_t *__restrict__ bbox_idle) {
     const int32_t mi = blockIdx.z;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) bbox_idle[4 * mi + threadIdx.x] = 0;
     int32_t x0, y0, x1, y1;
     bbox_decode(bbox + 4 * mi, g.W, g.H, x0, y0, x1, y1);
     const int32_t tx0 = blockIdx.x * APPLY_TW, ty0 = blockIdx.y * APPLY_TH;
@@ -127,93 +213,173 @@ k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Likelihood field.  One workgroup = one LK_TW x LK_TH output tile.
-//   phase 1: thresholded cells of the tile + k-halo -> LDS codes (0 -> 0.0, 1 -> 0.5, 2 -> 1.0,
-//            255 -> outside the map, tap skipped: Util.java:396,418)
-//   phase 2: horizontal sums for the tile's rows + k-halo rows -> LDS doubles
-//   phase 3: vertical sums -> likelihoodData
+// Likelihood field (GridMap.computeLikelihoodMap, GridMap.java:233-250 + Util.doGaussianBlurdSeparable,
+// Util.java:378-426).  Persistent workgroups walk LK_TW x LK_TH output tiles:
+//   phase 1  threshold the tile + k-halo into LDS as doubles {0, 0.5, 1} (GridMap.java:239-244).
+//            Cells outside the map are staged as 0.0: the reference skips those taps
+//            (Util.java:396,418), and `total + tap*0.0` leaves a non-negative total unchanged, so the
+//            sums stay bit-identical without a branch per tap.
+//   uniform  if every staged cell holds the same value c and the halo is inside the map, every output
+//            of the tile is the same constant (the in-order tap sums of c): written without blurring.
+//            Free space and unexplored space -- most of a map -- take this path.
+//   phase 2  horizontal sums, 8 outputs per thread from a register window, taps in the reference's
+//            order, multiply then add (no FMA)                                  (Util.java:387-404)
+//   phase 3  vertical sums the same way, coalesced store of likelihoodData      (Util.java:410-425)
+// dirty_only: tiles that cannot have changed (outside the touched box dilated by k) are skipped.
 // ---------------------------------------------------------------------------------------------
 #define LK_TW 64
 #define LK_TH 32
+#define LK_STRIP 8
 
-template <int KH>   // KH > 0: compile-time half width; KH == 0: runtime g.khalf
+template <int KH>   // KH > 0: compile-time half width; KH == 0: runtime g.khalf (generic, slower)
 __global__ void __launch_bounds__(256)
-k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik,
-             const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
+k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
+             int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
              int32_t tiles_x, int32_t tiles_y) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int32_t k = KH > 0 ? KH : g.khalf;
     const int32_t ntaps = 2 * k + 1;
-    const int32_t RW = LK_TW + 2 * k;          // staged columns
-    const int32_t RH = LK_TH + 2 * k;          // staged rows
-    double *hs = reinterpret_cast<double *>(smem);                       // [RH][LK_TW]
-    double *taps = hs + (size_t)RH * LK_TW;                              // [ntaps]
-    unsigned char *codes = reinterpret_cast<unsigned char *>(taps + ntaps);   // [RH][RW]
+    const int32_t RW = LK_TW + 2 * k, RH = LK_TH + 2 * k;     // staged columns / rows
+    const int32_t PIN = RW + 1, PHS = LK_TW + 1;              // LDS pitches (doubles)
+    double *in_s = reinterpret_cast<double *>(smem);          // [RH][PIN]
+    double *hs = in_s + (size_t)RH * PIN;                     // [RH][PHS]
+    double *taps_s = hs + (size_t)RH * PHS;                   // [ntaps] (generic path)
+    __shared__ int32_t s_mask;
 
     const int32_t mi = blockIdx.y;
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each
-    // XCD a contiguous band of tiles and let the halo re-reads hit its own L2.
-    int32_t bid = blockIdx.x;
-    const int32_t ntiles = tiles_x * tiles_y;
-    if ((ntiles & 7) == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
-    const int32_t tx0 = (bid % tiles_x) * LK_TW, ty0 = (bid / tiles_x) * LK_TH;
-
-    if (dirty_only) {
-        int32_t x0, y0, x1, y1;
-        bbox_decode(bbox + 4 * mi, g.W, g.H, x0, y0, x1, y1);
-        if (x1 <= 0) return;
-        // outputs that can change: the touched box dilated by k
-        if (tx0 >= x1 + k || tx0 + LK_TW <= x0 - k || ty0 >= y1 + k || ty0 + LK_TH <= y0 - k) return;
-    }
-
     const double *mlog = logd + (size_t)mi * g.cells;
-    for (int32_t i = threadIdx.x; i < ntaps; i += blockDim.x) taps[i] = taps_g[i];
-
-    // phase 1
-    for (int32_t idx = threadIdx.x; idx < RH * RW; idx += blockDim.x) {
-        const int32_t r = idx / RW, c = idx - r * RW;
-        const int32_t gy = ty0 - k + r, gx = tx0 - k + c;
-        unsigned char code = 255;
-        if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
-            const double v = mlog[(size_t)gy * g.W + gx];
-            code = v > 0.0 ? 2 : (v < 0.0 ? 0 : 1);                       // GridMap.java:239-244
-        }
-        codes[idx] = code;
-    }
-    __syncthreads();
-
-    // phase 2 (Util.java:387-404)
-    for (int32_t idx = threadIdx.x; idx < RH * LK_TW; idx += blockDim.x) {
-        const int32_t r = idx / LK_TW, c = idx - r * LK_TW;
-        const int32_t gy = ty0 - k + r;
-        double total = 0.0;
-        if (gy >= 0 && gy < g.H) {
-            const unsigned char *row = codes + r * RW + c;
-#pragma unroll
-            for (int32_t i = 0; i < (KH > 0 ? 2 * KH + 1 : ntaps); i++) {
-                const unsigned char cd = row[i];
-                if (cd != 255) total += taps[i] * ((double)cd * 0.5);
-            }
-        }
-        hs[idx] = total;
-    }
-    __syncthreads();
-
-    // phase 3 (Util.java:410-425)
     double *mlik = lik + (size_t)mi * g.cells;
-    for (int32_t idx = threadIdx.x; idx < LK_TH * LK_TW; idx += blockDim.x) {
-        const int32_t r = idx / LK_TW, c = idx - r * LK_TW;
-        const int32_t gy = ty0 + r, gx = tx0 + c;
-        if (gx < g.W && gy < g.H) {
-            double total = 0.0;
-#pragma unroll
-            for (int32_t i = 0; i < (KH > 0 ? 2 * KH + 1 : ntaps); i++) {
-                const int32_t y2 = gy - k + i;
-                if (y2 >= 0 && y2 < g.H) total += taps[i] * hs[(r + i) * LK_TW + c];
+    double *mfac = fac + (size_t)mi * fac_stride;
+    // tile rectangle to process: the whole map, or the tiles that intersect the touched box dilated
+    // by k (enumerated directly, so the persistent workgroups share the dirty tiles evenly)
+    int32_t qx0 = 0, qy0 = 0, qnx = tiles_x, qny = tiles_y;
+    if (dirty_only) {
+        int32_t bx0, by0, bx1, by1;
+        bbox_decode(bbox + 4 * mi, g.W, g.H, bx0, by0, bx1, by1);
+        if (bx1 <= 0) return;
+        const int32_t x_lo = max(bx0 - k, 0), y_lo = max(by0 - k, 0);
+        const int32_t x_hi = min(bx1 + k, g.W) - 1, y_hi = min(by1 + k, g.H) - 1;     // inclusive
+        qx0 = x_lo / LK_TW; qy0 = y_lo / LK_TH;
+        qnx = x_hi / LK_TW - qx0 + 1; qny = y_hi / LK_TH - qy0 + 1;
+    }
+    const int32_t ntiles = qnx * qny;
+    if (KH == 0)
+        for (int32_t i = threadIdx.x; i < ntaps; i += blockDim.x) taps_s[i] = taps_g[i];
+
+    for (int32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // XCD-aware order (full rebuild): workgroups b and b+8 share an XCD, so each XCD walks a
+        // contiguous band of tiles and the halo re-reads hit its own L2
+        int32_t tile = t;
+        if (!dirty_only && (ntiles & 7) == 0) tile = (t & 7) * (ntiles >> 3) + (t >> 3);
+        const int32_t tx0 = (qx0 + tile % qnx) * LK_TW, ty0 = (qy0 + tile / qnx) * LK_TH;
+
+        __syncthreads();                                       // previous tile's LDS reads are done
+        if (threadIdx.x == 0) s_mask = 0;
+        __syncthreads();
+
+        // ---- phase 1
+        int32_t seen = 0;                                      // bit c: a cell of code c; bit 3: outside the map
+        for (int32_t idx = threadIdx.x; idx < RH * RW; idx += blockDim.x) {
+            const int32_t r = idx / RW, c = idx - r * RW;
+            const int32_t gy = ty0 - k + r, gx = tx0 - k + c;
+            double val = 0.0;
+            if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
+                const double v = mlog[(size_t)gy * g.W + gx];
+                const int32_t code = v > 0.0 ? 2 : (v < 0.0 ? 0 : 1);             // GridMap.java:239-244
+                val = 0.5 * (double)code;
+                seen |= 1 << code;
+            } else {
+                seen |= 8;
             }
-            mlik[(size_t)gy * g.W + gx] = total;
+            in_s[r * PIN + c] = val;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) seen |= __shfl_xor(seen, o, GMS_WAVE);
+        if ((threadIdx.x & 63) == 0) atomicOr(&s_mask, seen);
+        __syncthreads();
+        const int32_t mask = s_mask;
+
+        if (mask == 1 || mask == 2 || mask == 4) {
+            // ---- uniform tile: every in-order sum sees the same inputs
+            const double cval = mask == 1 ? 0.0 : (mask == 2 ? 0.5 : 1.0);
+            double hc = 0.0;
+            for (int32_t i = 0; i < ntaps; i++) hc += taps_g[i] * cval;           // Util.java:393-401
+            double vc = 0.0;
+            for (int32_t i = 0; i < ntaps; i++) vc += taps_g[i] * hc;             // Util.java:415-422
+            const double fc = lik_factor(g, vc);
+            for (int32_t idx = threadIdx.x; idx < LK_TH * LK_TW; idx += blockDim.x) {
+                const int32_t r = idx / LK_TW, c = idx - r * LK_TW;
+                const size_t o = (size_t)(ty0 + r) * g.W + tx0 + c;               // tile is inside the map (bit 3 clear)
+                mlik[o] = vc;
+                mfac[o] = fc;
+            }
+            continue;
+        }
+
+        if (KH > 0) {
+            // ---- phase 2: strips of LK_STRIP outputs along x
+            for (int32_t sidx = threadIdx.x; sidx < RH * (LK_TW / LK_STRIP); sidx += blockDim.x) {
+                const int32_t r = sidx / (LK_TW / LK_STRIP), c0 = (sidx - r * (LK_TW / LK_STRIP)) * LK_STRIP;
+                double v[LK_STRIP + 2 * (KH > 0 ? KH : 1)];
+                const double *row = in_s + r * PIN + c0;
+#pragma unroll
+                for (int j = 0; j < LK_STRIP + 2 * KH; j++) v[j] = row[j];
+#pragma unroll
+                for (int o = 0; o < LK_STRIP; o++) {
+                    double total = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 2 * KH + 1; i++) total += taps_g[i] * v[o + i];
+                    hs[r * PHS + c0 + o] = total;
+                }
+            }
+            __syncthreads();
+            // ---- phase 3: strips of LK_STRIP outputs along y
+            {
+                const int32_t c = threadIdx.x & (LK_TW - 1), r0 = (threadIdx.x >> 6) * LK_STRIP;
+                double v[LK_STRIP + 2 * (KH > 0 ? KH : 1)];
+#pragma unroll
+                for (int j = 0; j < LK_STRIP + 2 * KH; j++) v[j] = hs[(r0 + j) * PHS + c];
+                const int32_t gx = tx0 + c;
+#pragma unroll
+                for (int o = 0; o < LK_STRIP; o++) {
+                    double total = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 2 * KH + 1; i++) total += taps_g[i] * v[o + i];
+                    const int32_t gy = ty0 + r0 + o;
+                    if (gx < g.W && gy < g.H) {
+                        mlik[(size_t)gy * g.W + gx] = total;
+                        mfac[(size_t)gy * g.W + gx] = lik_factor(g, total);
+                    }
+                }
+            }
+        } else {
+            // ---- generic half width: one output per thread per step, taps from LDS
+            for (int32_t idx = threadIdx.x; idx < RH * LK_TW; idx += blockDim.x) {
+                const int32_t r = idx / LK_TW, c = idx - r * LK_TW;
+                double total = 0.0;
+                for (int32_t i = 0; i < ntaps; i++) total += taps_s[i] * in_s[r * PIN + c + i];
+                hs[r * PHS + c] = total;
+            }
+            __syncthreads();
+            for (int32_t idx = threadIdx.x; idx < LK_TH * LK_TW; idx += blockDim.x) {
+                const int32_t r = idx / LK_TW, c = idx - r * LK_TW;
+                const int32_t gy = ty0 + r, gx = tx0 + c;
+                if (gx < g.W && gy < g.H) {
+                    double total = 0.0;
+                    for (int32_t i = 0; i < ntaps; i++) total += taps_s[i] * hs[(r + i) * PHS + c];
+                    mlik[(size_t)gy * g.W + gx] = total;
+                    mfac[(size_t)gy * g.W + gx] = lik_factor(g, total);
+                }
+            }
         }
     }
+}
+
+// scoring factors from an existing likelihood field (upload / copy); entry [cells] = neutral 1.0
+__global__ void k_factors(GridDev g, const double *__restrict__ lik, double *__restrict__ fac, int64_t fac_stride) {
+    const int32_t mi = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= g.cells; i += (int64_t)gridDim.x * blockDim.x)
+        fac[(size_t)mi * fac_stride + i] = i < g.cells ? lik_factor(g, lik[(size_t)mi * g.cells + i]) : 1.0;
 }
 
 __global__ void k_fill(double *__restrict__ d, double v, int64_t n) {
@@ -239,19 +405,34 @@ __global__ void k_debug_f32(int32_t op, const float *__restrict__ a, float *__re
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses) {
+static inline int32_t rc_nw_max(const gms_map *m) { return (m->gd.W + m->gd.H + 1 + 31) / 32; }
+static inline size_t rc_smem(const gms_map *m) { return (size_t)rc_nw_max(m) * RC_RAYS * 2 * sizeof(uint32_t); }
+
+template <bool TRACE>
+static void rc_prepare(const gms_map *m) {
+    const size_t smem = rc_smem(m);
+    if (smem > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast<TRACE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem);
+}
+
+void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
+                        int32_t pose_stride) {
     ProfScope ps(m, GMS_K_RAYCAST);
-    dim3 grid((B + 63) / 64, m->n_maps);
-    hipLaunchKernelGGL(k_raycast<false>, grid, dim3(64), 0, m->stream, m->gd, d_beams, B, beam_stride, d_poses,
-                       (const RayIn *)nullptr, m->d_cnt, m->d_bbox, (int32_t *)nullptr, (uint8_t *)nullptr, 0,
-                       (int32_t *)nullptr);
+    rc_prepare<false>(m);
+    dim3 grid((B + RC_RAYS - 1) / RC_RAYS, m->n_maps);
+    hipLaunchKernelGGL(k_raycast<false>, grid, dim3(RC_THREADS), rc_smem(m), m->stream, m->gd, d_beams, B, beam_stride,
+                       d_poses, pose_stride, (const RayIn *)nullptr, m->d_cnt, m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, (int32_t *)nullptr,
+                       (uint8_t *)nullptr, 0, (int32_t *)nullptr, rc_nw_max(m));
 }
 
 void gms_launch_trace_scan(gms_map *m, const gms_beam *d_beams, int32_t B, const float *d_pose, int32_t *d_cells,
                            uint8_t *d_cls, int32_t cap, int32_t *d_counts) {
-    dim3 grid((B + 63) / 64, 1);
-    hipLaunchKernelGGL(k_raycast<true>, grid, dim3(64), 0, m->stream, m->gd, d_beams, B, m->max_beams, d_pose,
-                       (const RayIn *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, d_cells, d_cls, cap, d_counts);
+    rc_prepare<true>(m);
+    dim3 grid((B + RC_RAYS - 1) / RC_RAYS, 1);
+    hipLaunchKernelGGL(k_raycast<true>, grid, dim3(RC_THREADS), rc_smem(m), m->stream, m->gd, d_beams, B, m->max_beams,
+                       d_pose, 3, (const RayIn *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, d_cells, d_cls, cap,
+                       d_counts, rc_nw_max(m));
 }
 
 void gms_launch_trace_ray(gms_map *m, float x0, float y0, float x1, float y1, int32_t extra, int32_t *d_cells,
@@ -267,15 +448,19 @@ void gms_launch_apply_ray(gms_map *m, RayIn ray) {
     RayIn *d_ray = reinterpret_cast<RayIn *>(m->d_beams);
     hipLaunchKernelGGL(k_store_ray, dim3(1), dim3(1), 0, m->stream, d_ray, ray);
     ProfScope ps(m, GMS_K_RAYCAST);
-    hipLaunchKernelGGL(k_raycast<false>, dim3(1, 1), dim3(64), 0, m->stream, m->gd, (const gms_beam *)nullptr, 1,
-                       m->max_beams, (const float *)nullptr, (const RayIn *)d_ray, m->d_cnt, m->d_bbox,
-                       (int32_t *)nullptr, (uint8_t *)nullptr, 0, (int32_t *)nullptr);
+    rc_prepare<false>(m);
+    hipLaunchKernelGGL(k_raycast<false>, dim3(1, 1), dim3(RC_THREADS), rc_smem(m), m->stream, m->gd,
+                       (const gms_beam *)nullptr, 1, m->max_beams, (const float *)nullptr, 3, (const RayIn *)d_ray,
+                       m->d_cnt, m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, (int32_t *)nullptr, (uint8_t *)nullptr, 0,
+                       (int32_t *)nullptr, rc_nw_max(m));
 }
 
 void gms_launch_apply_counts(gms_map *m) {
     ProfScope ps(m, GMS_K_APPLY);
     dim3 grid((m->gd.W + APPLY_TW - 1) / APPLY_TW, (m->gd.H + APPLY_TH - 1) / APPLY_TH, m->n_maps);
-    hipLaunchKernelGGL(k_apply, grid, dim3(256), 0, m->stream, m->gd, m->d_log, m->d_cnt, m->d_bbox);
+    int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4;
+    hipLaunchKernelGGL(k_apply, grid, dim3(256), 0, m->stream, m->gd, m->d_log, m->d_cnt, cur, idle);
+    m->bbox_dirty = 1;
 }
 
 void gms_launch_likelihood(gms_map *m, int32_t dirty_only) {
@@ -283,20 +468,30 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only) {
     const int32_t k = m->gd.khalf;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
     const size_t RH = LK_TH + 2 * k, RW = LK_TW + 2 * k;
-    const size_t smem = RH * LK_TW * sizeof(double) + (2 * k + 1) * sizeof(double) + RH * RW;
-    dim3 grid(tiles_x * tiles_y, m->n_maps);
+    const size_t smem = (RH * (RW + 1) + RH * (LK_TW + 1) + (2 * k + 1)) * sizeof(double);
+    // persistent workgroups: 4 per CU when LDS allows, each walks tiles blockIdx.x, += gridDim.x
+    int32_t blocks = tiles_x * tiles_y;
+    const int32_t cap = (smem <= 40 * 1024 ? 1024 : 512) / (m->n_maps > 4 ? 4 : m->n_maps);
+    if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) & ~7;                      // keep the XCD round-robin aligned
+    dim3 grid(blocks, m->n_maps);
+    const int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;
 #define LK_LAUNCH(KH)                                                                                         \
     do {                                                                                                      \
         if (smem > 48 * 1024)                                                                                 \
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_likelihood<KH>),                           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                       \
         hipLaunchKernelGGL(k_likelihood<KH>, grid, dim3(256), smem, m->stream, m->gd, m->d_log, m->d_lik,     \
-                           m->d_taps, m->d_bbox, dirty_only, tiles_x, tiles_y);                               \
+                           m->d_fac, m->fac_stride, m->d_taps, bb, dirty_only, tiles_x, tiles_y);                                      \
     } while (0)
     if (k == 3) LK_LAUNCH(3);
     else if (k == 5) LK_LAUNCH(5);
     else LK_LAUNCH(0);
 #undef LK_LAUNCH
+}
+
+void gms_launch_factors(gms_map *m) {
+    hipLaunchKernelGGL(k_factors, dim3(1024, m->n_maps), dim3(256), 0, m->stream, m->gd, m->d_lik, m->d_fac, m->fac_stride);
 }
 
 void gms_launch_fill(gms_map *m, double *d, double v, int64_t n) {

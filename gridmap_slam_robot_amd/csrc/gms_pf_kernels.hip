@@ -16,28 +16,35 @@
 #include "gms_device.h"
 
 #define SCAN_CHUNK 64
+#ifndef SCORE_U
+#define SCORE_U 4     // likelihood look-ups in flight per lane in the scoring loops
+#endif
 
 // ---------------------------------------------------------------------------------------------
-__global__ void k_pf_init(float *x, float *y, float *th, double *w, double *logw, int64_t total, double w0) {
+__global__ void k_pf_init(float *pose, double *w, double *logw, int64_t total, double w0) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) { x[i] = 0.0f; y[i] = 0.0f; th[i] = 0.0f; w[i] = w0; logw[i] = 0.0; }
+    if (i < total) { pose[3 * i] = 0.0f; pose[3 * i + 1] = 0.0f; pose[3 * i + 2] = 0.0f; w[i] = w0; logw[i] = 0.0; }
 }
 
-__global__ void k_pf_prep(const float *__restrict__ th, float *__restrict__ cs, int64_t total) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) {
-        float c, s;
-        pose_trig(th[i], c, s);
-        cs[2 * i] = c;
-        cs[2 * i + 1] = s;
+// One launch before scoring: blocks [0, trig_blocks) compute the per-particle float-rounded trig
+// (Transform.java:15-16); the last n_maps blocks compact the beams with wasHit (GridMap.java:269),
+// preserving their order.
+__global__ void __launch_bounds__(256)
+k_pf_prep(const float *__restrict__ pose, float *__restrict__ cs, int64_t total, int32_t trig_blocks,
+          const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride, int32_t out_stride,
+          double *__restrict__ hitbeams, int32_t *__restrict__ nhit) {
+    if ((int32_t)blockIdx.x < trig_blocks) {
+        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < total) {
+            float c, s;
+            pose_trig(pose[3 * i + 2], c, s);
+            cs[2 * i] = c;
+            cs[2 * i + 1] = s;
+        }
+        return;
     }
-}
-
-// one wave per map: order-preserving compaction of the beams with wasHit
-__global__ void __launch_bounds__(64)
-k_compact_beams(const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride, int32_t out_stride,
-                double *__restrict__ hitbeams, int32_t *__restrict__ nhit) {
-    const int32_t mi = blockIdx.x;
+    if (threadIdx.x >= 64) return;
+    const int32_t mi = blockIdx.x - trig_blocks;
     const int32_t lane = threadIdx.x;
     const gms_beam *mb = beams + (size_t)mi * beam_stride;
     double *out = hitbeams + (size_t)mi * out_stride * 2;
@@ -57,17 +64,27 @@ k_compact_beams(const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stri
 }
 
 // ---------------------------------------------------------------------------------------------
-// probabilityOf: factor of one beam end point (GridMap.java:273-288)
+// probabilityOf: one beam end point (GridMap.java:273-288).  The factor f(likelihoodData[cell]) is
+// read from the map's factor table, which the likelihood kernel keeps in step with likelihoodData
+// (same multiply-then-add, same `== 0.5` test: GridMap.java:285-288); a beam whose end point falls
+// outside the map (:276) reads the neutral entry [cells] = 1.0, so the loop has no branch.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double beam_factor(const GridDev &g, const double *__restrict__ lik, const XformDev &t,
-                                              double lx, double ly) {
-    const int32_t gx = j_d2i((xform_x(t, lx, ly) - g.posx) / g.res);   // :273
-    const int32_t gy = j_d2i((xform_y(t, lx, ly) - g.posy) / g.res);   // :274
-    if (!(gx < 0 || gy < 0 || gx >= g.W || gy >= g.H)) {               // :276
-        const double val = lik[(size_t)gy * g.W + gx];                 // :277
-        return val == 0.5 ? g.inv_max : g.z_hit * val + g.c_rand;      // :285-288
-    }
-    return 1.0;   // beam skipped: the product is left alone
+__device__ __forceinline__ uint32_t cell_or_neutral(const GridDev &g, int32_t gx, int32_t gy) {
+    const bool in = (uint32_t)gx < (uint32_t)g.W && (uint32_t)gy < (uint32_t)g.H;    // :276
+    const uint32_t m = in ? 0xffffffffu : 0u;                                       // arithmetic select: no branch
+    return (((uint32_t)gy * (uint32_t)g.W + (uint32_t)gx) & m) | ((uint32_t)g.cells & ~m);
+}
+// fast form (no division, no branch); `guard` accumulates "an exact quotient is needed"
+__device__ __forceinline__ uint32_t beam_cell_fast(const GridDev &g, const XformDev &t, double lx, double ly, bool &guard) {
+    const int32_t gx = j_cell_fast(xform_x(t, lx, ly) - g.posx, g.rinv, guard);     // :273
+    const int32_t gy = j_cell_fast(xform_y(t, lx, ly) - g.posy, g.rinv, guard);     // :274
+    return cell_or_neutral(g, gx, gy);
+}
+// the reference's expression, used for the whole batch when any guard tripped (rare)
+__device__ __forceinline__ uint32_t beam_cell(const GridDev &g, const XformDev &t, double lx, double ly) {
+    const int32_t gx = j_cell_exact(xform_x(t, lx, ly) - g.posx, g.res);
+    const int32_t gy = j_cell_exact(xform_y(t, lx, ly) - g.posy, g.res);
+    return cell_or_neutral(g, gx, gy);
 }
 
 // multiply two (mantissa, exponent) products; scaling by powers of two is exact, so the mantissa
@@ -81,10 +98,9 @@ __device__ __forceinline__ void mx_mul(double &m, int32_t &e, double m2, int32_t
 }
 
 __global__ void __launch_bounds__(256)
-k_score(GridDev g, const double *__restrict__ lik_all, const double *__restrict__ hitbeams,
-        const int32_t *__restrict__ nhit, int32_t beam_stride, const float *__restrict__ px,
-        const float *__restrict__ py, const float *__restrict__ cs, int32_t n, double *__restrict__ w,
-        double *__restrict__ logw) {
+k_score(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const double *__restrict__ hitbeams,
+        const int32_t *__restrict__ nhit, int32_t beam_stride, const float *__restrict__ pose,
+        const float *__restrict__ cs, int32_t n, double *__restrict__ w, double *__restrict__ logw) {
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *sb = reinterpret_cast<double2 *>(smem);
     const int32_t mi = blockIdx.y;
@@ -93,18 +109,41 @@ k_score(GridDev g, const double *__restrict__ lik_all, const double *__restrict_
     for (int32_t i = threadIdx.x; i < nb; i += blockDim.x) sb[i] = hb[i];
     __syncthreads();
 
-    const double *lik = lik_all + (size_t)mi * g.cells;
-    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const double *fac = fac_all + (size_t)mi * fac_stride;
+    const int32_t lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // provably wave-uniform: scalar loads below
     for (int32_t p = blockIdx.x * wpb + wave; p < n; p += gridDim.x * wpb) {
         const size_t gi = (size_t)mi * n + p;
         XformDev t;
         t.c = (double)cs[2 * gi]; t.s = (double)cs[2 * gi + 1];       // Transform.java:15-16
-        t.px = (double)px[gi];    t.py = (double)py[gi];
+        t.px = (double)pose[3 * gi]; t.py = (double)pose[3 * gi + 1];
         double prod = 1.0;                                             // GridMap.java:262
-#pragma unroll 4
-        for (int32_t j = lane; j < nb; j += 64) {
-            const double2 bm = sb[j];
-            prod *= beam_factor(g, lik, t, bm.x, bm.y);
+        // SCORE_U look-ups in flight per lane: indices first, then the gathers, then the factors
+        for (int32_t base = 0; base < nb; base += 64 * SCORE_U) {
+            uint32_t cell[SCORE_U];
+            double2 bm[SCORE_U];
+            bool guard = false;
+#pragma unroll
+            for (int u = 0; u < SCORE_U; u++) {
+                const int32_t j = base + u * 64 + lane;
+                bm[u] = sb[j < nb ? j : 0];
+                const uint32_t c = beam_cell_fast(g, t, bm[u].x, bm[u].y, guard);
+                cell[u] = j < nb ? c : (uint32_t)g.cells;
+            }
+            if (__builtin_expect(guard, 0)) {                          // ~4e-6 of the end points
+                asm volatile("; exact quotients for this batch" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < SCORE_U; u++) {
+                    const int32_t j = base + u * 64 + lane;
+                    const uint32_t c = beam_cell(g, t, bm[u].x, bm[u].y);
+                    cell[u] = j < nb ? c : (uint32_t)g.cells;
+                }
+            }
+            double f[SCORE_U];
+#pragma unroll
+            for (int u = 0; u < SCORE_U; u++) f[u] = fac[cell[u]];
+#pragma unroll
+            for (int u = 0; u < SCORE_U; u++) prod *= f[u];
         }
         int e;
         double mnt = frexp(prod, &e);
@@ -122,16 +161,181 @@ k_score(GridDev g, const double *__restrict__ lik_all, const double *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// blocked reductions.  Block sum shape (identical everywhere): 64-lane xor butterfly per wave,
-// then ((w0 + w1) + w2) + w3 over the four waves.
+// probabilityOf, lane-per-particle form.  A workgroup = 64 particles x S beam segments: lane l of every
+// wavefront owns particle 64*blockIdx.x + l, wavefront s walks the hit beams [s*L, (s+1)*L) in order.
+// The beam (localX, localY) is wave-uniform -> scalar loads, SGPR operands; the 64 end points of one
+// wave-instruction are the same beam seen from 64 neighbouring poses, and consecutive beams move that
+// patch by a couple of cells, so a line fetched into L1 is reused across the following beams.
+// Each lane multiplies its factors sequentially in beam order -- the reference's order
+// (GridMap.java:267-288) -- within a segment; the S segment products are then multiplied in segment
+// order.  With S = 1 (large filters) the product is the reference's, operation for operation.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double block_sum_256(double v, double *lds4) {
+#define SCORE_B_MAXSEG 16
+__global__ void __launch_bounds__(SCORE_B_MAXSEG * 64)
+k_score_b(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const double *__restrict__ hitbeams,
+          const int32_t *__restrict__ nhit, int32_t beam_stride, const float *__restrict__ pose,
+          const float *__restrict__ cs, int32_t n, double *__restrict__ w, double *__restrict__ logw) {
+    __shared__ double s_m[SCORE_B_MAXSEG][64];
+    __shared__ int32_t s_e[SCORE_B_MAXSEG][64];
+    const int32_t mi = blockIdx.y;
+    const int32_t lane = threadIdx.x & 63;
+    const int32_t seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t nseg = blockDim.x >> 6;
+    const int32_t nb = nhit[mi];
+    const int32_t L = (nb + nseg - 1) / nseg;
+    const int32_t j0 = seg * L, j1 = min(nb, j0 + L);
+    const double2 *hb = reinterpret_cast<const double2 *>(hitbeams + (size_t)mi * beam_stride * 2);
+    const double *fac = fac_all + (size_t)mi * fac_stride;
+    const int32_t p = blockIdx.x * 64 + lane;
+    const bool active = p < n;
+    const size_t gi = (size_t)mi * n + (active ? p : 0);
+    XformDev t;
+    t.c = (double)cs[2 * gi]; t.s = (double)cs[2 * gi + 1];           // Transform.java:15-16
+    t.px = (double)pose[3 * gi]; t.py = (double)pose[3 * gi + 1];
+    double prod = 1.0;                                                 // GridMap.java:262
+    for (int32_t base = j0; base < j1; base += SCORE_U) {
+        uint32_t cell[SCORE_U];
+        double2 bm[SCORE_U];
+        bool guard = false;
+#pragma unroll
+        for (int u = 0; u < SCORE_U; u++) {
+            const int32_t j = base + u;
+            bm[u] = hb[j < j1 ? j : j0];                              // wave-uniform
+            const uint32_t c = beam_cell_fast(g, t, bm[u].x, bm[u].y, guard);
+            cell[u] = j < j1 ? c : (uint32_t)g.cells;
+        }
+        if (__builtin_expect(guard, 0)) {                              // ~4e-6 of the end points
+            asm volatile("; exact quotients for this batch" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < SCORE_U; u++) {
+                const int32_t j = base + u;
+                const uint32_t c = beam_cell(g, t, bm[u].x, bm[u].y);
+                cell[u] = j < j1 ? c : (uint32_t)g.cells;
+            }
+        }
+        double f[SCORE_U];
+#pragma unroll
+        for (int u = 0; u < SCORE_U; u++) f[u] = fac[cell[u]];
+#pragma unroll
+        for (int u = 0; u < SCORE_U; u++) prod *= f[u];
+    }
+    int e;
+    double mnt = frexp(prod, &e);
+    s_m[seg][lane] = mnt; s_e[seg][lane] = e;
+    __syncthreads();
+    if (seg == 0 && active) {
+        for (int32_t k = 1; k < nseg; k++) mx_mul(mnt, e, s_m[k][lane], s_e[k][lane]);
+        w[gi] = ldexp(mnt, e);
+        logw[gi] = log(mnt) + (double)e * 0.6931471805599453;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// probabilityOf, cache-blocked form (the default).  PMC counters on MI355X show the two kernels above
+// bound by L2->L1 line fills (TCP_PENDING_STALL, TA_ADDR_STALLED_BY_TC: every 8-byte look-up drags a
+// 128-byte line into a 32 KiB L1 that 16 wavefronts with 16 different access patches keep evicting).
+// Here a workgroup is up to 1024 particles (lane = particle, 16 wavefronts) x ONE beam segment: all
+// wavefronts of a CU walk the same few dozen beams, so their look-ups fall into one patch of the map
+// (the beam's end point seen from a cloud of neighbouring poses) that stays L1-resident and is
+// reused by every wavefront and by the following beams.  grid = (particle groups, beam segments).
+// Each lane multiplies its factors sequentially in beam order (the reference's order,
+// GridMap.java:267-288); with more than one segment the per-segment products are stored and
+// multiplied in segment order by k_score_combine.  One segment => the reference's product exactly.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const double *__restrict__ hitbeams,
+          const int32_t *__restrict__ nhit, int32_t beam_stride, const float *__restrict__ pose,
+          const float *__restrict__ cs, int32_t n, int32_t nseg, double *__restrict__ part,
+          double *__restrict__ w, double *__restrict__ logw) {
+    const int32_t mi = blockIdx.z, seg = blockIdx.y;
+    const int32_t nb = nhit[mi];
+    const int32_t L = (nb + nseg - 1) / nseg;
+    const int32_t j0 = seg * L, j1 = min(nb, j0 + L);
+    const double2 *hb = reinterpret_cast<const double2 *>(hitbeams + (size_t)mi * beam_stride * 2);
+    const double *fac = fac_all + (size_t)mi * fac_stride;
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const size_t gi = (size_t)mi * n + p;
+    XformDev t;
+    t.c = (double)cs[2 * gi]; t.s = (double)cs[2 * gi + 1];           // Transform.java:15-16
+    t.px = (double)pose[3 * gi]; t.py = (double)pose[3 * gi + 1];
+    double prod = 1.0;                                                 // GridMap.java:262
+    for (int32_t base = j0; base < j1; base += SCORE_U) {
+        uint32_t cell[SCORE_U];
+        double2 bm[SCORE_U];
+        bool guard = false;
+#pragma unroll
+        for (int u = 0; u < SCORE_U; u++) {
+            const int32_t j = base + u;
+            bm[u] = hb[j < j1 ? j : j0];                              // workgroup-uniform: scalar loads
+            const uint32_t c = beam_cell_fast(g, t, bm[u].x, bm[u].y, guard);
+            cell[u] = j < j1 ? c : (uint32_t)g.cells;
+        }
+        if (__builtin_expect(guard, 0)) {                              // ~4e-6 of the end points
+            asm volatile("; exact quotients for this batch" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < SCORE_U; u++) {
+                const int32_t j = base + u;
+                const uint32_t c = beam_cell(g, t, bm[u].x, bm[u].y);
+                cell[u] = j < j1 ? c : (uint32_t)g.cells;
+            }
+        }
+        double f[SCORE_U];
+#pragma unroll
+        for (int u = 0; u < SCORE_U; u++) f[u] = fac[cell[u]];
+#pragma unroll
+        for (int u = 0; u < SCORE_U; u++) prod *= f[u];
+    }
+    if (nseg == 1) {
+        int e;
+        const double mnt = frexp(prod, &e);
+        w[gi] = prod;
+        logw[gi] = log(mnt) + (double)e * 0.6931471805599453;
+    } else {
+        part[((size_t)mi * nseg + seg) * n + p] = prod;               // <= 128 factors >= 0.01: no underflow
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_score_combine(const double *__restrict__ part, int32_t n, int32_t nseg, double *__restrict__ w,
+                double *__restrict__ logw) {
+    const int32_t mi = blockIdx.y;
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int e;
+    double mnt = frexp(part[((size_t)mi * nseg) * n + p], &e);
+    for (int32_t s = 1; s < nseg; s++) {
+        int e2;
+        const double m2 = frexp(part[((size_t)mi * nseg + s) * n + p], &e2);
+        mx_mul(mnt, e, m2, e2);
+    }
+    const size_t gi = (size_t)mi * n + p;
+    w[gi] = ldexp(mnt, e);
+    logw[gi] = log(mnt) + (double)e * 0.6931471805599453;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Blocked reductions.  A reduction block is GMS_BLOCK = 1024 consecutive particles (by GLOBAL index)
+// and is reduced by a "group" of 256 consecutive threads (4 waves), EPT = 4 particles per thread.
+// Shape, identical in every kernel that uses it:
+//   thread t folds its particles t, t+256, t+512, t+768 of the block sequentially,
+//   64-lane xor butterfly per wave, then ((w0 + w1) + w2) + w3 over the group's four waves;
+//   blocks are folded in block order (thread t takes blocks t, t+256, ... then the group shape).
+// Kernels run 1 or 4 groups per workgroup; every thread of the workgroup must make the calls (they
+// contain barriers).  Because the shape depends only on global indices, the results are the same for
+// any number of GPUs.
+// ---------------------------------------------------------------------------------------------
+#define MAX_WAVES 16
+#define GRP 256
+#define EPT (GMS_BLOCK / GRP)
+
+__device__ __forceinline__ double group_sum(double v, double *lds /* [MAX_WAVES] */) {
     v = wave_sum_f64(v);
-    const int32_t wave = threadIdx.x >> 6;
+    const int32_t wave = threadIdx.x >> 6, g4 = (wave >> 2) << 2;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) lds4[wave] = v;
+    if ((threadIdx.x & 63) == 0) lds[wave] = v;
     __syncthreads();
-    return ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+    return ((lds[g4] + lds[g4 + 1]) + lds[g4 + 2]) + lds[g4 + 3];
 }
 
 // (value, index) max with "first maximum wins" (SLAM.java:110-115: strict >); NaN never wins
@@ -139,235 +343,355 @@ __device__ __forceinline__ void argmax_merge(double &v, double &i, double v2, do
     if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
 }
 
-__device__ __forceinline__ void block_argmax_256(double &v, double &i, double *ldsv, double *ldsi) {
+__device__ __forceinline__ void group_argmax(double &v, double &i, double *ldsv, double *ldsi) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const double v2 = __shfl_xor(v, o, GMS_WAVE), i2 = __shfl_xor(i, o, GMS_WAVE);
         argmax_merge(v, i, v2, i2);
     }
-    const int32_t wave = threadIdx.x >> 6;
+    const int32_t wave = threadIdx.x >> 6, g4 = (wave >> 2) << 2;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { ldsv[wave] = v; ldsi[wave] = i; }
     __syncthreads();
-    v = ldsv[0]; i = ldsi[0];
-    for (int k = 1; k < 4; k++) argmax_merge(v, i, ldsv[k], ldsi[k]);
+    v = ldsv[g4]; i = ldsi[g4];
+    for (int k = 1; k < 4; k++) argmax_merge(v, i, ldsv[g4 + k], ldsi[g4 + k]);
 }
 
-// phase 1: this shard's block partials {sum, max, argmax, n_zero, max_logw} at their global slots
-__global__ void __launch_bounds__(256)
-k_partials(const double *__restrict__ w, const double *__restrict__ logw, int32_t n, int64_t offset,
-           int64_t nblk_global, double *__restrict__ partials) {
-    __shared__ double l4[4], lv[4], li[4];
-    const int32_t mi = blockIdx.y;
-    const int32_t i = blockIdx.x * GMS_BLOCK + threadIdx.x;
-    const bool in = i < n;
-    const double v = in ? w[(size_t)mi * n + i] : 0.0;
-    const double lw = in ? logw[(size_t)mi * n + i] : -INFINITY;
-    const double s = block_sum_256(v, l4);
-    double mv = (in && v == v) ? v : -INFINITY;
-    double mx = (double)(offset + i);
-    block_argmax_256(mv, mx, lv, li);
-    const double nz = block_sum_256((in && v == 0.0) ? 1.0 : 0.0, l4);
-    double ml = (lw == lw) ? lw : -INFINITY, mli = 0.0;
-    block_argmax_256(ml, mli, lv, li);
+struct RedLds {
+    double a[MAX_WAVES], b[MAX_WAVES];
+    double m[GMS_PARTIAL_STRIDE][MAX_WAVES];
+};
+
+// Partial columns of one block of GMS_BLOCK particles (GMS_PARTIAL_STRIDE = 9):
+//   0 sum w            (SLAM.java:100)          5 sum w*w          (-> calculateNeff, SLAM.java:180-190)
+//   1 max w            (SLAM.java:110-115)      6 sum x*w          (-> getWeightedPose, SLAM.java:165-178)
+//   2 first argmax (global index)               7 sum y*w
+//   3 count of w == 0                           8 sum angleConstrain(theta)*w
+//   4 max log-weight
+// One pass over the raw weights yields everything SLAM.update reports: with S = sum w,
+//   normalised weight = w / S, Neff = S*S / sum w*w, weighted pose = (sum x*w) / S.
+// The reference computes Neff and the pose from the already-normalised weights (three dependent
+// sums); algebraically identical, and the rounding difference is ~1e-15 relative, ten orders of
+// magnitude inside the 1e-5 parity bar (DESIGN.md "Bookkeeping").
+#define COL_SUM 0
+#define COL_MAX 1
+#define COL_ARG 2
+#define COL_NZ 3
+#define COL_MLW 4
+#define COL_SQ 5
+#define COL_XW 6
+#define COL_YW 7
+#define COL_TW 8
+
+__device__ __forceinline__ void block_partials(const double *__restrict__ w, const double *__restrict__ logw,
+                                               const float *__restrict__ pose, int64_t cnt, int64_t base,
+                                               double out[GMS_PARTIAL_STRIDE], RedLds &L) {
+    const int32_t tl = threadIdx.x & (GRP - 1);
+    double s = 0.0, nz = 0.0, mv = -INFINITY, mx = 9.0e15, ml = -INFINITY, sq = 0.0, xw = 0.0, yw = 0.0, tw = 0.0;
+#pragma unroll
+    for (int e0 = 0; e0 < EPT; e0 += 4) {             // four particles in flight per thread
+        double v[4], lw[4];
+        float px[4], py[4], pt[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int64_t i = tl + (e0 + e) * GRP;
+            const bool in = i < cnt;
+            v[e] = in ? w[i] : 0.0;
+            lw[e] = in ? logw[i] : -INFINITY;
+            px[e] = in ? pose[3 * i] : 0.0f; py[e] = in ? pose[3 * i + 1] : 0.0f; pt[e] = in ? pose[3 * i + 2] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int64_t i = tl + (e0 + e) * GRP;
+            if (i < cnt) {
+                s += v[e];
+                sq += v[e] * v[e];
+                xw += (double)px[e] * v[e];                               // SLAM.java:170
+                yw += (double)py[e] * v[e];                               // :171
+                tw += angle_constrain((double)pt[e]) * v[e];              // :172
+                if (v[e] == 0.0) nz += 1.0;
+                if (v[e] > mv) { mv = v[e]; mx = (double)(base + i); }    // ascending index: strict > keeps the first
+                else if (mx > 8.0e15 && v[e] == v[e]) { mv = v[e]; mx = (double)(base + i); }
+                if (lw[e] > ml) ml = lw[e];
+            }
+        }
+    }
+    // one barrier pair for all nine columns: wave butterflies first, then the four waves of the group
+    // are combined in wave order by every thread (same shape as group_sum / group_argmax)
+    double sums[6] = { s, nz, sq, xw, yw, tw };
+#pragma unroll
+    for (int c = 0; c < 6; c++) sums[c] = wave_sum_f64(sums[c]);
+    double mli = 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(mv, o, GMS_WAVE), i2 = __shfl_xor(mx, o, GMS_WAVE);
+        argmax_merge(mv, mx, v2, i2);
+        const double l2 = __shfl_xor(ml, o, GMS_WAVE);
+        if (l2 > ml) ml = l2;
+    }
+    const int32_t wave = threadIdx.x >> 6, g4 = (wave >> 2) << 2;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) L.m[c][wave] = sums[c];
+        L.m[6][wave] = mv; L.m[7][wave] = mx; L.m[8][wave] = ml;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 6; c++) sums[c] = ((L.m[c][g4] + L.m[c][g4 + 1]) + L.m[c][g4 + 2]) + L.m[c][g4 + 3];
+    mv = L.m[6][g4]; mx = L.m[7][g4]; ml = L.m[8][g4];
+    for (int k = 1; k < 4; k++) {
+        argmax_merge(mv, mx, L.m[6][g4 + k], L.m[7][g4 + k]);
+        if (L.m[8][g4 + k] > ml) ml = L.m[8][g4 + k];
+    }
+    (void)mli;
+    out[COL_SUM] = sums[0]; out[COL_NZ] = sums[1]; out[COL_SQ] = sums[2];
+    out[COL_XW] = sums[3]; out[COL_YW] = sums[4]; out[COL_TW] = sums[5];
+    out[COL_MAX] = mv; out[COL_ARG] = mx; out[COL_MLW] = ml;
+}
+
+// fold per-block partials in block order
+__device__ __forceinline__ double fold_sum(const double *__restrict__ p, int64_t nblk, int col, double *lds) {
+    double acc = 0.0;
+    for (int64_t b = threadIdx.x & (GRP - 1); b < nblk; b += GRP) acc += p[b * GMS_PARTIAL_STRIDE + col];
+    return group_sum(acc, lds);
+}
+
+__device__ __forceinline__ void fold_argmax(const double *__restrict__ p, int64_t nblk, int colv, int coli, double &mv,
+                                            double &mx, RedLds &L) {
+    mv = -INFINITY; mx = 9.0e15;
+    bool first = true;
+    for (int64_t b = threadIdx.x & (GRP - 1); b < nblk; b += GRP) {
+        const double v2 = p[b * GMS_PARTIAL_STRIDE + colv], i2 = coli >= 0 ? p[b * GMS_PARTIAL_STRIDE + coli] : (double)b;
+        if (first) { mv = v2; mx = i2; first = false; } else argmax_merge(mv, mx, v2, i2);
+    }
+    group_argmax(mv, mx, L.a, L.b);
+}
+
+// all statistics from the (all-reduced) partial vector; every thread of the workgroup must call
+__device__ __forceinline__ double fold_stats(const double *__restrict__ p, int64_t nblk, PfStatsDev *s, bool write,
+                                             const float *__restrict__ pose, int64_t pose_base, int64_t pose_n, RedLds &L) {
+    const double sum = fold_sum(p, nblk, COL_SUM, L.a);
+    if (!write) return sum;
+    const double nz = fold_sum(p, nblk, COL_NZ, L.a);
+    const double sq = fold_sum(p, nblk, COL_SQ, L.a);
+    const double xw = fold_sum(p, nblk, COL_XW, L.a), yw = fold_sum(p, nblk, COL_YW, L.a), tw = fold_sum(p, nblk, COL_TW, L.a);
+    double mv, mx, ml, mli;
+    fold_argmax(p, nblk, COL_MAX, COL_ARG, mv, mx, L);
+    fold_argmax(p, nblk, COL_MLW, -1, ml, mli, L);
     if (threadIdx.x == 0) {
-        const int64_t gb = offset / GMS_BLOCK + blockIdx.x;
-        double *p = partials + ((size_t)mi * nblk_global + gb) * GMS_PARTIAL_STRIDE;
-        p[0] = s; p[1] = mv; p[2] = mx; p[3] = nz; p[4] = ml;
+        s->weight_sum = sum;
+        s->max_w = mv;
+        s->strongest = mx < 8.0e15 ? (int32_t)mx : 0;
+        s->n_zero = (int32_t)nz;
+        s->max_logw = ml;
+        s->norm_sum = sum / sum;
+        s->sq_sum = sq / (sum * sum);                                  // Neff = 1 / sq_sum (SLAM.java:189)
+        s->xs = xw; s->ys = yw; s->ts = tw;
+        s->wpose[0] = (float)(xw / sum);                               // SLAM.java:176
+        s->wpose[1] = (float)(yw / sum);
+        s->wpose[2] = (float)(tw / sum);
+        // strongest particle's pose, when this shard holds it
+        const int64_t st = (int64_t)s->strongest - pose_base;
+        if (pose && st >= 0 && st < pose_n) {
+            s->spose[0] = pose[3 * st]; s->spose[1] = pose[3 * st + 1]; s->spose[2] = pose[3 * st + 2];
+        }
     }
+    return sum;
 }
 
-// every block folds the (all-reduced) partials in block order: thread t takes partials t, t+256, ...
-// sequentially, then the block shape above.  Deterministic for a given nblk_global.
-__device__ __forceinline__ void fold_partials(const double *__restrict__ p, int64_t nblk, int stride,
-                                              int ncols, double *out, double *l4) {
-    for (int c = 0; c < ncols; c++) {
-        double acc = 0.0;
-        for (int64_t b = threadIdx.x; b < nblk; b += GMS_BLOCK) acc += p[b * stride + c];
-        out[c] = block_sum_256(acc, l4);
-    }
+__device__ __forceinline__ int64_t block_count(int64_t n, int64_t blk) {
+    const int64_t left = n - blk * GMS_BLOCK;
+    return left < 0 ? 0 : (left > GMS_BLOCK ? GMS_BLOCK : left);
 }
 
-// phase 2: weightSum, strongest; weight /= weightSum; pack {w,x,y,theta} for the all-gather
+// phase 1: this shard's block partials at their global slots; blocks of other shards are zeroed so
+// that an all-reduce(SUM) assembles the full vector exactly.  grid = (nblk_global, n_maps).
+__global__ void __launch_bounds__(256)
+k_partials(const double *__restrict__ w, const double *__restrict__ logw, const float *__restrict__ pose, int32_t n,
+           int64_t offset, int64_t nblk_global, double *__restrict__ partials) {
+    __shared__ RedLds L;
+    const int32_t mi = blockIdx.y;
+    const int64_t gb = blockIdx.x;
+    const int64_t lb = gb - offset / GMS_BLOCK;                       // block index inside the shard
+    const int64_t nlb = ((int64_t)n + GMS_BLOCK - 1) / GMS_BLOCK;
+    double *p = partials + ((size_t)mi * nblk_global + gb) * GMS_PARTIAL_STRIDE;
+    if (lb < 0 || lb >= nlb) {                                        // uniform per workgroup
+        if (threadIdx.x < GMS_PARTIAL_STRIDE) p[threadIdx.x] = 0.0;
+        return;
+    }
+    double out[GMS_PARTIAL_STRIDE];
+    const size_t o = (size_t)mi * n + lb * GMS_BLOCK;
+    block_partials(w + o, logw + o, pose + 3 * o, block_count(n, lb), offset + lb * GMS_BLOCK, out, L);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < GMS_PARTIAL_STRIDE; k++) p[k] = out[k];
+}
+
+// phase 2: every workgroup folds the (all-reduced) partials; weight /= weightSum (SLAM.java:120-121);
+// packs {w,x,y,theta} (the all-gather payload / the resampling source) and the dense weight copy.
 __global__ void __launch_bounds__(256)
 k_normalize_pack(const double *__restrict__ partials_all, int64_t nblk_global, double *__restrict__ w,
-                 const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ th, int32_t n,
-                 int64_t packed_stride, PackedParticle *__restrict__ packed, PfStatsDev *__restrict__ stats) {
-    __shared__ double l4[4], lv[4], li[4];
+                 const float *__restrict__ pose, int32_t n, int64_t offset, PackedParticle *__restrict__ packed,
+                 double *__restrict__ wdense_local, PfStatsDev *__restrict__ stats) {
+    __shared__ RedLds L;
     const int32_t mi = blockIdx.y;
     const double *p = partials_all + (size_t)mi * nblk_global * GMS_PARTIAL_STRIDE;
-    double sum;
-    fold_partials(p, nblk_global, GMS_PARTIAL_STRIDE, 1, &sum, l4);
-    if (blockIdx.x == 0) {
-        double nz;
-        {
-            double acc = 0.0;
-            for (int64_t b = threadIdx.x; b < nblk_global; b += GMS_BLOCK) acc += p[b * GMS_PARTIAL_STRIDE + 3];
-            nz = block_sum_256(acc, l4);
-        }
-        double mv = -INFINITY, mx = 0.0;
-        bool first = true;
-        for (int64_t b = threadIdx.x; b < nblk_global; b += GMS_BLOCK) {
-            const double v2 = p[b * GMS_PARTIAL_STRIDE + 1], i2 = p[b * GMS_PARTIAL_STRIDE + 2];
-            if (first) { mv = v2; mx = i2; first = false; } else argmax_merge(mv, mx, v2, i2);
-        }
-        if (first) { mv = -INFINITY; mx = 9.0e15; }
-        block_argmax_256(mv, mx, lv, li);
-        double ml = -INFINITY, mli = 0.0;
-        for (int64_t b = threadIdx.x; b < nblk_global; b += GMS_BLOCK) {
-            const double v2 = p[b * GMS_PARTIAL_STRIDE + 4];
-            if (v2 > ml) ml = v2;
-        }
-        block_argmax_256(ml, mli, lv, li);
-        if (threadIdx.x == 0) {
-            PfStatsDev *s = stats + mi;
-            s->weight_sum = sum;
-            s->max_w = mv;
-            s->strongest = (int32_t)mx;
-            s->n_zero = (int32_t)nz;
-            s->max_logw = ml;
-        }
-    }
-    const int32_t i = blockIdx.x * GMS_BLOCK + threadIdx.x;
+    const double sum = fold_stats(p, nblk_global, stats + mi, blockIdx.x == 0, pose + (size_t)mi * n * 3, offset, n, L);
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
         const size_t gi = (size_t)mi * n + i;
-        const double wn = w[gi] / sum;                                 // SLAM.java:120-121
+        const double wn = w[gi] / sum;
         w[gi] = wn;
         PackedParticle pp;
-        pp.w = wn; pp.x = x[gi]; pp.y = y[gi]; pp.theta = th[gi]; pp.pad = 0u;
-        packed[(size_t)mi * packed_stride + i] = pp;
+        pp.w = wn; pp.x = pose[3 * gi]; pp.y = pose[3 * gi + 1]; pp.theta = pose[3 * gi + 2]; pp.pad = 0u;
+        packed[gi] = pp;
+        if (wdense_local) wdense_local[gi] = wn;
     }
 }
 
-// pack without normalising (stand-alone resample / getWeightedPose on the current particles)
-__global__ void k_pack(const double *__restrict__ w, const float *__restrict__ x, const float *__restrict__ y,
-                       const float *__restrict__ th, int32_t n, int64_t stride, PackedParticle *__restrict__ packed) {
+// statistics only (getWeightedPose / calculateNeff on the current particles, nothing rewritten)
+__global__ void __launch_bounds__(256)
+k_stats_only(const double *__restrict__ partials_all, int64_t nblk_global, const float *__restrict__ pose, int32_t n,
+             int64_t offset, PfStatsDev *__restrict__ stats) {
+    __shared__ RedLds L;
+    const int32_t mi = blockIdx.x;
+    fold_stats(partials_all + (size_t)mi * nblk_global * GMS_PARTIAL_STRIDE, nblk_global, stats + mi, true,
+               pose + (size_t)mi * n * 3, offset, n, L);
+}
+
+// pack without normalising
+__global__ void k_pack(const double *__restrict__ w, const float *__restrict__ pose, int32_t n,
+                       PackedParticle *__restrict__ packed, double *__restrict__ wdense_local) {
     const int32_t mi = blockIdx.y;
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const size_t gi = (size_t)mi * n + i;
     PackedParticle pp;
-    pp.w = w[gi]; pp.x = x[gi]; pp.y = y[gi]; pp.theta = th[gi]; pp.pad = 0u;
-    packed[(size_t)mi * stride + i] = pp;
+    pp.w = w[gi]; pp.x = pose[3 * gi]; pp.y = pose[3 * gi + 1]; pp.theta = pose[3 * gi + 2]; pp.pad = 0u;
+    packed[gi] = pp;
+    if (wdense_local) wdense_local[gi] = pp.w;
 }
 
-// phase 3a: over the GLOBAL normalised population: block partials {sum w, sum x*w, sum y*w, sum th*w}
-__global__ void __launch_bounds__(256)
-k_global_partials(const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nblk_global,
-                  double *__restrict__ partials2) {
-    __shared__ double l4[4];
-    const int32_t mi = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * GMS_BLOCK + threadIdx.x;
-    double w = 0.0, xw = 0.0, yw = 0.0, tw = 0.0;
-    if (i < n_global) {
-        const PackedParticle pp = glob[(size_t)mi * n_global + i];
-        w = pp.w;
-        xw = (double)pp.x * pp.w;                                      // SLAM.java:170
-        yw = (double)pp.y * pp.w;                                      // :171
-        tw = angle_constrain((double)pp.theta) * pp.w;                 // :172
+// after the all-gather: dense copy of the global population's weights (scan input)
+// (+ the strongest particle's pose, which only the rank that owns it could fill in before)
+__global__ void k_unpack_weights(const PackedParticle *__restrict__ glob, int64_t total, int64_t n_global,
+                                 double *__restrict__ wdense, PfStatsDev *__restrict__ stats) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const PackedParticle pp = glob[i];
+    wdense[i] = pp.w;
+    const int64_t mi = i / n_global;
+    if (i - mi * n_global == (int64_t)stats[mi].strongest) {
+        stats[mi].spose[0] = pp.x; stats[mi].spose[1] = pp.y; stats[mi].spose[2] = pp.theta;
     }
-    const double s0 = block_sum_256(w, l4), s1 = block_sum_256(xw, l4), s2 = block_sum_256(yw, l4),
-                 s3 = block_sum_256(tw, l4);
-    if (threadIdx.x == 0) {
-        double *p = partials2 + ((size_t)mi * nblk_global + blockIdx.x) * 4;
-        p[0] = s0; p[1] = s1; p[2] = s2; p[3] = s3;
-    }
-}
-
-// phase 3b: fold 3a (every block), then block partials of (w/sum)^2 (SLAM.java:185-187)
-__global__ void __launch_bounds__(256)
-k_global_sq(const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nblk_global,
-            const double *__restrict__ partials2, double *__restrict__ partials3, PfStatsDev *__restrict__ stats) {
-    __shared__ double l4[4];
-    const int32_t mi = blockIdx.y;
-    double f[4];
-    fold_partials(partials2 + (size_t)mi * nblk_global * 4, nblk_global, 4, 4, f, l4);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        PfStatsDev *s = stats + mi;
-        s->norm_sum = f[0]; s->xs = f[1]; s->ys = f[2]; s->ts = f[3];
-        s->wpose[0] = (float)(f[1] / f[0]);                            // SLAM.java:176
-        s->wpose[1] = (float)(f[2] / f[0]);
-        s->wpose[2] = (float)(f[3] / f[0]);
-        int64_t st = s->strongest;
-        if (st < 0) st = 0;
-        if (st >= n_global) st = n_global - 1;
-        const PackedParticle pp = glob[(size_t)mi * n_global + st];
-        s->spose[0] = pp.x; s->spose[1] = pp.y; s->spose[2] = pp.theta;
-    }
-    const int64_t i = (int64_t)blockIdx.x * GMS_BLOCK + threadIdx.x;
-    double q = 0.0;
-    if (i < n_global) {
-        const double w = glob[(size_t)mi * n_global + i].w;
-        q = (w / f[0]) * (w / f[0]);
-    }
-    q = block_sum_256(q, l4);
-    if (threadIdx.x == 0) partials3[(size_t)mi * nblk_global + blockIdx.x] = q;
-}
-
-// phase 3c: fold the squared partials -> sq_sum (Neff = 1 / sq_sum)
-__global__ void __launch_bounds__(256)
-k_fold_sq(const double *__restrict__ partials3, int64_t nblk_global, PfStatsDev *__restrict__ stats) {
-    __shared__ double l4[4];
-    const int32_t mi = blockIdx.x;
-    double q;
-    fold_partials(partials3 + (size_t)mi * nblk_global, nblk_global, 1, 1, &q, l4);
-    if (threadIdx.x == 0) stats[mi].sq_sum = q;
 }
 
 // ---------------------------------------------------------------------------------------------
 // resampling
 // ---------------------------------------------------------------------------------------------
-// one lane per chunk of SCAN_CHUNK particles: sequential inclusive sums (the reference's order inside
-// the chunk)
-__global__ void k_scan_chunks(const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nchunks,
-                              double *__restrict__ cum, double *__restrict__ chunk_tot) {
-    const int32_t mi = blockIdx.y;
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks) return;
-    const PackedParticle *g = glob + (size_t)mi * n_global;
+// Cumulative weights, fixed shape (depends on n_global only, so every rank of a sharded filter
+// computes the same values):
+//   level 0  chunk of SCAN_CHUNK = 64 weights: one lane adds them in index order -- the reference's
+//            `c += w[i]` (SLAM.java:144) inside the chunk -- and stores the running sums;
+//   level 1  super-chunk of 64 chunks: one lane per wavefront adds the chunk totals in order;
+//   level 2  one lane adds the super-chunk totals in order.
+// offset[c] = level2[c / 64] + level1[c]; cumulative weight of particle i = offset[i / 64] + cum[i].
+// One workgroup of 1024 lanes per map: 65 536 particles per sweep.
+#define SCAN_THREADS 1024
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_scan(const double *__restrict__ wdense, int64_t n_global, int64_t nchunks, double *__restrict__ cum,
+       double *__restrict__ chunk_off, PfStatsDev *__restrict__ stats) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *s_tot = reinterpret_cast<double *>(smem);          // [SCAN_THREADS] chunk totals -> level-1 offsets
+    double *s_sup = s_tot + SCAN_THREADS;                      // [nsuper + 1] super-chunk totals -> level-2 offsets
+    const int32_t mi = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    const double *wd = wdense + (size_t)mi * n_global;
     double *cm = cum + (size_t)mi * n_global;
-    double acc = 0.0;
-    const int64_t i0 = c * SCAN_CHUNK;
-    for (int64_t i = i0; i < i0 + SCAN_CHUNK && i < n_global; i++) {
-        acc = (i == i0) ? g[i].w : acc + g[i].w;
-        cm[i] = acc;
+    double *off = chunk_off + (size_t)mi * (nchunks + 1);
+    const int64_t nsuper = (nchunks + 63) / 64;
+    if (t == 0) stats[mi].n_ambiguous = 0;
+
+    for (int64_t cb = 0; cb < nchunks; cb += SCAN_THREADS) {
+        const int64_t c = cb + t;
+        const int64_t i0 = c * SCAN_CHUNK;
+        double acc = 0.0;
+        if (c < nchunks) {
+            if (i0 + SCAN_CHUNK <= n_global) {                 // full chunk: 32 x 16-byte loads in flight
+                double2 v[SCAN_CHUNK / 2];
+                const double2 *src = reinterpret_cast<const double2 *>(wd + i0);
+#pragma unroll
+                for (int j = 0; j < SCAN_CHUNK / 2; j++) v[j] = src[j];
+                double2 *dst = reinterpret_cast<double2 *>(cm + i0);
+#pragma unroll
+                for (int j = 0; j < SCAN_CHUNK / 2; j++) {
+                    acc = (j == 0) ? v[j].x : acc + v[j].x;
+                    v[j].x = acc;
+                    acc = acc + v[j].y;
+                    v[j].y = acc;
+                    dst[j] = v[j];
+                }
+            } else {                                           // ragged tail
+                for (int64_t i = i0; i < n_global; i++) {
+                    acc = (i == i0) ? wd[i] : acc + wd[i];
+                    cm[i] = acc;
+                }
+            }
+        }
+        s_tot[t] = acc;
+        __syncthreads();
+        if (lane == 0) {                                       // level 1: this wavefront's 64 chunk totals, in order
+            double a1 = 0.0;
+            double *p = s_tot + (t & ~63);
+#pragma unroll 8
+            for (int j = 0; j < 64; j++) {
+                const double v = p[j];
+                p[j] = a1;
+                a1 = (j == 0) ? v : a1 + v;
+            }
+            const int64_t sidx = (cb + t) >> 6;
+            if (sidx < nsuper) s_sup[sidx] = a1;
+        }
+        __syncthreads();
+        if (c < nchunks) off[c] = s_tot[t];                    // level-1 offset for now; level 2 added below
+        __syncthreads();
     }
-    chunk_tot[(size_t)mi * (nchunks + 1) + c] = acc;
+    if (t == 0) {                                              // level 2: super-chunk totals, in order
+        double a2 = 0.0;
+        for (int64_t sidx = 0; sidx < nsuper; sidx++) {
+            const double v = s_sup[sidx];
+            s_sup[sidx] = a2;
+            a2 = (sidx == 0) ? v : a2 + v;
+        }
+        s_sup[nsuper] = a2;
+        off[nchunks] = a2;                                     // grand total
+    }
+    __syncthreads();
+    for (int64_t c = 64 + t; c < nchunks; c += SCAN_THREADS) off[c] = s_sup[c >> 6] + off[c];   // super-chunk 0 adds nothing
 }
 
-// one lane per map: chunk totals -> exclusive offsets, in order; slot [nchunks] = grand total
-__global__ void k_scan_offsets(double *__restrict__ chunk_tot, int64_t nchunks, PfStatsDev *__restrict__ stats) {
-    const int32_t mi = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    stats[mi].n_ambiguous = 0;
-    double *t = chunk_tot + (size_t)mi * (nchunks + 1);
-    double acc = 0.0;
-    for (int64_t c = 0; c < nchunks; c++) {
-        const double v = t[c];
-        t[c] = acc;
-        acc = (c == 0) ? v : acc + v;
-    }
-    t[nchunks] = acc;
-}
-
-// one lane per output slot (SLAM.java:140-149)
+// one lane per output slot (SLAM.java:140-149); the chunk offsets are staged in LDS for the first search level
 __global__ void __launch_bounds__(256)
-k_resample(const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nchunks,
-           const double *__restrict__ cum, const double *__restrict__ chunk_off, const double *__restrict__ r01,
-           double fraction, int32_t n, int64_t offset, float *__restrict__ x2, float *__restrict__ y2,
-           float *__restrict__ th2, double *__restrict__ w2, int32_t *__restrict__ idx_out,
-           PfStatsDev *__restrict__ stats) {
+k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks,
+           const double *__restrict__ cum_all, const double *__restrict__ chunk_off, const double *__restrict__ r01,
+           double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, double *__restrict__ w2,
+           int32_t *__restrict__ idx_out, PfStatsDev *__restrict__ stats) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *off = reinterpret_cast<double *>(smem);                    // [nchunks + 1]
     const int32_t mi = blockIdx.y;
-    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
     const PfStatsDev *st = stats + mi;
     const bool go = fraction < 0.0 || (1.0 / st->sq_sum) < fraction * (double)n_global;   // GridMapApp.java:185
-    const PackedParticle *g = glob + (size_t)mi * n_global;
+    if (go) {
+        const double *src = chunk_off + (size_t)mi * (nchunks + 1);
+        for (int64_t c = threadIdx.x; c <= nchunks; c += blockDim.x) off[c] = src[c];
+        __syncthreads();
+    }
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const PackedParticle *g = glob_all + (size_t)mi * n_global;
     const int64_t m0 = offset + t;              // m - 1
     int64_t src = m0;
     if (go) {
-        const double *off = chunk_off + (size_t)mi * (nchunks + 1);
-        const double *cm = cum + (size_t)mi * n_global;
+        const double *cm = cum_all + (size_t)mi * n_global;
         const double N = (double)n_global;
         const double r = r01[mi] * 1.0 / N;                             // SLAM.java:136
         const double U = r + (double)m0 * 1.0 / N;                      // :141
@@ -386,35 +710,25 @@ k_resample(const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nc
             const int64_t len = b;
             while (a < b) {
                 const int64_t mid = (a + b) >> 1;
-                const double c = (lo == 0) ? cm[i0 + mid] : base + cm[i0 + mid];
-                if (U > c) a = mid + 1; else b = mid;
+                if (U > base + cm[i0 + mid]) a = mid + 1; else b = mid;
             }
             src = i0 + (a < len ? a : len - 1);
             // boundary within rounding distance of U: a sequential scan may choose a neighbour
-            const double tot = off[nchunks];
-            const double tol = N * 4.5e-16 * fabs(tot);
-            const double c_hit = (lo == 0) ? cm[src] : base + cm[src];
-            bool amb = fabs(U - c_hit) <= tol;
+            const double tol = N * 4.5e-16 * fabs(off[nchunks]);
+            bool amb = fabs(U - (base + cm[src])) <= tol;
             if (src > 0) {
                 const int64_t pc = (src - 1) / SCAN_CHUNK;
-                const double c_prev = (pc == 0) ? cm[src - 1] : off[pc] + cm[src - 1];
-                amb = amb || fabs(U - c_prev) <= tol;
+                amb = amb || fabs(U - (off[pc] + cm[src - 1])) <= tol;
             }
             if (amb) atomicAdd(&stats[mi].n_ambiguous, 1);
         }
     }
     const PackedParticle pp = g[src];
     const size_t o = (size_t)mi * n + t;
-    x2[o] = pp.x; y2[o] = pp.y; th2[o] = pp.theta; w2[o] = pp.w;       // copies keep their weight (SLAM.java:42)
+    pose2[3 * o] = pp.x; pose2[3 * o + 1] = pp.y; pose2[3 * o + 2] = pp.theta;
+    w2[o] = pp.w;                                                       // copies keep their weight (SLAM.java:42)
     if (idx_out) idx_out[o] = (int32_t)src;
     if (t == 0) stats[mi].did_resample = go ? 1 : 0;
-}
-
-__global__ void k_pose_from_stats(const PfStatsDev *__restrict__ stats, int32_t which, float *__restrict__ poses) {
-    const int32_t mi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (mi >= (int32_t)gridDim.x * (int32_t)blockDim.x) return;
-    const float *src = which == 0 ? stats[mi].wpose : stats[mi].spose;
-    poses[3 * mi] = src[0]; poses[3 * mi + 1] = src[1]; poses[3 * mi + 2] = src[2];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,9 +737,8 @@ __global__ void k_pose_from_stats(const PfStatsDev *__restrict__ stats, int32_t 
 // ---------------------------------------------------------------------------------------------
 #define REFINE_MAX_STEPS 16
 __global__ void __launch_bounds__(256)
-k_refine(GridDev g, const double *__restrict__ lik_all, const double *__restrict__ hitbeams,
-         const int32_t *__restrict__ nhit, int32_t beam_stride, float *__restrict__ px, float *__restrict__ py,
-         float *__restrict__ pth, int32_t n) {
+k_refine(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const double *__restrict__ hitbeams,
+         const int32_t *__restrict__ nhit, int32_t beam_stride, float *__restrict__ pose, int32_t n) {
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *sb = reinterpret_cast<double2 *>(smem);
     __shared__ float s_dx[REFINE_MAX_STEPS], s_dy[REFINE_MAX_STEPS], s_dt[REFINE_MAX_STEPS];
@@ -450,8 +763,8 @@ k_refine(GridDev g, const double *__restrict__ lik_all, const double *__restrict
     }
     __syncthreads();
     const size_t gi = (size_t)mi * n + p;
-    const float x0 = px[gi], y0 = py[gi], t0 = pth[gi];
-    const double *lik = lik_all + (size_t)mi * g.cells;
+    const float x0 = pose[3 * gi], y0 = pose[3 * gi + 1], t0 = pose[3 * gi + 2];
+    const double *fac = fac_all + (size_t)mi * fac_stride;
     const int32_t nx = s_n[0], ny = s_n[1], nt = s_n[2], total = nx * ny * nt;
     const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double best = 0.0;            // maxProb = 0 (:321)
@@ -466,7 +779,7 @@ k_refine(GridDev g, const double *__restrict__ lik_all, const double *__restrict
         double prod = 1.0;
         for (int32_t j = lane; j < nb; j += 64) {
             const double2 bm = sb[j];
-            prod *= beam_factor(g, lik, t, bm.x, bm.y);
+            prod *= fac[beam_cell(g, t, bm.x, bm.y)];
         }
         int e;
         double mnt = frexp(prod, &e);
@@ -489,7 +802,7 @@ k_refine(GridDev g, const double *__restrict__ lik_all, const double *__restrict
         }
         if (bi >= 0) {
             const int32_t it = bi % nt, iy = (bi / nt) % ny, ix = bi / (nt * ny);
-            px[gi] = x0 + s_dx[ix]; py[gi] = y0 + s_dy[iy]; pth[gi] = t0 + s_dt[it];
+            pose[3 * gi] = x0 + s_dx[ix]; pose[3 * gi + 1] = y0 + s_dy[iy]; pose[3 * gi + 2] = t0 + s_dt[it];
         }
     }
 }
@@ -502,34 +815,50 @@ static inline int64_t nchunks_of(const gms_pf *pf) { return (pf->n_global + SCAN
 
 void gms_launch_pf_init(gms_pf *pf) {
     const int64_t total = (int64_t)pf->n_maps * pf->n;
-    hipLaunchKernelGGL(k_pf_init, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pf->map->stream, pf->d_x,
-                       pf->d_y, pf->d_th, pf->d_w, pf->d_logw, total, 1.0 / (double)pf->n_global);
-}
-
-__global__ void k_set_poses_aos(const float *__restrict__ aos, float *__restrict__ x, float *__restrict__ y,
-                                float *__restrict__ th, int64_t total) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) { x[i] = aos[3 * i]; y[i] = aos[3 * i + 1]; th[i] = aos[3 * i + 2]; }
-}
-
-void gms_launch_pf_set_poses_aos(gms_pf *pf, const float *d_xytheta) {
-    const int64_t total = (int64_t)pf->n_maps * pf->n;
-    hipLaunchKernelGGL(k_set_poses_aos, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pf->map->stream, d_xytheta,
-                       pf->d_x, pf->d_y, pf->d_th, total);
+    hipLaunchKernelGGL(k_pf_init, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pf->map->stream, pf->d_pose,
+                       pf->d_w, pf->d_logw, total, 1.0 / (double)pf->n_global);
 }
 
 void gms_launch_pf_prep(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride) {
     gms_map *m = pf->map;
     const int64_t total = (int64_t)pf->n_maps * pf->n;
-    hipLaunchKernelGGL(k_pf_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, pf->d_th, pf->d_cs,
-                       total);
-    hipLaunchKernelGGL(k_compact_beams, dim3(pf->n_maps), dim3(64), 0, m->stream, d_beams, B, beam_stride,
-                       m->max_beams, pf->d_hitbeams, pf->d_nhit);
+    const int32_t trig_blocks = (int32_t)((total + 255) / 256);
+    hipLaunchKernelGGL(k_pf_prep, dim3(trig_blocks + pf->n_maps), dim3(256), 0, m->stream, pf->d_pose, pf->d_cs, total,
+                       trig_blocks, d_beams, B, beam_stride, m->max_beams, pf->d_hitbeams, pf->d_nhit);
 }
 
 void gms_launch_pf_score(gms_pf *pf, int32_t B) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_SCORE);
+    if (m->score_variant == 2) {
+        const int32_t threads = pf->n >= 1024 ? 1024 : ((pf->n + 63) / 64) * 64;
+        const int64_t groups = ((int64_t)pf->n + threads - 1) / threads;
+        int64_t nseg = 256 / (groups * pf->n_maps);                   // ~1 workgroup of 16 wavefronts per CU (measured best at C3)
+        const int64_t min_seg = ((int64_t)B + 127) / 128;             // <= 128 factors per segment product
+        if (nseg > GMS_SCORE_MAXSEG) nseg = GMS_SCORE_MAXSEG;
+        if (nseg < min_seg) nseg = min_seg;
+        if (nseg < 1) nseg = 1;
+        if (m->score_segments > 0) nseg = m->score_segments < min_seg ? min_seg : m->score_segments;
+        if (nseg > GMS_SCORE_MAXSEG) nseg = GMS_SCORE_MAXSEG;
+        hipLaunchKernelGGL(k_score_c, dim3((unsigned)groups, (unsigned)nseg, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
+                           m->d_fac, m->fac_stride, pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_pose, pf->d_cs, pf->n,
+                           (int32_t)nseg, pf->d_part, pf->d_w, pf->d_logw);
+        if (nseg > 1)
+            hipLaunchKernelGGL(k_score_combine, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, pf->d_part,
+                               pf->n, (int32_t)nseg, pf->d_w, pf->d_logw);
+        return;
+    }
+    if (m->score_variant == 1) {
+        const int64_t groups = ((int64_t)pf->n + 63) / 64;
+        int64_t nseg = 4096 / (groups * pf->n_maps);
+        if (nseg > SCORE_B_MAXSEG) nseg = SCORE_B_MAXSEG;
+        if (nseg < 1) nseg = 1;
+        if (m->score_segments > 0) nseg = m->score_segments;
+        hipLaunchKernelGGL(k_score_b, dim3((unsigned)groups, pf->n_maps), dim3((unsigned)nseg * 64), 0, m->stream, m->gd,
+                           m->d_fac, m->fac_stride, pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_pose, pf->d_cs, pf->n, pf->d_w,
+                           pf->d_logw);
+        return;
+    }
     const int32_t wpb = 4;
     int64_t blocks = ((int64_t)pf->n + wpb - 1) / wpb;
     // enough waves to fill the chip, few enough that the beam table is staged a bounded number of times
@@ -540,60 +869,66 @@ void gms_launch_pf_score(gms_pf *pf, int32_t B) {
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_score), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
-    hipLaunchKernelGGL(k_score, dim3((unsigned)blocks, pf->n_maps), dim3(64 * wpb), smem, m->stream, m->gd, m->d_lik,
-                       pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_x, pf->d_y, pf->d_cs, pf->n, pf->d_w,
-                       pf->d_logw);
+    hipLaunchKernelGGL(k_score, dim3((unsigned)blocks, pf->n_maps), dim3(64 * wpb), smem, m->stream, m->gd, m->d_fac,
+                       m->fac_stride, pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_pose, pf->d_cs, pf->n, pf->d_w, pf->d_logw);
 }
 
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
-    hipMemsetAsync(d_partials, 0, sizeof(double) * (size_t)pf->n_maps * nblk * GMS_PARTIAL_STRIDE, m->stream);
-    hipLaunchKernelGGL(k_partials, dim3((pf->n + GMS_BLOCK - 1) / GMS_BLOCK, pf->n_maps), dim3(GMS_BLOCK), 0,
-                       m->stream, pf->d_w, pf->d_logw, pf->n, pf->offset, nblk, d_partials);
+    hipLaunchKernelGGL(k_partials, dim3((unsigned)nblk, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw,
+                       pf->d_pose, pf->n, pf->offset, nblk, d_partials);
 }
 
 void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
-    // packed_stride: a stand-alone filter packs straight into its global population
-    const int64_t stride = (d_packed_local == pf->d_global) ? pf->n_global : pf->n;
-    hipLaunchKernelGGL(k_normalize_pack, dim3((pf->n + GMS_BLOCK - 1) / GMS_BLOCK, pf->n_maps), dim3(GMS_BLOCK), 0,
-                       m->stream, d_partials, nblk, pf->d_w, pf->d_x, pf->d_y, pf->d_th, pf->n, stride,
-                       d_packed_local, pf->d_stats);
+    // a stand-alone filter packs straight into its own population and dense weight array
+    double *wd = (d_packed_local == pf->d_global) ? pf->d_wdense : nullptr;
+    hipLaunchKernelGGL(k_normalize_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, d_partials, nblk,
+                       pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local, wd, pf->d_stats);
 }
 
-void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed, int64_t stride) {
-    gms_map *m = pf->map;
-    hipLaunchKernelGGL(k_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_x, pf->d_y,
-                       pf->d_th, pf->n, stride, d_packed);
-}
-
-void gms_launch_pf_global_stats(gms_pf *pf) {
+void gms_launch_pf_stats_only(gms_pf *pf, const double *d_partials, PfStatsDev *d_stats_out) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_REDUCE);
-    const int64_t nblk = nblk_global_of(pf);
-    double *p2 = pf->d_partials2;
-    double *p3 = pf->d_partials2 + (size_t)pf->n_maps * nblk * 4;
-    hipLaunchKernelGGL(k_global_partials, dim3((unsigned)nblk, pf->n_maps), dim3(GMS_BLOCK), 0, m->stream,
-                       pf->d_global, pf->n_global, nblk, p2);
-    hipLaunchKernelGGL(k_global_sq, dim3((unsigned)nblk, pf->n_maps), dim3(GMS_BLOCK), 0, m->stream, pf->d_global,
-                       pf->n_global, nblk, p2, p3, pf->d_stats);
-    hipLaunchKernelGGL(k_fold_sq, dim3(pf->n_maps), dim3(GMS_BLOCK), 0, m->stream, p3, nblk, pf->d_stats);
+    hipLaunchKernelGGL(k_stats_only, dim3(pf->n_maps), dim3(256), 0, m->stream, d_partials, nblk_global_of(pf), pf->d_pose,
+                       pf->n, pf->offset, d_stats_out);
+}
+
+void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed) {
+    gms_map *m = pf->map;
+    double *wd = (d_packed == pf->d_global) ? pf->d_wdense : nullptr;
+    hipLaunchKernelGGL(k_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_pose,
+                       pf->n, d_packed, wd);
+}
+
+void gms_launch_pf_unpack_weights(gms_pf *pf) {
+    gms_map *m = pf->map;
+    const int64_t total = (int64_t)pf->n_maps * pf->n_global;
+    hipLaunchKernelGGL(k_unpack_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, pf->d_global, total,
+                       pf->n_global, pf->d_wdense, pf->d_stats);
 }
 
 void gms_launch_pf_resample(gms_pf *pf, double fraction) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_RESAMPLE);
     const int64_t nch = nchunks_of(pf);
-    hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)((nch + 63) / 64), pf->n_maps), dim3(64), 0, m->stream,
-                       pf->d_global, pf->n_global, nch, pf->d_cum, pf->d_chunk_tot);
-    hipLaunchKernelGGL(k_scan_offsets, dim3(pf->n_maps), dim3(64), 0, m->stream, pf->d_chunk_tot, nch, pf->d_stats);
-    hipLaunchKernelGGL(k_resample, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, pf->d_global,
+    const size_t smem_scan = (size_t)(SCAN_THREADS + (nch + 63) / 64 + 1) * sizeof(double);
+    if (smem_scan > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem_scan);
+    hipLaunchKernelGGL(k_scan, dim3(pf->n_maps), dim3(SCAN_THREADS), smem_scan, m->stream, pf->d_wdense, pf->n_global,
+                       nch, pf->d_cum, pf->d_chunk_tot, pf->d_stats);
+    const size_t smem = (size_t)(nch + 1) * sizeof(double);
+    if (smem > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resample), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem);
+    hipLaunchKernelGGL(k_resample, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), smem, m->stream, pf->d_global,
                        pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->d_r01, fraction, pf->n, pf->offset,
-                       pf->d_x2, pf->d_y2, pf->d_th2, pf->d_w2, pf->d_idx, pf->d_stats);
+                       pf->d_pose2, pf->d_w2, pf->d_idx, pf->d_stats);
 }
 
 void gms_launch_pf_refine(gms_pf *pf, int32_t B) {
@@ -603,10 +938,6 @@ void gms_launch_pf_refine(gms_pf *pf, int32_t B) {
     if (smem > 32 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_refine), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
-    hipLaunchKernelGGL(k_refine, dim3(pf->n, pf->n_maps), dim3(256), smem, m->stream, m->gd, m->d_lik,
-                       pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_x, pf->d_y, pf->d_th, pf->n);
-}
-
-void gms_launch_pose_from_pf(gms_map *m, gms_pf *pf, int32_t which, float *d_poses) {
-    hipLaunchKernelGGL(k_pose_from_stats, dim3(1), dim3(m->n_maps), 0, m->stream, pf->d_stats, which, d_poses);
+    hipLaunchKernelGGL(k_refine, dim3(pf->n, pf->n_maps), dim3(256), smem, m->stream, m->gd, m->d_fac, m->fac_stride,
+                       pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_pose, pf->n);
 }

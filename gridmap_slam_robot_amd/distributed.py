@@ -6,15 +6,16 @@ north_star asks for.  Rank r holds the contiguous particle block [r*n, (r+1)*n) 
 the map (the deterministic integer-count map update is run redundantly: 720 rays are cheaper than
 broadcasting 32 MiB).  Per scan:
 
-  1. all-reduce(SUM) of the block-partial vector (GMS_PARTIAL_STRIDE doubles per 256-particle block,
+  1. all-reduce(SUM) of the block-partial vector (GMS_PARTIAL_STRIDE doubles per 1024-particle block,
      each rank's own blocks filled, zero elsewhere).  Adding zeros is exact, so every rank ends up
      with the same partials whatever the rank count, and folds them in block order: weightSum,
      strongest, n_zero are bit-identical for 1, 2, 4, 8 GPUs (SLAM.java:87-121).
+     The same vector carries sum w^2 and sum x*w, y*w, theta*w, so Neff and the weighted pose
+     (SLAM.java:165-190) need no further exchange.
   2. all-gather of the packed normalised particles {w, x, y, theta} (24 B each): every rank then
-     computes Neff and the weighted pose (SLAM.java:165-190) and its own slots of the systematic
-     resample (SLAM.java:133-153) from the same global array.
+     fills its own slots of the systematic resample (SLAM.java:133-153) from the same global array.
 
-Both messages are small (6 KiB and 1.5 MiB at 65 536 particles): latency-bound, one RCCL call each.
+Both messages are small (4.5 KiB and 1.5 MiB at 65 536 particles): latency-bound, one RCCL call each.
 
 The collective logic is independent of where the shard kernels run: `ops` is the object that performs
 them.  The product uses HipShardOps (libgridmapslam.so, device pointers of torch CUDA tensors, the
@@ -57,8 +58,8 @@ class HipShardOps:
     def apply_partials(self, partials: torch.Tensor, packed_local: torch.Tensor):
         self.pf.apply_partials(partials.data_ptr(), packed_local.data_ptr())
 
-    def pack(self, packed_local: torch.Tensor):
-        self.pf.pack(packed_local.data_ptr())
+    def stats_from_partials(self, partials: torch.Tensor):
+        self.pf.stats_from_partials(partials.data_ptr())
 
     def import_global(self, packed_global: torch.Tensor):
         self.pf.import_global(packed_global.data_ptr())
@@ -126,11 +127,13 @@ class ShardedParticleFilter:
         (J/app/GridMapApp.java:185-186).  Every rank must pass the same r01."""
         self.ops.resample(r01, fraction)
 
-    def refresh_global(self):
-        """All-gather the current (e.g. resampled) particles again, for getWeightedPose after a resample."""
-        self.ops.pack(self.packed_local)
-        self._all_gather()
-        self.ops.import_global(self.packed_global)
+    def refresh_stats(self):
+        """Weighted pose / Neff of the CURRENT (e.g. resampled) particles: one more all-reduce of the
+        partial vector, nothing rewritten (getWeightedPose after resample, J/app/GridMapApp.java:192)."""
+        self.ops.local_partials(self.partials)
+        if self.world > 1:
+            dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
+        self.ops.stats_from_partials(self.partials)
 
     def stats(self) -> dict:
         return self.ops.stats()

@@ -456,6 +456,9 @@ class ParticleFilter:
     def apply_partials(self, dev_partials: int, dev_packed: int):
         check(load().gms_pf_apply_partials(self._h, C.c_void_p(dev_partials), C.c_void_p(dev_packed)))
 
+    def stats_from_partials(self, dev_partials: int):
+        check(load().gms_pf_stats_from_partials(self._h, C.c_void_p(dev_partials)))
+
     def pack(self, dev_packed: int):
         check(load().gms_pf_pack(self._h, C.c_void_p(dev_packed)))
 

@@ -40,7 +40,7 @@ extern "C" {
 #define GMS_VERSION_MINOR 1
 
 #define GMS_MAX_TAPS 129        /* likelihood kernel taps (odd) */
-#define GMS_BLOCK 256           /* particles per reduction block; shard offsets are multiples of it */
+#define GMS_BLOCK 1024          /* particles per reduction block; shard offsets are multiples of it */
 
 enum {
     GMS_OK = 0,
@@ -212,20 +212,25 @@ int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B);
 
 /* ---- multi-GPU plumbing (particles sharded over ranks; collectives stay with the caller) ------- */
 /* Number of doubles of the block-partial vector exchanged by an all-reduce(SUM):
- * 3 per global block of GMS_BLOCK particles {sum, max, first index of max}. */
+ * 9 per global block of GMS_BLOCK particles {sum w, max w, first index of max, zero count, max
+ * log-weight, sum w^2, sum x*w, sum y*w, sum theta*w}: everything SLAM.update reports follows from them. */
 int gms_pf_partials_len(const gms_pf *pf, int64_t *n_doubles);
 /* Phase 1 of normalise on a shard: writes this shard's block partials into dev_partials (device
  * pointer, zero elsewhere), ready for all-reduce(SUM) -- adding zeros is exact, so the reduced
  * vector is the same for any number of ranks. */
 int gms_pf_local_partials(gms_pf *pf, double *dev_partials);
-/* Phase 2: consumes the all-reduced partials: weightSum, strongest, weight /= weightSum; then packs
+/* Phase 2: consumes the all-reduced partials: weightSum, strongest, Neff, weighted pose,
+ * weight /= weightSum; then packs
  * this shard's {weight, x, y, theta} (24 B per particle) into dev_packed for the all-gather. */
 int gms_pf_apply_partials(gms_pf *pf, const double *dev_partials, void *dev_packed);
+/* Statistics only (weighted pose, Neff) of the CURRENT particles from an all-reduced partial vector,
+ * nothing rewritten: e.g. getWeightedPose after a resample (J/app/GridMapApp.java:192). */
+int gms_pf_stats_from_partials(gms_pf *pf, const double *dev_partials);
 /* Packs this shard's current {weight, x, y, theta} without normalising (e.g. to all-gather the
  * population again after a resample, for getWeightedPose). */
 int gms_pf_pack(gms_pf *pf, void *dev_packed);
-/* Phase 3: consumes the all-gathered [n_global] packed particles: Neff, weighted pose, and keeps
- * them as the source population for gms_pf_resample. */
+/* Phase 3: consumes the all-gathered [n_global] packed particles: they become the source population
+ * of gms_pf_resample (every rank then fills its own slots from the same global array). */
 int gms_pf_import_global(gms_pf *pf, const void *dev_packed_global);
 
 /* ---- measurement ------------------------------------------------------------------------------- */

@@ -355,3 +355,65 @@ def test_batched_maps_equal_independent_maps():
         assert st == stb[i]
         idx, _ = pf.resample([0.1, 0.5, 0.9][i], want_indices=True)
         assert np.array_equal(idx, idxb[i])
+
+
+# ------------------------------------------------------------------ sharded plumbing on one GPU
+def test_sharded_phases_equal_fused_normalize():
+    """The 3-phase (all-reduce / all-gather) path and the single-launch path perform the same
+    arithmetic: with one rank they must agree bit for bit, also when the particle range is cut into
+    two shards that exchange through host memory (what RCCL would do over xGMI)."""
+    import torch
+    from gridmap_slam_robot_amd import _lib
+    m = GridMap(3.2, 3.2, 0.05, (-1.6, -1.6))
+    rng = np.random.default_rng(17)
+    N = 4 * _lib.GMS_BLOCK
+    w = rng.uniform(0, 1, N) ** 5
+    P = rng.normal(0, 1, (N, 3)).astype(np.float32)
+    ref = ParticleFilter(m, N)
+    ref.set_poses(P)
+    ref.set_weights(w)
+    st_ref = ref.normalize()
+    w_ref = ref.get_weights()
+    wp_ref = ref.weighted_pose()
+    idx_ref, _ = ref.resample(0.3, want_indices=True)
+
+    assert torch.cuda.is_available(), "torch and libgridmapslam must share one HIP runtime (_lib._share_hip_runtime_with_torch)"
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream()                 # a non-default torch stream, handed to the library
+    m.set_stream(side.cuda_stream)
+    for shards in (1, 2, 4):
+        n = N // shards
+        pfs = []
+        for r in range(shards):
+            pf = ParticleFilter(m, n)
+            pf.set_shard(r * n, N)
+            pf.set_poses(P[r * n:(r + 1) * n])
+            pf.set_weights(w[r * n:(r + 1) * n])
+            pfs.append(pf)
+        plen = pfs[0].partials_len()
+        parts = [torch.zeros(plen, dtype=torch.float64, device=dev) for _ in range(shards)]
+        for pf, t in zip(pfs, parts):
+            pf.local_partials(t.data_ptr())
+        m.synchronize()
+        total = torch.stack(parts).sum(0)                      # all-reduce(SUM)
+        for t in parts:                                       # each slot is written by exactly one shard
+            assert int(((t != 0).to(torch.int32)).sum()) <= plen
+        packed_local = [torch.zeros(3 * n, dtype=torch.float64, device=dev) for _ in range(shards)]
+        for pf, pl in zip(pfs, packed_local):
+            pf.apply_partials(total.data_ptr(), pl.data_ptr())
+        m.synchronize()
+        packed_global = torch.cat(packed_local)               # all-gather
+        idx_all = []
+        for r, pf in enumerate(pfs):
+            pf.import_global(packed_global.data_ptr())
+            st = pf.stats()
+            assert st == st_ref
+            assert np.array_equal(pf.weighted_pose(), wp_ref)
+            assert np.array_equal(pf.get_weights(), w_ref[r * n:(r + 1) * n])
+            idx, _ = pf.resample(0.3, want_indices=True)
+            idx_all.append(idx)
+            assert np.array_equal(pf.get_poses(), P[idx])
+        assert np.array_equal(np.concatenate(idx_all), idx_ref)
+        for pf in pfs:
+            pf.close()
+    m.set_stream(None)

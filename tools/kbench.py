@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Kernel micro-bench: runs each entry point of the hot path in isolation on the C3 (or chosen) workload
+and prints the average device time per kernel class (HIP events inside the library).
+Usage: python tools/kbench.py [--config C3] [--iters 100] [--only raycast,score,...]"""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--particles", type=int, default=0)
+    ap.add_argument("--sigma", type=float, default=0.10)
+    args = ap.parse_args()
+    import torch
+    from gridmap_slam_robot_amd import GridMap, ParticleFilter, synth, _lib
+    cfg = synth.CONFIGS[args.config]
+    N = args.particles or cfg["particles"]; B = cfg["beams"]; ext = cfg["extent"]; res = cfg["resolution"]
+    T = 64
+    tr = synth.make_trace(ext, res, B, T=T, seed=1234, n_scans=T // 2 + 8)
+    m = GridMap(ext, ext, res, (-ext / 2, -ext / 2), max_beams=max(2048, B))
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    for t in range(T // 2):
+        m.update(tr.scans[t], tr.poses[t])
+    dev = torch.device("cuda", 0)
+    scans_dev = torch.from_numpy(tr.scans.view(np.uint8).reshape(len(tr.scans), -1).copy()).to(dev)
+    poses_dev = torch.from_numpy(tr.poses.copy()).to(dev)
+    P = torch.from_numpy(synth.make_particles(tr.poses[T // 2], N, seed=99, sigma_xy=args.sigma)).to(dev)
+    pf = ParticleFilter(m, N)
+    pf.set_poses_dev(P.data_ptr())
+    t = T // 2
+    only = set(args.only.split(",")) if args.only else None
+    def want(k): return only is None or k in only
+    out = {}
+    def run(name, fn, iters=args.iters):
+        for _ in range(5): fn()
+        torch.cuda.synchronize()
+        m.profile_reset(); m.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(iters): fn()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / iters * 1e6
+        prof = m.profile_get(); m.profile(False)
+        out[name] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items() if v[1]}
+        out[name]["wall_us"] = round(wall, 2)
+    if want("score"):
+        run("score", lambda: pf.score_dev(scans_dev[t].data_ptr(), B))
+    pf.score_dev(scans_dev[t].data_ptr(), B)
+    if want("normalize"):
+        def f():
+            pf.score_dev(scans_dev[t].data_ptr(), B); pf.normalize(fetch=False)
+        run("score+normalize", f)
+    pf.normalize(fetch=False)
+    if want("resample"):
+        def f():
+            pf.set_poses_dev(P.data_ptr()); pf.score_dev(scans_dev[t].data_ptr(), B); pf.normalize(fetch=False); pf.resample(0.37)
+        run("set+score+normalize+resample", f)
+    if want("raycast"):
+        run("integrate", lambda: m.integrate_dev(scans_dev[t].data_ptr(), B, poses_dev[t].data_ptr()))
+    if want("update"):
+        run("update(dirty)", lambda: m.update_dev(scans_dev[t].data_ptr(), B, poses_dev[t].data_ptr()))
+    if want("likelihood"):
+        run("likelihood(full)", lambda: m.compute_likelihood_map())
+    print(json.dumps(out))
+
+if __name__ == "__main__":
+    main()
