@@ -1,0 +1,36 @@
+package com.fmsz.gridmapgl.slam;
+
+/** Native entry points of libgms_jni.so (jni/gms_jni.c) -> libgridmapslam.so (include/gridmapslam.h). */
+final class NativeSlam {
+    static { System.loadLibrary("gms_jni"); }
+    private NativeSlam() {}
+
+    static native long mapCreate(float w, float h, float res, float px, float py, double lFree, double lOcc, double[] kernel, int maxBeams);
+    static native void mapDestroy(long m);
+    static native void mapReset(long m);
+    static native void mapIntegrate(long m, double[] beams, int B, float x, float y, float theta);
+    static native void mapApplyRay(long m, float sx, float sy, float ex, float ey, float measured, boolean hit);
+    static native void mapBuildLikelihood(long m);
+    static native void mapDownload(long m, double[] logData, double[] likelihoodData);
+    static native void mapUploadLog(long m, double[] logData);
+    static native void mapUpdateAt(long m, double[] beams, int B, long pf);
+    static native long pfCreate(long m, int n);
+    static native void pfDestroy(long pf);
+    static native void pfSetPoses(long pf, float[] xytheta);
+    static native void pfGetParticles(long pf, float[] xytheta, double[] weights);
+    static native void pfScore(long pf, double[] beams, int B);
+    static native void pfNormalize(long pf, double[] weightSumNeffStrongest);
+    static native void pfResample(long pf, double r01);
+    static native void pfWeightedPose(long pf, float[] out3);
+
+    /** Observation -> double[4*B] {localX, localY, distance, wasHit} (Observation.java:37-41). */
+    static double[] flatten(Observation obs) {
+        java.util.List<Observation.Measurement> ms = obs.getMeasurements();
+        double[] out = new double[4 * ms.size()];
+        int i = 0;
+        for (Observation.Measurement m : ms) {
+            out[i++] = m.localX; out[i++] = m.localY; out[i++] = m.distance; out[i++] = m.wasHit ? 1.0 : 0.0;
+        }
+        return out;
+    }
+}

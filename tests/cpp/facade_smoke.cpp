@@ -1,0 +1,31 @@
+// C++ consumer of the C-ABI through include/gridmapslam.hpp: one small SLAM step on the GPU.
+// Built and run by tests/test_cpp_facade.py on the GPU box; prints "ok <neff> <weight of pose 0>".
+#include <cstdio>
+
+#include "gridmapslam.hpp"
+
+int main() {
+    try {
+        gms::SLAM slam(256, 6.4f, 6.4f, 0.05f, -3.2f, -3.2f);
+        gms::Observation z;
+        for (int b = 0; b < 90; b++) z.addMeasurement((float)(b * 2.0 * 3.14159265358979 / 90.0), 2.0f, true);
+        gms::Pose origin(0.f, 0.f, 0.f);
+        for (int i = 0; i < 3; i++) slam.getGridMap().update(z, origin);
+        std::vector<gms::Pose> poses(256);
+        for (int i = 0; i < 256; i++) poses[i] = gms::Pose(0.002f * (i % 16), 0.002f * (i / 16), 0.001f * i);
+        const double neff = slam.update(z, &poses, 0.0);
+        const double p0 = slam.getGridMap().probabilityOf(z, origin);
+        slam.resample(0.5);
+        const gms::Pose wp = slam.getWeightedPose();
+        if (!(neff >= 1.0 && neff <= 256.0) || !(p0 > 0.0) || !(wp.x == wp.x)) { std::printf("bad values\n"); return 1; }
+        // out-of-bounds getRawAt throws in Java (ArrayIndexOutOfBounds): here an Error
+        bool threw = false;
+        try { slam.getGridMap().getRawAt(100000, 0); } catch (const gms::Error &) { threw = true; }
+        if (!threw) { std::printf("no error on bad index\n"); return 1; }
+        std::printf("ok %.6f %.6e\n", neff, p0);
+        return 0;
+    } catch (const gms::Error &e) {
+        std::printf("error %d: %s\n", e.code, e.what());
+        return 2;
+    }
+}
