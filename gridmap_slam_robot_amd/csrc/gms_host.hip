@@ -537,8 +537,7 @@ static int64_t nchunks_of(int64_t n) { return (n + 63) / 64; }
 
 static void pf_free_global(gms_pf *pf) {
     hipFree(pf->d_partials); hipFree(pf->d_global); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum);
-    hipFree(pf->d_wdense);
-    pf->d_partials = nullptr; pf->d_global = nullptr; pf->d_chunk_tot = pf->d_cum = pf->d_wdense = nullptr;
+    pf->d_partials = nullptr; pf->d_global = nullptr; pf->d_chunk_tot = pf->d_cum = nullptr;
 }
 
 static int pf_alloc_global(gms_pf *pf) {
@@ -549,7 +548,6 @@ static int pf_alloc_global(gms_pf *pf) {
     HIPCHK(hipMalloc(&pf->d_global, M * pf->n_global * sizeof(PackedParticle)));
     HIPCHK(hipMalloc(&pf->d_chunk_tot, M * (nch + 1) * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_cum, M * pf->n_global * sizeof(double)));
-    HIPCHK(hipMalloc(&pf->d_wdense, M * pf->n_global * sizeof(double)));
     return GMS_OK;
 }
 
@@ -557,7 +555,7 @@ int gms_pf_destroy(gms_pf *pf) {
     if (!pf) return GMS_OK;
     hipSetDevice(pf->map->device);
     hipStreamSynchronize(pf->map->stream);
-    hipFree(pf->d_pose); hipFree(pf->d_pose2); hipFree(pf->d_part);
+    hipFree(pf->d_pose); hipFree(pf->d_pose2); hipFree(pf->d_part); hipFree(pf->d_cs2);
     hipFree(pf->d_w); hipFree(pf->d_w2); hipFree(pf->d_logw); hipFree(pf->d_cs); hipFree(pf->d_hitbeams);
     hipFree(pf->d_nhit); hipFree(pf->d_stats); hipFree(pf->d_r01); hipFree(pf->d_idx);
     pf_free_global(pf);
@@ -580,6 +578,7 @@ int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // Partic
     ok = ok && hipMalloc(&pf->d_pose, T * 12) == hipSuccess && hipMalloc(&pf->d_pose2, T * 12) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_w, T * 8) == hipSuccess && hipMalloc(&pf->d_w2, T * 8) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_logw, T * 8) == hipSuccess && hipMalloc(&pf->d_cs, T * 8) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_cs2, T * 8) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_hitbeams, (size_t)m->n_maps * m->max_beams * 16) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_nhit, (size_t)m->n_maps * 4) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_part, T * GMS_SCORE_MAXSEG * 8) == hipSuccess;
@@ -616,6 +615,7 @@ int gms_pf_set_poses(gms_pf *pf, const float *xytheta) {
     const size_t bytes = (size_t)pf->n * pf->n_maps * 3 * sizeof(float);
     memcpy(pf->h_stage, xytheta, bytes);
     HIPCHK(hipMemcpyAsync(pf->d_pose, pf->h_stage, bytes, hipMemcpyHostToDevice, m->stream));
+    gms_launch_pf_pose_trig(pf, pf->d_pose);
     pf->have_global = 0;
     pf->stats_current = 0;
     return GMS_OK;
@@ -644,16 +644,19 @@ static int pf_copy_f64(gms_pf *pf, double *dev, double *host, bool to_device) {
 
 int gms_pf_set_weights(gms_pf *pf, const double *w) {
     REQUIRE(pf && w, "null argument");
+    pf->pending_nseg = 0;
     pf->have_global = 0;
     pf->stats_current = 0;
     return pf_copy_f64(pf, pf->d_w, const_cast<double *>(w), true);
 }
 int gms_pf_get_weights(gms_pf *pf, double *w) {
     REQUIRE(pf && w, "null argument");
+    gms_launch_pf_combine(pf);
     return pf_copy_f64(pf, pf->d_w, w, false);
 }
 int gms_pf_get_log_weights(gms_pf *pf, double *lw) {
     REQUIRE(pf && lw, "null argument");
+    gms_launch_pf_combine(pf);
     return pf_copy_f64(pf, pf->d_logw, lw, false);
 }
 
@@ -662,8 +665,7 @@ int gms_pf_score(gms_pf *pf, const gms_beam *beams, int32_t B) {       // GridMa
     gms_map *m = pf->map;
     int rc = stage_beams(m, beams, B);
     if (rc) return rc;
-    gms_launch_pf_prep(pf, m->d_beams, B, m->max_beams);
-    gms_launch_pf_score(pf, B);
+    gms_launch_pf_score(pf, m->d_beams, B, m->max_beams);
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
@@ -675,8 +677,7 @@ int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B) {
     gms_map *m = pf->map;
     REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
     HIPCHK(hipSetDevice(m->device));
-    gms_launch_pf_prep(pf, dev_beams, B, B);
-    gms_launch_pf_score(pf, B);
+    gms_launch_pf_score(pf, dev_beams, B, B);
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
@@ -686,8 +687,7 @@ int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B) {
 int gms_pf_set_poses_dev(gms_pf *pf, const float *dev_xytheta) {
     REQUIRE(pf && dev_xytheta, "null argument");
     HIPCHK(hipSetDevice(pf->map->device));
-    HIPCHK(hipMemcpyAsync(pf->d_pose, dev_xytheta, (size_t)pf->n * pf->n_maps * 3 * sizeof(float),
-                          hipMemcpyDeviceToDevice, pf->map->stream));
+    gms_launch_pf_pose_trig(pf, dev_xytheta);          // copy + the per-particle trig, one launch
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
@@ -771,6 +771,7 @@ int gms_pf_stats_from_partials(gms_pf *pf, const double *dev_partials) {
 int gms_pf_pack(gms_pf *pf, void *dev_packed) {
     REQUIRE(pf && dev_packed, "null argument");
     HIPCHK(hipSetDevice(pf->map->device));
+    gms_launch_pf_combine(pf);
     gms_launch_pf_pack(pf, reinterpret_cast<PackedParticle *>(dev_packed));
     HIPCHK(hipGetLastError());
     return GMS_OK;
@@ -782,7 +783,7 @@ int gms_pf_import_global(gms_pf *pf, const void *dev_packed_global) {
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipMemcpyAsync(pf->d_global, dev_packed_global, (size_t)pf->n_maps * pf->n_global * sizeof(PackedParticle),
                           hipMemcpyDeviceToDevice, m->stream));
-    gms_launch_pf_unpack_weights(pf);
+    gms_launch_pf_after_gather(pf);
     pf->have_global = 1;
     HIPCHK(hipGetLastError());
     return GMS_OK;
@@ -793,6 +794,7 @@ static int ensure_global(gms_pf *pf) {
     if (pf->have_global) return GMS_OK;
     if (pf->offset != 0 || pf->n_global != pf->n)
         return fail(GMS_ERR_STATE, "sharded filter: all-gather the packed particles and call gms_pf_import_global first");
+    gms_launch_pf_combine(pf);
     gms_launch_pf_pack(pf, pf->d_global);
     pf->have_global = 1;
     return GMS_OK;
@@ -832,7 +834,7 @@ static int do_resample(gms_pf *pf, const double *r01, double fraction, int32_t *
     memcpy(h_r, r01, (size_t)pf->n_maps * sizeof(double));
     HIPCHK(hipMemcpyAsync(pf->d_r01, h_r, (size_t)pf->n_maps * sizeof(double), hipMemcpyHostToDevice, m->stream));
     gms_launch_pf_resample(pf, fraction);
-    std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_w, pf->d_w2);
+    std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
@@ -871,8 +873,7 @@ int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B) {   // Gri
     gms_map *m = pf->map;
     int rc = stage_beams(m, beams, B);
     if (rc) return rc;
-    gms_launch_pf_prep(pf, m->d_beams, B, m->max_beams);
-    gms_launch_pf_refine(pf, B);
+    gms_launch_pf_refine(pf, m->d_beams, B, m->max_beams);
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());

@@ -107,6 +107,7 @@ struct gms_pf {
     int32_t n_maps;
     float *d_pose;                  // [n_maps][n][3] current poses x,y,theta (as at the boundary)
     float *d_pose2;                 // resample double buffer
+    float *d_cs2;                   // ... and its trig
     double *d_w, *d_w2;             // [n_maps][n] weights
     double *d_logw, *d_logw2;       // [n_maps][n] sum(log factor)
     float *d_cs;                    // [n_maps][n][2] float-rounded cos/sin of theta
@@ -115,7 +116,6 @@ struct gms_pf {
     int32_t *d_nhit;                // [n_maps]
     double *d_partials;             // [n_maps][nblk_global][GMS_PARTIAL_STRIDE]
     PackedParticle *d_global;       // [n_maps][n_global] source population (own copy when unsharded)
-    double *d_wdense;               // [n_maps][n_global] its weights, dense (scan input)
     double *d_chunk_tot;            // [n_maps][nchunks] scan chunk totals / offsets
     double *d_cum;                  // [n_maps][n_global] in-chunk inclusive sums
     PfStatsDev *d_stats;            // [2][n_maps]: [0] of the last normalise, [1] of the current particles (recomputed on demand)
@@ -125,6 +125,8 @@ struct gms_pf {
     int32_t *d_idx;                 // [n_maps][n]
     float *h_stage;                 // pinned staging for poses
     int32_t have_global;            // d_global holds the current normalised population
+    int32_t chunks_ready;           // d_cum / d_chunk_tot hold level 0 of the scan of d_global
+    int32_t pending_nseg;           // > 0: d_w is stale, the weights are still d_part's segment products
 };
 
 // ---- kernel launchers (gms_map_kernels.hip / gms_pf_kernels.hip) -----------------------------
@@ -143,15 +145,16 @@ void gms_launch_get_raw(gms_map *m, int32_t mi, int32_t x, int32_t y, double *d_
 void gms_launch_debug_f32(gms_map *m, int32_t op, const float *d_a, float *d_out, int64_t n);
 
 void gms_launch_pf_init(gms_pf *pf);
-void gms_launch_pf_prep(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);
-void gms_launch_pf_score(gms_pf *pf, int32_t B);
+void gms_launch_pf_pose_trig(gms_pf *pf, const float *d_src);
+void gms_launch_pf_combine(gms_pf *pf);
+void gms_launch_pf_after_gather(gms_pf *pf);
+void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials);
 void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed);
 void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local);
 void gms_launch_pf_stats_only(gms_pf *pf, const double *d_partials, PfStatsDev *d_stats_out);
-void gms_launch_pf_unpack_weights(gms_pf *pf);
 void gms_launch_pf_resample(gms_pf *pf, double fraction /* <0: unconditional */);
-void gms_launch_pf_refine(gms_pf *pf, int32_t B);
+void gms_launch_pf_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);
 
 // profiling brackets
 void gms_prof_begin(gms_map *m, int32_t k);

@@ -21,30 +21,34 @@
 #endif
 
 // ---------------------------------------------------------------------------------------------
-__global__ void k_pf_init(float *pose, double *w, double *logw, int64_t total, double w0) {
+__global__ void k_pf_init(float *pose, float *cs, double *w, double *logw, int64_t total, double w0) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) { pose[3 * i] = 0.0f; pose[3 * i + 1] = 0.0f; pose[3 * i + 2] = 0.0f; w[i] = w0; logw[i] = 0.0; }
+    if (i < total) {
+        pose[3 * i] = 0.0f; pose[3 * i + 1] = 0.0f; pose[3 * i + 2] = 0.0f;
+        cs[2 * i] = 1.0f; cs[2 * i + 1] = 0.0f;           // (float)cos(0), (float)sin(0)
+        w[i] = w0; logw[i] = 0.0;
+    }
 }
 
-// One launch before scoring: blocks [0, trig_blocks) compute the per-particle float-rounded trig
-// (Transform.java:15-16); the last n_maps blocks compact the beams with wasHit (GridMap.java:269),
-// preserving their order.
+// Poses enter the filter through this kernel: copy (src may equal dst) + the per-particle float-rounded
+// trig of Transform.fromRobotToWorld (Transform.java:15-16).  Invariant: cs[] always matches pose[].
 __global__ void __launch_bounds__(256)
-k_pf_prep(const float *__restrict__ pose, float *__restrict__ cs, int64_t total, int32_t trig_blocks,
-          const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride, int32_t out_stride,
-          double *__restrict__ hitbeams, int32_t *__restrict__ nhit) {
-    if ((int32_t)blockIdx.x < trig_blocks) {
-        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (i < total) {
-            float c, s;
-            pose_trig(pose[3 * i + 2], c, s);
-            cs[2 * i] = c;
-            cs[2 * i + 1] = s;
-        }
-        return;
-    }
-    if (threadIdx.x >= 64) return;
-    const int32_t mi = blockIdx.x - trig_blocks;
+k_pose_trig(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ cs, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float x = src[3 * i], y = src[3 * i + 1], th = src[3 * i + 2];
+    dst[3 * i] = x; dst[3 * i + 1] = y; dst[3 * i + 2] = th;
+    float c, s;
+    pose_trig(th, c, s);
+    cs[2 * i] = c; cs[2 * i + 1] = s;
+}
+
+// One wavefront per map: order-preserving compaction of the beams with wasHit (GridMap.java:269); used
+// by the wavefront-per-particle kernels and the lattice search.
+__global__ void __launch_bounds__(64)
+k_compact_beams(const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride, int32_t out_stride,
+                double *__restrict__ hitbeams, int32_t *__restrict__ nhit) {
+    const int32_t mi = blockIdx.x;
     const int32_t lane = threadIdx.x;
     const gms_beam *mb = beams + (size_t)mi * beam_stride;
     double *out = hitbeams + (size_t)mi * out_stride * 2;
@@ -243,16 +247,30 @@ k_score_b(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
 // multiplied in segment order by k_score_combine.  One segment => the reference's product exactly.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const double *__restrict__ hitbeams,
-          const int32_t *__restrict__ nhit, int32_t beam_stride, const float *__restrict__ pose,
-          const float *__restrict__ cs, int32_t n, int32_t nseg, double *__restrict__ part,
-          double *__restrict__ w, double *__restrict__ logw) {
+k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const gms_beam *__restrict__ beams,
+          int32_t B, int32_t beam_stride, const float *__restrict__ pose, const float *__restrict__ cs, int32_t n,
+          int32_t nseg, double *__restrict__ part, double *__restrict__ w, double *__restrict__ logw) {
+    __shared__ double2 s_beam[128 + SCORE_U];        // this segment's beams with wasHit, in order
+    __shared__ int32_t s_nb;
     const int32_t mi = blockIdx.z, seg = blockIdx.y;
-    const int32_t nb = nhit[mi];
-    const int32_t L = (nb + nseg - 1) / nseg;
-    const int32_t j0 = seg * L, j1 = min(nb, j0 + L);
-    const double2 *hb = reinterpret_cast<const double2 *>(hitbeams + (size_t)mi * beam_stride * 2);
+    const int32_t L = (B + nseg - 1) / nseg;          // <= 128 (launcher)
+    const int32_t j0 = seg * L, j1 = min(B, j0 + L);
+    const gms_beam *mb = beams + (size_t)mi * beam_stride;
     const double *fac = fac_all + (size_t)mi * fac_stride;
+    if (threadIdx.x < 64) {                            // first wavefront: order-preserving compaction (GridMap.java:269)
+        int32_t base = 0;
+        for (int32_t b0 = j0; b0 < j1; b0 += 64) {
+            const int32_t b = b0 + (int32_t)threadIdx.x;
+            const bool hit = b < j1 && mb[b].hit != 0;
+            const unsigned long long mask = __ballot(hit);
+            if (hit) s_beam[base + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = make_double2(mb[b].local_x, mb[b].local_y);
+            base += __popcll(mask);
+        }
+        if (threadIdx.x < SCORE_U) s_beam[base + threadIdx.x] = make_double2(0.0, 0.0);   // padding of the last batch
+        if (threadIdx.x == 0) s_nb = base;
+    }
+    __syncthreads();
+    const int32_t nb = s_nb;
     const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const size_t gi = (size_t)mi * n + p;
@@ -260,24 +278,22 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     t.c = (double)cs[2 * gi]; t.s = (double)cs[2 * gi + 1];           // Transform.java:15-16
     t.px = (double)pose[3 * gi]; t.py = (double)pose[3 * gi + 1];
     double prod = 1.0;                                                 // GridMap.java:262
-    for (int32_t base = j0; base < j1; base += SCORE_U) {
+    for (int32_t base = 0; base < nb; base += SCORE_U) {
         uint32_t cell[SCORE_U];
         double2 bm[SCORE_U];
         bool guard = false;
 #pragma unroll
         for (int u = 0; u < SCORE_U; u++) {
-            const int32_t j = base + u;
-            bm[u] = hb[j < j1 ? j : j0];                              // workgroup-uniform: scalar loads
+            bm[u] = s_beam[base + u];                                  // same address in every lane: LDS broadcast
             const uint32_t c = beam_cell_fast(g, t, bm[u].x, bm[u].y, guard);
-            cell[u] = j < j1 ? c : (uint32_t)g.cells;
+            cell[u] = base + u < nb ? c : (uint32_t)g.cells;
         }
         if (__builtin_expect(guard, 0)) {                              // ~4e-6 of the end points
             asm volatile("; exact quotients for this batch" ::: "memory");
 #pragma unroll
             for (int u = 0; u < SCORE_U; u++) {
-                const int32_t j = base + u;
                 const uint32_t c = beam_cell(g, t, bm[u].x, bm[u].y);
-                cell[u] = j < j1 ? c : (uint32_t)g.cells;
+                cell[u] = base + u < nb ? c : (uint32_t)g.cells;
             }
         }
         double f[SCORE_U];
@@ -296,22 +312,39 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     }
 }
 
+// product of the per-segment products, in segment order, with an exact exponent (no underflow on the
+// way); the loads of eight segments are issued together
+__device__ __forceinline__ void combine_segments(const double *__restrict__ part, int32_t mi, int32_t n, int32_t nseg,
+                                                 int64_t p, double &wv, double &lwv) {
+    const double *q = part + ((size_t)mi * nseg) * n + p;
+    double mnt = 1.0;
+    int32_t e = 0;
+    for (int32_t s0 = 0; s0 < nseg; s0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = s0 + k < nseg ? q[(size_t)(s0 + k) * n] : 1.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int e2;
+            const double m2 = frexp(v[k], &e2);
+            if (s0 + k == 0) { mnt = m2; e = e2; }
+            else if (s0 + k < nseg) mx_mul(mnt, e, m2, e2);
+        }
+    }
+    wv = ldexp(mnt, e);
+    lwv = log(mnt) + (double)e * 0.6931471805599453;
+}
+
 __global__ void __launch_bounds__(256)
 k_score_combine(const double *__restrict__ part, int32_t n, int32_t nseg, double *__restrict__ w,
                 double *__restrict__ logw) {
     const int32_t mi = blockIdx.y;
     const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    int e;
-    double mnt = frexp(part[((size_t)mi * nseg) * n + p], &e);
-    for (int32_t s = 1; s < nseg; s++) {
-        int e2;
-        const double m2 = frexp(part[((size_t)mi * nseg + s) * n + p], &e2);
-        mx_mul(mnt, e, m2, e2);
-    }
-    const size_t gi = (size_t)mi * n + p;
-    w[gi] = ldexp(mnt, e);
-    logw[gi] = log(mnt) + (double)e * 0.6931471805599453;
+    double wv, lwv;
+    combine_segments(part, mi, n, nseg, p, wv, lwv);
+    w[(size_t)mi * n + p] = wv;
+    logw[(size_t)mi * n + p] = lwv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -383,9 +416,13 @@ struct RedLds {
 #define COL_YW 7
 #define COL_TW 8
 
-__device__ __forceinline__ void block_partials(const double *__restrict__ w, const double *__restrict__ logw,
+// part != nullptr: the weights are still per-segment products from k_score_c: combine them here (and
+// store weight and log-weight) instead of in a launch of their own.
+__device__ __forceinline__ void block_partials(double *__restrict__ w, double *__restrict__ logw,
                                                const float *__restrict__ pose, int64_t cnt, int64_t base,
-                                               double out[GMS_PARTIAL_STRIDE], RedLds &L) {
+                                               double out[GMS_PARTIAL_STRIDE], RedLds &L,
+                                               const double *__restrict__ part = nullptr, int32_t part_mi = 0,
+                                               int32_t part_n = 0, int32_t part_nseg = 0, int64_t part_p0 = 0) {
     const int32_t tl = threadIdx.x & (GRP - 1);
     double s = 0.0, nz = 0.0, mv = -INFINITY, mx = 9.0e15, ml = -INFINITY, sq = 0.0, xw = 0.0, yw = 0.0, tw = 0.0;
 #pragma unroll
@@ -396,8 +433,16 @@ __device__ __forceinline__ void block_partials(const double *__restrict__ w, con
         for (int e = 0; e < 4; e++) {
             const int64_t i = tl + (e0 + e) * GRP;
             const bool in = i < cnt;
-            v[e] = in ? w[i] : 0.0;
-            lw[e] = in ? logw[i] : -INFINITY;
+            if (part) {
+                v[e] = 0.0; lw[e] = -INFINITY;
+                if (in) {
+                    combine_segments(part, part_mi, part_n, part_nseg, part_p0 + i, v[e], lw[e]);
+                    w[i] = v[e]; logw[i] = lw[e];
+                }
+            } else {
+                v[e] = in ? w[i] : 0.0;
+                lw[e] = in ? logw[i] : -INFINITY;
+            }
             px[e] = in ? pose[3 * i] : 0.0f; py[e] = in ? pose[3 * i + 1] : 0.0f; pt[e] = in ? pose[3 * i + 2] : 0.0f;
         }
 #pragma unroll
@@ -480,6 +525,7 @@ __device__ __forceinline__ double fold_stats(const double *__restrict__ p, int64
     fold_argmax(p, nblk, COL_MAX, COL_ARG, mv, mx, L);
     fold_argmax(p, nblk, COL_MLW, -1, ml, mli, L);
     if (threadIdx.x == 0) {
+        s->n_ambiguous = 0;
         s->weight_sum = sum;
         s->max_w = mv;
         s->strongest = mx < 8.0e15 ? (int32_t)mx : 0;
@@ -508,8 +554,9 @@ __device__ __forceinline__ int64_t block_count(int64_t n, int64_t blk) {
 // phase 1: this shard's block partials at their global slots; blocks of other shards are zeroed so
 // that an all-reduce(SUM) assembles the full vector exactly.  grid = (nblk_global, n_maps).
 __global__ void __launch_bounds__(256)
-k_partials(const double *__restrict__ w, const double *__restrict__ logw, const float *__restrict__ pose, int32_t n,
-           int64_t offset, int64_t nblk_global, double *__restrict__ partials) {
+k_partials(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n,
+           int64_t offset, int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part,
+           int32_t part_nseg) {
     __shared__ RedLds L;
     const int32_t mi = blockIdx.y;
     const int64_t gb = blockIdx.x;
@@ -522,31 +569,93 @@ k_partials(const double *__restrict__ w, const double *__restrict__ logw, const 
     }
     double out[GMS_PARTIAL_STRIDE];
     const size_t o = (size_t)mi * n + lb * GMS_BLOCK;
-    block_partials(w + o, logw + o, pose + 3 * o, block_count(n, lb), offset + lb * GMS_BLOCK, out, L);
+    block_partials(w + o, logw + o, pose + 3 * o, block_count(n, lb), offset + lb * GMS_BLOCK, out, L, part, mi, n,
+                   part_nseg, lb * GMS_BLOCK);
     if (threadIdx.x == 0)
         for (int k = 0; k < GMS_PARTIAL_STRIDE; k++) p[k] = out[k];
 }
 
+// Level 0 of the cumulative weights for one 64-particle chunk held in LDS: sequential, index order --
+// the reference's `c += w[i]` (SLAM.java:144) inside the chunk.
+__device__ __forceinline__ double chunk_sums_lds(double *row, int32_t len) {
+    double acc = 0.0;
+#pragma unroll 8
+    for (int32_t j = 0; j < SCAN_CHUNK; j++) {
+        if (j < len) {
+            acc = (j == 0) ? row[j] : acc + row[j];
+            row[j] = acc;
+        }
+    }
+    return acc;
+}
+
 // phase 2: every workgroup folds the (all-reduced) partials; weight /= weightSum (SLAM.java:120-121);
-// packs {w,x,y,theta} (the all-gather payload / the resampling source) and the dense weight copy.
+// packs {w,x,y,theta} (the all-gather payload / the resampling source).  A stand-alone filter also
+// gets the dense weight copy and level 0 of the cumulative weights here (cum != nullptr).
 __global__ void __launch_bounds__(256)
 k_normalize_pack(const double *__restrict__ partials_all, int64_t nblk_global, double *__restrict__ w,
                  const float *__restrict__ pose, int32_t n, int64_t offset, PackedParticle *__restrict__ packed,
-                 double *__restrict__ wdense_local, PfStatsDev *__restrict__ stats) {
+                 double *__restrict__ cum, double *__restrict__ chunk_tot, int64_t nchunks,
+                 PfStatsDev *__restrict__ stats) {
     __shared__ RedLds L;
+    __shared__ double s_w[256 + 4];
     const int32_t mi = blockIdx.y;
     const double *p = partials_all + (size_t)mi * nblk_global * GMS_PARTIAL_STRIDE;
     const double sum = fold_stats(p, nblk_global, stats + mi, blockIdx.x == 0, pose + (size_t)mi * n * 3, offset, n, L);
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    double wn = 0.0;
     if (i < n) {
         const size_t gi = (size_t)mi * n + i;
-        const double wn = w[gi] / sum;
+        wn = w[gi] / sum;
         w[gi] = wn;
         PackedParticle pp;
         pp.w = wn; pp.x = pose[3 * gi]; pp.y = pose[3 * gi + 1]; pp.theta = pose[3 * gi + 2]; pp.pad = 0u;
         packed[gi] = pp;
-        if (wdense_local) wdense_local[gi] = wn;
     }
+    if (cum) {                                        // uniform
+        const int32_t t = threadIdx.x;
+        s_w[t + (t >> 6)] = wn;                       // pitch 65: the four chunk rows start on different banks
+        __syncthreads();
+        if (t < 4) {
+            const int64_t c = (int64_t)blockIdx.x * 4 + t;
+            if (c < nchunks) {
+                const int64_t left = (int64_t)n - c * SCAN_CHUNK;
+                const double tot = chunk_sums_lds(s_w + t * 65, (int32_t)(left < SCAN_CHUNK ? left : SCAN_CHUNK));
+                chunk_tot[(size_t)mi * (nchunks + 1) + c] = tot;
+            }
+        }
+        __syncthreads();
+        if (i < n) cum[(size_t)mi * n + i] = s_w[t + (t >> 6)];
+    }
+}
+
+// Level 0 as a kernel of its own (sharded filters after the all-gather; resample without normalise):
+// one lane per chunk of the GLOBAL population, 64 chunks per wavefront.
+__global__ void __launch_bounds__(64)
+k_chunk_sums(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks, double *__restrict__ cum_all,
+             double *__restrict__ chunk_tot, PfStatsDev *__restrict__ stats) {
+    const int32_t mi = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[mi].n_ambiguous = 0;
+    if (c >= nchunks) return;
+    const PackedParticle *g = glob_all + (size_t)mi * n_global;
+    double *cm = cum_all + (size_t)mi * n_global;
+    const int64_t i0 = c * SCAN_CHUNK;
+    const int64_t len = n_global - i0 < SCAN_CHUNK ? n_global - i0 : SCAN_CHUNK;
+    double acc = 0.0;
+    for (int64_t j0 = 0; j0 < len; j0 += 8) {         // eight independent loads in flight
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = j0 + j < len ? g[i0 + j0 + j].w : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j0 + j < len) {
+                acc = (j0 + j == 0) ? v[j] : acc + v[j];
+                cm[i0 + j0 + j] = acc;
+            }
+        }
+    }
+    chunk_tot[(size_t)mi * (nchunks + 1) + c] = acc;
 }
 
 // statistics only (getWeightedPose / calculateNeff on the current particles, nothing rewritten)
@@ -561,7 +670,7 @@ k_stats_only(const double *__restrict__ partials_all, int64_t nblk_global, const
 
 // pack without normalising
 __global__ void k_pack(const double *__restrict__ w, const float *__restrict__ pose, int32_t n,
-                       PackedParticle *__restrict__ packed, double *__restrict__ wdense_local) {
+                       PackedParticle *__restrict__ packed) {
     const int32_t mi = blockIdx.y;
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -569,120 +678,68 @@ __global__ void k_pack(const double *__restrict__ w, const float *__restrict__ p
     PackedParticle pp;
     pp.w = w[gi]; pp.x = pose[3 * gi]; pp.y = pose[3 * gi + 1]; pp.theta = pose[3 * gi + 2]; pp.pad = 0u;
     packed[gi] = pp;
-    if (wdense_local) wdense_local[gi] = pp.w;
 }
 
-// after the all-gather: dense copy of the global population's weights (scan input)
-// (+ the strongest particle's pose, which only the rank that owns it could fill in before)
-__global__ void k_unpack_weights(const PackedParticle *__restrict__ glob, int64_t total, int64_t n_global,
-                                 double *__restrict__ wdense, PfStatsDev *__restrict__ stats) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const PackedParticle pp = glob[i];
-    wdense[i] = pp.w;
-    const int64_t mi = i / n_global;
-    if (i - mi * n_global == (int64_t)stats[mi].strongest) {
-        stats[mi].spose[0] = pp.x; stats[mi].spose[1] = pp.y; stats[mi].spose[2] = pp.theta;
-    }
+// after the all-gather: the strongest particle's pose, which only the rank that owns it could fill in
+__global__ void k_set_spose(const PackedParticle *__restrict__ glob, int64_t n_global, PfStatsDev *__restrict__ stats) {
+    const int32_t mi = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int64_t st = stats[mi].strongest;
+    if (st < 0) st = 0;
+    if (st >= n_global) st = n_global - 1;
+    const PackedParticle pp = glob[(size_t)mi * n_global + st];
+    stats[mi].spose[0] = pp.x; stats[mi].spose[1] = pp.y; stats[mi].spose[2] = pp.theta;
 }
 
 // ---------------------------------------------------------------------------------------------
-// resampling
-// ---------------------------------------------------------------------------------------------
-// Cumulative weights, fixed shape (depends on n_global only, so every rank of a sharded filter
-// computes the same values):
-//   level 0  chunk of SCAN_CHUNK = 64 weights: one lane adds them in index order -- the reference's
-//            `c += w[i]` (SLAM.java:144) inside the chunk -- and stores the running sums;
-//   level 1  super-chunk of 64 chunks: one lane per wavefront adds the chunk totals in order;
+// resampling.  Cumulative weights, fixed shape (depends on n_global only, so every rank of a sharded
+// filter computes the same values):
+//   level 0  chunk of SCAN_CHUNK = 64 weights: added in index order (chunk_sums_lds / k_chunk_sums);
+//   level 1  super-chunk of 64 chunks: one lane adds the chunk totals in order;
 //   level 2  one lane adds the super-chunk totals in order.
 // offset[c] = level2[c / 64] + level1[c]; cumulative weight of particle i = offset[i / 64] + cum[i].
-// One workgroup of 1024 lanes per map: 65 536 particles per sweep.
-#define SCAN_THREADS 1024
-__global__ void __launch_bounds__(SCAN_THREADS)
-k_scan(const double *__restrict__ wdense, int64_t n_global, int64_t nchunks, double *__restrict__ cum,
-       double *__restrict__ chunk_off, PfStatsDev *__restrict__ stats) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    double *s_tot = reinterpret_cast<double *>(smem);          // [SCAN_THREADS] chunk totals -> level-1 offsets
-    double *s_sup = s_tot + SCAN_THREADS;                      // [nsuper + 1] super-chunk totals -> level-2 offsets
-    const int32_t mi = blockIdx.x, t = threadIdx.x, lane = t & 63;
-    const double *wd = wdense + (size_t)mi * n_global;
-    double *cm = cum + (size_t)mi * n_global;
-    double *off = chunk_off + (size_t)mi * (nchunks + 1);
-    const int64_t nsuper = (nchunks + 63) / 64;
-    if (t == 0) stats[mi].n_ambiguous = 0;
-
-    for (int64_t cb = 0; cb < nchunks; cb += SCAN_THREADS) {
-        const int64_t c = cb + t;
-        const int64_t i0 = c * SCAN_CHUNK;
-        double acc = 0.0;
-        if (c < nchunks) {
-            if (i0 + SCAN_CHUNK <= n_global) {                 // full chunk: 32 x 16-byte loads in flight
-                double2 v[SCAN_CHUNK / 2];
-                const double2 *src = reinterpret_cast<const double2 *>(wd + i0);
-#pragma unroll
-                for (int j = 0; j < SCAN_CHUNK / 2; j++) v[j] = src[j];
-                double2 *dst = reinterpret_cast<double2 *>(cm + i0);
-#pragma unroll
-                for (int j = 0; j < SCAN_CHUNK / 2; j++) {
-                    acc = (j == 0) ? v[j].x : acc + v[j].x;
-                    v[j].x = acc;
-                    acc = acc + v[j].y;
-                    v[j].y = acc;
-                    dst[j] = v[j];
-                }
-            } else {                                           // ragged tail
-                for (int64_t i = i0; i < n_global; i++) {
-                    acc = (i == i0) ? wd[i] : acc + wd[i];
-                    cm[i] = acc;
-                }
-            }
-        }
-        s_tot[t] = acc;
-        __syncthreads();
-        if (lane == 0) {                                       // level 1: this wavefront's 64 chunk totals, in order
-            double a1 = 0.0;
-            double *p = s_tot + (t & ~63);
-#pragma unroll 8
-            for (int j = 0; j < 64; j++) {
-                const double v = p[j];
-                p[j] = a1;
-                a1 = (j == 0) ? v : a1 + v;
-            }
-            const int64_t sidx = (cb + t) >> 6;
-            if (sidx < nsuper) s_sup[sidx] = a1;
-        }
-        __syncthreads();
-        if (c < nchunks) off[c] = s_tot[t];                    // level-1 offset for now; level 2 added below
-        __syncthreads();
-    }
-    if (t == 0) {                                              // level 2: super-chunk totals, in order
-        double a2 = 0.0;
-        for (int64_t sidx = 0; sidx < nsuper; sidx++) {
-            const double v = s_sup[sidx];
-            s_sup[sidx] = a2;
-            a2 = (sidx == 0) ? v : a2 + v;
-        }
-        s_sup[nsuper] = a2;
-        off[nchunks] = a2;                                     // grand total
-    }
-    __syncthreads();
-    for (int64_t c = 64 + t; c < nchunks; c += SCAN_THREADS) off[c] = s_sup[c >> 6] + off[c];   // super-chunk 0 adds nothing
-}
-
+// Levels 1 and 2 are a few hundred additions: every workgroup of k_resample redoes them in LDS.
+// ---------------------------------------------------------------------------------------------
 // one lane per output slot (SLAM.java:140-149); the chunk offsets are staged in LDS for the first search level
 __global__ void __launch_bounds__(256)
 k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks,
            const double *__restrict__ cum_all, const double *__restrict__ chunk_off, const double *__restrict__ r01,
-           double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, double *__restrict__ w2,
-           int32_t *__restrict__ idx_out, PfStatsDev *__restrict__ stats) {
+           double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, float *__restrict__ cs2,
+           double *__restrict__ w2, int32_t *__restrict__ idx_out, PfStatsDev *__restrict__ stats) {
     extern __shared__ __align__(16) unsigned char smem[];
     double *off = reinterpret_cast<double *>(smem);                    // [nchunks + 1]
     const int32_t mi = blockIdx.y;
     const PfStatsDev *st = stats + mi;
     const bool go = fraction < 0.0 || (1.0 / st->sq_sum) < fraction * (double)n_global;   // GridMapApp.java:185
+    const int64_t nsuper = (nchunks + 63) / 64;
+    double *sup = off + nchunks + 1;                                   // [nsuper + 1]
     if (go) {
-        const double *src = chunk_off + (size_t)mi * (nchunks + 1);
-        for (int64_t c = threadIdx.x; c <= nchunks; c += blockDim.x) off[c] = src[c];
+        const double *tot = chunk_off + (size_t)mi * (nchunks + 1);
+        for (int64_t c = threadIdx.x; c < nchunks; c += blockDim.x) off[c] = tot[c];
+        __syncthreads();
+        for (int64_t sidx = threadIdx.x; sidx < nsuper; sidx += blockDim.x) {     // level 1
+            double a1 = 0.0;
+            const int64_t c0 = sidx * 64, c1 = c0 + 64 < nchunks ? c0 + 64 : nchunks;
+#pragma unroll 8
+            for (int64_t c = c0; c < c1; c++) {
+                const double v = off[c];
+                off[c] = a1;
+                a1 = (c == c0) ? v : a1 + v;
+            }
+            sup[sidx] = a1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {                                                   // level 2
+            double a2 = 0.0;
+            for (int64_t sidx = 0; sidx < nsuper; sidx++) {
+                const double v = sup[sidx];
+                sup[sidx] = a2;
+                a2 = (sidx == 0) ? v : a2 + v;
+            }
+            off[nchunks] = a2;                                                    // grand total
+        }
+        __syncthreads();
+        for (int64_t c = 64 + threadIdx.x; c < nchunks; c += blockDim.x) off[c] = sup[c >> 6] + off[c];   // super-chunk 0 adds nothing
         __syncthreads();
     }
     const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -726,6 +783,9 @@ k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_
     const PackedParticle pp = g[src];
     const size_t o = (size_t)mi * n + t;
     pose2[3 * o] = pp.x; pose2[3 * o + 1] = pp.y; pose2[3 * o + 2] = pp.theta;
+    float tc, ts;
+    pose_trig(pp.theta, tc, ts);                                        // keep cs[] in step with pose[]
+    cs2[2 * o] = tc; cs2[2 * o + 1] = ts;
     w2[o] = pp.w;                                                       // copies keep their weight (SLAM.java:42)
     if (idx_out) idx_out[o] = (int32_t)src;
     if (t == 0) stats[mi].did_resample = go ? 1 : 0;
@@ -738,7 +798,8 @@ k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_
 #define REFINE_MAX_STEPS 16
 __global__ void __launch_bounds__(256)
 k_refine(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const double *__restrict__ hitbeams,
-         const int32_t *__restrict__ nhit, int32_t beam_stride, float *__restrict__ pose, int32_t n) {
+         const int32_t *__restrict__ nhit, int32_t beam_stride, float *__restrict__ pose, float *__restrict__ cs,
+         int32_t n) {
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *sb = reinterpret_cast<double2 *>(smem);
     __shared__ float s_dx[REFINE_MAX_STEPS], s_dy[REFINE_MAX_STEPS], s_dt[REFINE_MAX_STEPS];
@@ -803,6 +864,9 @@ k_refine(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, cons
         if (bi >= 0) {
             const int32_t it = bi % nt, iy = (bi / nt) % ny, ix = bi / (nt * ny);
             pose[3 * gi] = x0 + s_dx[ix]; pose[3 * gi + 1] = y0 + s_dy[iy]; pose[3 * gi + 2] = t0 + s_dt[it];
+            float tc, ts;
+            pose_trig(t0 + s_dt[it], tc, ts);
+            cs[2 * gi] = tc; cs[2 * gi + 1] = ts;
         }
     }
 }
@@ -816,20 +880,26 @@ static inline int64_t nchunks_of(const gms_pf *pf) { return (pf->n_global + SCAN
 void gms_launch_pf_init(gms_pf *pf) {
     const int64_t total = (int64_t)pf->n_maps * pf->n;
     hipLaunchKernelGGL(k_pf_init, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pf->map->stream, pf->d_pose,
-                       pf->d_w, pf->d_logw, total, 1.0 / (double)pf->n_global);
+                       pf->d_cs, pf->d_w, pf->d_logw, total, 1.0 / (double)pf->n_global);
 }
 
-void gms_launch_pf_prep(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride) {
-    gms_map *m = pf->map;
+void gms_launch_pf_pose_trig(gms_pf *pf, const float *d_src) {
     const int64_t total = (int64_t)pf->n_maps * pf->n;
-    const int32_t trig_blocks = (int32_t)((total + 255) / 256);
-    hipLaunchKernelGGL(k_pf_prep, dim3(trig_blocks + pf->n_maps), dim3(256), 0, m->stream, pf->d_pose, pf->d_cs, total,
-                       trig_blocks, d_beams, B, beam_stride, m->max_beams, pf->d_hitbeams, pf->d_nhit);
+    hipLaunchKernelGGL(k_pose_trig, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pf->map->stream, d_src, pf->d_pose,
+                       pf->d_cs, total);
 }
 
-void gms_launch_pf_score(gms_pf *pf, int32_t B) {
+static void launch_compact(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride) {
     gms_map *m = pf->map;
+    hipLaunchKernelGGL(k_compact_beams, dim3(pf->n_maps), dim3(64), 0, m->stream, d_beams, B, beam_stride, m->max_beams,
+                       pf->d_hitbeams, pf->d_nhit);
+}
+
+void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride) {
+    gms_map *m = pf->map;
+    if (m->score_variant != 2) launch_compact(pf, d_beams, B, beam_stride);
     ProfScope ps(m, GMS_K_SCORE);
+    pf->pending_nseg = 0;
     if (m->score_variant == 2) {
         const int32_t threads = pf->n >= 1024 ? 1024 : ((pf->n + 63) / 64) * 64;
         const int64_t groups = ((int64_t)pf->n + threads - 1) / threads;
@@ -841,11 +911,9 @@ void gms_launch_pf_score(gms_pf *pf, int32_t B) {
         if (m->score_segments > 0) nseg = m->score_segments < min_seg ? min_seg : m->score_segments;
         if (nseg > GMS_SCORE_MAXSEG) nseg = GMS_SCORE_MAXSEG;
         hipLaunchKernelGGL(k_score_c, dim3((unsigned)groups, (unsigned)nseg, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
-                           m->d_fac, m->fac_stride, pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_pose, pf->d_cs, pf->n,
-                           (int32_t)nseg, pf->d_part, pf->d_w, pf->d_logw);
-        if (nseg > 1)
-            hipLaunchKernelGGL(k_score_combine, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, pf->d_part,
-                               pf->n, (int32_t)nseg, pf->d_w, pf->d_logw);
+                           m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
+                           pf->d_part, pf->d_w, pf->d_logw);
+        if (nseg > 1) pf->pending_nseg = (int32_t)nseg;               // combined by the next consumer of the weights
         return;
     }
     if (m->score_variant == 1) {
@@ -853,7 +921,7 @@ void gms_launch_pf_score(gms_pf *pf, int32_t B) {
         int64_t nseg = 4096 / (groups * pf->n_maps);
         if (nseg > SCORE_B_MAXSEG) nseg = SCORE_B_MAXSEG;
         if (nseg < 1) nseg = 1;
-        if (m->score_segments > 0) nseg = m->score_segments;
+        if (m->score_segments > 0 && m->score_segments <= SCORE_B_MAXSEG) nseg = m->score_segments;
         hipLaunchKernelGGL(k_score_b, dim3((unsigned)groups, pf->n_maps), dim3((unsigned)nseg * 64), 0, m->stream, m->gd,
                            m->d_fac, m->fac_stride, pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_pose, pf->d_cs, pf->n, pf->d_w,
                            pf->d_logw);
@@ -873,22 +941,36 @@ void gms_launch_pf_score(gms_pf *pf, int32_t B) {
                        m->fac_stride, pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_pose, pf->d_cs, pf->n, pf->d_w, pf->d_logw);
 }
 
+// materialise weight / log-weight from the per-segment products if nobody has yet
+void gms_launch_pf_combine(gms_pf *pf) {
+    if (!pf->pending_nseg) return;
+    gms_map *m = pf->map;
+    ProfScope ps(m, GMS_K_SCORE);
+    hipLaunchKernelGGL(k_score_combine, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, pf->d_part, pf->n,
+                       pf->pending_nseg, pf->d_w, pf->d_logw);
+    pf->pending_nseg = 0;
+}
+
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
     hipLaunchKernelGGL(k_partials, dim3((unsigned)nblk, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw,
-                       pf->d_pose, pf->n, pf->offset, nblk, d_partials);
+                       pf->d_pose, pf->n, pf->offset, nblk, d_partials,
+                       pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg);
+    pf->pending_nseg = 0;                                             // k_partials stored the combined weights
 }
 
 void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
-    // a stand-alone filter packs straight into its own population and dense weight array
-    double *wd = (d_packed_local == pf->d_global) ? pf->d_wdense : nullptr;
+    // a stand-alone filter packs straight into its own population and gets level 0 of the scan with it
+    const bool own = d_packed_local == pf->d_global;
     hipLaunchKernelGGL(k_normalize_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, d_partials, nblk,
-                       pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local, wd, pf->d_stats);
+                       pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local, own ? pf->d_cum : (double *)nullptr,
+                       own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf), pf->d_stats);
+    pf->chunks_ready = own ? 1 : 0;
 }
 
 void gms_launch_pf_stats_only(gms_pf *pf, const double *d_partials, PfStatsDev *d_stats_out) {
@@ -900,44 +982,43 @@ void gms_launch_pf_stats_only(gms_pf *pf, const double *d_partials, PfStatsDev *
 
 void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed) {
     gms_map *m = pf->map;
-    double *wd = (d_packed == pf->d_global) ? pf->d_wdense : nullptr;
     hipLaunchKernelGGL(k_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_pose,
-                       pf->n, d_packed, wd);
+                       pf->n, d_packed);
+    if (d_packed == pf->d_global) pf->chunks_ready = 0;
 }
 
-void gms_launch_pf_unpack_weights(gms_pf *pf) {
+void gms_launch_pf_after_gather(gms_pf *pf) {
     gms_map *m = pf->map;
-    const int64_t total = (int64_t)pf->n_maps * pf->n_global;
-    hipLaunchKernelGGL(k_unpack_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, pf->d_global, total,
-                       pf->n_global, pf->d_wdense, pf->d_stats);
+    hipLaunchKernelGGL(k_set_spose, dim3(pf->n_maps), dim3(64), 0, m->stream, pf->d_global, pf->n_global, pf->d_stats);
+    pf->chunks_ready = 0;
 }
 
 void gms_launch_pf_resample(gms_pf *pf, double fraction) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_RESAMPLE);
     const int64_t nch = nchunks_of(pf);
-    const size_t smem_scan = (size_t)(SCAN_THREADS + (nch + 63) / 64 + 1) * sizeof(double);
-    if (smem_scan > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem_scan);
-    hipLaunchKernelGGL(k_scan, dim3(pf->n_maps), dim3(SCAN_THREADS), smem_scan, m->stream, pf->d_wdense, pf->n_global,
-                       nch, pf->d_cum, pf->d_chunk_tot, pf->d_stats);
-    const size_t smem = (size_t)(nch + 1) * sizeof(double);
+    if (!pf->chunks_ready) {
+        hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)((nch + 63) / 64), pf->n_maps), dim3(64), 0, m->stream, pf->d_global,
+                           pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->d_stats);
+        pf->chunks_ready = 1;
+    }
+    const size_t smem = (size_t)(nch + 1 + (nch + 63) / 64 + 1) * sizeof(double);
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resample), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
     hipLaunchKernelGGL(k_resample, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), smem, m->stream, pf->d_global,
                        pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->d_r01, fraction, pf->n, pf->offset,
-                       pf->d_pose2, pf->d_w2, pf->d_idx, pf->d_stats);
+                       pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_stats);
 }
 
-void gms_launch_pf_refine(gms_pf *pf, int32_t B) {
+void gms_launch_pf_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride) {
     gms_map *m = pf->map;
+    launch_compact(pf, d_beams, B, beam_stride);
     ProfScope ps(m, GMS_K_REFINE);
     const size_t smem = (size_t)B * sizeof(double2);
     if (smem > 32 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_refine), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
     hipLaunchKernelGGL(k_refine, dim3(pf->n, pf->n_maps), dim3(256), smem, m->stream, m->gd, m->d_fac, m->fac_stride,
-                       pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_pose, pf->n);
+                       pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_pose, pf->d_cs, pf->n);
 }
