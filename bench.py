@@ -56,6 +56,22 @@ def algorithmic_bytes(kind: str, *, n_particles=0, n_hit=0, n_beams=0, cells=0, 
     return 0.0
 
 
+def pmc_traffic(kernel_class: str):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/*/pmc_traffic.json: separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of this
+    command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None when not collected."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+            if kernel_class in d:
+                best = d[kernel_class].get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    return best
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +82,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=0, help="scans of the CPU baseline sample (0 = auto)")
     ap.add_argument("--full-rebuild", action="store_true", help="rebuild the whole likelihood field every scan")
+    ap.add_argument("--force-sharded", action="store_true", help="run the sharded (all-reduce / all-gather) code path even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -112,7 +129,7 @@ def main() -> int:
     n_hit = int(tr.scans[T // 2]["hit"].sum())
     r01 = np.random.default_rng(7).random(4096)
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
         ops = HipShardOps(m, n_local, rank * n_local, n_global)
         spf = ShardedParticleFilter(n_global, ops)
         pf = ops.pf
@@ -124,6 +141,9 @@ def main() -> int:
         s = i % n_sets
         t = T // 2 + s
         beams_ptr = scans_dev[t].data_ptr()
+        if spf is None and not args.full_rebuild:
+            pf.slam_update_dev(pose_sets[s].data_ptr(), beams_ptr, B, r01[i % 4096], 0.5, True)   # one C-ABI call per scan
+            return
         pf.set_poses_dev(pose_sets[s].data_ptr())
         pf.score_dev(beams_ptr, B)
         if spf is None:
@@ -236,7 +256,7 @@ def main() -> int:
         "filter": {"neff": st["neff"], "n_zero_weights": st["n_zero"], "weight_sum": st["weight_sum"]},
         "roofline": {
             "kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dominant),
             "algorithmic_bytes_per_launch": alg / per_launch_scale,
             "avg_launch_us": dom_avg_s * 1e6 / per_launch_scale, "launches_timed": dom_n,
         },

@@ -829,10 +829,14 @@ static int do_resample(gms_pf *pf, const double *r01, double fraction, int32_t *
     HIPCHK(hipSetDevice(m->device));
     int rc = ensure_global(pf);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(m->stream));          // h_stats tail doubles as the r01 staging area
-    double *h_r = reinterpret_cast<double *>(reinterpret_cast<char *>(pf->h_stats) + (size_t)pf->n_maps * sizeof(PfStatsDev));
-    memcpy(h_r, r01, (size_t)pf->n_maps * sizeof(double));
-    HIPCHK(hipMemcpyAsync(pf->d_r01, h_r, (size_t)pf->n_maps * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    if (pf->n_maps == 1) {
+        pf->r01_scalar = r01[0];                       // travels as a kernel argument: no copy, no synchronisation
+    } else {
+        HIPCHK(hipStreamSynchronize(m->stream));       // h_stats tail doubles as the r01 staging area
+        double *h_r = reinterpret_cast<double *>(reinterpret_cast<char *>(pf->h_stats) + (size_t)pf->n_maps * sizeof(PfStatsDev));
+        memcpy(h_r, r01, (size_t)pf->n_maps * sizeof(double));
+        HIPCHK(hipMemcpyAsync(pf->d_r01, h_r, (size_t)pf->n_maps * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    }
     gms_launch_pf_resample(pf, fraction);
     std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);
     pf->have_global = 0;
@@ -857,6 +861,24 @@ int gms_pf_resample(gms_pf *pf, const double *r01, int32_t *indices, int32_t *n_
 int gms_pf_resample_if(gms_pf *pf, const double *r01, double fraction) {   // GridMapApp.java:185-186
     REQUIRE(fraction >= 0.0, "fraction must be non-negative");
     return do_resample(pf, r01, fraction, nullptr, nullptr);
+}
+
+// SLAM.update(z, u) (SLAM.java:80-131) + the resampling rule of its caller (GridMapApp.java:185-186) as one
+// call on device-resident inputs: poses := dev_xytheta (the motion-model samples), weights, bookkeeping,
+// conditional resample, map update at the weighted pose, likelihood rebuild.  Nothing is read back.
+int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, const double *r01,
+                        double resample_fraction, int32_t integrate) {
+    REQUIRE(pf && dev_beams && r01, "null argument");
+    gms_map *m = pf->map;
+    if (pf->offset != 0 || pf->n_global != pf->n)
+        return fail(GMS_ERR_STATE, "sharded filter: the collectives belong to the caller (see distributed.py)");
+    int rc = GMS_OK;
+    if (dev_xytheta) rc = gms_pf_set_poses_dev(pf, dev_xytheta);                  // SLAM.java:90
+    if (!rc) rc = gms_pf_score_dev(pf, dev_beams, B);                            // :99
+    if (!rc) rc = gms_pf_normalize(pf, nullptr);                                 // :100-124
+    if (!rc && resample_fraction >= 0.0) rc = gms_pf_resample_if(pf, r01, resample_fraction);   // GridMapApp.java:185-186
+    if (!rc && integrate) rc = gms_map_update_at_dev(m, dev_beams, B, pf, 0);    // SLAM.java:102-105, :93
+    return rc;
 }
 
 int gms_pf_did_resample(gms_pf *pf, int32_t *flags) {

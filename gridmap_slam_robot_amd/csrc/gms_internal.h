@@ -121,7 +121,8 @@ struct gms_pf {
     PfStatsDev *d_stats;            // [2][n_maps]: [0] of the last normalise, [1] of the current particles (recomputed on demand)
     int32_t stats_current;          // d_stats[0] still describes the current particles
     PfStatsDev *h_stats;            // pinned
-    double *d_r01;                  // [n_maps]
+    double *d_r01;                  // [n_maps] (batched maps; a single map passes r01 as a kernel argument)
+    double r01_scalar;
     int32_t *d_idx;                 // [n_maps][n]
     float *h_stage;                 // pinned staging for poses
     int32_t have_global;            // d_global holds the current normalised population

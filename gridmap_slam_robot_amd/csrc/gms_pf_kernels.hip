@@ -704,7 +704,7 @@ __global__ void k_set_spose(const PackedParticle *__restrict__ glob, int64_t n_g
 __global__ void __launch_bounds__(256)
 k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks,
            const double *__restrict__ cum_all, const double *__restrict__ chunk_off, const double *__restrict__ r01,
-           double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, float *__restrict__ cs2,
+           double r01_scalar, double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, float *__restrict__ cs2,
            double *__restrict__ w2, int32_t *__restrict__ idx_out, PfStatsDev *__restrict__ stats) {
     extern __shared__ __align__(16) unsigned char smem[];
     double *off = reinterpret_cast<double *>(smem);                    // [nchunks + 1]
@@ -750,7 +750,7 @@ k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_
     if (go) {
         const double *cm = cum_all + (size_t)mi * n_global;
         const double N = (double)n_global;
-        const double r = r01[mi] * 1.0 / N;                             // SLAM.java:136
+        const double r = (r01 ? r01[mi] : r01_scalar) * 1.0 / N;        // SLAM.java:136
         const double U = r + (double)m0 * 1.0 / N;                      // :141
         // first chunk whose end value stops the `while (U > c)` loop: !(U > off[c+1])
         int64_t lo = 0, hi = nchunks;           // answer in [0, nchunks]; nchunks = none
@@ -1007,7 +1007,8 @@ void gms_launch_pf_resample(gms_pf *pf, double fraction) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resample), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
     hipLaunchKernelGGL(k_resample, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), smem, m->stream, pf->d_global,
-                       pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->d_r01, fraction, pf->n, pf->offset,
+                       pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01,
+                       pf->r01_scalar, fraction, pf->n, pf->offset,
                        pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_stats);
 }
 

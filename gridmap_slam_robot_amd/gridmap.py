@@ -391,6 +391,12 @@ class ParticleFilter:
     def score_dev(self, dev_beams: int, B: int):
         check(load().gms_pf_score_dev(self._h, C.c_void_p(dev_beams), B))
 
+    def slam_update_dev(self, dev_xytheta: int, dev_beams: int, B: int, r01, fraction: float = 0.5, integrate: bool = True):
+        """SLAM.update + `if (neff < fraction*N) resample()` in one call on device-resident inputs."""
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(r01, dtype=np.float64), (self.n_maps,)))
+        check(load().gms_slam_update_dev(self._h, C.c_void_p(dev_xytheta or 0), C.c_void_p(dev_beams), B, ptr(r), fraction,
+                                         1 if integrate else 0))
+
     def _stats(self, arr):
         out = [dict(weight_sum=s.weight_sum, neff=s.neff, strongest=s.strongest, n_zero=s.n_zero,
                     max_log_weight=s.max_log_weight) for s in arr]

@@ -209,6 +209,12 @@ int gms_map_update_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, const f
 int gms_map_update_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, gms_pf *pf, int32_t which);
 int gms_pf_set_poses_dev(gms_pf *pf, const float *dev_xytheta);
 int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B);
+/* One scan through the whole path: SLAM.update(z, u) (J/slam/SLAM.java:80-131) followed by its caller's
+ * `if (neff < fraction * N) resample()` (J/app/GridMapApp.java:185-186).  dev_xytheta (may be NULL) are the
+ * motion-model samples; resample_fraction < 0 skips the resampling; integrate = 0 is the skipUpdate case
+ * (SLAM.java:82).  r01[n_maps] is read on the host.  Nothing is read back. */
+int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, const double *r01,
+                        double resample_fraction, int32_t integrate);
 
 /* ---- multi-GPU plumbing (particles sharded over ranks; collectives stay with the caller) ------- */
 /* Number of doubles of the block-partial vector exchanged by an all-reduce(SUM):
