@@ -182,31 +182,42 @@ __global__ void k_trace_ray(int32_t W, int32_t H, float x0, float y0, float x1, 
     *count_out = count;
 }
 
-// log += n_free*l_free + n_occ*l_occ on the touched box; counts cleared.
+// log += n_free*l_free + n_occ*l_occ on the touched box; counts cleared.  Persistent workgroups
+// enumerate only the 256 x 4 cell tiles that intersect the box; a lane owns 4 consecutive cells.
 #define APPLY_TW 256
 #define APPLY_TH 4
 __global__ void __launch_bounds__(256)
 k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
         int32_t *__restrict__ bbox_idle) {
-    const int32_t mi = blockIdx.z;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) bbox_idle[4 * mi + threadIdx.x] = 0;
+    const int32_t mi = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x < 4) bbox_idle[4 * mi + threadIdx.x] = 0;
     int32_t x0, y0, x1, y1;
     bbox_decode(bbox + 4 * mi, g.W, g.H, x0, y0, x1, y1);
-    const int32_t tx0 = blockIdx.x * APPLY_TW, ty0 = blockIdx.y * APPLY_TH;
-    if (x1 <= 0 || tx0 >= x1 || tx0 + APPLY_TW <= x0 || ty0 >= y1 || ty0 + APPLY_TH <= y0) return;
-    const int32_t y = ty0 + (threadIdx.x >> 6);
-    if (y >= g.H) return;
-    const int32_t xb = tx0 + (threadIdx.x & 63) * 4;
-    const size_t row = (size_t)mi * g.cells + (size_t)y * g.W;
+    if (x1 <= 0) return;
+    const int32_t qx0 = x0 / APPLY_TW, qy0 = y0 / APPLY_TH;
+    const int32_t qnx = (x1 - 1) / APPLY_TW - qx0 + 1, qny = (y1 - 1) / APPLY_TH - qy0 + 1;
+    const bool vec = (g.W & 3) == 0;
+    for (int32_t t = blockIdx.x; t < qnx * qny; t += gridDim.x) {
+        const int32_t tx0 = (qx0 + t % qnx) * APPLY_TW, ty0 = (qy0 + t / qnx) * APPLY_TH;
+        const int32_t y = ty0 + (threadIdx.x >> 6);
+        const int32_t xb = tx0 + (threadIdx.x & 63) * 4;
+        if (y >= g.H || xb >= g.W) continue;
+        const size_t o = (size_t)mi * g.cells + (size_t)y * g.W + xb;
+        if (vec) {                                       // rows are 16-byte aligned: one 16-byte count load
+            const uint4 c = *reinterpret_cast<const uint4 *>(cnt + o);
+            if ((c.x | c.y | c.z | c.w) == 0u) continue;
+            const uint32_t cc[4] = { c.x, c.y, c.z, c.w };
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int32_t x = xb + i;
-        if (x < g.W) {
-            const uint32_t c = cnt[row + x];
-            if (c) {
-                const double nf = (double)(c & 0xffffu), no = (double)(c >> 16);
-                logd[row + x] = logd[row + x] + (nf * g.l_free + no * g.l_occ);
-                cnt[row + x] = 0u;
+            for (int i = 0; i < 4; i++)
+                if (cc[i]) logd[o + i] = logd[o + i] + ((double)(cc[i] & 0xffffu) * g.l_free + (double)(cc[i] >> 16) * g.l_occ);
+            *reinterpret_cast<uint4 *>(cnt + o) = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            for (int i = 0; i < 4 && xb + i < g.W; i++) {
+                const uint32_t c = cnt[o + i];
+                if (c) {
+                    logd[o + i] = logd[o + i] + ((double)(c & 0xffffu) * g.l_free + (double)(c >> 16) * g.l_occ);
+                    cnt[o + i] = 0u;
+                }
             }
         }
     }
@@ -279,6 +290,7 @@ k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ li
 
         // ---- phase 1
         int32_t seen = 0;                                      // bit c: a cell of code c; bit 3: outside the map
+#pragma unroll 4
         for (int32_t idx = threadIdx.x; idx < RH * RW; idx += blockDim.x) {
             const int32_t r = idx / RW, c = idx - r * RW;
             const int32_t gy = ty0 - k + r, gx = tx0 - k + c;
@@ -457,7 +469,8 @@ void gms_launch_apply_ray(gms_map *m, RayIn ray) {
 
 void gms_launch_apply_counts(gms_map *m) {
     ProfScope ps(m, GMS_K_APPLY);
-    dim3 grid((m->gd.W + APPLY_TW - 1) / APPLY_TW, (m->gd.H + APPLY_TH - 1) / APPLY_TH, m->n_maps);
+    const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
+    dim3 grid(all < 2048 ? all : 2048, m->n_maps);
     int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4;
     hipLaunchKernelGGL(k_apply, grid, dim3(256), 0, m->stream, m->gd, m->d_log, m->d_cnt, cur, idle);
     m->bbox_dirty = 1;
