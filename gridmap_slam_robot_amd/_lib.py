@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgridmapslam.so")
 
 GMS_MAX_TAPS = 129
-GMS_BLOCK = 1024
+GMS_BLOCK = 256
 GMS_PARTIAL_STRIDE = 9
 PACKED_BYTES = 24
 

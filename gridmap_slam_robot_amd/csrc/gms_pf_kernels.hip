@@ -348,10 +348,10 @@ k_score_combine(const double *__restrict__ part, int32_t n, int32_t nseg, double
 }
 
 // ---------------------------------------------------------------------------------------------
-// Blocked reductions.  A reduction block is GMS_BLOCK = 1024 consecutive particles (by GLOBAL index)
-// and is reduced by a "group" of 256 consecutive threads (4 waves), EPT = 4 particles per thread.
+// Blocked reductions.  A reduction block is GMS_BLOCK = 256 consecutive particles (by GLOBAL index)
+// and is reduced by a "group" of 256 consecutive threads (4 waves), EPT = GMS_BLOCK/256 particles per thread.
 // Shape, identical in every kernel that uses it:
-//   thread t folds its particles t, t+256, t+512, t+768 of the block sequentially,
+//   thread t folds its EPT particles t, t+256, ... of the block sequentially (EPT = 1: just its own),
 //   64-lane xor butterfly per wave, then ((w0 + w1) + w2) + w3 over the group's four waves;
 //   blocks are folded in block order (thread t takes blocks t, t+256, ... then the group shape).
 // Kernels run 1 or 4 groups per workgroup; every thread of the workgroup must make the calls (they
@@ -361,6 +361,7 @@ k_score_combine(const double *__restrict__ part, int32_t n, int32_t nseg, double
 #define MAX_WAVES 16
 #define GRP 256
 #define EPT (GMS_BLOCK / GRP)
+#define EPB (EPT < 4 ? EPT : 4)      // particles in flight per thread
 
 __device__ __forceinline__ double group_sum(double v, double *lds /* [MAX_WAVES] */) {
     v = wave_sum_f64(v);
@@ -426,11 +427,11 @@ __device__ __forceinline__ void block_partials(double *__restrict__ w, double *_
     const int32_t tl = threadIdx.x & (GRP - 1);
     double s = 0.0, nz = 0.0, mv = -INFINITY, mx = 9.0e15, ml = -INFINITY, sq = 0.0, xw = 0.0, yw = 0.0, tw = 0.0;
 #pragma unroll
-    for (int e0 = 0; e0 < EPT; e0 += 4) {             // four particles in flight per thread
-        double v[4], lw[4];
-        float px[4], py[4], pt[4];
+    for (int e0 = 0; e0 < EPT; e0 += EPB) {
+        double v[EPB], lw[EPB];
+        float px[EPB], py[EPB], pt[EPB];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
+        for (int e = 0; e < EPB; e++) {
             const int64_t i = tl + (e0 + e) * GRP;
             const bool in = i < cnt;
             if (part) {
@@ -446,7 +447,7 @@ __device__ __forceinline__ void block_partials(double *__restrict__ w, double *_
             px[e] = in ? pose[3 * i] : 0.0f; py[e] = in ? pose[3 * i + 1] : 0.0f; pt[e] = in ? pose[3 * i + 2] : 0.0f;
         }
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
+        for (int e = 0; e < EPB; e++) {
             const int64_t i = tl + (e0 + e) * GRP;
             if (i < cnt) {
                 s += v[e];

@@ -6,7 +6,7 @@ north_star asks for.  Rank r holds the contiguous particle block [r*n, (r+1)*n) 
 the map (the deterministic integer-count map update is run redundantly: 720 rays are cheaper than
 broadcasting 32 MiB).  Per scan:
 
-  1. all-reduce(SUM) of the block-partial vector (GMS_PARTIAL_STRIDE doubles per 1024-particle block,
+  1. all-reduce(SUM) of the block-partial vector (GMS_PARTIAL_STRIDE doubles per 256-particle block,
      each rank's own blocks filled, zero elsewhere).  Adding zeros is exact, so every rank ends up
      with the same partials whatever the rank count, and folds them in block order: weightSum,
      strongest, n_zero are bit-identical for 1, 2, 4, 8 GPUs (SLAM.java:87-121).
@@ -15,7 +15,7 @@ broadcasting 32 MiB).  Per scan:
   2. all-gather of the packed normalised particles {w, x, y, theta} (24 B each): every rank then
      fills its own slots of the systematic resample (SLAM.java:133-153) from the same global array.
 
-Both messages are small (4.5 KiB and 1.5 MiB at 65 536 particles): latency-bound, one RCCL call each.
+Both messages are small (18 KiB and 1.5 MiB at 65 536 particles): latency-bound, one RCCL call each.
 
 The collective logic is independent of where the shard kernels run: `ops` is the object that performs
 them.  The product uses HipShardOps (libgridmapslam.so, device pointers of torch CUDA tensors, the

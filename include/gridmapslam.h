@@ -40,7 +40,7 @@ extern "C" {
 #define GMS_VERSION_MINOR 1
 
 #define GMS_MAX_TAPS 129        /* likelihood kernel taps (odd) */
-#define GMS_BLOCK 1024          /* particles per reduction block; shard offsets are multiples of it */
+#define GMS_BLOCK 256           /* particles per reduction block; shard offsets are multiples of it */
 
 enum {
     GMS_OK = 0,
