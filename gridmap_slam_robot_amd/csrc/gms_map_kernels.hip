@@ -38,87 +38,56 @@ __device__ __forceinline__ void bbox_decode(const int32_t *bb, int32_t W, int32_
 // hasNext (:108) stops at the first out-of-bounds cell; x and y move monotonically, so step k is
 // emitted iff cell 0 and cell k are both inside, and no walk is longer than W + H + 1 steps.
 // ---------------------------------------------------------------------------------------------
-#ifndef RC_RAYS
-#define RC_RAYS 4      // measured on MI355X at C3: 4 -> 18 us, 8 -> 20 us, 16 -> 24 us per scan
-#endif
-#define RC_THREADS (RC_RAYS * 64)
+// Rays per workgroup of the fused kernel.  One scan (720 rays) is latency-bound: 4 rays per workgroup spread it
+// over the most CUs (measured at C3: 4 -> 18 us, 8 -> 20 us, 16 -> 24 us).  Batched maps (tens of thousands of
+// rays) are throughput-bound and use 16 (a split phase-A / phase-B pair of kernels was measured slower at
+// config 5: 0.30 vs 0.22 ms; the u32 atomics, ~150 G/s scattered, are the floor there).
 
 struct RayMeta {
     int32_t x0, y0, x_inc, y_inc, n_eff, hit;
     float sx, sy, measured;
 };
 
-template <bool TRACE>
-__global__ void __launch_bounds__(RC_THREADS)
-k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride,
-          const float *__restrict__ poses, int32_t pose_stride, const RayIn *__restrict__ single,
-          uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox, int32_t *__restrict__ t_cells,
-          uint8_t *__restrict__ t_cls, int32_t cap, int32_t *__restrict__ t_counts, int32_t nw_max) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *s_words = reinterpret_cast<uint32_t *>(smem);            // [nw_max][RC_RAYS]
-    uint32_t *s_ybase = s_words + (size_t)nw_max * RC_RAYS;            // [nw_max][RC_RAYS]
-    __shared__ RayMeta s_meta[RC_RAYS];
-
-    const int32_t mi = blockIdx.y;
-    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    // ---- phase A: wave 0, lane r = ray r of this workgroup -------------------------------------
-    if (wave == 0 && lane < RC_RAYS) {
-        const int32_t b = blockIdx.x * RC_RAYS + lane;
-        RayMeta mt;
-        mt.n_eff = 0; mt.x0 = mt.y0 = mt.x_inc = mt.y_inc = mt.hit = 0; mt.sx = mt.sy = mt.measured = 0.0f;
-        if (b < B) {
-            RayIn ray;
-            if (single) ray = *single;
-            else ray = make_ray(g, beams[(size_t)mi * beam_stride + b], poses + (size_t)pose_stride * mi);
-            RayDev r;
-            ray_init(r, ray.sx + 0.5f, ray.sy + 0.5f, ray.ex + 0.5f, ray.ey + 0.5f, g.extra);   // GridMap.java:210
-            mt.x0 = r.x; mt.y0 = r.y; mt.x_inc = r.x_inc; mt.y_inc = r.y_inc;
-            mt.sx = ray.sx; mt.sy = ray.sy; mt.measured = ray.measured; mt.hit = ray.hit;
-            const bool inb0 = !(r.x < 0 || r.x >= g.W || r.y < 0 || r.y >= g.H);
-            mt.n_eff = (inb0 && r.n > 0) ? min(r.n, g.W + g.H + 1) : 0;
-            float err = r.error;
-            const float ndx = -r.dx, dy = r.dy;
-#ifdef GMS_EXP_HALF_A
-            const int32_t nwords = (mt.n_eff + 63) >> 6;
-#else
-            const int32_t nwords = (mt.n_eff + 31) >> 5;
-#endif
-            uint32_t ycount = 0;
-            for (int32_t w = 0; w < nwords; ++w) {
-                uint32_t word = 0;
+// phase A for one ray: meta + decision words (word w of ray slot `slot` at words[w * stride + slot])
+__device__ __forceinline__ RayMeta ray_phase_a(const GridDev &g, const RayIn &ray, uint32_t *__restrict__ words,
+                                               uint32_t *__restrict__ ybase, int32_t stride, int32_t slot) {
+    RayMeta mt;
+    RayDev r;
+    ray_init(r, ray.sx + 0.5f, ray.sy + 0.5f, ray.ex + 0.5f, ray.ey + 0.5f, g.extra);   // GridMap.java:210
+    mt.x0 = r.x; mt.y0 = r.y; mt.x_inc = r.x_inc; mt.y_inc = r.y_inc;
+    mt.sx = ray.sx; mt.sy = ray.sy; mt.measured = ray.measured; mt.hit = ray.hit;
+    const bool inb0 = !(r.x < 0 || r.x >= g.W || r.y < 0 || r.y >= g.H);
+    mt.n_eff = (inb0 && r.n > 0) ? min(r.n, g.W + g.H + 1) : 0;
+    float err = r.error;
+    const float ndx = -r.dx, dy = r.dy;
+    const int32_t nwords = (mt.n_eff + 31) >> 5;
+    uint32_t ycount = 0;
+    for (int32_t w = 0; w < nwords; ++w) {
+        uint32_t word = 0;
 #pragma unroll
-                for (int32_t j = 0; j < 32; ++j) {
-                    const bool c = err > 0.0f;                 // RayIterator.java:117
-                    word |= (c ? 1u : 0u) << j;
-                    err = err + (c ? ndx : dy);                // :119 / :122 (a - b == a + (-b) exactly)
-                }
-                s_words[w * RC_RAYS + lane] = word;
-                s_ybase[w * RC_RAYS + lane] = ycount;
-                ycount += __popc(word);
-            }
+        for (int32_t j = 0; j < 32; ++j) {
+            const bool c = err > 0.0f;                 // RayIterator.java:117
+            word |= (c ? 1u : 0u) << j;
+            err = err + (c ? ndx : dy);                // :119 / :122 (a - b == a + (-b) exactly)
         }
-        s_meta[lane] = mt;
+        words[w * stride + slot] = word;
+        ybase[w * stride + slot] = ycount;
+        ycount += __popc(word);
     }
-    __syncthreads();
+    return mt;
+}
 
-#ifdef GMS_EXP_NO_PHASE_B
-    if (s_meta[0].n_eff >= 0) return;
-#endif
-    // ---- phase B: wave v owns ray v ------------------------------------------------------------
-    const int32_t b = blockIdx.x * RC_RAYS + wave;
-    const RayMeta mt = s_meta[wave];
-    int32_t bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;   // encoded bbox contributions
+// phase B for one ray, executed by one wavefront; returns the number of cells visited (lane 0's count)
+template <bool TRACE>
+__device__ __forceinline__ int32_t ray_phase_b(const GridDev &g, const RayMeta &mt, const uint32_t *__restrict__ words,
+                                               const uint32_t *__restrict__ ybase, int32_t stride, int32_t slot, int32_t lane,
+                                               uint32_t *__restrict__ mcnt, int32_t bb[4], int32_t b, int32_t *__restrict__ t_cells,
+                                               uint8_t *__restrict__ t_cls, int32_t cap) {
     int32_t count = 0;
-    uint32_t *mcnt = TRACE ? nullptr : cnt + (size_t)mi * g.cells;
-#ifdef GMS_EXP_B_ONCE
-    for (int32_t k = lane; k < min(mt.n_eff, 64); k += 64) {
-#else
     for (int32_t k = lane; k < mt.n_eff; k += 64) {
-#endif
         const int32_t w = k >> 5, j = k & 31;
-        const uint32_t word = s_words[w * RC_RAYS + wave];
-        const int32_t ny = (int32_t)(s_ybase[w * RC_RAYS + wave] + __popc(word & ((1u << j) - 1u)));
+        const uint32_t word = words[w * stride + slot];
+        const int32_t ny = (int32_t)(ybase[w * stride + slot] + __popc(word & ((1u << j) - 1u)));
         const int32_t nx = k - ny;
         const int32_t cx = mt.x0 + mt.x_inc * nx, cy = mt.y0 + mt.y_inc * ny;
         const bool valid = !(cx < 0 || cx >= g.W || cy < 0 || cy >= g.H);                 // :108
@@ -132,38 +101,74 @@ k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam
                     if (t_cls) t_cls[o] = (uint8_t)cls;
                 }
             } else if (cls != 1) {
-#ifndef GMS_EXP_NO_ATOMIC
                 atomicAdd(&mcnt[(size_t)cy * g.W + cx], cls == 0 ? 1u : 0x10000u);
-#endif
-                bx0 = max(bx0, g.W - 1 - cx); by0 = max(by0, g.H - 1 - cy);
-                bx1 = max(bx1, cx + 1);       by1 = max(by1, cy + 1);
+                bb[0] = max(bb[0], g.W - 1 - cx); bb[1] = max(bb[1], g.H - 1 - cy);
+                bb[2] = max(bb[2], cx + 1);       bb[3] = max(bb[3], cy + 1);
             }
         }
         count += __popcll(__ballot(valid));
     }
+    return count;
+}
+
+// workgroup-level max of the encoded box in LDS, then at most four global atomics per workgroup, and only
+// where they would raise the box (same-address global atomics serialise in L2: ~10 ns each)
+__device__ __forceinline__ void bbox_commit(int32_t bb[4], int32_t lane, int32_t *__restrict__ bbox_map, int32_t *s_bb) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        for (int q = 0; q < 4; q++) bb[q] = max(bb[q], __shfl_xor(bb[q], o, GMS_WAVE));
+    if (threadIdx.x < 4) s_bb[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane == 0 && bb[2] > 0)
+        for (int q = 0; q < 4; q++) atomicMax(&s_bb[q], bb[q]);
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int32_t v = s_bb[threadIdx.x];
+        if (v > 0 && v > __hip_atomic_load(&bbox_map[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&bbox_map[threadIdx.x], v);
+    }
+}
+
+// fused form: one workgroup = RC_RAYS rays, phase A by wave 0, phase B by one wavefront per ray, words in LDS
+template <bool TRACE, int RC_RAYS>
+__global__ void __launch_bounds__(RC_RAYS * 64)
+k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride,
+          const float *__restrict__ poses, int32_t pose_stride, const RayIn *__restrict__ single,
+          uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox, int32_t *__restrict__ t_cells,
+          uint8_t *__restrict__ t_cls, int32_t cap, int32_t *__restrict__ t_counts, int32_t nw_max) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *s_words = reinterpret_cast<uint32_t *>(smem);            // [nw_max][RC_RAYS]
+    uint32_t *s_ybase = s_words + (size_t)nw_max * RC_RAYS;            // [nw_max][RC_RAYS]
+    __shared__ RayMeta s_meta[RC_RAYS];
+    __shared__ int32_t s_bb[4];
+
+    const int32_t mi = blockIdx.y;
+    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0 && lane < RC_RAYS) {
+        const int32_t b = blockIdx.x * RC_RAYS + lane;
+        RayMeta mt;
+        mt.n_eff = 0; mt.x0 = mt.y0 = mt.x_inc = mt.y_inc = mt.hit = 0; mt.sx = mt.sy = mt.measured = 0.0f;
+        if (b < B) {
+            RayIn ray;
+            if (single) ray = *single;
+            else ray = make_ray(g, beams[(size_t)mi * beam_stride + b], poses + (size_t)pose_stride * mi);
+            mt = ray_phase_a(g, ray, s_words, s_ybase, RC_RAYS, lane);
+        }
+        s_meta[lane] = mt;
+    }
+    __syncthreads();
+#ifdef GMS_EXP_NO_PHASE_B
+    if (s_meta[0].n_eff >= 0) return;
+#endif
+    const int32_t b = blockIdx.x * RC_RAYS + wave;
+    const RayMeta mt = s_meta[wave];
+    int32_t bb[4] = { 0, 0, 0, 0 };
+    const int32_t count = ray_phase_b<TRACE>(g, mt, s_words, s_ybase, RC_RAYS, wave, lane,
+                                             TRACE ? nullptr : cnt + (size_t)mi * g.cells, bb, b, t_cells, t_cls, cap);
     if (TRACE) {
         if (lane == 0 && b < B && t_counts) t_counts[b] = count;
     } else {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            bx0 = max(bx0, __shfl_xor(bx0, o, GMS_WAVE)); by0 = max(by0, __shfl_xor(by0, o, GMS_WAVE));
-            bx1 = max(bx1, __shfl_xor(bx1, o, GMS_WAVE)); by1 = max(by1, __shfl_xor(by1, o, GMS_WAVE));
-        }
-        // workgroup-level max in LDS, then at most four global atomics per workgroup, and only where they
-        // would raise the box (same-address global atomics serialise in L2: ~10 ns each)
-        __shared__ int32_t s_bb[4];
-        if (threadIdx.x < 4) s_bb[threadIdx.x] = 0;
-        __syncthreads();
-        if (lane == 0 && bx1 > 0) {
-            atomicMax(&s_bb[0], bx0); atomicMax(&s_bb[1], by0); atomicMax(&s_bb[2], bx1); atomicMax(&s_bb[3], by1);
-        }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            int32_t *bb = bbox + 4 * mi;
-            const int32_t v = s_bb[threadIdx.x];
-            if (v > 0 && v > __hip_atomic_load(&bb[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMax(&bb[threadIdx.x], v);
-        }
+        bbox_commit(bb, lane, bbox + 4 * mi, s_bb);
     }
 }
 
@@ -418,33 +423,36 @@ __global__ void k_debug_f32(int32_t op, const float *__restrict__ a, float *__re
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline int32_t rc_nw_max(const gms_map *m) { return (m->gd.W + m->gd.H + 1 + 31) / 32; }
-static inline size_t rc_smem(const gms_map *m) { return (size_t)rc_nw_max(m) * RC_RAYS * 2 * sizeof(uint32_t); }
+static inline size_t rc_smem(const gms_map *m, int rays) { return (size_t)rc_nw_max(m) * rays * 2 * sizeof(uint32_t); }
 
-template <bool TRACE>
-static void rc_prepare(const gms_map *m) {
-    const size_t smem = rc_smem(m);
+template <bool TRACE, int RAYS>
+static void rc_launch(gms_map *m, dim3 grid, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
+                      int32_t pose_stride, const RayIn *single, uint32_t *cnt, int32_t *bbox, int32_t *t_cells, uint8_t *t_cls,
+                      int32_t cap, int32_t *t_counts) {
+    const size_t smem = rc_smem(m, RAYS);
     if (smem > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast<TRACE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast<TRACE, RAYS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
+    hipLaunchKernelGGL((k_raycast<TRACE, RAYS>), grid, dim3(RAYS * 64), smem, m->stream, m->gd, d_beams, B, beam_stride, d_poses,
+                       pose_stride, single, cnt, bbox, t_cells, t_cls, cap, t_counts, rc_nw_max(m));
 }
 
 void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
                         int32_t pose_stride) {
     ProfScope ps(m, GMS_K_RAYCAST);
-    rc_prepare<false>(m);
-    dim3 grid((B + RC_RAYS - 1) / RC_RAYS, m->n_maps);
-    hipLaunchKernelGGL(k_raycast<false>, grid, dim3(RC_THREADS), rc_smem(m), m->stream, m->gd, d_beams, B, beam_stride,
-                       d_poses, pose_stride, (const RayIn *)nullptr, m->d_cnt, m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, (int32_t *)nullptr,
-                       (uint8_t *)nullptr, 0, (int32_t *)nullptr, rc_nw_max(m));
+    int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;
+    if ((int64_t)B * m->n_maps > 4096)       // batched maps: throughput-bound, 16 lanes of the phase-A wavefront busy
+        rc_launch<false, 16>(m, dim3((B + 15) / 16, m->n_maps), d_beams, B, beam_stride, d_poses, pose_stride, nullptr, m->d_cnt, bb,
+                             nullptr, nullptr, 0, nullptr);
+    else
+        rc_launch<false, 4>(m, dim3((B + 3) / 4, m->n_maps), d_beams, B, beam_stride, d_poses, pose_stride, nullptr, m->d_cnt, bb,
+                            nullptr, nullptr, 0, nullptr);
 }
 
 void gms_launch_trace_scan(gms_map *m, const gms_beam *d_beams, int32_t B, const float *d_pose, int32_t *d_cells,
                            uint8_t *d_cls, int32_t cap, int32_t *d_counts) {
-    rc_prepare<true>(m);
-    dim3 grid((B + RC_RAYS - 1) / RC_RAYS, 1);
-    hipLaunchKernelGGL(k_raycast<true>, grid, dim3(RC_THREADS), rc_smem(m), m->stream, m->gd, d_beams, B, m->max_beams,
-                       d_pose, 3, (const RayIn *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, d_cells, d_cls, cap,
-                       d_counts, rc_nw_max(m));
+    rc_launch<true, 4>(m, dim3((B + 3) / 4, 1), d_beams, B, m->max_beams, d_pose, 3, nullptr, nullptr, nullptr, d_cells, d_cls, cap,
+                       d_counts);
 }
 
 void gms_launch_trace_ray(gms_map *m, float x0, float y0, float x1, float y1, int32_t extra, int32_t *d_cells,
@@ -460,11 +468,8 @@ void gms_launch_apply_ray(gms_map *m, RayIn ray) {
     RayIn *d_ray = reinterpret_cast<RayIn *>(m->d_beams);
     hipLaunchKernelGGL(k_store_ray, dim3(1), dim3(1), 0, m->stream, d_ray, ray);
     ProfScope ps(m, GMS_K_RAYCAST);
-    rc_prepare<false>(m);
-    hipLaunchKernelGGL(k_raycast<false>, dim3(1, 1), dim3(RC_THREADS), rc_smem(m), m->stream, m->gd,
-                       (const gms_beam *)nullptr, 1, m->max_beams, (const float *)nullptr, 3, (const RayIn *)d_ray,
-                       m->d_cnt, m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, (int32_t *)nullptr, (uint8_t *)nullptr, 0,
-                       (int32_t *)nullptr, rc_nw_max(m));
+    rc_launch<false, 4>(m, dim3(1, 1), nullptr, 1, m->max_beams, nullptr, 3, d_ray, m->d_cnt,
+                        m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, nullptr, nullptr, 0, nullptr);
 }
 
 void gms_launch_apply_counts(gms_map *m) {
