@@ -538,8 +538,8 @@ static int64_t nblk_of(int64_t n) { return (n + GMS_BLOCK - 1) / GMS_BLOCK; }
 static int64_t nchunks_of(int64_t n) { return (n + 63) / 64; }
 
 static void pf_free_global(gms_pf *pf) {
-    hipFree(pf->d_partials); hipFree(pf->d_global); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum);
-    pf->d_partials = nullptr; pf->d_global = nullptr; pf->d_chunk_tot = pf->d_cum = nullptr;
+    hipFree(pf->d_partials); hipFree(pf->d_p2); hipFree(pf->d_global); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum);
+    pf->d_partials = pf->d_p2 = nullptr; pf->d_global = nullptr; pf->d_chunk_tot = pf->d_cum = nullptr;
 }
 
 static int pf_alloc_global(gms_pf *pf) {
@@ -547,6 +547,7 @@ static int pf_alloc_global(gms_pf *pf) {
     const size_t M = pf->n_maps;
     const size_t nblk = nblk_of(pf->n_global), nch = nchunks_of(pf->n_global);
     HIPCHK(hipMalloc(&pf->d_partials, M * nblk * GMS_PARTIAL_STRIDE * sizeof(double)));
+    HIPCHK(hipMalloc(&pf->d_p2, M * nblk * 2 * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_global, M * pf->n_global * sizeof(PackedParticle)));
     HIPCHK(hipMalloc(&pf->d_chunk_tot, M * (nch + 1) * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_cum, M * pf->n_global * sizeof(double)));
@@ -717,6 +718,7 @@ static int pull_stats(gms_pf *pf) {
 int gms_pf_get_stats(gms_pf *pf, gms_pf_stats *stats) {
     REQUIRE(pf && stats, "null argument");
     HIPCHK(hipSetDevice(pf->map->device));
+    if (pf->have_global) gms_launch_pf_fold_neff(pf);      // calculateNeff from the normalised population
     int rc = pull_stats(pf);
     if (rc) return rc;
     fill_stats(pf, stats);

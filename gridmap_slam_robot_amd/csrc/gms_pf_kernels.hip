@@ -402,11 +402,14 @@ struct RedLds {
 //   2 first argmax (global index)               7 sum y*w
 //   3 count of w == 0                           8 sum angleConstrain(theta)*w
 //   4 max log-weight
-// One pass over the raw weights yields everything SLAM.update reports: with S = sum w,
-//   normalised weight = w / S, Neff = S*S / sum w*w, weighted pose = (sum x*w) / S.
-// The reference computes Neff and the pose from the already-normalised weights (three dependent
-// sums); algebraically identical, and the rounding difference is ~1e-15 relative, ten orders of
-// magnitude inside the 1e-5 parity bar (DESIGN.md "Bookkeeping").
+// One pass over the raw weights yields the weight sum, the strongest particle and the weighted pose:
+// with S = sum w, normalised weight = w / S and pose = (sum x*w) / S.  The reference computes the pose
+// from the already-normalised weights; algebraically identical, and the rounding difference is ~1e-15
+// relative, ten orders of magnitude inside the 1e-5 parity bar (DESIGN.md "Bookkeeping").
+// Neff is NOT derived from column 5: raw weights are products of hundreds of factors (1e-150 is
+// typical at 720 beams) and their squares underflow.  Like the reference (SLAM.java:180-190) it is
+// computed from the normalised weights: k_normalize_pack / k_global_sq leave per-block
+// {sum wn, sum wn^2}, fold_neff() folds them where Neff is consumed.
 #define COL_SUM 0
 #define COL_MAX 1
 #define COL_ARG 2
@@ -520,7 +523,6 @@ __device__ __forceinline__ double fold_stats(const double *__restrict__ p, int64
     const double sum = fold_sum(p, nblk, COL_SUM, L.a);
     if (!write) return sum;
     const double nz = fold_sum(p, nblk, COL_NZ, L.a);
-    const double sq = fold_sum(p, nblk, COL_SQ, L.a);
     const double xw = fold_sum(p, nblk, COL_XW, L.a), yw = fold_sum(p, nblk, COL_YW, L.a), tw = fold_sum(p, nblk, COL_TW, L.a);
     double mv, mx, ml, mli;
     fold_argmax(p, nblk, COL_MAX, COL_ARG, mv, mx, L);
@@ -532,8 +534,6 @@ __device__ __forceinline__ double fold_stats(const double *__restrict__ p, int64
         s->strongest = mx < 8.0e15 ? (int32_t)mx : 0;
         s->n_zero = (int32_t)nz;
         s->max_logw = ml;
-        s->norm_sum = sum / sum;
-        s->sq_sum = sq / (sum * sum);                                  // Neff = 1 / sq_sum (SLAM.java:189)
         s->xs = xw; s->ys = yw; s->ts = tw;
         s->wpose[0] = (float)(xw / sum);                               // SLAM.java:176
         s->wpose[1] = (float)(yw / sum);
@@ -550,6 +550,41 @@ __device__ __forceinline__ double fold_stats(const double *__restrict__ p, int64
 __device__ __forceinline__ int64_t block_count(int64_t n, int64_t blk) {
     const int64_t left = n - blk * GMS_BLOCK;
     return left < 0 ? 0 : (left > GMS_BLOCK ? GMS_BLOCK : left);
+}
+
+// calculateNeff (SLAM.java:180-190) from the per-block {sum wn, sum wn^2} of the normalised population:
+// sum = fold(sum wn); sq_sum = fold(sum wn^2) / sum^2; Neff = 1 / sq_sum.  Every thread of the workgroup calls.
+__device__ __forceinline__ void fold_neff(const double *__restrict__ p2, int64_t nblk, double &norm_sum, double &sq_sum,
+                                          double *lds) {
+    double a = 0.0, q = 0.0;
+    for (int64_t b = threadIdx.x & (GRP - 1); b < nblk; b += GRP) { a += p2[2 * b]; q += p2[2 * b + 1]; }
+    norm_sum = group_sum(a, lds);
+    const double qq = group_sum(q, lds);
+    sq_sum = qq / (norm_sum * norm_sum);
+}
+
+__global__ void __launch_bounds__(256)
+k_fold_neff(const double *__restrict__ p2_all, int64_t nblk, PfStatsDev *__restrict__ stats) {
+    __shared__ RedLds L;
+    const int32_t mi = blockIdx.x;
+    double ns, sq;
+    fold_neff(p2_all + (size_t)mi * nblk * 2, nblk, ns, sq, L.a);
+    if (threadIdx.x == 0) { stats[mi].norm_sum = ns; stats[mi].sq_sum = sq; }
+}
+
+// {sum wn, sum wn^2} per block of the GLOBAL packed population (sharded filters after the all-gather,
+// or a resample without a preceding normalise)
+__global__ void __launch_bounds__(256)
+k_global_sq(const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nblk, double *__restrict__ p2_all) {
+    __shared__ RedLds L;
+    const int32_t mi = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * GMS_BLOCK + threadIdx.x;          // GMS_BLOCK == 256 == blockDim.x
+    const double wn = i < n_global ? glob[(size_t)mi * n_global + i].w : 0.0;
+    const double a = group_sum(wn, L.a), q = group_sum(wn * wn, L.a);
+    if (threadIdx.x == 0) {
+        double *p = p2_all + ((size_t)mi * nblk + blockIdx.x) * 2;
+        p[0] = a; p[1] = q;
+    }
 }
 
 // phase 1: this shard's block partials at their global slots; blocks of other shards are zeroed so
@@ -597,7 +632,7 @@ __global__ void __launch_bounds__(256)
 k_normalize_pack(const double *__restrict__ partials_all, int64_t nblk_global, double *__restrict__ w,
                  const float *__restrict__ pose, int32_t n, int64_t offset, PackedParticle *__restrict__ packed,
                  double *__restrict__ cum, double *__restrict__ chunk_tot, int64_t nchunks,
-                 PfStatsDev *__restrict__ stats) {
+                 double *__restrict__ p2_all, PfStatsDev *__restrict__ stats) {
     __shared__ RedLds L;
     __shared__ double s_w[256 + 4];
     const int32_t mi = blockIdx.y;
@@ -612,6 +647,13 @@ k_normalize_pack(const double *__restrict__ partials_all, int64_t nblk_global, d
         PackedParticle pp;
         pp.w = wn; pp.x = pose[3 * gi]; pp.y = pose[3 * gi + 1]; pp.theta = pose[3 * gi + 2]; pp.pad = 0u;
         packed[gi] = pp;
+    }
+    if (p2_all) {                                     // uniform: {sum wn, sum wn^2} of this 256-particle block
+        const double a = group_sum(wn, L.a), q = group_sum(wn * wn, L.a);
+        if (threadIdx.x == 0) {
+            double *pp2 = p2_all + ((size_t)mi * nblk_global + blockIdx.x) * 2;
+            pp2[0] = a; pp2[1] = q;
+        }
     }
     if (cum) {                                        // uniform
         const int32_t t = threadIdx.x;
@@ -706,12 +748,16 @@ __global__ void __launch_bounds__(256)
 k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks,
            const double *__restrict__ cum_all, const double *__restrict__ chunk_off, const double *__restrict__ r01,
            double r01_scalar, double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, float *__restrict__ cs2,
-           double *__restrict__ w2, int32_t *__restrict__ idx_out, PfStatsDev *__restrict__ stats) {
+           double *__restrict__ w2, int32_t *__restrict__ idx_out, const double *__restrict__ p2_all, int64_t nblk_global,
+           PfStatsDev *__restrict__ stats) {
     extern __shared__ __align__(16) unsigned char smem[];
     double *off = reinterpret_cast<double *>(smem);                    // [nchunks + 1]
     const int32_t mi = blockIdx.y;
-    const PfStatsDev *st = stats + mi;
-    const bool go = fraction < 0.0 || (1.0 / st->sq_sum) < fraction * (double)n_global;   // GridMapApp.java:185
+    __shared__ RedLds L;
+    double norm_sum, sq_sum;
+    fold_neff(p2_all + (size_t)mi * nblk_global * 2, nblk_global, norm_sum, sq_sum, L.a);   // calculateNeff (SLAM.java:180-190)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[mi].norm_sum = norm_sum; stats[mi].sq_sum = sq_sum; }
+    const bool go = fraction < 0.0 || (1.0 / sq_sum) < fraction * (double)n_global;         // GridMapApp.java:185
     const int64_t nsuper = (nchunks + 63) / 64;
     double *sup = off + nchunks + 1;                                   // [nsuper + 1]
     if (go) {
@@ -970,8 +1016,10 @@ void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedPa
     const bool own = d_packed_local == pf->d_global;
     hipLaunchKernelGGL(k_normalize_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, d_partials, nblk,
                        pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local, own ? pf->d_cum : (double *)nullptr,
-                       own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf), pf->d_stats);
+                       own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf), own ? pf->d_p2 : (double *)nullptr, pf->d_stats);
     pf->chunks_ready = own ? 1 : 0;
+    pf->p2_ready = own ? 1 : 0;
+    pf->neff_folded = 0;
 }
 
 void gms_launch_pf_stats_only(gms_pf *pf, const double *d_partials, PfStatsDev *d_stats_out) {
@@ -985,13 +1033,33 @@ void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed) {
     gms_map *m = pf->map;
     hipLaunchKernelGGL(k_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_pose,
                        pf->n, d_packed);
-    if (d_packed == pf->d_global) pf->chunks_ready = 0;
+    if (d_packed == pf->d_global) { pf->chunks_ready = 0; pf->p2_ready = 0; pf->neff_folded = 0; }
+}
+
+// make d_p2 describe d_global (paths that did not come through a stand-alone normalise)
+static void ensure_p2(gms_pf *pf) {
+    if (pf->p2_ready) return;
+    gms_map *m = pf->map;
+    const int64_t nblk = nblk_global_of(pf);
+    hipLaunchKernelGGL(k_global_sq, dim3((unsigned)nblk, pf->n_maps), dim3(256), 0, m->stream, pf->d_global, pf->n_global, nblk,
+                       pf->d_p2);
+    pf->p2_ready = 1;
+}
+
+void gms_launch_pf_fold_neff(gms_pf *pf) {
+    if (pf->neff_folded) return;
+    gms_map *m = pf->map;
+    ensure_p2(pf);
+    hipLaunchKernelGGL(k_fold_neff, dim3(pf->n_maps), dim3(256), 0, m->stream, pf->d_p2, nblk_global_of(pf), pf->d_stats);
+    pf->neff_folded = 1;
 }
 
 void gms_launch_pf_after_gather(gms_pf *pf) {
     gms_map *m = pf->map;
     hipLaunchKernelGGL(k_set_spose, dim3(pf->n_maps), dim3(64), 0, m->stream, pf->d_global, pf->n_global, pf->d_stats);
     pf->chunks_ready = 0;
+    pf->p2_ready = 0;
+    pf->neff_folded = 0;
 }
 
 void gms_launch_pf_resample(gms_pf *pf, double fraction) {
@@ -1003,6 +1071,7 @@ void gms_launch_pf_resample(gms_pf *pf, double fraction) {
                            pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->d_stats);
         pf->chunks_ready = 1;
     }
+    ensure_p2(pf);
     const size_t smem = (size_t)(nch + 1 + (nch + 63) / 64 + 1) * sizeof(double);
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resample), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1010,7 +1079,8 @@ void gms_launch_pf_resample(gms_pf *pf, double fraction) {
     hipLaunchKernelGGL(k_resample, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), smem, m->stream, pf->d_global,
                        pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01,
                        pf->r01_scalar, fraction, pf->n, pf->offset,
-                       pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_stats);
+                       pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats);
+    pf->neff_folded = 1;
 }
 
 void gms_launch_pf_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride) {

@@ -1,0 +1,176 @@
+"""BASELINE.json's full sizes on the GPU (configs C2, C3, and a slice of C5): parity against the oracle where
+it finishes in seconds (it does: the C port scores 16 384 x 720 in ~0.1 s), plus the size-independent
+properties the domain offers -- order independence of two scans, dirty rebuild == full rebuild, count
+checksum of the ray cast, permutation equivariance of the weights, sortedness and copy counts of the
+systematic resample -- and the edge cases (empty scan, one particle, all-miss scan, ragged grid)."""
+import numpy as np
+import pytest
+
+from gridmap_slam_robot_amd import GridMap, Observation, ParticleFilter, synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)) if a.size else 0.0
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3"])
+def test_full_size_scan_step_against_the_oracle(cfg):
+    c = synth.CONFIGS[cfg]
+    ext, res, B, N = c["extent"], c["resolution"], c["beams"], c["particles"]
+    tr = synth.make_trace(ext, res, B, T=16, seed=1234, n_scans=6)
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    m = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    assert (m.W, m.H) == (g.W, g.H) == ((1024, 1024) if cfg == "C2" else (2048, 2048))
+    log = g.new_log()
+    visits = 0
+    for t in range(4):
+        visits += g.integrate(log, tr.scans[t], tr.poses[t])
+        m.update(tr.scans[t], tr.poses[t])                       # integrate + dirty-rect rebuild
+    got_log = m.download_log().reshape(-1)
+    assert np.array_equal(got_log != 0, log != 0)
+    nz = log != 0
+    assert rel_err(got_log[nz], log[nz]) <= 1e-13                 # bar 1e-5
+    lik = g.build_likelihood(got_log)                            # same map from here on
+    assert np.array_equal(m.download_likelihood().reshape(-1), lik)          # dirty rebuilds == the reference's full rebuild
+    m.compute_likelihood_map()
+    assert np.array_equal(m.download_likelihood().reshape(-1), lik)          # idempotent
+
+    P = synth.make_particles(tr.poses[4], N, seed=99, sigma_xy=res, sigma_theta_deg=0.3)
+    pf = ParticleFilter(m, N)
+    pf.set_poses(P)
+    pf.score(tr.scans[4])
+    w = pf.get_weights()
+    want = g.score(lik, tr.scans[4], P)
+    ok = want > 1e-290
+    assert ok.sum() > N // 10
+    assert rel_err(w[ok], want[ok]) <= 1e-11                      # bar 1e-5
+    st = pf.normalize()
+    wn = want.copy()
+    ws, strongest = orc.normalize(wn)
+    assert st["strongest"] == strongest
+    assert abs(st["weight_sum"] - ws) <= 1e-11 * ws
+    assert abs(st["neff"] - orc.neff(wn)) <= 1e-9 * orc.neff(wn)
+    assert np.allclose(pf.weighted_pose(), orc.weighted_pose(P, wn), rtol=0, atol=2e-6)
+    got_n = pf.get_weights()
+    assert abs(got_n.sum() - 1.0) <= 1e-12
+    idx, amb = pf.resample(0.61803, want_indices=True)
+    want_idx, _ = orc.resample_indices(np.ascontiguousarray(got_n), 0.61803)     # same weights in, same slots out
+    if amb == 0:
+        assert np.array_equal(idx, want_idx)
+    # systematic resampling: non-decreasing sources, copy count within 1 of N*w
+    assert (np.diff(idx) >= 0).all() and idx.min() >= 0 and idx.max() < N
+    copies = np.bincount(idx, minlength=N)
+    assert np.max(np.abs(copies - N * got_n)) <= 1.0 + 1e-9
+
+
+def test_two_scans_commute_and_counts_add_up():
+    c = synth.CONFIGS["C3"]
+    ext, res, B = c["extent"], c["resolution"], c["beams"]
+    tr = synth.make_trace(ext, res, B, T=16, seed=77, n_scans=2)
+    a = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    b = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    a.integrate_observation(tr.scans[0], tr.poses[0]); a.integrate_observation(tr.scans[1], tr.poses[1])
+    b.integrate_observation(tr.scans[1], tr.poses[1]); b.integrate_observation(tr.scans[0], tr.poses[0])
+    la = a.download_log()
+    assert np.array_equal(la, b.download_log())                    # x + y == y + x: the update is order-independent
+    # checksum: every visited cell whose class is free or occupied moved the map by exactly one constant
+    _, cls0, n0 = a.trace_scan(tr.scans[0], tr.poses[0])
+    _, cls1, n1 = a.trace_scan(tr.scans[1], tr.poses[1])
+    n_free = sum(int((cls[i, :n[i]] == 0).sum()) for cls, n in ((cls0, n0), (cls1, n1)) for i in range(B))
+    n_occ = sum(int((cls[i, :n[i]] == 2).sum()) for cls, n in ((cls0, n0), (cls1, n1)) for i in range(B))
+    lf, lo = a.params.l_free, a.params.l_occ
+    assert abs(la.sum() - (n_free * lf + n_occ * lo)) <= 1e-9 * abs(n_free * lf)
+
+
+def test_weights_are_equivariant_under_particle_permutation():
+    c = synth.CONFIGS["C2"]
+    ext, res, B, N = c["extent"], c["resolution"], c["beams"], 4096
+    tr = synth.make_trace(ext, res, B, T=16, seed=5, n_scans=5)
+    m = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    for t in range(4):
+        m.update(tr.scans[t], tr.poses[t])
+    P = synth.make_particles(tr.poses[4], N, seed=3, sigma_xy=0.05, sigma_theta_deg=1.0)
+    P[100] = P[7]                                                 # duplicates score identically
+    perm = np.random.default_rng(0).permutation(N)
+    pf = ParticleFilter(m, N)
+    pf.set_poses(P); pf.score(tr.scans[4]); w = pf.get_weights()
+    pf.set_poses(P[perm]); pf.score(tr.scans[4]); wp = pf.get_weights()
+    assert np.array_equal(wp, w[perm])
+    assert w[100] == w[7]
+
+
+def test_edge_cases_empty_scan_single_particle_all_miss_ragged_grid():
+    m = GridMap(3.3, 2.1, 0.07, (0.0, 1.0))                       # 48 x 30: W % 4 == 0 but ragged tiles
+    g = orc.Grid(3.3, 2.1, 0.07, 0.0, 1.0)
+    assert (m.W, m.H) == (g.W, g.H)
+    m2 = GridMap(3.0, 2.1, 0.07, (0.0, 1.0))                      # 43 x 30: W % 4 != 0 (scalar apply path)
+    g2 = orc.Grid(3.0, 2.1, 0.07, 0.0, 1.0)
+    rng = np.random.default_rng(4)
+    for mm, gg in ((m, g), (m2, g2)):
+        B = 50
+        ang = rng.uniform(-np.pi, np.pi, B)
+        dist = rng.uniform(0.2, 4.0, B)
+        hits = rng.uniform(0, 1, B) < 0.7
+        obs = Observation.from_polar(ang, np.where(hits, dist, 10.0), hits)
+        pose = np.array([1.5, 2.0, 0.4], dtype=np.float32)
+        log = gg.new_log()
+        for _ in range(3):
+            gg.integrate(log, obs.beams, pose)
+            mm.update(obs, pose)
+        got = mm.download_log().reshape(-1)
+        assert np.array_equal(got != 0, log != 0) and np.max(np.abs(got - log)) <= 1e-12
+        assert np.array_equal(mm.download_likelihood().reshape(-1), gg.build_likelihood(got))
+        # one particle (N = 1), and the same through probabilityOf
+        lik = gg.build_likelihood(got)
+        assert abs(mm.probability_of(obs, pose) - gg.probability_of(lik, obs.beams, pose)) <= 1e-13 * gg.probability_of(lik, obs.beams, pose)
+        # empty scan: nothing touched, every weight is the empty product
+        before = mm.download_log()
+        empty = Observation(np.zeros(0, dtype=obs.beams.dtype))
+        mm.update(empty, pose)
+        assert np.array_equal(mm.download_log(), before)
+        pf = ParticleFilter(mm, 5)
+        pf.score(empty)
+        assert np.array_equal(pf.get_weights(), np.ones(5))
+        # all-miss scan: free cells only, and probabilityOf skips every beam (weight 1)
+        miss = Observation.from_polar(ang, np.full(B, 10.0), np.zeros(B, dtype=bool))
+        log2 = got.copy()
+        gg.integrate(log2, miss.beams, pose)
+        mm.integrate_observation(miss, pose)
+        assert np.max(np.abs(mm.download_log().reshape(-1) - log2)) <= 1e-12
+        pf.score(miss)
+        assert np.array_equal(pf.get_weights(), np.ones(5))
+        st = pf.normalize()
+        assert st["weight_sum"] == 5.0 and st["strongest"] == 0 and abs(st["neff"] - 5.0) < 1e-12
+
+
+def test_config5_slice_batched_against_the_oracle():
+    c = synth.CONFIGS["C5"]
+    M, B, N = 4, c["beams"], 1024
+    ext, res = c["extent"], c["resolution"]
+    traces = [synth.make_trace(ext, res, B, T=8, seed=60 + i, n_scans=4) for i in range(M)]
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    mb = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M, max_beams=2048)    # > 4096 rays: the 16-ray workgroups
+    logs = [g.new_log() for _ in range(M)]
+    for t in range(3):
+        mb.update(np.stack([tr.scans[t] for tr in traces]), np.stack([tr.poses[t] for tr in traces]))
+        for i in range(M):
+            g.integrate(logs[i], traces[i].scans[t], traces[i].poses[t])
+    lb = mb.download_log().reshape(M, -1)
+    kb = mb.download_likelihood().reshape(M, -1)
+    P = np.stack([synth.make_particles(traces[i].poses[3], N, seed=i, sigma_xy=0.05, sigma_theta_deg=0.5) for i in range(M)])
+    pf = ParticleFilter(mb, N)
+    pf.set_poses(P)
+    pf.score(np.stack([tr.scans[3] for tr in traces]))
+    w = pf.get_weights()
+    for i in range(M):
+        assert np.array_equal(lb[i] != 0, logs[i] != 0)
+        assert rel_err(lb[i][logs[i] != 0], logs[i][logs[i] != 0]) <= 1e-13
+        lik = g.build_likelihood(lb[i])
+        assert np.array_equal(kb[i], lik)
+        want = g.score(lik, traces[i].scans[3], P[i])
+        ok = want > 1e-290
+        assert rel_err(w[i][ok], want[ok]) <= 1e-11
