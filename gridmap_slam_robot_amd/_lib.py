@@ -119,6 +119,8 @@ def load() -> C.CDLL:
     sig("gms_map_download_likelihood", C.c_int, vp, vp)
     sig("gms_map_copy", C.c_int, vp, vp)
     sig("gms_map_get_raw_at", C.c_int, vp, i32, i32, i32, vp, vp)
+    sig("gms_map_combine", C.c_int, vp, vp)
+    sig("gms_map_deskew", C.c_int, vp, vp, vp, vp, i32, f64, f64, vp, vp)
     sig("gms_map_integrate", C.c_int, vp, vp, i32, vp)
     sig("gms_map_integrate_at", C.c_int, vp, vp, i32, vp, i32)
     sig("gms_map_apply_ray", C.c_int, vp, f32, f32, f32, f32, f32, i32)
@@ -150,6 +152,7 @@ def load() -> C.CDLL:
     sig("gms_pf_resample_if", C.c_int, vp, vp, f64)
     sig("gms_pf_did_resample", C.c_int, vp, vp)
     sig("gms_pf_refine_poses", C.c_int, vp, vp, i32)
+    sig("gms_pf_sample_motion", C.c_int, vp, f64, f64, C.c_uint64, C.c_uint64)
     sig("gms_pf_partials_len", C.c_int, vp, vp)
     sig("gms_pf_local_partials", C.c_int, vp, vp)
     sig("gms_pf_apply_partials", C.c_int, vp, vp, vp)

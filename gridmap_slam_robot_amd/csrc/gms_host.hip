@@ -318,6 +318,44 @@ int gms_map_copy(gms_map *dst, const gms_map *src) {                  // GridMap
     return GMS_OK;
 }
 
+int gms_map_combine(gms_map *dst, gms_map *src) {                        // GridMapApp.java:439-458
+    REQUIRE(dst && src, "null argument");
+    REQUIRE(dst->n_maps == 1 && dst->gd.W == src->gd.W && dst->gd.H == src->gd.H, "gms_map_combine: dst must be one map of the same size");
+    HIPCHK(hipSetDevice(dst->device));
+    HIPCHK(hipStreamSynchronize(src->stream));
+    gms_launch_combine(src, dst);
+    dst->need_full_build = 1;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+// raw polar scan (host) -> de-skewed beams in the map's device staging buffer; returns its device address
+int gms_map_deskew(gms_map *m, const double *angle, const double *distance, const uint8_t *hit, int32_t length,
+                   double d_center, double d_theta, gms_beam *beams_out, const gms_beam **dev_beams_out) {
+    REQUIRE(m && angle && distance && hit, "null argument");
+    REQUIRE(length >= 0 && length <= m->max_beams, "measurement count exceeds gms_params.max_beams");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    // raw input travels through the pinned beam staging area: [angle | distance | hit]
+    double *h_a = reinterpret_cast<double *>(m->h_beams), *h_d = h_a + length;
+    uint8_t *h_h = reinterpret_cast<uint8_t *>(h_d + length);
+    memcpy(h_a, angle, (size_t)length * 8); memcpy(h_d, distance, (size_t)length * 8); memcpy(h_h, hit, (size_t)length);
+    const size_t raw_bytes = (size_t)length * 17;
+    uint8_t *d_raw = reinterpret_cast<uint8_t *>(m->d_beams) + (size_t)m->max_beams * sizeof(gms_beam) - ((raw_bytes + 15) & ~(size_t)15);
+    if (m->n_maps > 1) d_raw = reinterpret_cast<uint8_t *>(m->d_beams) + (size_t)m->max_beams * sizeof(gms_beam);
+    else REQUIRE((size_t)length * sizeof(gms_beam) + raw_bytes + 16 <= (size_t)m->max_beams * sizeof(gms_beam), "scan too long for the staging buffer");
+    HIPCHK(hipMemcpyAsync(d_raw, h_a, raw_bytes, hipMemcpyHostToDevice, m->stream));
+    const double *d_a = reinterpret_cast<const double *>(d_raw), *d_d = d_a + length;
+    gms_launch_deskew(m, d_a, d_d, reinterpret_cast<const uint8_t *>(d_d + length), length, d_center, d_theta, m->d_beams);
+    HIPCHK(hipGetLastError());
+    if (dev_beams_out) *dev_beams_out = m->d_beams;
+    if (beams_out) {
+        HIPCHK(hipMemcpyAsync(beams_out, m->d_beams, (size_t)length * sizeof(gms_beam), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    return GMS_OK;
+}
+
 int gms_map_get_raw_at(gms_map *m, int32_t mi, int32_t x, int32_t y, double *raw, double *prob) {
     REQUIRE(m, "null map");
     // Java would throw ArrayIndexOutOfBounds (GridMap.java:135)
@@ -885,6 +923,16 @@ int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *de
     if (!rc && resample_fraction >= 0.0) rc = gms_pf_resample_if(pf, r01, resample_fraction);   // GridMapApp.java:185-186
     if (!rc && integrate) rc = gms_map_update_at_dev(m, dev_beams, B, pf, 0);    // SLAM.java:102-105, :93
     return rc;
+}
+
+int gms_pf_sample_motion(gms_pf *pf, double d_center, double d_theta, uint64_t seed, uint64_t sequence) {   // Odometry.java:77-96
+    REQUIRE(pf, "null filter");
+    HIPCHK(hipSetDevice(pf->map->device));
+    gms_launch_pf_motion(pf, d_center, d_theta, seed, sequence);
+    pf->have_global = 0;
+    pf->stats_current = 0;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
 }
 
 int gms_pf_did_resample(gms_pf *pf, int32_t *flags) {

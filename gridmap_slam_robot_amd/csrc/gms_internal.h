@@ -143,6 +143,9 @@ void gms_launch_apply_ray(gms_map *m, RayIn ray);
 void gms_launch_apply_counts(gms_map *m);
 void gms_launch_likelihood(gms_map *m, int32_t dirty_only);
 void gms_launch_fill(gms_map *m, double *d, double v, int64_t n);
+void gms_launch_combine(gms_map *src, gms_map *dst);
+void gms_launch_deskew(gms_map *m, const double *d_angle, const double *d_distance, const uint8_t *d_hit, int32_t length,
+                       double d_center, double d_theta, gms_beam *d_out);
 void gms_launch_factors(gms_map *m);   // d_fac from d_lik (after an upload / copy)
 void gms_launch_get_raw(gms_map *m, int32_t mi, int32_t x, int32_t y, double *d_out2);
 void gms_launch_debug_f32(gms_map *m, int32_t op, const float *d_a, float *d_out, int64_t n);
@@ -150,6 +153,7 @@ void gms_launch_debug_f32(gms_map *m, int32_t op, const float *d_a, float *d_out
 void gms_launch_pf_init(gms_pf *pf);
 void gms_launch_pf_pose_trig(gms_pf *pf, const float *d_src);
 void gms_launch_pf_combine(gms_pf *pf);
+void gms_launch_pf_motion(gms_pf *pf, double d_center, double d_theta, uint64_t seed, uint64_t sequence);
 void gms_launch_pf_after_gather(gms_pf *pf);
 void gms_launch_pf_fold_neff(gms_pf *pf);
 void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);

@@ -399,6 +399,40 @@ __global__ void k_factors(GridDev g, const double *__restrict__ lik, double *__r
         fac[(size_t)mi * fac_stride + i] = i < g.cells ? lik_factor(g, lik[(size_t)mi * g.cells + i]) : 1.0;
 }
 
+// GridMapApp.calculateCombined (J/app/GridMapApp.java:439-458): one combined map out of the n_maps of a batch,
+// log-odds of 1 - prod(1 - p_m), the maps multiplied in index order (Util.invLogOdds / logOdds: Util.java:35-48).
+__global__ void k_combine(const double *__restrict__ logs, int32_t n_maps, int64_t cells, double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+        double product = 1.0;
+        for (int32_t m = 0; m < n_maps; m++) {
+            const double l = logs[(size_t)m * cells + i];
+            product *= 1.0 - ((double)1.0f - (double)1.0f / (1.0 + exp(l)));
+        }
+        const double odds = 1.0 - product;
+        out[i] = log(odds / ((double)1.0f - odds));
+    }
+}
+
+// The de-skew loop of GridMapApp.onHandleData (J/app/GridMapApp.java:143-175) + Measurement(x, y, wasHit, dummy)
+// (J/slam/Observation.java:69-76): raw polar measurements {angle, distance, hit} -> beams, on the device.
+__global__ void k_deskew(const double *__restrict__ angle, const double *__restrict__ distance,
+                         const uint8_t *__restrict__ hit, int32_t length, double d_center, double d_theta,
+                         gms_beam *__restrict__ out) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= length) return;
+    const double d_i = -(double)(length - i) / (double)length;                    // :150
+    const double delta_theta = d_theta * d_i, delta_x = d_center * d_i;           // :157-158
+    const double a = angle[i] + delta_theta;
+    const double x_a = distance[i] * cos(a) + delta_x;                            // :166
+    const double y_a = distance[i] * sin(a);                                      // :167
+    gms_beam b;
+    b.local_x = x_a; b.local_y = y_a;
+    b.distance = sqrt(x_a * x_a + y_a * y_a);                                     // Observation.java:71
+    b.hit = hit[i] ? 1 : 0;
+    for (int k = 0; k < 7; k++) b.pad_[k] = 0;
+    out[i] = b;
+}
+
 __global__ void k_fill(double *__restrict__ d, double v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = v;
 }
@@ -510,6 +544,16 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only) {
 
 void gms_launch_factors(gms_map *m) {
     hipLaunchKernelGGL(k_factors, dim3(1024, m->n_maps), dim3(256), 0, m->stream, m->gd, m->d_lik, m->d_fac, m->fac_stride);
+}
+
+void gms_launch_combine(gms_map *src, gms_map *dst) {
+    hipLaunchKernelGGL(k_combine, dim3(2048), dim3(256), 0, dst->stream, src->d_log, src->n_maps, src->gd.cells, dst->d_log);
+}
+
+void gms_launch_deskew(gms_map *m, const double *d_angle, const double *d_distance, const uint8_t *d_hit, int32_t length,
+                       double d_center, double d_theta, gms_beam *d_out) {
+    hipLaunchKernelGGL(k_deskew, dim3((length + 255) / 256), dim3(256), 0, m->stream, d_angle, d_distance, d_hit, length,
+                       d_center, d_theta, d_out);
 }
 
 void gms_launch_fill(gms_map *m, double *d, double v, int64_t n) {

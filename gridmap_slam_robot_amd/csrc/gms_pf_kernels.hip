@@ -43,6 +43,48 @@ k_pose_trig(const float *__restrict__ src, float *__restrict__ dst, float *__res
     cs[2 * i] = c; cs[2 * i + 1] = s;
 }
 
+// Odometry.apply for every particle (J/slam/Odometry.java:60-96): d ~ N(dCenter, dCenterSD), theta ~ N(dTheta,
+// dThetaSD); heading first, then the step along the new heading (float pose, double arithmetic).  The
+// reference's stream (commons-math Well1024a, unseeded: Odometry.java:28-30) cannot be reproduced; the variates
+// come from Philox4x32-10 keyed by `seed` with counter {GLOBAL particle index, sequence} -- the same numbers
+// whatever the sharding -- through Box-Muller on two 53-bit uniforms.  cs[] is refreshed in the same pass.
+__device__ __forceinline__ void philox_round(uint32_t c[4], const uint32_t k[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void __launch_bounds__(256)
+k_motion(float *__restrict__ pose, float *__restrict__ cs, int32_t n, int64_t offset, double d_center, double d_theta,
+         double d_center_sd, double d_theta_sd, uint64_t seed, uint64_t sequence) {
+    const int32_t mi = blockIdx.y;
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t index = (uint64_t)(offset + i) + ((uint64_t)mi << 40);      // maps draw from disjoint counters
+    uint32_t c[4] = { (uint32_t)index, (uint32_t)(index >> 32), (uint32_t)sequence, (uint32_t)(sequence >> 32) };
+    uint32_t k[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+    const double u1 = ((double)(((uint64_t)(c[0] >> 5) << 26) | (uint64_t)(c[1] >> 6)) + 0.5) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)(((uint64_t)(c[2] >> 5) << 26) | (uint64_t)(c[3] >> 6)) + 0.5) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    const double z0 = rad * cos(2.0 * 3.141592653589793 * u2), z1 = rad * sin(2.0 * 3.141592653589793 * u2);
+    const double d = d_center + d_center_sd * z0;                                // ndCenter.sample()  :80
+    const double theta = d_theta + d_theta_sd * z1;                              // ndTheta.sample()   :81
+    const size_t gi = (size_t)mi * n + i;
+    const float th = (float)angle_constrain((double)pose[3 * gi + 2] + theta);   // :92
+    float fc, fs;
+    pose_trig(th, fc, fs);                                                       // MathUtil.cos(float) :93
+    pose[3 * gi + 2] = th;
+    pose[3 * gi] = (float)((double)pose[3 * gi] + (double)fc * d);               // :93  p.x += cos * d
+    pose[3 * gi + 1] = (float)((double)pose[3 * gi + 1] + (double)fs * d);       // :94
+    cs[2 * gi] = fc; cs[2 * gi + 1] = fs;
+}
+
 // One wavefront per map: order-preserving compaction of the beams with wasHit (GridMap.java:269); used
 // by the wavefront-per-particle kernels and the lattice search.
 __global__ void __launch_bounds__(64)
@@ -934,6 +976,13 @@ void gms_launch_pf_pose_trig(gms_pf *pf, const float *d_src) {
     const int64_t total = (int64_t)pf->n_maps * pf->n;
     hipLaunchKernelGGL(k_pose_trig, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pf->map->stream, d_src, pf->d_pose,
                        pf->d_cs, total);
+}
+
+void gms_launch_pf_motion(gms_pf *pf, double d_center, double d_theta, uint64_t seed, uint64_t sequence) {
+    const double d_center_sd = (0.01 + fabs(d_center) * 0.05) / 2;               // Odometry.java:63
+    const double d_theta_sd = 5 * (3.141592653589793 / 180.0) + 0.1 * fabs(d_theta);   // :64
+    hipLaunchKernelGGL(k_motion, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, pf->map->stream, pf->d_pose, pf->d_cs,
+                       pf->n, pf->offset, d_center, d_theta, d_center_sd, d_theta_sd, seed, sequence);
 }
 
 static void launch_compact(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride) {

@@ -178,6 +178,19 @@ class GridMap:
         """createMapData(other) (GridMap.java:106-124)."""
         check(load().gms_map_copy(self._h, other._h))
 
+    def combine_from(self, batch: "GridMap"):
+        """calculateCombined (J/app/GridMapApp.java:439-458): this (single) map := combination of batch's maps."""
+        check(load().gms_map_combine(self._h, batch._h))
+
+    def deskew(self, angles, distances, hits, d_center: float, d_theta: float) -> "Observation":
+        """The de-skew loop of GridMapApp.onHandleData (J/app/GridMapApp.java:143-175), on the device."""
+        a = np.ascontiguousarray(angles, dtype=np.float64)
+        d = np.ascontiguousarray(distances, dtype=np.float64)
+        h = np.ascontiguousarray(hits, dtype=np.uint8)
+        out = np.zeros(len(a), dtype=BEAM_DTYPE)
+        check(load().gms_map_deskew(self._h, ptr(a), ptr(d), ptr(h), len(a), d_center, d_theta, ptr(out), None))
+        return Observation(out)
+
     def get_raw_at(self, x: int, y: int, mi: int = 0) -> float:
         raw = C.c_double()
         check(load().gms_map_get_raw_at(self._h, mi, x, y, C.byref(raw), None))
@@ -444,6 +457,10 @@ class ParticleFilter:
         f = np.empty(self.n_maps, dtype=np.int32)
         check(load().gms_pf_did_resample(self._h, ptr(f)))
         return bool(f[0]) if self.n_maps == 1 else f.astype(bool)
+
+    def sample_motion(self, d_center: float, d_theta: float, seed: int, sequence: int):
+        """pose[i] = sampleMotionModel(pose[i], u) (SLAM.java:155-163 -> Odometry.apply, Odometry.java:77-96)."""
+        check(load().gms_pf_sample_motion(self._h, d_center, d_theta, seed, sequence))
 
     def refine_poses(self, obs):
         """pose[i] = findBestPose(map, obs, pose[i]) (GridMap.java:319-346)."""

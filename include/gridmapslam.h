@@ -130,6 +130,15 @@ int gms_map_upload_likelihood(gms_map *m, const double *lik);
 int gms_map_download_likelihood(gms_map *m, double *lik);
 /* createMapData(other): device-to-device copy of both arrays (GridMap.java:106-124). */
 int gms_map_copy(gms_map *dst, const gms_map *src);
+/* GridMapApp.calculateCombined (J/app/GridMapApp.java:439-458): dst (one map) := logOdds(1 - prod_m (1 - prob_m)) over
+ * the n_maps of src, maps in index order; rebuild dst's likelihood field afterwards as the reference does (:457). */
+int gms_map_combine(gms_map *dst, gms_map *src);
+/* The scan de-skew of GridMapApp.onHandleData (J/app/GridMapApp.java:143-175): `length` raw measurements
+ * {angle, distance, wasHit} and the frame's odometry -> beams (Observation.java:69-76), computed on the device
+ * into the handle's staging buffer.  beams_out (host, may be NULL) receives a copy; *dev_beams_out (may be
+ * NULL) its device address, valid until the next call that stages beams, for the *_dev entry points. */
+int gms_map_deskew(gms_map *m, const double *angle, const double *distance, const uint8_t *hit, int32_t length,
+                   double d_center, double d_theta, gms_beam *beams_out, const gms_beam **dev_beams_out);
 /* getRawAt(map,x,y) / getProbAt (GridMap.java:134-140) for map index mi. */
 int gms_map_get_raw_at(gms_map *m, int32_t mi, int32_t x, int32_t y, double *raw, double *prob);
 
@@ -195,6 +204,12 @@ int gms_pf_resample(gms_pf *pf, const double *r01, int32_t *indices, int32_t *n_
 int gms_pf_resample_if(gms_pf *pf, const double *r01, double fraction);
 /* flags[n_maps]: whether the last gms_pf_resample / gms_pf_resample_if replaced the particles. */
 int gms_pf_did_resample(gms_pf *pf, int32_t *flags);
+/* SLAM.sampleMotionModel -> Odometry.apply(pose) for every particle (J/slam/SLAM.java:155-163,
+ * J/slam/Odometry.java:60-96): Gaussian step and heading change with the reference's standard deviations
+ * ((0.01 + 0.05|dCenter|)/2 and 5 deg + 0.1|dTheta|).  The reference's random stream is unseeded and
+ * cannot be reproduced; variates come from Philox4x32-10(seed; global particle index, sequence), so a
+ * sharded filter draws the same numbers as a stand-alone one. */
+int gms_pf_sample_motion(gms_pf *pf, double d_center, double d_theta, uint64_t seed, uint64_t sequence);
 /* GridMap.findBestPose(map, obs, startPose) lattice search around every particle
  * (GridMap.java:319-346): poses are replaced by the argmax pose. */
 int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B);

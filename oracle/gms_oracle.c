@@ -410,3 +410,81 @@ double orc_find_best_pose(const orc_grid *g, const double *lik, const orc_beam *
     if (n_evaluated) *n_evaluated = n;
     return max_prob;
 }
+
+/* ---- J/slam/Odometry.java:60-96 (motion model; "next" row f2) ------------------------------ */
+
+static inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+/* Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11) */
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c[4] = { ctr[0], ctr[1], ctr[2], ctr[3] };
+    uint32_t k[2] = { key[0], key[1] };
+    for (int r = 0; r < 10; r++) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+void orc_philox_normals(uint64_t seed, uint64_t sequence, uint64_t index, double *z0, double *z1) {
+    const uint32_t ctr[4] = { (uint32_t)index, (uint32_t)(index >> 32), (uint32_t)sequence, (uint32_t)(sequence >> 32) };
+    const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    uint32_t c[4];
+    orc_philox4x32(ctr, key, c);
+    /* two uniforms in (0,1) with 53 random bits each */
+    const double u1 = ((double)(((uint64_t)(c[0] >> 5) << 26) | (uint64_t)(c[1] >> 6)) + 0.5) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)(((uint64_t)(c[2] >> 5) << 26) | (uint64_t)(c[3] >> 6)) + 0.5) * (1.0 / 9007199254740992.0);
+    const double r = sqrt(-2.0 * log(u1));
+    *z0 = r * cos(2.0 * M_PI * u2);
+    *z1 = r * sin(2.0 * M_PI * u2);
+}
+
+void orc_sample_motion(float *poses, int32_t N, int64_t index_offset, double d_center, double d_theta,
+                       uint64_t seed, uint64_t sequence) {
+    const double d_center_sd = (0.01 + fabs(d_center) * 0.05) / 2;                 /* :63 */
+    const double d_theta_sd = 5 * (M_PI / 180.0) + 0.1 * fabs(d_theta);            /* :64 */
+    for (int32_t i = 0; i < N; i++) {
+        double z0, z1;
+        orc_philox_normals(seed, sequence, (uint64_t)(index_offset + i), &z0, &z1);
+        const double d = d_center + d_center_sd * z0;                              /* ndCenter.sample() :80 */
+        const double theta = d_theta + d_theta_sd * z1;                            /* ndTheta.sample()  :81 */
+        float *p = poses + 3 * (size_t)i;
+        p[2] = (float)angle_constrain((double)p[2] + theta);                       /* :92 */
+        double c, s;
+        orc_pose_trig(p[2], &c, &s);                                               /* MathUtil.cos(float) :93 */
+        p[0] = (float)((double)p[0] + c * d);                                      /* :93  p.x += cos * d */
+        p[1] = (float)((double)p[1] + s * d);                                      /* :94 */
+    }
+}
+
+/* ---- J/app/GridMapApp.java:439-458 (combined map; "next" row f4) --------------------------- */
+void orc_combine_maps(const double *logs, int32_t n_maps, int64_t cells, double *out) {
+    for (int64_t i = 0; i < cells; i++) {
+        double product = 1;                                                       /* :446 */
+        for (int32_t m = 0; m < n_maps; m++)
+            product *= 1 - orc_inv_log_odds(logs[(size_t)m * cells + i]);         /* :451 */
+        out[i] = orc_log_odds(1 - product);                                       /* :454 */
+    }
+}
+
+/* ---- J/app/GridMapApp.java:143-175 (scan de-skew; "next" row f3) --------------------------- */
+void orc_deskew(const double *angle, const double *distance, const uint8_t *hit, int32_t length, double d_center,
+                double d_theta, orc_beam *out) {
+    for (int32_t i = 0; i < length; i++) {
+        const double d_i = -(double)(length - i) / (double)length;                /* :150 int negate, then double divide */
+        const double delta_theta = d_theta * d_i;                                 /* :157 */
+        const double delta_x = d_center * d_i;                                    /* :158 */
+        const double x_a = distance[i] * cos(angle[i] + delta_theta) + delta_x;   /* :166 MathUtil.cos(double) */
+        const double y_a = distance[i] * sin(angle[i] + delta_theta);             /* :167 */
+        memset(&out[i], 0, sizeof(orc_beam));
+        out[i].local_x = x_a;                                                     /* Observation.java:74-75 */
+        out[i].local_y = y_a;
+        out[i].distance = sqrt(x_a * x_a + y_a * y_a);                            /* :71 */
+        out[i].hit = hit[i] ? 1 : 0;
+    }
+}

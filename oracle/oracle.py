@@ -96,6 +96,16 @@ def lib() -> C.CDLL:
         L.orc_resample_indices.argtypes = [dp, C.c_int32, C.c_double, ip]
         L.orc_find_best_pose.restype = C.c_double
         L.orc_find_best_pose.argtypes = [gp, dp, vp, C.c_int32, fp, fp, ip]
+        L.orc_sample_motion.restype = None
+        L.orc_sample_motion.argtypes = [fp, C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint64]
+        L.orc_combine_maps.restype = None
+        L.orc_combine_maps.argtypes = [dp, C.c_int32, C.c_int64, dp]
+        L.orc_deskew.restype = None
+        L.orc_deskew.argtypes = [dp, dp, C.POINTER(C.c_uint8), C.c_int32, C.c_double, C.c_double, vp]
+        L.orc_philox4x32.restype = None
+        L.orc_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_philox_normals.restype = None
+        L.orc_philox_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, dp, dp]
         L.orc_pose_trig.restype = None
         L.orc_pose_trig.argtypes = [C.c_float, dp, dp]
         _lib = L
@@ -256,3 +266,45 @@ def gaussian_kernel(sigma: float, size: int) -> np.ndarray:
 
 def log_odds(p: float) -> float:
     return lib().orc_log_odds(p)
+
+
+def sample_motion(poses: np.ndarray, d_center: float, d_theta: float, seed: int, sequence: int, index_offset: int = 0) -> np.ndarray:
+    """Odometry.apply on every pose (Odometry.java:77-96) with Philox-generated normals; returns new poses."""
+    out = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3).copy()
+    lib().orc_sample_motion(_fp(out), len(out), index_offset, d_center, d_theta, seed, sequence)
+    return out
+
+
+def philox_normals(seed: int, sequence: int, index: int):
+    a, b = C.c_double(), C.c_double()
+    lib().orc_philox_normals(seed, sequence, index, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def philox4x32(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32(c, k, o)
+    return [int(x) for x in o]
+
+
+def combine_maps(logs: np.ndarray) -> np.ndarray:
+    """calculateCombined (GridMapApp.java:439-458) over logs[n_maps][cells]."""
+    logs = np.ascontiguousarray(logs, dtype=np.float64)
+    M = logs.shape[0]
+    cells = logs.size // M
+    out = np.empty(cells, dtype=np.float64)
+    lib().orc_combine_maps(_dp(logs), M, cells, _dp(out))
+    return out
+
+
+def deskew(angle, distance, hit, d_center: float, d_theta: float) -> np.ndarray:
+    """The de-skew loop of GridMapApp.onHandleData (GridMapApp.java:143-175) -> beams."""
+    angle = np.ascontiguousarray(angle, dtype=np.float64)
+    distance = np.ascontiguousarray(distance, dtype=np.float64)
+    hit = np.ascontiguousarray(hit, dtype=np.uint8)
+    out = np.zeros(len(angle), dtype=BEAM_DTYPE)
+    lib().orc_deskew(_dp(angle), _dp(distance), hit.ctypes.data_as(C.POINTER(C.c_uint8)), len(angle), d_center, d_theta,
+                     out.ctypes.data)
+    return out

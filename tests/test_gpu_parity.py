@@ -417,3 +417,98 @@ def test_sharded_phases_equal_fused_normalize():
         for pf in pfs:
             pf.close()
     m.set_stream(None)
+
+
+# ------------------------------------------------------------------ Odometry.apply (motion model, "next" row f2)
+def test_motion_model_matches_the_oracle_and_the_reference_distribution():
+    m = GridMap(3.2, 3.2, 0.05, (-1.6, -1.6))
+    N = 20000
+    rng = np.random.default_rng(12)
+    P = np.column_stack([rng.normal(0, 1, N), rng.normal(0, 1, N), rng.uniform(-3.1, 3.1, N)]).astype(np.float32)
+    pf = ParticleFilter(m, N)
+    for (dc, dt, seed, seq) in ((0.10, 0.20, 7, 0), (-0.03, -1.0, 7, 1), (0.0, 0.0, 99, 5)):
+        pf.set_poses(P)
+        pf.sample_motion(dc, dt, seed, seq)
+        got = pf.get_poses()
+        want = orc.sample_motion(P, dc, dt, seed, seq)
+        # same counter-based variates, same arithmetic; device libm may differ from glibc in the last ulp of a double
+        assert np.max(np.abs(got - want)) <= 2e-6
+        assert (got == want).mean() > 0.999
+        # the distribution the reference draws from (Odometry.java:63-64,80-81)
+        dth = got[:, 2].astype(np.float64) - P[:, 2]
+        dth = (dth + np.pi) % (2 * np.pi) - np.pi
+        sd_t = np.radians(5) + 0.1 * abs(dt)
+        assert abs(dth.mean() - ((dt + np.pi) % (2 * np.pi) - np.pi)) < 5 * sd_t / np.sqrt(N) + 1e-3
+        assert abs(dth.std() - sd_t) < 0.03 * sd_t
+        step = np.hypot(got[:, 0] - P[:, 0], got[:, 1] - P[:, 1])
+        sd_c = (0.01 + abs(dc) * 0.05) / 2
+        assert abs(step.mean() - max(abs(dc), sd_c * 0.7979)) < 0.05 * max(abs(dc), sd_c)
+        # headings stay in (-pi, pi] (angleConstrain) and the scoring trig follows the new heading
+        assert got[:, 2].max() <= np.float32(np.pi) and got[:, 2].min() >= -np.float32(np.pi) - 1e-6
+    # sharding-independent: a shard starting at 4096 draws what particles 4096.. of the full filter draw
+    pf2 = ParticleFilter(m, 1024)
+    pf2.set_shard(4096, N)
+    pf2.set_poses(P[4096:5120])
+    pf2.sample_motion(0.10, 0.20, 7, 0)
+    pf.set_poses(P)
+    pf.sample_motion(0.10, 0.20, 7, 0)
+    assert np.array_equal(pf2.get_poses(), pf.get_poses()[4096:5120])
+
+
+# ------------------------------------------------------------------ combined map, de-skew + recorded traces ("next" rows f3, f4)
+def test_combined_map_matches_calculate_combined():
+    M, ext, res = 5, 3.2, 0.05
+    traces = [synth.make_trace(ext, res, 72, T=8, seed=80 + i, n_scans=4) for i in range(M)]
+    mb = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M)
+    for t in range(4):
+        mb.update(np.stack([tr.scans[t] for tr in traces]), np.stack([tr.poses[t] for tr in traces]))
+    logs = mb.download_log().reshape(M, -1)
+    want = orc.combine_maps(logs)
+    one = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    one.combine_from(mb)
+    got = one.download_log().reshape(-1)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    assert np.max(np.abs(got[fin] - want[fin])) <= 1e-5 * (1 + np.abs(want[fin])).max()     # north_star bar on log-odds
+    assert np.max(np.abs(got[fin] - want[fin]) / (1e-300 + np.abs(want[fin]) + 1e-9)) <= 1e-6
+    one.compute_likelihood_map()                                                            # GridMapApp.java:457
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    assert np.array_equal(one.download_likelihood().reshape(-1), g.build_likelihood(got))
+
+
+def test_deskew_and_recorded_trace_round_trip(tmp_path):
+    from gridmap_slam_robot_amd.trace import Frame, read_trace, write_trace
+    rng = np.random.default_rng(8)
+    frames = []
+    for k in range(5):
+        n = int(rng.integers(60, 200))
+        ang = np.sort(rng.uniform(-np.pi, np.pi, n))
+        dist = rng.uniform(0.3, 9.5, n)
+        hit = (rng.uniform(0, 1, n) < 0.85).astype(np.uint8)
+        frames.append(Frame(float(np.float32(0.1 * k)), float(rng.normal(0.05, 0.02)), float(rng.normal(0.0, 0.3)), ang, np.where(hit, dist, 10.0), hit))
+    path = str(tmp_path / "rec.bin")
+    write_trace(path, frames)
+    raw = open(path, "rb").read()
+    assert raw[0] == 0xFF and len(raw) == 3 + sum(22 + 17 * len(f.angle) for f in frames)      # DataOutputStream layout
+    back = read_trace(path)
+    m = GridMap(25.6, 25.6, 0.05, (-12.8, -12.8))
+    g = orc.Grid(25.6, 25.6, 0.05, -12.8, -12.8)
+    log = g.new_log()
+    pose = np.array([0.5, -0.25, 0.3], dtype=np.float32)
+    for f, b in zip(frames, back):
+        assert (b.time_stamp, b.d_center, b.d_theta) == (f.time_stamp, f.d_center, f.d_theta)
+        assert np.array_equal(b.angle, f.angle) and np.array_equal(b.distance, f.distance) and np.array_equal(b.hit, f.hit)
+        obs = m.deskew(b.angle, b.distance, b.hit, b.d_center, b.d_theta)
+        want = orc.deskew(b.angle, b.distance, b.hit, b.d_center, b.d_theta)
+        assert np.array_equal(obs.beams["hit"], want["hit"])
+        for k in ("local_x", "local_y", "distance"):
+            assert np.max(np.abs(obs.beams[k] - want[k])) <= 1e-14 * 10.0                     # device vs glibc trig: last ulps
+        m.update(obs, pose)
+        g.integrate(log, want, pose)
+    got = m.download_log().reshape(-1)
+    # a beam end point within 1e-14 m of a cell boundary could move one cell; none does in this trace
+    assert np.array_equal(got != 0, log != 0)
+    assert rel_err(got[log != 0], log[log != 0]) <= 1e-13
+    with pytest.raises(ValueError):
+        open(path, "wb").write(b"\x00\x00\x01")
+        read_trace(path)
