@@ -150,8 +150,12 @@ def main() -> int:
             pf.normalize(fetch=False)
             pf.resample_if(r01[i % 4096], 0.5)
         else:
-            spf.normalize()
+            # the map update needs only the weighted pose: it runs beside the all-gather (RCCL's own stream)
+            spf.normalize_begin()
+            m.update_at_dev(beams_ptr, B, pf)
+            spf.normalize_end()
             spf.resample(r01[i % 4096], 0.5)
+            return
         if args.full_rebuild:
             m.integrate_at_dev(beams_ptr, B, pf)
             m.compute_likelihood_map()

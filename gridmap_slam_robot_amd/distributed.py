@@ -103,24 +103,41 @@ class ShardedParticleFilter:
         return n, rank * n
 
     # ------------------------------------------------------------------------------------------
-    def _all_gather(self):
+    def _all_gather_start(self):
+        """Start the all-gather of the packed particles; returns a work handle (None = already complete)."""
         if self.world == 1:
             self.packed_global.copy_(self.packed_local)
-            return
+            return None
         try:
-            dist.all_gather_into_tensor(self.packed_global, self.packed_local, group=self.group)
-        except (RuntimeError, NotImplementedError):
+            return dist.all_gather_into_tensor(self.packed_global, self.packed_local, group=self.group, async_op=True)
+        except (RuntimeError, NotImplementedError, TypeError):
             parts = list(self.packed_global.chunk(self.world))
-            dist.all_gather(parts, self.packed_local, group=self.group)
+            return dist.all_gather(parts, self.packed_local, group=self.group, async_op=True)
 
-    def normalize(self):
-        """SLAM.update's bookkeeping over all ranks (SLAM.java:87-129)."""
+    def normalize_begin(self):
+        """SLAM.update's bookkeeping over all ranks (SLAM.java:87-129), first half: block partials,
+        all-reduce, weight /= weightSum (the statistics -- weight sum, strongest, weighted pose -- are final
+        after this), and the START of the all-gather of the packed normalised particles.  Work that needs
+        only the weighted pose (the map update) can be enqueued between normalize_begin and normalize_end:
+        RCCL runs the all-gather on its own stream beside it."""
         self.ops.local_partials(self.partials)
         if self.world > 1:
             dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
         self.ops.apply_partials(self.partials, self.packed_local)
-        self._all_gather()
+        self._pending = self._all_gather_start()
+
+    def normalize_end(self):
+        """Second half: wait for the all-gather (the current stream waits, not the host) and hand the global
+        population to the shard (resampling source)."""
+        work = getattr(self, "_pending", None)
+        if work is not None:
+            work.wait()
+        self._pending = None
         self.ops.import_global(self.packed_global)
+
+    def normalize(self):
+        self.normalize_begin()
+        self.normalize_end()
 
     def resample(self, r01: float, fraction: Optional[float] = None):
         """SLAM.resample (SLAM.java:133-153); with `fraction`, only if neff < fraction*N
