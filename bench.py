@@ -230,7 +230,11 @@ def main() -> int:
     kernels = {}
     for k, (ms, n) in prof.items():
         if n:
-            kernels[k] = {"ms_per_step": round(ms / nb, 5), "launches_per_step": round(n / nb, 2)}
+            ab = algorithmic_bytes(k, n_particles=n_local, n_hit=n_hit, n_beams=B, cells=m.W * m.H, visits=visits or 0)
+            if k == "likelihood" and not args.full_rebuild:
+                ab = None        # the dirty-rect rebuild touches a scan-dependent part of the 16 B/cell field
+            kernels[k] = {"ms_per_step": round(ms / nb, 5), "launches_per_step": round(n / nb, 2),
+                          "algorithmic_gb_per_s": (round(ab / (ms / nb * 1e-3) / 1e9, 1) if ab else None)}
     map_update_ms = sum(kernels.get(k, {}).get("ms_per_step", 0.0) for k in ("raycast", "apply", "likelihood"))
 
     out = {
@@ -273,7 +277,7 @@ def main() -> int:
         log = log0
         lik = g.build_likelihood(log)
         n_cpu = n_local
-        scans_cpu = args.cpu_scans or 16
+        scans_cpu = args.cpu_scans or 10 ** 6          # bounded by time: ~12 s of single-thread CPU work
         P = synth.make_particles(tr.poses[T // 2], n_global, seed=99)[:n_cpu]
         c0 = time.perf_counter()
         done = 0
@@ -288,7 +292,7 @@ def main() -> int:
             g.integrate(log, tr.scans[t], wp)
             lik = g.build_likelihood(log)
             done += 1
-            if time.perf_counter() - c0 > 30.0:
+            if time.perf_counter() - c0 > (30.0 if args.cpu_scans else 12.0):
                 break
         cpu_s = time.perf_counter() - c0
         out["cpu_baseline"] = {
