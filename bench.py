@@ -82,6 +82,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=0, help="scans of the CPU baseline sample (0 = auto)")
     ap.add_argument("--full-rebuild", action="store_true", help="rebuild the whole likelihood field every scan")
+    ap.add_argument("--host-inputs", action="store_true", help="hand poses and scans over as HOST buffers every step (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (all-reduce / all-gather) code path even with one rank")
     args = ap.parse_args()
 
@@ -126,6 +127,7 @@ def main() -> int:
         t = T // 2 + s
         allp = synth.make_particles(tr.poses[t], n_global, seed=99 + s)      # sigma 0.10 m / 5 deg
         pose_sets.append(torch.from_numpy(allp[rank * n_local:(rank + 1) * n_local].copy()).to(dev))
+    pose_sets_host = [p.cpu().numpy() for p in pose_sets] if args.host_inputs else None
     n_hit = int(tr.scans[T // 2]["hit"].sum())
     r01 = np.random.default_rng(7).random(4096)
 
@@ -141,6 +143,9 @@ def main() -> int:
         s = i % n_sets
         t = T // 2 + s
         beams_ptr = scans_dev[t].data_ptr()
+        if args.host_inputs and spf is None:
+            pf.slam_update(pose_sets_host[s], tr.scans[t], r01[i % 4096], 0.5, True)
+            return
         if spf is None and not args.full_rebuild:
             pf.slam_update_dev(pose_sets[s].data_ptr(), beams_ptr, B, r01[i % 4096], 0.5, True)   # one C-ABI call per scan
             return
@@ -256,6 +261,7 @@ def main() -> int:
             "particles_total": n_global, "beams": B, "grid": [m.W, m.H], "resolution_m": res,
             "parallelism": f"particles sharded x{world}, map replicated" if world > 1 else "single GPU",
             "likelihood_rebuild": "full" if args.full_rebuild else "dirty-rect (bit-identical to full)",
+            "inputs": "host buffers every step (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
         },
         "beam_evals_per_s": value * n_hit,
         "scans_per_s": steps / elapsed,

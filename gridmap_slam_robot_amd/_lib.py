@@ -136,6 +136,7 @@ def load() -> C.CDLL:
     sig("gms_pf_set_poses_dev", C.c_int, vp, vp)
     sig("gms_pf_score_dev", C.c_int, vp, vp, i32)
     sig("gms_slam_update_dev", C.c_int, vp, vp, vp, i32, vp, f64, i32)
+    sig("gms_slam_update", C.c_int, vp, vp, vp, i32, vp, f64, i32, sp)
     sig("gms_pf_create", C.c_int, vp, i32, C.POINTER(vp))
     sig("gms_pf_destroy", C.c_int, vp)
     sig("gms_pf_set_shard", C.c_int, vp, i64, i64)

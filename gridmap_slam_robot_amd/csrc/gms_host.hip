@@ -925,6 +925,37 @@ int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *de
     return rc;
 }
 
+// The same with host-resident inputs (what a JNI caller has): one staging copy of the scan, one of the poses.
+int gms_slam_update(gms_pf *pf, const float *xytheta, const gms_beam *beams, int32_t B, const double *r01,
+                    double resample_fraction, int32_t integrate, gms_pf_stats *stats) {
+    REQUIRE(pf && beams && r01, "null argument");
+    gms_map *m = pf->map;
+    if (pf->offset != 0 || pf->n_global != pf->n)
+        return fail(GMS_ERR_STATE, "sharded filter: the collectives belong to the caller (see distributed.py)");
+    int rc = GMS_OK;
+    if (xytheta) rc = gms_pf_set_poses(pf, xytheta);
+    if (!rc) rc = stage_beams(m, beams, B);
+    const gms_beam *d = m->d_beams;
+    const int32_t stride_ok = (m->n_maps == 1) || (B == m->max_beams);
+    if (!rc && !stride_ok) {
+        // batched handles stage [n_maps][max_beams]; the *_dev entry points expect [n_maps][B]: go through the
+        // staging-stride launchers instead
+        gms_launch_pf_score(pf, m->d_beams, B, m->max_beams);
+        pf->have_global = 0; pf->stats_current = 0;
+        rc = gms_pf_normalize(pf, nullptr);
+        if (!rc && resample_fraction >= 0.0) rc = gms_pf_resample_if(pf, r01, resample_fraction);
+        if (!rc && integrate) {
+            gms_launch_raycast(m, m->d_beams, B, m->max_beams, stats_pose_ptr(pf, 0), (int32_t)(sizeof(PfStatsDev) / sizeof(float)));
+            gms_launch_apply_counts(m);
+            rc = finish_likelihood(m, m->need_full_build ? 0 : 1);
+        }
+    } else if (!rc) {
+        rc = gms_slam_update_dev(pf, nullptr, d, B, r01, resample_fraction, integrate);
+    }
+    if (!rc && stats) rc = gms_pf_get_stats(pf, stats);
+    return rc;
+}
+
 int gms_pf_sample_motion(gms_pf *pf, double d_center, double d_theta, uint64_t seed, uint64_t sequence) {   // Odometry.java:77-96
     REQUIRE(pf, "null filter");
     HIPCHK(hipSetDevice(pf->map->device));

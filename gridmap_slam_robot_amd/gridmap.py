@@ -410,6 +410,15 @@ class ParticleFilter:
         check(load().gms_slam_update_dev(self._h, C.c_void_p(dev_xytheta or 0), C.c_void_p(dev_beams), B, ptr(r), fraction,
                                          1 if integrate else 0))
 
+    def slam_update(self, poses, obs, r01, fraction: float = 0.5, integrate: bool = True, fetch: bool = False):
+        """SLAM.update + conditional resample with HOST inputs (poses may be None)."""
+        b, B = self.map._beam_args(obs)
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(r01, dtype=np.float64), (self.n_maps,)))
+        p = None if poses is None else np.ascontiguousarray(poses, dtype=np.float32)
+        arr = (GmsPfStats * self.n_maps)() if fetch else None
+        check(load().gms_slam_update(self._h, None if p is None else ptr(p), ptr(b), B, ptr(r), fraction, 1 if integrate else 0, arr))
+        return self._stats(arr) if fetch else None
+
     def _stats(self, arr):
         out = [dict(weight_sum=s.weight_sum, neff=s.neff, strongest=s.strongest, n_zero=s.n_zero,
                     max_log_weight=s.max_log_weight) for s in arr]

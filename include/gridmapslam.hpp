@@ -212,12 +212,17 @@ public:
     /** update(z, u) (SLAM.java:80-131); `poses` are the motion-model samples, dTheta is u.dTheta */
     double update(const Observation &z, const std::vector<Pose> *poses = nullptr, double dTheta = 0.0) {
         const bool skipUpdate = std::fabs(dTheta) > (3.141592653589793 / 180.0) * 30;       // :82
-        if (poses) pf_.setPoses(*poses);                                                    // :90
-        pf_.score(z);                                                                       // :99
-        const gms_pf_stats st = pf_.normalize();                                            // :100-124
+        std::vector<float> p;
+        if (poses) {                                                                        // :90
+            p.resize(poses->size() * 3);
+            for (size_t i = 0; i < poses->size(); i++) { p[3 * i] = (*poses)[i].x; p[3 * i + 1] = (*poses)[i].y; p[3 * i + 2] = (*poses)[i].theta; }
+        }
+        const double unused_r01 = 0.0;
+        gms_pf_stats st{};
+        // one call: score (:99), bookkeeping (:100-124), map update at the weighted pose (:102-105, :93); no resample here
+        check(gms_slam_update(pf_.handle(), poses ? p.data() : nullptr, z.getMeasurements().data(), z.getNumberOfMeasurements(),
+                              &unused_r01, -1.0, skipUpdate ? 0 : 1, &st));
         strongest_ = st.strongest;
-        if (!skipUpdate)                                                                    // :102-105 (+ :93 for the next scan)
-            check(gms_map_update_at(gridMap_.handle(), z.getMeasurements().data(), z.getNumberOfMeasurements(), pf_.handle(), 0));
         return st.neff;
     }
     void resample(double r01) { pf_.resample(r01); }                                        // :133-153

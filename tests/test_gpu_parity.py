@@ -512,3 +512,19 @@ def test_deskew_and_recorded_trace_round_trip(tmp_path):
     with pytest.raises(ValueError):
         open(path, "wb").write(b"\x00\x00\x01")
         read_trace(path)
+
+
+def test_fused_scan_step_equals_the_separate_calls():
+    """gms_slam_update (host inputs) and gms_slam_update_dev are the separate entry points in one call."""
+    tr = synth.make_trace(6.4, 0.05, 120, T=12, seed=21, n_scans=8)
+    N = 600
+    a = GridMap(6.4, 6.4, 0.05, (-3.2, -3.2)); b = GridMap(6.4, 6.4, 0.05, (-3.2, -3.2))
+    pa, pb = ParticleFilter(a, N), ParticleFilter(b, N)
+    for t in range(6):
+        P = synth.make_particles(tr.poses[t], N, seed=t, sigma_xy=0.03, sigma_theta_deg=1.0)
+        st = pa.slam_update(P, tr.scans[t], 0.3 + 0.1 * t, 0.5, True, fetch=True)
+        pb.set_poses(P); pb.score(tr.scans[t]); st2 = pb.normalize(); pb.resample_if(0.3 + 0.1 * t, 0.5); b.update_at(tr.scans[t], pb)
+        assert st == st2
+        assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights())
+        assert np.array_equal(a.download_log(), b.download_log())
+        assert np.array_equal(a.download_likelihood(), b.download_likelihood())
