@@ -320,8 +320,10 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     t.c = (double)cs[2 * gi]; t.s = (double)cs[2 * gi + 1];           // Transform.java:15-16
     t.px = (double)pose[3 * gi]; t.py = (double)pose[3 * gi + 1];
     double prod = 1.0;                                                 // GridMap.java:262
-    for (int32_t base = 0; base < nb; base += SCORE_U) {
-        uint32_t cell[SCORE_U];
+    // Software pipeline: the cell indices of batch b+1 are computed while the look-ups of batch b are in
+    // flight, so the vector ALU work hides under the gather latency inside each wavefront (the gathers,
+    // not the arithmetic, are the scarcer resource: tools/microbench/gather8.hip).
+    auto cells_of = [&](int32_t base, uint32_t cell[SCORE_U]) {
         double2 bm[SCORE_U];
         bool guard = false;
 #pragma unroll
@@ -338,11 +340,16 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
                 cell[u] = base + u < nb ? c : (uint32_t)g.cells;
             }
         }
+    };
+    uint32_t cell[SCORE_U];
+    if (nb > 0) cells_of(0, cell);
+    for (int32_t base = 0; base < nb; base += SCORE_U) {
         double f[SCORE_U];
 #pragma unroll
-        for (int u = 0; u < SCORE_U; u++) f[u] = fac[cell[u]];
+        for (int u = 0; u < SCORE_U; u++) f[u] = fac[cell[u]];         // issue the look-ups of this batch
+        if (base + SCORE_U < nb) cells_of(base + SCORE_U, cell);       // ... and compute the next batch's cells meanwhile
 #pragma unroll
-        for (int u = 0; u < SCORE_U; u++) prod *= f[u];
+        for (int u = 0; u < SCORE_U; u++) prod *= f[u];                // beam order: batch by batch, u ascending
     }
     if (nseg == 1) {
         int e;
