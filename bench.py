@@ -97,7 +97,7 @@ def main() -> int:
             print("bench.py: --gpus N > 1 must be launched with torch.distributed.run", file=sys.stderr)
             return 2
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or (args.force_sharded and "RANK" in os.environ):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -219,7 +219,7 @@ def main() -> int:
         visits = int(counts.sum())
 
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return 0
@@ -311,7 +311,7 @@ def main() -> int:
         out["cpu_baseline"] = None
 
     print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -26,6 +26,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -83,6 +85,8 @@ class ShardedParticleFilter:
     def __init__(self, n_global: int, ops, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # measurement aid: run the collectives even on a one-rank group (GMS_FORCE_COLLECTIVES=1)
+        self.force = dist.is_initialized() and os.environ.get("GMS_FORCE_COLLECTIVES") == "1"
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_global = n_global
         self.n_local, self.offset = self.shard_of(n_global, self.world, self.rank)
@@ -105,7 +109,7 @@ class ShardedParticleFilter:
     # ------------------------------------------------------------------------------------------
     def _all_gather_start(self):
         """Start the all-gather of the packed particles; returns a work handle (None = already complete)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             self.packed_global.copy_(self.packed_local)
             return None
         try:
@@ -121,7 +125,7 @@ class ShardedParticleFilter:
         only the weighted pose (the map update) can be enqueued between normalize_begin and normalize_end:
         RCCL runs the all-gather on its own stream beside it."""
         self.ops.local_partials(self.partials)
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
         self.ops.apply_partials(self.partials, self.packed_local)
         self._pending = self._all_gather_start()
