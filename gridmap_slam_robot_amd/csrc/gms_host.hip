@@ -576,8 +576,8 @@ static int64_t nblk_of(int64_t n) { return (n + GMS_BLOCK - 1) / GMS_BLOCK; }
 static int64_t nchunks_of(int64_t n) { return (n + 63) / 64; }
 
 static void pf_free_global(gms_pf *pf) {
-    hipFree(pf->d_partials); hipFree(pf->d_p2); hipFree(pf->d_global); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum);
-    pf->d_partials = pf->d_p2 = nullptr; pf->d_global = nullptr; pf->d_chunk_tot = pf->d_cum = nullptr;
+    hipFree(pf->d_partials); hipFree(pf->d_p2); hipFree(pf->d_global_own); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum);
+    pf->d_partials = pf->d_p2 = nullptr; pf->d_global = pf->d_global_own = nullptr; pf->d_chunk_tot = pf->d_cum = nullptr;
 }
 
 static int pf_alloc_global(gms_pf *pf) {
@@ -586,7 +586,8 @@ static int pf_alloc_global(gms_pf *pf) {
     const size_t nblk = nblk_of(pf->n_global), nch = nchunks_of(pf->n_global);
     HIPCHK(hipMalloc(&pf->d_partials, M * nblk * GMS_PARTIAL_STRIDE * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_p2, M * nblk * 2 * sizeof(double)));
-    HIPCHK(hipMalloc(&pf->d_global, M * pf->n_global * sizeof(PackedParticle)));
+    HIPCHK(hipMalloc(&pf->d_global_own, M * pf->n_global * sizeof(PackedParticle)));
+    pf->d_global = pf->d_global_own;
     HIPCHK(hipMalloc(&pf->d_chunk_tot, M * (nch + 1) * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_cum, M * pf->n_global * sizeof(double)));
     return GMS_OK;
@@ -768,6 +769,7 @@ int gms_pf_normalize(gms_pf *pf, gms_pf_stats *stats) {                 // SLAM.
     if (pf->offset != 0 || pf->n_global != pf->n)
         return fail(GMS_ERR_STATE, "sharded filter: use gms_pf_local_partials / apply_partials / import_global");
     HIPCHK(hipSetDevice(pf->map->device));
+    pf->d_global = pf->d_global_own;
     gms_launch_pf_partials(pf, pf->d_partials);
     gms_launch_pf_apply_partials(pf, pf->d_partials, pf->d_global);
     pf->have_global = 1;
@@ -823,8 +825,8 @@ int gms_pf_import_global(gms_pf *pf, const void *dev_packed_global) {
     REQUIRE(pf && dev_packed_global, "null argument");
     gms_map *m = pf->map;
     HIPCHK(hipSetDevice(m->device));
-    HIPCHK(hipMemcpyAsync(pf->d_global, dev_packed_global, (size_t)pf->n_maps * pf->n_global * sizeof(PackedParticle),
-                          hipMemcpyDeviceToDevice, m->stream));
+    // zero copy: the gathered buffer becomes the resampling source as it is (see the header for its lifetime)
+    pf->d_global = const_cast<PackedParticle *>(reinterpret_cast<const PackedParticle *>(dev_packed_global));
     gms_launch_pf_after_gather(pf);
     pf->have_global = 1;
     HIPCHK(hipGetLastError());
@@ -836,6 +838,7 @@ static int ensure_global(gms_pf *pf) {
     if (pf->have_global) return GMS_OK;
     if (pf->offset != 0 || pf->n_global != pf->n)
         return fail(GMS_ERR_STATE, "sharded filter: all-gather the packed particles and call gms_pf_import_global first");
+    pf->d_global = pf->d_global_own;
     gms_launch_pf_combine(pf);
     gms_launch_pf_pack(pf, pf->d_global);
     pf->have_global = 1;

@@ -116,7 +116,8 @@ struct gms_pf {
     int32_t *d_nhit;                // [n_maps]
     double *d_partials;             // [n_maps][nblk_global][GMS_PARTIAL_STRIDE]
     double *d_p2;                   // [n_maps][nblk_global][2] {sum wn, sum wn^2} of the normalised global population
-    int32_t p2_ready, neff_folded;  // d_p2 describes d_global; stats.sq_sum has been folded from it
+    int32_t neff_folded;            // stats.sq_sum has been folded from d_p2 (d_p2 is produced with the chunk sums)
+    PackedParticle *d_global_own;   // the library's own buffer; d_global may alias a caller's all-gather result
     PackedParticle *d_global;       // [n_maps][n_global] source population (own copy when unsharded)
     double *d_chunk_tot;            // [n_maps][nchunks] scan chunk totals / offsets
     double *d_cum;                  // [n_maps][n_global] in-chunk inclusive sums
@@ -155,6 +156,7 @@ void gms_launch_pf_pose_trig(gms_pf *pf, const float *d_src);
 void gms_launch_pf_combine(gms_pf *pf);
 void gms_launch_pf_motion(gms_pf *pf, double d_center, double d_theta, uint64_t seed, uint64_t sequence);
 void gms_launch_pf_after_gather(gms_pf *pf);
+void gms_launch_pf_chunk_sums(gms_pf *pf);
 void gms_launch_pf_fold_neff(gms_pf *pf);
 void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials);

@@ -457,8 +457,8 @@ struct RedLds {
 // relative, ten orders of magnitude inside the 1e-5 parity bar (DESIGN.md "Bookkeeping").
 // Neff is NOT derived from column 5: raw weights are products of hundreds of factors (1e-150 is
 // typical at 720 beams) and their squares underflow.  Like the reference (SLAM.java:180-190) it is
-// computed from the normalised weights: k_normalize_pack / k_global_sq leave per-block
-// {sum wn, sum wn^2}, fold_neff() folds them where Neff is consumed.
+// computed from the normalised weights: level 0 of the cumulative-weight scan (k_normalize_pack /
+// k_chunk_sums) leaves per-block {sum wn, sum wn^2}, fold_neff() folds them where Neff is consumed.
 #define COL_SUM 0
 #define COL_MAX 1
 #define COL_ARG 2
@@ -621,21 +621,6 @@ k_fold_neff(const double *__restrict__ p2_all, int64_t nblk, PfStatsDev *__restr
     if (threadIdx.x == 0) { stats[mi].norm_sum = ns; stats[mi].sq_sum = sq; }
 }
 
-// {sum wn, sum wn^2} per block of the GLOBAL packed population (sharded filters after the all-gather,
-// or a resample without a preceding normalise)
-__global__ void __launch_bounds__(256)
-k_global_sq(const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nblk, double *__restrict__ p2_all) {
-    __shared__ RedLds L;
-    const int32_t mi = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * GMS_BLOCK + threadIdx.x;          // GMS_BLOCK == 256 == blockDim.x
-    const double wn = i < n_global ? glob[(size_t)mi * n_global + i].w : 0.0;
-    const double a = group_sum(wn, L.a), q = group_sum(wn * wn, L.a);
-    if (threadIdx.x == 0) {
-        double *p = p2_all + ((size_t)mi * nblk + blockIdx.x) * 2;
-        p[0] = a; p[1] = q;
-    }
-}
-
 // phase 1: this shard's block partials at their global slots; blocks of other shards are zeroed so
 // that an all-reduce(SUM) assembles the full vector exactly.  grid = (nblk_global, n_maps).
 __global__ void __launch_bounds__(256)
@@ -662,17 +647,21 @@ k_partials(double *__restrict__ w, double *__restrict__ logw, const float *__res
 
 // Level 0 of the cumulative weights for one 64-particle chunk held in LDS: sequential, index order --
 // the reference's `c += w[i]` (SLAM.java:144) inside the chunk.
-__device__ __forceinline__ double chunk_sums_lds(double *row, int32_t len) {
-    double acc = 0.0;
+__device__ __forceinline__ double chunk_sums_lds(double *row, int32_t len, double &sq) {
+    double acc = 0.0, q = 0.0;
 #pragma unroll 8
     for (int32_t j = 0; j < SCAN_CHUNK; j++) {
         if (j < len) {
-            acc = (j == 0) ? row[j] : acc + row[j];
+            const double v = row[j];
+            acc = (j == 0) ? v : acc + v;
+            q = (j == 0) ? v * v : q + v * v;                          // calculateNeff's squares, same order
             row[j] = acc;
         }
     }
+    sq = q;
     return acc;
 }
+static_assert(4 * SCAN_CHUNK == GMS_BLOCK, "a reduction block is four scan chunks");
 
 // phase 2: every workgroup folds the (all-reduced) partials; weight /= weightSum (SLAM.java:120-121);
 // packs {w,x,y,theta} (the all-gather payload / the resampling source).  A stand-alone filter also
@@ -697,57 +686,76 @@ k_normalize_pack(const double *__restrict__ partials_all, int64_t nblk_global, d
         pp.w = wn; pp.x = pose[3 * gi]; pp.y = pose[3 * gi + 1]; pp.theta = pose[3 * gi + 2]; pp.pad = 0u;
         packed[gi] = pp;
     }
-    if (p2_all) {                                     // uniform: {sum wn, sum wn^2} of this 256-particle block
-        const double a = group_sum(wn, L.a), q = group_sum(wn * wn, L.a);
-        if (threadIdx.x == 0) {
-            double *pp2 = p2_all + ((size_t)mi * nblk_global + blockIdx.x) * 2;
-            pp2[0] = a; pp2[1] = q;
-        }
-    }
     if (cum) {                                        // uniform
+        __shared__ double s_ct[4][2];
         const int32_t t = threadIdx.x;
         s_w[t + (t >> 6)] = wn;                       // pitch 65: the four chunk rows start on different banks
         __syncthreads();
         if (t < 4) {
             const int64_t c = (int64_t)blockIdx.x * 4 + t;
+            double tot = 0.0, sq = 0.0;
             if (c < nchunks) {
                 const int64_t left = (int64_t)n - c * SCAN_CHUNK;
-                const double tot = chunk_sums_lds(s_w + t * 65, (int32_t)(left < SCAN_CHUNK ? left : SCAN_CHUNK));
+                tot = chunk_sums_lds(s_w + t * 65, (int32_t)(left < SCAN_CHUNK ? left : SCAN_CHUNK), sq);
                 chunk_tot[(size_t)mi * (nchunks + 1) + c] = tot;
             }
+            s_ct[t][0] = tot; s_ct[t][1] = sq;
         }
         __syncthreads();
         if (i < n) cum[(size_t)mi * n + i] = s_w[t + (t >> 6)];
+        if (t == 0) {                                 // {sum wn, sum wn^2} of this block = its four chunks, in order
+            double *pp2 = p2_all + ((size_t)mi * nblk_global + blockIdx.x) * 2;
+            pp2[0] = ((s_ct[0][0] + s_ct[1][0]) + s_ct[2][0]) + s_ct[3][0];
+            pp2[1] = ((s_ct[0][1] + s_ct[1][1]) + s_ct[2][1]) + s_ct[3][1];
+        }
     }
 }
 
-// Level 0 as a kernel of its own (sharded filters after the all-gather; resample without normalise):
-// one lane per chunk of the GLOBAL population, 64 chunks per wavefront.
+// Level 0 as a kernel of its own (sharded filters after the all-gather; resample without normalise): one lane
+// per chunk of the GLOBAL population, 64 chunks per wavefront; also the per-block {sum wn, sum wn^2} (four
+// chunks per block, combined in order) and the strongest particle's pose, which only the owning rank knew.
 __global__ void __launch_bounds__(64)
 k_chunk_sums(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks, double *__restrict__ cum_all,
-             double *__restrict__ chunk_tot, PfStatsDev *__restrict__ stats) {
+             double *__restrict__ chunk_tot, double *__restrict__ p2_all, int64_t nblk_global, PfStatsDev *__restrict__ stats) {
     const int32_t mi = blockIdx.y;
     const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0) stats[mi].n_ambiguous = 0;
-    if (c >= nchunks) return;
     const PackedParticle *g = glob_all + (size_t)mi * n_global;
-    double *cm = cum_all + (size_t)mi * n_global;
-    const int64_t i0 = c * SCAN_CHUNK;
-    const int64_t len = n_global - i0 < SCAN_CHUNK ? n_global - i0 : SCAN_CHUNK;
-    double acc = 0.0;
-    for (int64_t j0 = 0; j0 < len; j0 += 8) {         // eight independent loads in flight
-        double v[8];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        stats[mi].n_ambiguous = 0;
+        int64_t st = stats[mi].strongest;
+        if (st < 0) st = 0;
+        if (st >= n_global) st = n_global - 1;
+        const PackedParticle pp = g[st];
+        stats[mi].spose[0] = pp.x; stats[mi].spose[1] = pp.y; stats[mi].spose[2] = pp.theta;
+    }
+    double acc = 0.0, q = 0.0;
+    if (c < nchunks) {
+        double *cm = cum_all + (size_t)mi * n_global;
+        const int64_t i0 = c * SCAN_CHUNK;
+        const int64_t len = n_global - i0 < SCAN_CHUNK ? n_global - i0 : SCAN_CHUNK;
+        for (int64_t j0 = 0; j0 < len; j0 += 8) {         // eight independent loads in flight
+            double v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = j0 + j < len ? g[i0 + j0 + j].w : 0.0;
+            for (int j = 0; j < 8; j++) v[j] = j0 + j < len ? g[i0 + j0 + j].w : 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (j0 + j < len) {
-                acc = (j0 + j == 0) ? v[j] : acc + v[j];
-                cm[i0 + j0 + j] = acc;
+            for (int j = 0; j < 8; j++) {
+                if (j0 + j < len) {
+                    acc = (j0 + j == 0) ? v[j] : acc + v[j];
+                    q = (j0 + j == 0) ? v[j] * v[j] : q + v[j] * v[j];
+                    cm[i0 + j0 + j] = acc;
+                }
             }
         }
+        chunk_tot[(size_t)mi * (nchunks + 1) + c] = acc;
     }
-    chunk_tot[(size_t)mi * (nchunks + 1) + c] = acc;
+    // block b = chunks 4b..4b+3 = four neighbouring lanes, combined in chunk order by the first of them
+    const double a1 = __shfl_down(acc, 1, GMS_WAVE), a2 = __shfl_down(acc, 2, GMS_WAVE), a3 = __shfl_down(acc, 3, GMS_WAVE);
+    const double q1 = __shfl_down(q, 1, GMS_WAVE), q2 = __shfl_down(q, 2, GMS_WAVE), q3 = __shfl_down(q, 3, GMS_WAVE);
+    if ((threadIdx.x & 3) == 0 && (c >> 2) < nblk_global) {
+        double *pp2 = p2_all + ((size_t)mi * nblk_global + (c >> 2)) * 2;
+        pp2[0] = ((acc + a1) + a2) + a3;
+        pp2[1] = ((q + q1) + q2) + q3;
+    }
 }
 
 // statistics only (getWeightedPose / calculateNeff on the current particles, nothing rewritten)
@@ -770,17 +778,6 @@ __global__ void k_pack(const double *__restrict__ w, const float *__restrict__ p
     PackedParticle pp;
     pp.w = w[gi]; pp.x = pose[3 * gi]; pp.y = pose[3 * gi + 1]; pp.theta = pose[3 * gi + 2]; pp.pad = 0u;
     packed[gi] = pp;
-}
-
-// after the all-gather: the strongest particle's pose, which only the rank that owns it could fill in
-__global__ void k_set_spose(const PackedParticle *__restrict__ glob, int64_t n_global, PfStatsDev *__restrict__ stats) {
-    const int32_t mi = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    int64_t st = stats[mi].strongest;
-    if (st < 0) st = 0;
-    if (st >= n_global) st = n_global - 1;
-    const PackedParticle pp = glob[(size_t)mi * n_global + st];
-    stats[mi].spose[0] = pp.x; stats[mi].spose[1] = pp.y; stats[mi].spose[2] = pp.theta;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1069,12 +1066,12 @@ void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedPa
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
     // a stand-alone filter packs straight into its own population and gets level 0 of the scan with it
-    const bool own = d_packed_local == pf->d_global;
+    const bool own = d_packed_local == pf->d_global_own;
+    if (own) pf->d_global = pf->d_global_own;
     hipLaunchKernelGGL(k_normalize_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, d_partials, nblk,
                        pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local, own ? pf->d_cum : (double *)nullptr,
                        own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf), own ? pf->d_p2 : (double *)nullptr, pf->d_stats);
     pf->chunks_ready = own ? 1 : 0;
-    pf->p2_ready = own ? 1 : 0;
     pf->neff_folded = 0;
 }
 
@@ -1089,45 +1086,40 @@ void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed) {
     gms_map *m = pf->map;
     hipLaunchKernelGGL(k_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_pose,
                        pf->n, d_packed);
-    if (d_packed == pf->d_global) { pf->chunks_ready = 0; pf->p2_ready = 0; pf->neff_folded = 0; }
+    if (d_packed == pf->d_global) { pf->chunks_ready = 0; pf->neff_folded = 0; }
 }
 
-// make d_p2 describe d_global (paths that did not come through a stand-alone normalise)
-static void ensure_p2(gms_pf *pf) {
-    if (pf->p2_ready) return;
+// level 0 of the scan + {sum wn, sum wn^2} + strongest pose from d_global (paths that did not come through a
+// stand-alone normalise: after the all-gather of a sharded filter, or a resample without a normalise)
+void gms_launch_pf_chunk_sums(gms_pf *pf) {
+    if (pf->chunks_ready) return;
     gms_map *m = pf->map;
-    const int64_t nblk = nblk_global_of(pf);
-    hipLaunchKernelGGL(k_global_sq, dim3((unsigned)nblk, pf->n_maps), dim3(256), 0, m->stream, pf->d_global, pf->n_global, nblk,
-                       pf->d_p2);
-    pf->p2_ready = 1;
+    ProfScope ps(m, GMS_K_RESAMPLE);
+    const int64_t nch = nchunks_of(pf);
+    hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)((nch + 63) / 64), pf->n_maps), dim3(64), 0, m->stream, pf->d_global,
+                       pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->d_p2, nblk_global_of(pf), pf->d_stats);
+    pf->chunks_ready = 1;
 }
 
 void gms_launch_pf_fold_neff(gms_pf *pf) {
     if (pf->neff_folded) return;
     gms_map *m = pf->map;
-    ensure_p2(pf);
+    gms_launch_pf_chunk_sums(pf);
     hipLaunchKernelGGL(k_fold_neff, dim3(pf->n_maps), dim3(256), 0, m->stream, pf->d_p2, nblk_global_of(pf), pf->d_stats);
     pf->neff_folded = 1;
 }
 
 void gms_launch_pf_after_gather(gms_pf *pf) {
-    gms_map *m = pf->map;
-    hipLaunchKernelGGL(k_set_spose, dim3(pf->n_maps), dim3(64), 0, m->stream, pf->d_global, pf->n_global, pf->d_stats);
     pf->chunks_ready = 0;
-    pf->p2_ready = 0;
     pf->neff_folded = 0;
+    gms_launch_pf_chunk_sums(pf);          // eagerly: it also publishes the strongest particle's pose
 }
 
 void gms_launch_pf_resample(gms_pf *pf, double fraction) {
     gms_map *m = pf->map;
+    gms_launch_pf_chunk_sums(pf);
     ProfScope ps(m, GMS_K_RESAMPLE);
     const int64_t nch = nchunks_of(pf);
-    if (!pf->chunks_ready) {
-        hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)((nch + 63) / 64), pf->n_maps), dim3(64), 0, m->stream, pf->d_global,
-                           pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->d_stats);
-        pf->chunks_ready = 1;
-    }
-    ensure_p2(pf);
     const size_t smem = (size_t)(nch + 1 + (nch + 63) / 64 + 1) * sizeof(double);
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resample), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -255,7 +255,9 @@ int gms_pf_stats_from_partials(gms_pf *pf, const double *dev_partials);
  * population again after a resample, for getWeightedPose). */
 int gms_pf_pack(gms_pf *pf, void *dev_packed);
 /* Phase 3: consumes the all-gathered [n_global] packed particles: they become the source population
- * of gms_pf_resample (every rank then fills its own slots from the same global array). */
+ * of gms_pf_resample (every rank then fills its own slots from the same global array).  Zero copy: the
+ * buffer is read in place by later calls and must stay valid and unmodified until the next
+ * gms_pf_import_global / gms_pf_normalize on this handle, or its destruction. */
 int gms_pf_import_global(gms_pf *pf, const void *dev_packed_global);
 
 /* ---- measurement ------------------------------------------------------------------------------- */
