@@ -160,6 +160,14 @@ def load() -> C.CDLL:
     sig("gms_pf_pack", C.c_int, vp, vp)
     sig("gms_pf_stats_from_partials", C.c_int, vp, vp)
     sig("gms_pf_import_global", C.c_int, vp, vp)
+    sig("gms_comm_load", C.c_int, C.c_char_p)
+    sig("gms_comm_unique_id", C.c_int, vp)
+    sig("gms_comm_create", C.c_int, C.POINTER(vp), vp, i32, i32, i32)
+    sig("gms_comm_destroy", C.c_int, vp)
+    sig("gms_comm_rank", C.c_int, vp, C.POINTER(i32), C.POINTER(i32))
+    sig("gms_pf_normalize_sharded_begin", C.c_int, vp, vp)
+    sig("gms_pf_normalize_sharded_end", C.c_int, vp, vp)
+    sig("gms_slam_update_sharded_dev", C.c_int, vp, vp, vp, vp, i32, vp, f64, i32)
     sig("gms_profile_enable", C.c_int, vp, i32)
     sig("gms_profile_reset", C.c_int, vp)
     sig("gms_profile_get", C.c_int, vp, i32, vp, vp)

@@ -2,6 +2,7 @@
 // stream ordering, and the launch sequences that make up each reference method.
 // There is no CPU path in this file: every compute entry point launches gfx950 kernels.
 #include <math.h>
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stddef.h>
 #include <stdio.h>
@@ -771,7 +772,7 @@ int gms_pf_normalize(gms_pf *pf, gms_pf_stats *stats) {                 // SLAM.
     HIPCHK(hipSetDevice(pf->map->device));
     pf->d_global = pf->d_global_own;
     gms_launch_pf_partials(pf, pf->d_partials);
-    gms_launch_pf_apply_partials(pf, pf->d_partials, pf->d_global);
+    gms_launch_pf_apply_partials(pf, pf->d_partials, pf->d_global, true);
     pf->have_global = 1;
     pf->stats_current = 1;
     HIPCHK(hipGetLastError());
@@ -796,7 +797,7 @@ int gms_pf_local_partials(gms_pf *pf, double *dev_partials) {
 int gms_pf_apply_partials(gms_pf *pf, const double *dev_partials, void *dev_packed) {
     REQUIRE(pf && dev_partials && dev_packed, "null argument");
     HIPCHK(hipSetDevice(pf->map->device));
-    gms_launch_pf_apply_partials(pf, dev_partials, reinterpret_cast<PackedParticle *>(dev_packed));
+    gms_launch_pf_apply_partials(pf, dev_partials, reinterpret_cast<PackedParticle *>(dev_packed), false);
     pf->have_global = 0;
     pf->stats_current = 1;
     HIPCHK(hipGetLastError());
@@ -988,6 +989,177 @@ int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B) {   // Gri
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sharded filters over RCCL, one process per GPU.  The particle population is split by global index,
+// the map is replicated; a scan step needs two exchanges (DESIGN.md "multi-GPU"):
+//   1. all-reduce(SUM) of the block partials: every slot is non-zero on exactly one rank, so the sum is exact and
+//      every rank folds the same vector in the same order as a stand-alone filter does;
+//   2. all-gather of the packed normalised particles {w,x,y,theta}: the resampling source.  It runs on the
+//      communicator's side stream while the map update runs on the handle's stream.
+// RCCL is bound at run time (no link-time dependency: a single-GPU consumer never loads it).
+// ---------------------------------------------------------------------------------------------
+typedef struct { char internal[128]; } rccl_unique_id;            // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
+enum { RCCL_INT8 = 0, RCCL_FLOAT64 = 8, RCCL_SUM = 0 };           // ncclDataType_t / ncclRedOp_t values
+
+static struct {
+    void *dl;
+    int (*GetUniqueId)(rccl_unique_id *);
+    int (*CommInitRank)(void **, int, rccl_unique_id, int);
+    int (*CommDestroy)(void *);
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t);
+    const char *(*GetErrorString)(int);
+} g_rccl;
+
+#define RCCLCHK(expr)                                                                                              \
+    do {                                                                                                           \
+        int r_ = (expr);                                                                                           \
+        if (r_ != 0) return fail(GMS_ERR_HIP, "%s: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"); \
+    } while (0)
+
+int gms_comm_load(const char *librccl_path) {
+    if (g_rccl.dl) return GMS_OK;
+    void *dl = nullptr;
+    if (librccl_path && *librccl_path) {
+        dl = dlopen(librccl_path, RTLD_NOW | RTLD_GLOBAL);
+    } else {
+        // a copy that the process already holds (PyTorch bundles one) first: one RCCL per process
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (const char *nm : names) if (!dl) dl = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char *nm : names) if (!dl) dl = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!dl) return fail(GMS_ERR_STATE, "RCCL not found: %s", dlerror());
+    *(void **)&g_rccl.GetUniqueId = dlsym(dl, "ncclGetUniqueId");
+    *(void **)&g_rccl.CommInitRank = dlsym(dl, "ncclCommInitRank");
+    *(void **)&g_rccl.CommDestroy = dlsym(dl, "ncclCommDestroy");
+    *(void **)&g_rccl.AllReduce = dlsym(dl, "ncclAllReduce");
+    *(void **)&g_rccl.AllGather = dlsym(dl, "ncclAllGather");
+    *(void **)&g_rccl.GetErrorString = dlsym(dl, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.AllGather)
+        return fail(GMS_ERR_STATE, "RCCL library lacks the collective entry points");
+    g_rccl.dl = dl;
+    return GMS_OK;
+}
+
+int gms_comm_unique_id(void *id128) {
+    REQUIRE(id128, "null argument");
+    int rc = gms_comm_load(nullptr);
+    if (rc) return rc;
+    RCCLCHK(g_rccl.GetUniqueId(reinterpret_cast<rccl_unique_id *>(id128)));
+    return GMS_OK;
+}
+
+int gms_comm_create(gms_comm **out, const void *id128, int32_t rank, int32_t world, int32_t device) {
+    REQUIRE(out && id128, "null argument");
+    REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank/world out of range");
+    int rc = gms_comm_load(nullptr);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    gms_comm *c = new gms_comm();
+    c->rank = rank; c->world = world; c->device = device;
+    // The event fork/join that puts the all-gather beside the map update costs ~18 us on the stream (measured,
+    // MI355X); an in-line gather costs its own latency.  Small groups gather little: in line up to 2 ranks.
+    c->overlap = world > 2;
+    if (const char *e = getenv("GMS_COMM_OVERLAP")) c->overlap = atoi(e) != 0;
+    rccl_unique_id id;
+    memcpy(&id, id128, sizeof(id));
+    int r = g_rccl.CommInitRank(&c->nccl, world, id, rank);        // blocks until every rank has joined
+    if (r != 0) { delete c; return fail(GMS_ERR_HIP, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"); }
+    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) { gms_comm_destroy(c); return fail(GMS_ERR_HIP, "communicator streams: %s", hipGetErrorString(e)); }
+    *out = c;
+    return GMS_OK;
+}
+
+int gms_comm_destroy(gms_comm *c) {
+    if (!c) return GMS_OK;
+    hipSetDevice(c->device);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl);
+    delete c;
+    return GMS_OK;
+}
+
+int gms_comm_rank(const gms_comm *c, int32_t *rank, int32_t *world) {
+    REQUIRE(c && rank && world, "null argument");
+    *rank = c->rank; *world = c->world;
+    return GMS_OK;
+}
+
+static int check_shard(const gms_pf *pf, const gms_comm *c) {
+    if (pf->n_maps != 1) return fail(GMS_ERR_STATE, "sharded filters hold one map per handle");
+    if (pf->n_global != (int64_t)pf->n * c->world || pf->offset != (int64_t)pf->n * c->rank)
+        return fail(GMS_ERR_INVALID, "shard mismatch: n_local %d offset %lld n_global %lld on rank %d of %d (equal shards, rank order)",
+                    pf->n, (long long)pf->offset, (long long)pf->n_global, c->rank, c->world);
+    if (c->world > 1 && pf->n % GMS_BLOCK)
+        return fail(GMS_ERR_INVALID, "shard size %d must be a multiple of GMS_BLOCK=%d", pf->n, GMS_BLOCK);
+    if (pf->map->device != c->device) return fail(GMS_ERR_INVALID, "filter and communicator are on different devices");
+    return GMS_OK;
+}
+
+// SLAM.java:100-124 across ranks: weight sum / strongest / normalise, and the START of the exchange of the
+// normalised population.  Statistics and the weighted pose are complete on return (stream order).
+int gms_pf_normalize_sharded_begin(gms_pf *pf, gms_comm *c) {
+    REQUIRE(pf && c, "null argument");
+    int rc = check_shard(pf, c);
+    if (rc) return rc;
+    gms_map *m = pf->map;
+    HIPCHK(hipSetDevice(m->device));
+    if (c->pending) return fail(GMS_ERR_STATE, "gms_pf_normalize_sharded_end has not been called for the previous exchange");
+    const size_t np = (size_t)nblk_of(pf->n_global) * GMS_PARTIAL_STRIDE;
+    gms_launch_pf_partials(pf, pf->d_partials);
+    RCCLCHK(g_rccl.AllReduce(pf->d_partials, pf->d_partials, np, RCCL_FLOAT64, RCCL_SUM, c->nccl, m->stream));
+    PackedParticle *own_slot = pf->d_global_own + pf->offset;
+    gms_launch_pf_apply_partials(pf, pf->d_partials, own_slot, false);
+    pf->have_global = 0;
+    pf->stats_current = 1;
+    hipStream_t s = m->stream;
+    if (c->overlap) {                                   // the gather proceeds beside whatever the caller enqueues next
+        HIPCHK(hipEventRecord(c->ev_fork, m->stream));
+        HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        s = c->side;
+    }
+    RCCLCHK(g_rccl.AllGather(own_slot, pf->d_global_own, (size_t)pf->n * sizeof(PackedParticle), RCCL_INT8, c->nccl, s));
+    if (c->overlap) HIPCHK(hipEventRecord(c->ev_join, c->side));
+    c->pending = 1;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+// joins the exchange: the gathered population becomes the resampling source
+int gms_pf_normalize_sharded_end(gms_pf *pf, gms_comm *c) {
+    REQUIRE(pf && c, "null argument");
+    if (!c->pending) return fail(GMS_ERR_STATE, "no exchange in flight");
+    gms_map *m = pf->map;
+    HIPCHK(hipSetDevice(m->device));
+    if (c->overlap) HIPCHK(hipStreamWaitEvent(m->stream, c->ev_join, 0));
+    c->pending = 0;
+    pf->d_global = pf->d_global_own;
+    gms_launch_pf_after_gather(pf);
+    pf->have_global = 1;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+// One scan step of a sharded filter, collectives included: what gms_slam_update_dev is for a stand-alone one.
+int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B,
+                                const double *r01, double resample_fraction, int32_t integrate) {
+    REQUIRE(pf && c && dev_beams && r01, "null argument");
+    gms_map *m = pf->map;
+    int rc = GMS_OK;
+    if (dev_xytheta) rc = gms_pf_set_poses_dev(pf, dev_xytheta);                  // SLAM.java:90
+    if (!rc) rc = gms_pf_score_dev(pf, dev_beams, B);                            // :99
+    if (!rc) rc = gms_pf_normalize_sharded_begin(pf, c);                         // :100-124
+    if (!rc && integrate) rc = gms_map_update_at_dev(m, dev_beams, B, pf, 0);    // :102-105, :93 on every replica
+    if (!rc) rc = gms_pf_normalize_sharded_end(pf, c);
+    if (!rc && resample_fraction >= 0.0) rc = gms_pf_resample_if(pf, r01, resample_fraction);   // GridMapApp.java:185-186
+    return rc;
 }
 
 }  // extern "C"

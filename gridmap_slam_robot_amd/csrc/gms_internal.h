@@ -133,7 +133,18 @@ struct gms_pf {
     int32_t pending_nseg;           // > 0: d_w is stale, the weights are still d_part's segment products
 };
 
+// one rank's side of the RCCL exchanges of a sharded filter (gms_host.hip)
+struct gms_comm {
+    void *nccl = nullptr;           // ncclComm_t
+    int32_t rank = 0, world = 1, device = 0;
+    int32_t overlap = 0;            // all-gather on the side stream (default: world > 2; GMS_COMM_OVERLAP=0/1 overrides)
+    int32_t pending = 0;            // an all-gather is in flight
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+
 // ---- kernel launchers (gms_map_kernels.hip / gms_pf_kernels.hip) -----------------------------
+
 void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
                         int32_t pose_stride);
 void gms_launch_trace_scan(gms_map *m, const gms_beam *d_beams, int32_t B, const float *d_pose,
@@ -161,7 +172,7 @@ void gms_launch_pf_fold_neff(gms_pf *pf);
 void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials);
 void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed);
-void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local);
+void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local, bool own);
 void gms_launch_pf_stats_only(gms_pf *pf, const double *d_partials, PfStatsDev *d_stats_out);
 void gms_launch_pf_resample(gms_pf *pf, double fraction /* <0: unconditional */);
 void gms_launch_pf_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);

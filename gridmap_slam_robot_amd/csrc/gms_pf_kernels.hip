@@ -1061,12 +1061,11 @@ void gms_launch_pf_partials(gms_pf *pf, double *d_partials) {
     pf->pending_nseg = 0;                                             // k_partials stored the combined weights
 }
 
-void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local) {
+void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local, bool own) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
     // a stand-alone filter packs straight into its own population and gets level 0 of the scan with it
-    const bool own = d_packed_local == pf->d_global_own;
     if (own) pf->d_global = pf->d_global_own;
     hipLaunchKernelGGL(k_normalize_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, d_partials, nblk,
                        pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local, own ? pf->d_cum : (double *)nullptr,

@@ -79,6 +79,39 @@ class HipShardOps:
         return self.pf.weighted_pose()
 
 
+class RcclComm:
+    """One rank's RCCL communicator owned by libgridmapslam.so (gms_comm_*): the two exchanges of a sharded
+    scan step are enqueued by the library itself, so a step is ONE C-ABI call and the host spends no time in
+    a Python collective wrapper.  torch.distributed is only the out-of-band channel for the 128-byte id."""
+
+    def __init__(self, device: Optional[int] = None, group=None):
+        import ctypes as C
+        lib = _lib.load()
+        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        _lib.check(lib.gms_comm_load(rccl.encode() if os.path.exists(rccl) else None))     # the copy torch already holds
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(lib.gms_comm_unique_id(uid))
+        if world > 1:
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = C.create_string_buffer(box[0], 128)
+        self.rank, self.world = rank, world
+        self.device = torch.cuda.current_device() if device is None else device
+        h = C.c_void_p()
+        _lib.check(lib.gms_comm_create(C.byref(h), uid, rank, world, self.device))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().gms_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
 class ShardedParticleFilter:
     """ParticleFilter whose particles are split over the ranks of a process group."""
 

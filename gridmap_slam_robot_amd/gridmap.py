@@ -497,6 +497,20 @@ class ParticleFilter:
     def import_global(self, dev_packed_global: int):
         check(load().gms_pf_import_global(self._h, C.c_void_p(dev_packed_global)))
 
+    # -- sharded filter with the exchanges inside the library (RCCL; see distributed.RcclComm) --------
+    def normalize_sharded_begin(self, comm):
+        check(load().gms_pf_normalize_sharded_begin(self._h, comm._h))
+
+    def normalize_sharded_end(self, comm):
+        check(load().gms_pf_normalize_sharded_end(self._h, comm._h))
+
+    def slam_update_sharded_dev(self, comm, dev_xytheta: int, dev_beams: int, B: int, r01, fraction: float = 0.5,
+                                integrate: bool = True):
+        """slam_update_dev for a sharded filter: both collectives happen inside the call."""
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(r01, dtype=np.float64), (self.n_maps,)))
+        check(load().gms_slam_update_sharded_dev(self._h, comm._h, C.c_void_p(dev_xytheta or 0), C.c_void_p(dev_beams), B,
+                                                 ptr(r), fraction, 1 if integrate else 0))
+
     getParticles = get_particles
     getWeightedPose = weighted_pose
 

@@ -83,6 +83,7 @@ typedef struct gms_params {
 
 typedef struct gms_map gms_map;      /* GridMap + GridMapData (n_maps of them) */
 typedef struct gms_pf gms_pf;        /* ParticleFilter / SLAM particle set bound to a gms_map */
+typedef struct gms_comm gms_comm;    /* one rank's RCCL communicator (multi-GPU filters) */
 
 /* Results of gms_pf_normalize, per map (SLAM.update's bookkeeping, J/slam/SLAM.java:87-129). */
 typedef struct gms_pf_stats {
@@ -259,6 +260,28 @@ int gms_pf_pack(gms_pf *pf, void *dev_packed);
  * buffer is read in place by later calls and must stay valid and unmodified until the next
  * gms_pf_import_global / gms_pf_normalize on this handle, or its destruction. */
 int gms_pf_import_global(gms_pf *pf, const void *dev_packed_global);
+
+/* ---- multi-GPU with the exchanges inside the library (RCCL, one process per GPU) ---------------- */
+/* RCCL is bound at run time.  gms_comm_load names the shared object (NULL/"" = the copy the process already
+ * holds, else the loader's librccl.so); the other entry points load the default on first use. */
+int gms_comm_load(const char *librccl_path);
+/* 128 opaque bytes (ncclUniqueId): one rank makes them, the host distributes them to every rank. */
+int gms_comm_unique_id(void *id128);
+/* Joins the communicator; blocks until all `world` ranks have called it.  One communicator per device. */
+int gms_comm_create(gms_comm **out, const void *id128, int32_t rank, int32_t world, int32_t device);
+int gms_comm_destroy(gms_comm *c);
+int gms_comm_rank(const gms_comm *c, int32_t *rank, int32_t *world);
+/* SLAM.update's weight bookkeeping (J/slam/SLAM.java:100-124) for a filter sharded with gms_pf_set_shard into
+ * equal shards in rank order: block partials -> all-reduce(SUM) -> normalise -> START of the all-gather of the
+ * packed normalised particles on the communicator's side stream.  On return (stream order) the statistics and
+ * the weighted / strongest pose are complete, so the map update can be enqueued beside the gather. */
+int gms_pf_normalize_sharded_begin(gms_pf *pf, gms_comm *c);
+/* Joins the gather; the global population becomes the source of gms_pf_resample[_if]. */
+int gms_pf_normalize_sharded_end(gms_pf *pf, gms_comm *c);
+/* gms_slam_update_dev for a sharded filter: every rank calls it with its shard's motion-model samples and the
+ * same scan and r01; both exchanges happen inside.  Results equal the stand-alone filter's bit for bit. */
+int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B,
+                                const double *r01, double resample_fraction, int32_t integrate);
 
 /* ---- measurement ------------------------------------------------------------------------------- */
 enum {

@@ -182,9 +182,33 @@ public:
     int size() const { return n_; }
     gms_pf *handle() { return h_; }
 
+    /** multi-GPU: this rank holds particles [offset, offset + size()) of nGlobal (equal shards in rank order) */
+    void setShard(int64_t offset, int64_t nGlobal) { check(gms_pf_set_shard(h_, offset, nGlobal)); }
+
 private:
     gms_pf *h_ = nullptr;
     int n_;
+};
+
+/** One rank's RCCL communicator (one process per GPU).  `id` is the 128-byte token of uniqueId(), made by one
+ *  rank and handed to the others by whatever channel the host has (a file, a socket, MPI ...). */
+class Comm {
+public:
+    static std::vector<char> uniqueId() { std::vector<char> id(128); check(gms_comm_unique_id(id.data())); return id; }
+    Comm(const std::vector<char> &id, int rank, int world, int device) { check(gms_comm_create(&h_, id.data(), rank, world, device)); }
+    ~Comm() { gms_comm_destroy(h_); }
+    Comm(const Comm &) = delete;
+    Comm &operator=(const Comm &) = delete;
+    gms_comm *handle() { return h_; }
+    /** SLAM.update (SLAM.java:80-131) + `if (neff < fraction * N) resample()` (GridMapApp.java:185-186) for a sharded
+     *  filter with device-resident inputs; both exchanges happen inside. */
+    void slamUpdate(ParticleFilter &pf, const float *devPoses, const gms_beam *devBeams, int B, double r01,
+                    double fraction = 0.5, bool integrate = true) {
+        check(gms_slam_update_sharded_dev(pf.handle(), h_, devPoses, devBeams, B, &r01, fraction, integrate ? 1 : 0));
+    }
+
+private:
+    gms_comm *h_ = nullptr;
 };
 
 inline double GridMap::probabilityOf(const Observation &obs, const Pose &p) {

@@ -4,10 +4,13 @@ Bars (BASELINE.json north_star): the cells touched by each ray bit-exact; log-od
 1e-5 (the tests below assert much tighter bounds where the arithmetic allows: the likelihood field is
 compared for equality, since every sum runs in the reference's order without FMA).
 """
+import os
+
 import numpy as np
 import pytest
 
 from gridmap_slam_robot_amd import GridMap, Observation, ParticleFilter, synth
+from gridmap_slam_robot_amd._lib import GmsError
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -528,3 +531,62 @@ def test_fused_scan_step_equals_the_separate_calls():
         assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights())
         assert np.array_equal(a.download_log(), b.download_log())
         assert np.array_equal(a.download_likelihood(), b.download_likelihood())
+
+
+def test_rccl_step_inside_library_equals_standalone_step():
+    """gms_slam_update_sharded_dev (partials -> ncclAllReduce -> normalise -> ncclAllGather beside the map update ->
+    resample, all enqueued by the library) against gms_slam_update_dev on a stand-alone filter: with a one-rank
+    communicator every particle, weight, statistic and map cell must agree bit for bit over several scans."""
+    import torch
+    from gridmap_slam_robot_amd import synth
+    from gridmap_slam_robot_amd.distributed import RcclComm
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    tr = synth.make_trace(6.4, 0.05, 180, T=10, seed=3)
+    N = 1000                                                  # not a multiple of the block or chunk size
+    maps, pfs = [], []
+    for k in range(2):
+        m = GridMap(6.4, 6.4, 0.05, (-3.2, -3.2))
+        m.set_stream(torch.cuda.current_stream().cuda_stream)
+        for t in range(3):
+            m.update(tr.scans[t], tr.poses[t])
+        maps.append(m)
+        pfs.append(ParticleFilter(m, N))
+    os.environ["GMS_COMM_OVERLAP"] = "1"                      # exercise the side-stream gather (default only for world > 2)
+    try:
+        comm = RcclComm()
+    finally:
+        del os.environ["GMS_COMM_OVERLAP"]
+    assert (comm.rank, comm.world) == (0, 1)
+    pfs[1].set_shard(0, N)
+    rng = np.random.default_rng(5)
+    for overlap in (True, False):
+        for t in range(3, 8):
+            P = torch.from_numpy(synth.make_particles(tr.poses[t], N, seed=t, sigma_xy=0.03, sigma_theta_deg=1.5)).to(dev)
+            beams = torch.from_numpy(tr.scans[t].view(np.uint8).copy()).to(dev)
+            r01 = float(rng.random())
+            B = len(tr.scans[t])
+            pfs[0].slam_update_dev(P.data_ptr(), beams.data_ptr(), B, r01, 0.9, True)
+            if overlap:
+                pfs[1].slam_update_sharded_dev(comm, P.data_ptr(), beams.data_ptr(), B, r01, 0.9, True)
+            else:                                             # the same exchange as separate calls
+                pfs[1].set_poses_dev(P.data_ptr())
+                pfs[1].score_dev(beams.data_ptr(), B)
+                pfs[1].normalize_sharded_begin(comm)
+                maps[1].update_at_dev(beams.data_ptr(), B, pfs[1])
+                pfs[1].normalize_sharded_end(comm)
+                pfs[1].resample_if(r01, 0.9)
+            torch.cuda.synchronize()
+            assert pfs[0].stats() == pfs[1].stats()
+            assert np.array_equal(pfs[0].get_poses(), pfs[1].get_poses())
+            assert np.array_equal(pfs[0].get_weights(), pfs[1].get_weights())
+            assert np.array_equal(maps[0].download_log(), maps[1].download_log())
+            assert np.array_equal(maps[0].download_likelihood(), maps[1].download_likelihood())
+    with pytest.raises(GmsError):                             # an end without a begin
+        pfs[1].normalize_sharded_end(comm)
+    pfs[1].set_shard(0, 2 * N)                                # shard does not match the communicator
+    with pytest.raises(GmsError):
+        pfs[1].normalize_sharded_begin(comm)
+    comm.close()
+    for pf in pfs:
+        pf.close()
