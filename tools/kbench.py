@@ -14,11 +14,13 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--particles", type=int, default=0)
     ap.add_argument("--sigma", type=float, default=0.10)
+    ap.add_argument("--beams", type=int, default=0, help="override beams per scan")
+    ap.add_argument("--sort", default="", help="order the particles on the host first: theta | cluster:<deg>:<m> (locality experiment)")
     args = ap.parse_args()
     import torch
     from gridmap_slam_robot_amd import GridMap, ParticleFilter, synth, _lib
     cfg = synth.CONFIGS[args.config]
-    N = args.particles or cfg["particles"]; B = cfg["beams"]; ext = cfg["extent"]; res = cfg["resolution"]
+    N = args.particles or cfg["particles"]; B = args.beams or cfg["beams"]; ext = cfg["extent"]; res = cfg["resolution"]
     T = 64
     tr = synth.make_trace(ext, res, B, T=T, seed=1234, n_scans=T // 2 + 8)
     m = GridMap(ext, ext, res, (-ext / 2, -ext / 2), max_beams=max(2048, B))
@@ -28,7 +30,29 @@ def main():
     dev = torch.device("cuda", 0)
     scans_dev = torch.from_numpy(tr.scans.view(np.uint8).reshape(len(tr.scans), -1).copy()).to(dev)
     poses_dev = torch.from_numpy(tr.poses.copy()).to(dev)
-    P = torch.from_numpy(synth.make_particles(tr.poses[T // 2], N, seed=99, sigma_xy=args.sigma)).to(dev)
+    Ph = synth.make_particles(tr.poses[T // 2], N, seed=99, sigma_xy=args.sigma)
+    if args.sort == "theta":
+        Ph = Ph[np.argsort(Ph[:, 2], kind="stable")]
+    elif args.sort.startswith("cluster"):
+        _, deg, met = args.sort.split(":")
+        kt = np.floor(Ph[:, 2] / np.radians(float(deg))).astype(np.int64)
+        ky = np.floor(Ph[:, 1] / float(met)).astype(np.int64)
+        kx = np.floor(Ph[:, 0] / float(met)).astype(np.int64)
+        Ph = Ph[np.lexsort((Ph[:, 0], kx, ky, kt))]
+    elif args.sort.startswith("kd"):
+        # recursive median split on the widest of (x, y, theta * lever) in cells: compact clusters at every scale
+        lever = float(args.sort.split(":")[1]) if ":" in args.sort else 150.0
+        K = np.stack([Ph[:, 0] / res, Ph[:, 1] / res, Ph[:, 2] * lever], axis=1)
+        def kd(idx):
+            if len(idx) <= 32:
+                return idx
+            sub = K[idx]
+            d = int(np.argmax(sub.max(0) - sub.min(0)))
+            o = idx[np.argsort(sub[:, d], kind="stable")]
+            h = len(o) // 2
+            return np.concatenate([kd(o[:h]), kd(o[h:])])
+        Ph = Ph[kd(np.arange(N))]
+    P = torch.from_numpy(np.ascontiguousarray(Ph)).to(dev)
     pf = ParticleFilter(m, N)
     pf.set_poses_dev(P.data_ptr())
     t = T // 2
