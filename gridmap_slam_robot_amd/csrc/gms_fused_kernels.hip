@@ -1,0 +1,154 @@
+// gms_fused_kernels.hip -- launches that run two independent kernels of a scan step side by side.
+//
+// After the weights are reduced a scan step has two independent branches (SLAM.java:100-124 vs :93,:102-105):
+//     weights:  normalise + pack  ->  [all-gather]  ->  cumulative sums  ->  resample
+//     map:      ray cast          ->  apply counts   ->  likelihood rebuild
+// Every one of those kernels is a few microseconds of latency on a small part of the GPU (the ray cast keeps 180
+// workgroups busy, the normalise 64).  On one in-order stream they run back to back; on two streams the event
+// fork/join costs more than it hides (measured: +18 us per step).  So the branches are paired inside single
+// launches instead: workgroups [0, n_first) run one kernel's body, the rest run the other's.  The bodies are
+// the same device functions the stand-alone kernels wrap, so results are bit-identical to the separate calls
+// (tests/test_gpu_parity.py::test_fused_scan_step_equals_the_separate_calls).
+//
+// This file is the device translation unit of the library: it includes the two kernel files.
+#include "gms_map_kernels.hip"
+#include "gms_pf_kernels.hip"
+
+// ---- A: normalise + pack  |  ray cast at the weighted pose --------------------------------------------------
+// The ray-cast workgroups fold the weighted pose from the partial vector themselves (the arithmetic of
+// fold_stats: SLAM.java:165-178), because the workgroup that publishes it runs beside them.
+__global__ void __launch_bounds__(256)
+k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox,
+               int32_t nw_max, uint32_t n_ray_blocks,
+               const double *__restrict__ partials, int64_t nblk_global, double *__restrict__ w, const float *__restrict__ pose,
+               int32_t n, int64_t offset, PackedParticle *__restrict__ packed, double *__restrict__ cum,
+               double *__restrict__ chunk_tot, int64_t nchunks, double *__restrict__ p2, PfStatsDev *__restrict__ stats) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x < n_ray_blocks) {
+        __shared__ RedLds L;
+        __shared__ float s_pose[3];
+        const double sum = fold_sum(partials, nblk_global, COL_SUM, L.a);
+        const double xw = fold_sum(partials, nblk_global, COL_XW, L.a), yw = fold_sum(partials, nblk_global, COL_YW, L.a),
+                     tw = fold_sum(partials, nblk_global, COL_TW, L.a);
+        if (threadIdx.x == 0) {
+            s_pose[0] = (float)(xw / sum);                             // SLAM.java:176
+            s_pose[1] = (float)(yw / sum);
+            s_pose[2] = (float)(tw / sum);
+        }
+        __syncthreads();
+        raycast_body<false, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,
+                               smem, s_pose);
+    } else {
+        normalize_pack_body(partials, nblk_global, w, pose, n, offset, packed, cum, chunk_tot, nchunks, p2, stats,
+                            blockIdx.x - n_ray_blocks, 0);
+    }
+}
+
+// ---- B: apply counts  |  cumulative sums of the gathered population (sharded filters) -----------------------
+__global__ void __launch_bounds__(256)
+k_apply_chunks(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
+               int32_t *__restrict__ bbox_idle, uint32_t n_chunk_blocks,
+               const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nchunks, double *__restrict__ cum,
+               double *__restrict__ chunk_tot, double *__restrict__ p2, int64_t nblk_global, PfStatsDev *__restrict__ stats) {
+    // the few long-running workgroups first
+    if (blockIdx.x < n_chunk_blocks) chunk_sums_body(glob, n_global, nchunks, cum, chunk_tot, p2, nblk_global, stats, blockIdx.x, 0);
+    else apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - n_chunk_blocks, 0, gridDim.x - n_chunk_blocks);
+}
+
+// ---- C: likelihood rebuild (dirty tiles)  |  resample ---------------------------------------------------------
+template <int KH>
+__global__ void __launch_bounds__(256)
+k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac, int64_t fac_stride,
+               const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t tiles_x, int32_t tiles_y,
+               uint32_t n_res_blocks,
+               const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nchunks, const double *__restrict__ cum,
+               const double *__restrict__ chunk_off, double r01, double fraction, int32_t n, int64_t offset,
+               float *__restrict__ pose2, float *__restrict__ cs2, double *__restrict__ w2, int32_t *__restrict__ idx_out,
+               const double *__restrict__ p2, int64_t nblk_global, PfStatsDev *__restrict__ stats) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x < n_res_blocks)                      // a multiple of 8 keeps the likelihood tiles' XCD round-robin aligned
+        resample_body(glob, n_global, nchunks, cum, chunk_off, nullptr, r01, fraction, n, offset, pose2, cs2, w2, idx_out, p2,
+                      nblk_global, stats, blockIdx.x, 0, smem);
+    else
+        likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, 1, tiles_x, tiles_y, blockIdx.x - n_res_blocks, 0,
+                            gridDim.x - n_res_blocks, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (single-map handles; the callers in gms_host.hip check the preconditions)
+// ---------------------------------------------------------------------------------------------
+bool gms_can_pair_launches(const gms_pf *pf, int32_t B) {
+    const gms_map *m = pf->map;
+    return pf->n_maps == 1 && B > 0 && B <= 4096 && !m->need_full_build && m->pair_launches;
+}
+
+// normalise (SLAM.java:120-124) beside integrateObservation at the weighted pose (:93, GridMap.java:173-191)
+void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local, bool own,
+                             const gms_beam *d_beams, int32_t B) {
+    gms_map *m = pf->map;
+    ProfScope ps(m, GMS_K_RAYCAST);
+    if (own) pf->d_global = pf->d_global_own;
+    const uint32_t n_ray = (uint32_t)((B + 3) / 4), n_norm = (uint32_t)((pf->n + 255) / 256);
+    const size_t smem = rc_smem(m, 4);
+    int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * 4;
+    if (smem > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_norm_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k_norm_raycast, dim3(n_ray + n_norm), dim3(256), smem, m->stream, m->gd, d_beams, B, m->d_cnt, bb,
+                       rc_nw_max(m), n_ray, d_partials, nblk_global_of(pf), pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local,
+                       own ? pf->d_cum : (double *)nullptr, own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf),
+                       own ? pf->d_p2 : (double *)nullptr, pf->d_stats);
+    pf->chunks_ready = own ? 1 : 0;
+    pf->neff_folded = 0;
+}
+
+// apply the counts beside level 0 of the cumulative weights of the gathered population
+void gms_launch_apply_chunks(gms_pf *pf) {
+    gms_map *m = pf->map;
+    ProfScope ps(m, GMS_K_APPLY);
+    const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
+    const uint32_t n_apply = (uint32_t)(all < 2048 ? all : 2048);
+    const int64_t nch = nchunks_of(pf);
+    const uint32_t n_chunk = (uint32_t)nblk_global_of(pf);
+    int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * 4;
+    hipLaunchKernelGGL(k_apply_chunks, dim3(n_apply + n_chunk), dim3(256), 0, m->stream, m->gd, m->d_log, m->d_cnt, cur, idle,
+                       n_chunk, pf->d_global, pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->d_p2, nblk_global_of(pf),
+                       pf->d_stats);
+    m->bbox_dirty = 1;
+    pf->chunks_ready = 1;
+    pf->neff_folded = 0;
+}
+
+// computeLikelihoodMap on the touched tiles (GridMap.java:233-250) beside resample() (SLAM.java:133-153)
+void gms_launch_lik_resample(gms_pf *pf, double fraction) {
+    gms_map *m = pf->map;
+    gms_launch_pf_chunk_sums(pf);                     // no-op when level 0 is already there
+    ProfScope ps(m, GMS_K_LIKELIHOOD);
+    const int32_t k = m->gd.khalf;
+    const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
+    const size_t RH = LK_TH + 2 * k, RW = LK_TW + 2 * k;
+    const size_t smem_l = (RH * (RW + 1) + RH * (LK_TW + 1) + (2 * k + 1)) * sizeof(double);
+    int32_t blocks = tiles_x * tiles_y;
+    const int32_t cap = smem_l <= 40 * 1024 ? 1024 : 512;
+    if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) & ~7;
+    const int64_t nch = nchunks_of(pf);
+    const size_t smem_r = (size_t)(nch + 1 + (nch + 63) / 64 + 1) * sizeof(double);
+    const size_t smem = smem_l > smem_r ? smem_l : smem_r;
+    const uint32_t n_res = (uint32_t)((pf->n + 255) / 256);
+    const int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * 4;
+#define LR_LAUNCH(KH)                                                                                                     \
+    do {                                                                                                                  \
+        if (smem > 48 * 1024)                                                                                             \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lik_resample<KH>),                                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
+        hipLaunchKernelGGL(k_lik_resample<KH>, dim3((uint32_t)blocks + n_res), dim3(256), smem, m->stream, m->gd, m->d_log, \
+                           m->d_lik, m->d_fac, m->fac_stride, m->d_taps, bb, tiles_x, tiles_y, n_res, pf->d_global, \
+                           pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->r01_scalar, fraction, pf->n, pf->offset,     \
+                           pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats);       \
+    } while (0)
+    if (k == 3) LR_LAUNCH(3);
+    else if (k == 5) LR_LAUNCH(5);
+    else LR_LAUNCH(0);
+#undef LR_LAUNCH
+    pf->neff_folded = 1;
+}

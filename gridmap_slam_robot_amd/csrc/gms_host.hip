@@ -234,6 +234,8 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     m->need_full_build = 1;
     m->score_variant = 2;
     if (const char *v = getenv("GMS_SCORE_VARIANT")) m->score_variant = atoi(v);
+    m->pair_launches = 1;
+    if (const char *v = getenv("GMS_PAIR_LAUNCHES")) m->pair_launches = atoi(v) != 0;
     if (const char *v = getenv("GMS_SCORE_SEGMENTS")) m->score_segments = atoi(v);
     *out = m;
     return GMS_OK;
@@ -909,6 +911,24 @@ int gms_pf_resample_if(gms_pf *pf, const double *r01, double fraction) {   // Gr
     return do_resample(pf, r01, fraction, nullptr, nullptr);
 }
 
+// the tail of a paired scan step: dirty-tile likelihood rebuild beside the conditional resample
+static int paired_likelihood_resample(gms_pf *pf, const double *r01, double fraction) {
+    gms_map *m = pf->map;
+    if (fraction >= 0.0) {
+        pf->r01_scalar = r01[0];
+        gms_launch_lik_resample(pf, fraction);
+        std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);
+        pf->have_global = 0;
+        pf->stats_current = 0;
+    } else {
+        gms_launch_likelihood(m, 1);
+    }
+    m->bbox_cur = 1 - m->bbox_cur;        // the box is consumed; the other half was cleared by the apply pass
+    m->bbox_dirty = 0;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
 // SLAM.update(z, u) (SLAM.java:80-131) + the resampling rule of its caller (GridMapApp.java:185-186) as one
 // call on device-resident inputs: poses := dev_xytheta (the motion-model samples), weights, bookkeeping,
 // conditional resample, map update at the weighted pose, likelihood rebuild.  Nothing is read back.
@@ -921,9 +941,18 @@ int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *de
     int rc = GMS_OK;
     if (dev_xytheta) rc = gms_pf_set_poses_dev(pf, dev_xytheta);                  // SLAM.java:90
     if (!rc) rc = gms_pf_score_dev(pf, dev_beams, B);                            // :99
+    if (!rc && integrate && gms_can_pair_launches(pf, B)) {
+        // The weight branch and the map branch are independent once the partials exist: they share launches
+        // (gms_fused_kernels.hip).  (Two streams were measured: the event fork/join costs more than it hides.)
+        pf->d_global = pf->d_global_own;
+        gms_launch_pf_partials(pf, pf->d_partials);
+        gms_launch_norm_raycast(pf, pf->d_partials, pf->d_global, true, dev_beams, B);    // :100-124 | :93
+        pf->have_global = 1;
+        pf->stats_current = 1;
+        gms_launch_apply_counts(m);
+        return paired_likelihood_resample(pf, r01, resample_fraction);           // :105 | GridMapApp.java:185-186
+    }
     if (!rc) rc = gms_pf_normalize(pf, nullptr);                                 // :100-124
-    // (Running the resample on a second stream beside the map update was measured: the event fork/join
-    // costs more than the 10 us it hides -- 116 vs 98 us per step -- so the step stays on one stream.)
     if (!rc && resample_fraction >= 0.0) rc = gms_pf_resample_if(pf, r01, resample_fraction);   // GridMapApp.java:185-186
     if (!rc && integrate) rc = gms_map_update_at_dev(m, dev_beams, B, pf, 0);    // SLAM.java:102-105, :93
     return rc;
@@ -1155,6 +1184,23 @@ int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xythet
     int rc = GMS_OK;
     if (dev_xytheta) rc = gms_pf_set_poses_dev(pf, dev_xytheta);                  // SLAM.java:90
     if (!rc) rc = gms_pf_score_dev(pf, dev_beams, B);                            // :99
+    if (!rc && integrate && gms_can_pair_launches(pf, B) && !c->pending) {
+        // partials -> all-reduce -> [normalise | ray cast] -> all-gather -> [apply | cumulative sums] ->
+        // [likelihood | resample]: the gather is in line (nothing independent is left to put beside it)
+        rc = check_shard(pf, c);
+        if (rc) return rc;
+        const size_t np = (size_t)nblk_of(pf->n_global) * GMS_PARTIAL_STRIDE;
+        PackedParticle *own_slot = pf->d_global_own + pf->offset;
+        gms_launch_pf_partials(pf, pf->d_partials);
+        RCCLCHK(g_rccl.AllReduce(pf->d_partials, pf->d_partials, np, RCCL_FLOAT64, RCCL_SUM, c->nccl, m->stream));
+        gms_launch_norm_raycast(pf, pf->d_partials, own_slot, false, dev_beams, B);
+        pf->stats_current = 1;
+        RCCLCHK(g_rccl.AllGather(own_slot, pf->d_global_own, (size_t)pf->n * sizeof(PackedParticle), RCCL_INT8, c->nccl, m->stream));
+        pf->d_global = pf->d_global_own;
+        gms_launch_apply_chunks(pf);
+        pf->have_global = 1;
+        return paired_likelihood_resample(pf, r01, resample_fraction);
+    }
     if (!rc) rc = gms_pf_normalize_sharded_begin(pf, c);                         // :100-124
     if (!rc && integrate) rc = gms_map_update_at_dev(m, dev_beams, B, pf, 0);    // :102-105, :93 on every replica
     if (!rc) rc = gms_pf_normalize_sharded_end(pf, c);

@@ -133,28 +133,31 @@ __device__ __forceinline__ void bbox_commit(int32_t bb[4], int32_t lane, int32_t
 }
 
 // fused form: one workgroup = RC_RAYS rays, phase A by wave 0, phase B by one wavefront per ray, words in LDS
+// (bx, by) = workgroup / map index and `smem` = the dynamic LDS: the body is shared by k_raycast and by the
+// launch that runs the ray cast beside the weight normalisation (gms_fused_kernels.hip); pose_lds, when given,
+// replaces poses[] (a pose the workgroup has just folded itself).
 template <bool TRACE, int RC_RAYS>
-__global__ void __launch_bounds__(RC_RAYS * 64)
-k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride,
-          const float *__restrict__ poses, int32_t pose_stride, const RayIn *__restrict__ single,
-          uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox, int32_t *__restrict__ t_cells,
-          uint8_t *__restrict__ t_cls, int32_t cap, int32_t *__restrict__ t_counts, int32_t nw_max) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void
+raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride,
+             const float *__restrict__ poses, int32_t pose_stride, const RayIn *__restrict__ single,
+             uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox, int32_t *__restrict__ t_cells,
+             uint8_t *__restrict__ t_cls, int32_t cap, int32_t *__restrict__ t_counts, int32_t nw_max,
+             uint32_t bx, uint32_t by, unsigned char *smem, const float *pose_lds) {
     uint32_t *s_words = reinterpret_cast<uint32_t *>(smem);            // [nw_max][RC_RAYS]
     uint32_t *s_ybase = s_words + (size_t)nw_max * RC_RAYS;            // [nw_max][RC_RAYS]
     __shared__ RayMeta s_meta[RC_RAYS];
     __shared__ int32_t s_bb[4];
 
-    const int32_t mi = blockIdx.y;
+    const int32_t mi = (int32_t)by;
     const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave == 0 && lane < RC_RAYS) {
-        const int32_t b = blockIdx.x * RC_RAYS + lane;
+        const int32_t b = (int32_t)bx * RC_RAYS + lane;
         RayMeta mt;
         mt.n_eff = 0; mt.x0 = mt.y0 = mt.x_inc = mt.y_inc = mt.hit = 0; mt.sx = mt.sy = mt.measured = 0.0f;
         if (b < B) {
             RayIn ray;
             if (single) ray = *single;
-            else ray = make_ray(g, beams[(size_t)mi * beam_stride + b], poses + (size_t)pose_stride * mi);
+            else ray = make_ray(g, beams[(size_t)mi * beam_stride + b], pose_lds ? pose_lds : poses + (size_t)pose_stride * mi);
             mt = ray_phase_a(g, ray, s_words, s_ybase, RC_RAYS, lane);
         }
         s_meta[lane] = mt;
@@ -163,7 +166,7 @@ k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam
 #ifdef GMS_EXP_NO_PHASE_B
     if (s_meta[0].n_eff >= 0) return;
 #endif
-    const int32_t b = blockIdx.x * RC_RAYS + wave;
+    const int32_t b = (int32_t)bx * RC_RAYS + wave;
     const RayMeta mt = s_meta[wave];
     int32_t bb[4] = { 0, 0, 0, 0 };
     const int32_t count = ray_phase_b<TRACE>(g, mt, s_words, s_ybase, RC_RAYS, wave, lane,
@@ -173,6 +176,17 @@ k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam
     } else {
         bbox_commit(bb, lane, bbox + 4 * mi, s_bb);
     }
+}
+
+template <bool TRACE, int RC_RAYS>
+__global__ void __launch_bounds__(RC_RAYS * 64)
+k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride,
+          const float *__restrict__ poses, int32_t pose_stride, const RayIn *__restrict__ single,
+          uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox, int32_t *__restrict__ t_cells,
+          uint8_t *__restrict__ t_cls, int32_t cap, int32_t *__restrict__ t_counts, int32_t nw_max) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    raycast_body<TRACE, RC_RAYS>(g, beams, B, beam_stride, poses, pose_stride, single, cnt, bbox, t_cells, t_cls, cap, t_counts,
+                                 nw_max, blockIdx.x, blockIdx.y, smem, nullptr);
 }
 
 // plain RayIterator walk (gms_map_trace_ray)
@@ -194,18 +208,18 @@ __global__ void k_trace_ray(int32_t W, int32_t H, float x0, float y0, float x1, 
 // enumerate only the 256 x 4 cell tiles that intersect the box; a lane owns 4 consecutive cells.
 #define APPLY_TW 256
 #define APPLY_TH 4
-__global__ void __launch_bounds__(256)
-k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
-        int32_t *__restrict__ bbox_idle) {
-    const int32_t mi = blockIdx.y;
-    if (blockIdx.x == 0 && threadIdx.x < 4) bbox_idle[4 * mi + threadIdx.x] = 0;
+__device__ __forceinline__ void
+apply_body(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
+           int32_t *__restrict__ bbox_idle, uint32_t bx, uint32_t by, uint32_t gdx) {
+    const int32_t mi = (int32_t)by;
+    if (bx == 0 && threadIdx.x < 4) bbox_idle[4 * mi + threadIdx.x] = 0;
     int32_t x0, y0, x1, y1;
     bbox_decode(bbox + 4 * mi, g.W, g.H, x0, y0, x1, y1);
     if (x1 <= 0) return;
     const int32_t qx0 = x0 / APPLY_TW, qy0 = y0 / APPLY_TH;
     const int32_t qnx = (x1 - 1) / APPLY_TW - qx0 + 1, qny = (y1 - 1) / APPLY_TH - qy0 + 1;
     const bool vec = (g.W & 3) == 0;
-    for (int32_t t = blockIdx.x; t < qnx * qny; t += gridDim.x) {
+    for (int32_t t = (int32_t)bx; t < qnx * qny; t += (int32_t)gdx) {
         const int32_t tx0 = (qx0 + t % qnx) * APPLY_TW, ty0 = (qy0 + t / qnx) * APPLY_TH;
         const int32_t y = ty0 + (threadIdx.x >> 6);
         const int32_t xb = tx0 + (threadIdx.x & 63) * 4;
@@ -231,6 +245,12 @@ k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const 
     }
 }
 
+__global__ void __launch_bounds__(256)
+k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
+        int32_t *__restrict__ bbox_idle) {
+    apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Likelihood field (GridMap.computeLikelihoodMap, GridMap.java:233-250 + Util.doGaussianBlurdSeparable,
 // Util.java:378-426).  Persistent workgroups walk LK_TW x LK_TH output tiles:
@@ -251,11 +271,10 @@ k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const 
 #define LK_STRIP 8
 
 template <int KH>   // KH > 0: compile-time half width; KH == 0: runtime g.khalf (generic, slower)
-__global__ void __launch_bounds__(256)
-k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
-             int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
-             int32_t tiles_x, int32_t tiles_y) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void
+likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
+                int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
+                int32_t tiles_x, int32_t tiles_y, uint32_t bx, uint32_t by, uint32_t gdx, unsigned char *smem) {
     const int32_t k = KH > 0 ? KH : g.khalf;
     const int32_t ntaps = 2 * k + 1;
     const int32_t RW = LK_TW + 2 * k, RH = LK_TH + 2 * k;     // staged columns / rows
@@ -265,7 +284,7 @@ k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ li
     double *taps_s = hs + (size_t)RH * PHS;                   // [ntaps] (generic path)
     __shared__ int32_t s_mask;
 
-    const int32_t mi = blockIdx.y;
+    const int32_t mi = (int32_t)by;
     const double *mlog = logd + (size_t)mi * g.cells;
     double *mlik = lik + (size_t)mi * g.cells;
     double *mfac = fac + (size_t)mi * fac_stride;
@@ -285,7 +304,7 @@ k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ li
     if (KH == 0)
         for (int32_t i = threadIdx.x; i < ntaps; i += blockDim.x) taps_s[i] = taps_g[i];
 
-    for (int32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (int32_t t = (int32_t)bx; t < ntiles; t += (int32_t)gdx) {
         // XCD-aware order (full rebuild): workgroups b and b+8 share an XCD, so each XCD walks a
         // contiguous band of tiles and the halo re-reads hit its own L2
         int32_t tile = t;
@@ -393,6 +412,16 @@ k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ li
             }
         }
     }
+}
+
+template <int KH>
+__global__ void __launch_bounds__(256)
+k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
+             int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
+             int32_t tiles_x, int32_t tiles_y) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, dirty_only, tiles_x, tiles_y, blockIdx.x, blockIdx.y,
+                        gridDim.x, smem);
 }
 
 // scoring factors from an existing likelihood field (upload / copy); entry [cells] = neutral 1.0

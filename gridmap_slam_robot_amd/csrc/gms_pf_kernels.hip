@@ -645,38 +645,51 @@ k_partials(double *__restrict__ w, double *__restrict__ logw, const float *__res
         for (int k = 0; k < GMS_PARTIAL_STRIDE; k++) p[k] = out[k];
 }
 
-// Level 0 of the cumulative weights for one 64-particle chunk held in LDS: sequential, index order --
-// the reference's `c += w[i]` (SLAM.java:144) inside the chunk.
-__device__ __forceinline__ double chunk_sums_lds(double *row, int32_t len, double &sq) {
-    double acc = 0.0, q = 0.0;
-#pragma unroll 8
-    for (int32_t j = 0; j < SCAN_CHUNK; j++) {
-        if (j < len) {
-            const double v = row[j];
-            acc = (j == 0) ? v : acc + v;
-            q = (j == 0) ? v * v : q + v * v;                          // calculateNeff's squares, same order
-            row[j] = acc;
-        }
+// Level 0 of the cumulative weights: one wavefront = one 64-particle chunk, lane = particle, inclusive scan by
+// six shuffle steps (a fixed shape, identical wherever it runs: every rank of a sharded filter, the normalise pass
+// and the pass over a gathered population all produce the same bits); a 256-thread workgroup = one reduction
+// block = four chunks, whose {sum wn, sum wn^2} are combined in chunk order for calculateNeff (SLAM.java:180-190).
+// Every thread of the workgroup calls; v = normalised weight of particle i of this map (0 beyond the population).
+__device__ __forceinline__ void block_chunk_scan(double v, int64_t i, int64_t n_pop, int64_t blk, int64_t nchunks,
+                                                 double *__restrict__ cum, double *__restrict__ chunk_tot,
+                                                 double *__restrict__ p2_blk) {
+    __shared__ double s_ct[4][2];
+    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(inc, o, GMS_WAVE);
+        if (lane >= o) inc += up;
     }
-    sq = q;
-    return acc;
+    const double sq = wave_sum_f64(v * v);
+    const double tot = __shfl(inc, 63, GMS_WAVE);
+    if (i < n_pop) cum[i] = inc;
+    if (lane == 0) {
+        const int64_t c = blk * 4 + wave;
+        if (c < nchunks) chunk_tot[c] = tot;
+        s_ct[wave][0] = tot; s_ct[wave][1] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p2_blk[0] = ((s_ct[0][0] + s_ct[1][0]) + s_ct[2][0]) + s_ct[3][0];
+        p2_blk[1] = ((s_ct[0][1] + s_ct[1][1]) + s_ct[2][1]) + s_ct[3][1];
+    }
 }
 static_assert(4 * SCAN_CHUNK == GMS_BLOCK, "a reduction block is four scan chunks");
 
 // phase 2: every workgroup folds the (all-reduced) partials; weight /= weightSum (SLAM.java:120-121);
 // packs {w,x,y,theta} (the all-gather payload / the resampling source).  A stand-alone filter also
 // gets the dense weight copy and level 0 of the cumulative weights here (cum != nullptr).
-__global__ void __launch_bounds__(256)
-k_normalize_pack(const double *__restrict__ partials_all, int64_t nblk_global, double *__restrict__ w,
-                 const float *__restrict__ pose, int32_t n, int64_t offset, PackedParticle *__restrict__ packed,
-                 double *__restrict__ cum, double *__restrict__ chunk_tot, int64_t nchunks,
-                 double *__restrict__ p2_all, PfStatsDev *__restrict__ stats) {
+__device__ __forceinline__ void
+normalize_pack_body(const double *__restrict__ partials_all, int64_t nblk_global, double *__restrict__ w,
+                    const float *__restrict__ pose, int32_t n, int64_t offset, PackedParticle *__restrict__ packed,
+                    double *__restrict__ cum, double *__restrict__ chunk_tot, int64_t nchunks,
+                    double *__restrict__ p2_all, PfStatsDev *__restrict__ stats, uint32_t bx, uint32_t by) {
     __shared__ RedLds L;
-    __shared__ double s_w[256 + 4];
-    const int32_t mi = blockIdx.y;
+    const int32_t mi = (int32_t)by;
     const double *p = partials_all + (size_t)mi * nblk_global * GMS_PARTIAL_STRIDE;
-    const double sum = fold_stats(p, nblk_global, stats + mi, blockIdx.x == 0, pose + (size_t)mi * n * 3, offset, n, L);
-    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    const double sum = fold_stats(p, nblk_global, stats + mi, bx == 0, pose + (size_t)mi * n * 3, offset, n, L);
+    const int32_t i = (int32_t)bx * 256 + threadIdx.x;
     double wn = 0.0;
     if (i < n) {
         const size_t gi = (size_t)mi * n + i;
@@ -686,41 +699,30 @@ k_normalize_pack(const double *__restrict__ partials_all, int64_t nblk_global, d
         pp.w = wn; pp.x = pose[3 * gi]; pp.y = pose[3 * gi + 1]; pp.theta = pose[3 * gi + 2]; pp.pad = 0u;
         packed[gi] = pp;
     }
-    if (cum) {                                        // uniform
-        __shared__ double s_ct[4][2];
-        const int32_t t = threadIdx.x;
-        s_w[t + (t >> 6)] = wn;                       // pitch 65: the four chunk rows start on different banks
-        __syncthreads();
-        if (t < 4) {
-            const int64_t c = (int64_t)blockIdx.x * 4 + t;
-            double tot = 0.0, sq = 0.0;
-            if (c < nchunks) {
-                const int64_t left = (int64_t)n - c * SCAN_CHUNK;
-                tot = chunk_sums_lds(s_w + t * 65, (int32_t)(left < SCAN_CHUNK ? left : SCAN_CHUNK), sq);
-                chunk_tot[(size_t)mi * (nchunks + 1) + c] = tot;
-            }
-            s_ct[t][0] = tot; s_ct[t][1] = sq;
-        }
-        __syncthreads();
-        if (i < n) cum[(size_t)mi * n + i] = s_w[t + (t >> 6)];
-        if (t == 0) {                                 // {sum wn, sum wn^2} of this block = its four chunks, in order
-            double *pp2 = p2_all + ((size_t)mi * nblk_global + blockIdx.x) * 2;
-            pp2[0] = ((s_ct[0][0] + s_ct[1][0]) + s_ct[2][0]) + s_ct[3][0];
-            pp2[1] = ((s_ct[0][1] + s_ct[1][1]) + s_ct[2][1]) + s_ct[3][1];
-        }
-    }
+    if (cum)                                          // uniform
+        block_chunk_scan(wn, i, n, bx, nchunks, cum + (size_t)mi * n, chunk_tot + (size_t)mi * (nchunks + 1),
+                         p2_all + ((size_t)mi * nblk_global + bx) * 2);
 }
 
-// Level 0 as a kernel of its own (sharded filters after the all-gather; resample without normalise): one lane
-// per chunk of the GLOBAL population, 64 chunks per wavefront; also the per-block {sum wn, sum wn^2} (four
-// chunks per block, combined in order) and the strongest particle's pose, which only the owning rank knew.
-__global__ void __launch_bounds__(64)
-k_chunk_sums(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks, double *__restrict__ cum_all,
-             double *__restrict__ chunk_tot, double *__restrict__ p2_all, int64_t nblk_global, PfStatsDev *__restrict__ stats) {
-    const int32_t mi = blockIdx.y;
-    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(256)
+k_normalize_pack(const double *__restrict__ partials_all, int64_t nblk_global, double *__restrict__ w,
+                 const float *__restrict__ pose, int32_t n, int64_t offset, PackedParticle *__restrict__ packed,
+                 double *__restrict__ cum, double *__restrict__ chunk_tot, int64_t nchunks,
+                 double *__restrict__ p2_all, PfStatsDev *__restrict__ stats) {
+    normalize_pack_body(partials_all, nblk_global, w, pose, n, offset, packed, cum, chunk_tot, nchunks, p2_all, stats, blockIdx.x,
+                        blockIdx.y);
+}
+
+// Level 0 as a kernel of its own (sharded filters after the all-gather; resample without normalise): the same
+// scan over the GLOBAL population, plus the strongest particle's pose, which only the owning rank knew.
+// 256 threads per workgroup, one particle per thread.
+__device__ __forceinline__ void
+chunk_sums_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks, double *__restrict__ cum_all,
+                double *__restrict__ chunk_tot, double *__restrict__ p2_all, int64_t nblk_global, PfStatsDev *__restrict__ stats,
+                uint32_t bx, uint32_t by) {
+    const int32_t mi = (int32_t)by;
     const PackedParticle *g = glob_all + (size_t)mi * n_global;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bx == 0 && threadIdx.x == 0) {
         stats[mi].n_ambiguous = 0;
         int64_t st = stats[mi].strongest;
         if (st < 0) st = 0;
@@ -728,34 +730,16 @@ k_chunk_sums(const PackedParticle *__restrict__ glob_all, int64_t n_global, int6
         const PackedParticle pp = g[st];
         stats[mi].spose[0] = pp.x; stats[mi].spose[1] = pp.y; stats[mi].spose[2] = pp.theta;
     }
-    double acc = 0.0, q = 0.0;
-    if (c < nchunks) {
-        double *cm = cum_all + (size_t)mi * n_global;
-        const int64_t i0 = c * SCAN_CHUNK;
-        const int64_t len = n_global - i0 < SCAN_CHUNK ? n_global - i0 : SCAN_CHUNK;
-        for (int64_t j0 = 0; j0 < len; j0 += 8) {         // eight independent loads in flight
-            double v[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = j0 + j < len ? g[i0 + j0 + j].w : 0.0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if (j0 + j < len) {
-                    acc = (j0 + j == 0) ? v[j] : acc + v[j];
-                    q = (j0 + j == 0) ? v[j] * v[j] : q + v[j] * v[j];
-                    cm[i0 + j0 + j] = acc;
-                }
-            }
-        }
-        chunk_tot[(size_t)mi * (nchunks + 1) + c] = acc;
-    }
-    // block b = chunks 4b..4b+3 = four neighbouring lanes, combined in chunk order by the first of them
-    const double a1 = __shfl_down(acc, 1, GMS_WAVE), a2 = __shfl_down(acc, 2, GMS_WAVE), a3 = __shfl_down(acc, 3, GMS_WAVE);
-    const double q1 = __shfl_down(q, 1, GMS_WAVE), q2 = __shfl_down(q, 2, GMS_WAVE), q3 = __shfl_down(q, 3, GMS_WAVE);
-    if ((threadIdx.x & 3) == 0 && (c >> 2) < nblk_global) {
-        double *pp2 = p2_all + ((size_t)mi * nblk_global + (c >> 2)) * 2;
-        pp2[0] = ((acc + a1) + a2) + a3;
-        pp2[1] = ((q + q1) + q2) + q3;
-    }
+    const int64_t i = (int64_t)bx * 256 + threadIdx.x;
+    const double v = i < n_global ? g[i].w : 0.0;
+    block_chunk_scan(v, i, n_global, bx, nchunks, cum_all + (size_t)mi * n_global, chunk_tot + (size_t)mi * (nchunks + 1),
+                     p2_all + ((size_t)mi * nblk_global + bx) * 2);
+}
+
+__global__ void __launch_bounds__(256)
+k_chunk_sums(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks, double *__restrict__ cum_all,
+             double *__restrict__ chunk_tot, double *__restrict__ p2_all, int64_t nblk_global, PfStatsDev *__restrict__ stats) {
+    chunk_sums_body(glob_all, n_global, nchunks, cum_all, chunk_tot, p2_all, nblk_global, stats, blockIdx.x, blockIdx.y);
 }
 
 // statistics only (getWeightedPose / calculateNeff on the current particles, nothing rewritten)
@@ -783,26 +767,25 @@ __global__ void k_pack(const double *__restrict__ w, const float *__restrict__ p
 // ---------------------------------------------------------------------------------------------
 // resampling.  Cumulative weights, fixed shape (depends on n_global only, so every rank of a sharded
 // filter computes the same values):
-//   level 0  chunk of SCAN_CHUNK = 64 weights: added in index order (chunk_sums_lds / k_chunk_sums);
+//   level 0  chunk of SCAN_CHUNK = 64 weights: one wavefront's inclusive shuffle scan (block_chunk_scan);
 //   level 1  super-chunk of 64 chunks: one lane adds the chunk totals in order;
 //   level 2  one lane adds the super-chunk totals in order.
 // offset[c] = level2[c / 64] + level1[c]; cumulative weight of particle i = offset[i / 64] + cum[i].
 // Levels 1 and 2 are a few hundred additions: every workgroup of k_resample redoes them in LDS.
 // ---------------------------------------------------------------------------------------------
 // one lane per output slot (SLAM.java:140-149); the chunk offsets are staged in LDS for the first search level
-__global__ void __launch_bounds__(256)
-k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks,
-           const double *__restrict__ cum_all, const double *__restrict__ chunk_off, const double *__restrict__ r01,
-           double r01_scalar, double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, float *__restrict__ cs2,
-           double *__restrict__ w2, int32_t *__restrict__ idx_out, const double *__restrict__ p2_all, int64_t nblk_global,
-           PfStatsDev *__restrict__ stats) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void
+resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks,
+              const double *__restrict__ cum_all, const double *__restrict__ chunk_off, const double *__restrict__ r01,
+              double r01_scalar, double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, float *__restrict__ cs2,
+              double *__restrict__ w2, int32_t *__restrict__ idx_out, const double *__restrict__ p2_all, int64_t nblk_global,
+              PfStatsDev *__restrict__ stats, uint32_t bx, uint32_t by, unsigned char *smem) {
     double *off = reinterpret_cast<double *>(smem);                    // [nchunks + 1]
-    const int32_t mi = blockIdx.y;
+    const int32_t mi = (int32_t)by;
     __shared__ RedLds L;
     double norm_sum, sq_sum;
     fold_neff(p2_all + (size_t)mi * nblk_global * 2, nblk_global, norm_sum, sq_sum, L.a);   // calculateNeff (SLAM.java:180-190)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[mi].norm_sum = norm_sum; stats[mi].sq_sum = sq_sum; }
+    if (bx == 0 && threadIdx.x == 0) { stats[mi].norm_sum = norm_sum; stats[mi].sq_sum = sq_sum; }
     const bool go = fraction < 0.0 || (1.0 / sq_sum) < fraction * (double)n_global;         // GridMapApp.java:185
     const int64_t nsuper = (nchunks + 63) / 64;
     double *sup = off + nchunks + 1;                                   // [nsuper + 1]
@@ -835,7 +818,7 @@ k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_
         for (int64_t c = 64 + threadIdx.x; c < nchunks; c += blockDim.x) off[c] = sup[c >> 6] + off[c];   // super-chunk 0 adds nothing
         __syncthreads();
     }
-    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t t = (int32_t)bx * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const PackedParticle *g = glob_all + (size_t)mi * n_global;
     const int64_t m0 = offset + t;              // m - 1
@@ -882,6 +865,17 @@ k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_
     w2[o] = pp.w;                                                       // copies keep their weight (SLAM.java:42)
     if (idx_out) idx_out[o] = (int32_t)src;
     if (t == 0) stats[mi].did_resample = go ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_t nchunks,
+           const double *__restrict__ cum_all, const double *__restrict__ chunk_off, const double *__restrict__ r01,
+           double r01_scalar, double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, float *__restrict__ cs2,
+           double *__restrict__ w2, int32_t *__restrict__ idx_out, const double *__restrict__ p2_all, int64_t nblk_global,
+           PfStatsDev *__restrict__ stats) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    resample_body(glob_all, n_global, nchunks, cum_all, chunk_off, r01, r01_scalar, fraction, n, offset, pose2, cs2, w2, idx_out,
+                  p2_all, nblk_global, stats, blockIdx.x, blockIdx.y, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1095,7 +1089,7 @@ void gms_launch_pf_chunk_sums(gms_pf *pf) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_RESAMPLE);
     const int64_t nch = nchunks_of(pf);
-    hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)((nch + 63) / 64), pf->n_maps), dim3(64), 0, m->stream, pf->d_global,
+    hipLaunchKernelGGL(k_chunk_sums, dim3((unsigned)nblk_global_of(pf), pf->n_maps), dim3(256), 0, m->stream, pf->d_global,
                        pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->d_p2, nblk_global_of(pf), pf->d_stats);
     pf->chunks_ready = 1;
 }
