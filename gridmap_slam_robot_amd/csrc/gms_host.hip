@@ -717,16 +717,21 @@ int gms_pf_score(gms_pf *pf, const gms_beam *beams, int32_t B) {       // GridMa
     return GMS_OK;
 }
 
-int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B) {
+// poses := dev_xytheta (may be NULL: keep the current ones), then weights: one launch with the default scoring kernel
+static int set_poses_and_score_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B) {
     REQUIRE(pf && dev_beams, "null argument");
     gms_map *m = pf->map;
     REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
     HIPCHK(hipSetDevice(m->device));
-    gms_launch_pf_score(pf, dev_beams, B, B);
+    gms_launch_pf_score(pf, dev_beams, B, B, dev_xytheta);
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
+}
+
+int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B) {
+    return set_poses_and_score_dev(pf, nullptr, dev_beams, B);
 }
 
 int gms_pf_set_poses_dev(gms_pf *pf, const float *dev_xytheta) {
@@ -939,8 +944,7 @@ int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *de
     if (pf->offset != 0 || pf->n_global != pf->n)
         return fail(GMS_ERR_STATE, "sharded filter: the collectives belong to the caller (see distributed.py)");
     int rc = GMS_OK;
-    if (dev_xytheta) rc = gms_pf_set_poses_dev(pf, dev_xytheta);                  // SLAM.java:90
-    if (!rc) rc = gms_pf_score_dev(pf, dev_beams, B);                            // :99
+    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B);                 // SLAM.java:90, :99
     if (!rc && integrate && gms_can_pair_launches(pf, B)) {
         // The weight branch and the map branch are independent once the partials exist: they share launches
         // (gms_fused_kernels.hip).  (Two streams were measured: the event fork/join costs more than it hides.)
@@ -1182,8 +1186,7 @@ int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xythet
     REQUIRE(pf && c && dev_beams && r01, "null argument");
     gms_map *m = pf->map;
     int rc = GMS_OK;
-    if (dev_xytheta) rc = gms_pf_set_poses_dev(pf, dev_xytheta);                  // SLAM.java:90
-    if (!rc) rc = gms_pf_score_dev(pf, dev_beams, B);                            // :99
+    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B);                 // SLAM.java:90, :99
     if (!rc && integrate && gms_can_pair_launches(pf, B) && !c->pending) {
         // partials -> all-reduce -> [normalise | ray cast] -> all-gather -> [apply | cumulative sums] ->
         // [likelihood | resample]: the gather is in line (nothing independent is left to put beside it)

@@ -176,7 +176,8 @@ void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticl
 void gms_launch_apply_chunks(gms_pf *pf);
 void gms_launch_lik_resample(gms_pf *pf, double fraction);
 void gms_launch_pf_fold_neff(gms_pf *pf);
-void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);
+void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride,
+                         const float *d_pose_src = nullptr);   // d_pose_src: set the poses in the same launch
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials);
 void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed);
 void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local, bool own);

@@ -291,7 +291,8 @@ k_score_b(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
 __global__ void __launch_bounds__(1024)
 k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const gms_beam *__restrict__ beams,
           int32_t B, int32_t beam_stride, const float *__restrict__ pose, const float *__restrict__ cs, int32_t n,
-          int32_t nseg, double *__restrict__ part, double *__restrict__ w, double *__restrict__ logw) {
+          int32_t nseg, double *__restrict__ part, double *__restrict__ w, double *__restrict__ logw,
+          const float *__restrict__ pose_src, float *__restrict__ pose_dst, float *__restrict__ cs_dst) {
     __shared__ double2 s_beam[128 + SCORE_U];        // this segment's beams with wasHit, in order
     __shared__ int32_t s_nb;
     const int32_t mi = blockIdx.z, seg = blockIdx.y;
@@ -311,14 +312,28 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
         if (threadIdx.x < SCORE_U) s_beam[base + threadIdx.x] = make_double2(0.0, 0.0);   // padding of the last batch
         if (threadIdx.x == 0) s_nb = base;
     }
+    // pose_src: the poses enter the filter through this launch (SLAM.java:90): every segment's workgroup takes its
+    // particles' trig itself -- the arithmetic hides under the first wavefront's beam compaction -- and segment 0
+    // stores pose and trig where the other kernels expect them (what k_pose_trig does in a launch of its own)
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gi = (size_t)mi * n + (p < n ? p : 0);
+    XformDev t;
+    if (pose_src) {
+        const float x = pose_src[3 * gi], y = pose_src[3 * gi + 1], th = pose_src[3 * gi + 2];
+        float c, sn;
+        pose_trig(th, c, sn);                                          // Transform.java:15-16
+        t.c = (double)c; t.s = (double)sn; t.px = (double)x; t.py = (double)y;
+        if (seg == 0 && p < n) {
+            pose_dst[3 * gi] = x; pose_dst[3 * gi + 1] = y; pose_dst[3 * gi + 2] = th;
+            cs_dst[2 * gi] = c; cs_dst[2 * gi + 1] = sn;
+        }
+    } else {
+        t.c = (double)cs[2 * gi]; t.s = (double)cs[2 * gi + 1];
+        t.px = (double)pose[3 * gi]; t.py = (double)pose[3 * gi + 1];
+    }
     __syncthreads();
     const int32_t nb = s_nb;
-    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const size_t gi = (size_t)mi * n + p;
-    XformDev t;
-    t.c = (double)cs[2 * gi]; t.s = (double)cs[2 * gi + 1];           // Transform.java:15-16
-    t.px = (double)pose[3 * gi]; t.py = (double)pose[3 * gi + 1];
     double prod = 1.0;                                                 // GridMap.java:262
     // Software pipeline: the cell indices of batch b+1 are computed while the look-ups of batch b are in
     // flight, so the vector ALU work hides under the gather latency inside each wavefront (the gathers,
@@ -989,8 +1004,9 @@ static void launch_compact(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32
                        pf->d_hitbeams, pf->d_nhit);
 }
 
-void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride) {
+void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_pose_src) {
     gms_map *m = pf->map;
+    if (d_pose_src && m->score_variant != 2) { gms_launch_pf_pose_trig(pf, d_pose_src); d_pose_src = nullptr; }
     if (m->score_variant != 2) launch_compact(pf, d_beams, B, beam_stride);
     ProfScope ps(m, GMS_K_SCORE);
     pf->pending_nseg = 0;
@@ -1006,7 +1022,7 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
         if (nseg > GMS_SCORE_MAXSEG) nseg = GMS_SCORE_MAXSEG;
         hipLaunchKernelGGL(k_score_c, dim3((unsigned)groups, (unsigned)nseg, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
                            m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
-                           pf->d_part, pf->d_w, pf->d_logw);
+                           pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pf->d_pose, pf->d_cs);
         if (nseg > 1) pf->pending_nseg = (int32_t)nseg;               // combined by the next consumer of the weights
         return;
     }
