@@ -317,20 +317,52 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
 
         // ---- phase 1
         int32_t seen = 0;                                      // bit c: a cell of code c; bit 3: outside the map
-#pragma unroll 4
-        for (int32_t idx = threadIdx.x; idx < RH * RW; idx += blockDim.x) {
-            const int32_t r = idx / RW, c = idx - r * RW;
-            const int32_t gy = ty0 - k + r, gx = tx0 - k + c;
-            double val = 0.0;
-            if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
-                const double v = mlog[(size_t)gy * g.W + gx];
-                const int32_t code = v > 0.0 ? 2 : (v < 0.0 ? 0 : 1);             // GridMap.java:239-244
-                val = 0.5 * (double)code;
-                seen |= 1 << code;
-            } else {
-                seen |= 8;
+        if (KH > 0) {
+            // every load of the staged rectangle is issued before the first one is consumed: the addresses are
+            // clamped into the map so that no load sits behind a branch (13 dependent round trips otherwise)
+            constexpr int32_t CRW = LK_TW + 2 * (KH > 0 ? KH : 1), CRH = LK_TH + 2 * (KH > 0 ? KH : 1);
+            constexpr int32_t P1 = (CRW * CRH + 255) / 256;
+            double lv[P1];
+#pragma unroll
+            for (int q = 0; q < P1; q++) {
+                const int32_t idx = (int32_t)threadIdx.x + q * 256;
+                const int32_t r = idx / CRW, c = idx - r * CRW;
+                const int32_t gy = min(max(ty0 - KH + r, 0), g.H - 1), gx = min(max(tx0 - KH + c, 0), g.W - 1);
+                lv[q] = mlog[(size_t)gy * g.W + gx];
             }
-            in_s[r * PIN + c] = val;
+#pragma unroll
+            for (int q = 0; q < P1; q++) {
+                const int32_t idx = (int32_t)threadIdx.x + q * 256;
+                const int32_t r = idx / CRW, c = idx - r * CRW;
+                const int32_t gy = ty0 - KH + r, gx = tx0 - KH + c;
+                if (idx < CRW * CRH) {
+                    double val = 0.0;
+                    if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
+                        const int32_t code = lv[q] > 0.0 ? 2 : (lv[q] < 0.0 ? 0 : 1);     // GridMap.java:239-244
+                        val = 0.5 * (double)code;
+                        seen |= 1 << code;
+                    } else {
+                        seen |= 8;
+                    }
+                    in_s[r * PIN + c] = val;
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int32_t idx = threadIdx.x; idx < RH * RW; idx += blockDim.x) {
+                const int32_t r = idx / RW, c = idx - r * RW;
+                const int32_t gy = ty0 - k + r, gx = tx0 - k + c;
+                double val = 0.0;
+                if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
+                    const double v = mlog[(size_t)gy * g.W + gx];
+                    const int32_t code = v > 0.0 ? 2 : (v < 0.0 ? 0 : 1);             // GridMap.java:239-244
+                    val = 0.5 * (double)code;
+                    seen |= 1 << code;
+                } else {
+                    seen |= 8;
+                }
+                in_s[r * PIN + c] = val;
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) seen |= __shfl_xor(seen, o, GMS_WAVE);
