@@ -377,18 +377,18 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
 }
 
 // product of the per-segment products, in segment order, with an exact exponent (no underflow on the
-// way); the loads of eight segments are issued together
+// way); the loads of sixteen segments are issued together
 __device__ __forceinline__ void combine_segments(const double *__restrict__ part, int32_t mi, int32_t n, int32_t nseg,
                                                  int64_t p, double &wv, double &lwv) {
     const double *q = part + ((size_t)mi * nseg) * n + p;
     double mnt = 1.0;
     int32_t e = 0;
-    for (int32_t s0 = 0; s0 < nseg; s0 += 8) {
-        double v[8];
+    for (int32_t s0 = 0; s0 < nseg; s0 += 16) {                        // the default 16 segments: one round trip
+        double v[16];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = s0 + k < nseg ? q[(size_t)(s0 + k) * n] : 1.0;
+        for (int k = 0; k < 16; k++) v[k] = s0 + k < nseg ? q[(size_t)(s0 + k) * n] : 1.0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < 16; k++) {
             int e2;
             const double m2 = frexp(v[k], &e2);
             if (s0 + k == 0) { mnt = m2; e = e2; }
