@@ -2,7 +2,7 @@
 //
 // After the weights are reduced a scan step has two independent branches (SLAM.java:100-124 vs :93,:102-105):
 //     weights:  normalise + pack  ->  [all-gather]  ->  cumulative sums  ->  resample
-//     map:      ray cast          ->  apply counts   ->  likelihood rebuild
+//     map:      ray cast          ->  likelihood rebuild (counts added on the fly)  ...  apply counts (next step)
 // Every one of those kernels is a few microseconds of latency on a small part of the GPU (the ray cast keeps 180
 // workgroups busy, the normalise 64).  On one in-order stream they run back to back; on two streams the event
 // fork/join costs more than it hides (measured: +18 us per step).  So the branches are paired inside single
@@ -44,15 +44,16 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
     }
 }
 
-// ---- B: apply counts  |  cumulative sums of the gathered population (sharded filters) -----------------------
+// ---- B: block partials of the weights  |  the PREVIOUS scan's apply pass -------------------------------------
+// The likelihood pass of a paired step adds the scan's counts on the fly, so `logData += ...` (GridMap.java:223)
+// is off the critical path: it runs here, beside the next scan's weight reduction, before that scan's ray cast.
 __global__ void __launch_bounds__(256)
-k_apply_chunks(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
-               int32_t *__restrict__ bbox_idle, uint32_t n_chunk_blocks,
-               const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nchunks, double *__restrict__ cum,
-               double *__restrict__ chunk_tot, double *__restrict__ p2, int64_t nblk_global, PfStatsDev *__restrict__ stats) {
-    // the few long-running workgroups first
-    if (blockIdx.x < n_chunk_blocks) chunk_sums_body(glob, n_global, nchunks, cum, chunk_tot, p2, nblk_global, stats, blockIdx.x, 0);
-    else apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - n_chunk_blocks, 0, gridDim.x - n_chunk_blocks);
+k_partials_apply(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n, int64_t offset,
+                 int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part, int32_t part_nseg,
+                 GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
+                 int32_t *__restrict__ bbox_idle) {
+    if (blockIdx.x < (uint32_t)nblk_global) partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, 0);
+    else apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - (uint32_t)nblk_global, 0, gridDim.x - (uint32_t)nblk_global);
 }
 
 // ---- C: likelihood rebuild (dirty tiles)  |  resample ---------------------------------------------------------
@@ -60,7 +61,7 @@ template <int KH>
 __global__ void __launch_bounds__(256)
 k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac, int64_t fac_stride,
                const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t tiles_x, int32_t tiles_y,
-               uint32_t n_res_blocks,
+               const uint32_t *__restrict__ cnt_pending, uint32_t n_res_blocks,
                const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nchunks, const double *__restrict__ cum,
                const double *__restrict__ chunk_off, double r01, double fraction, int32_t n, int64_t offset,
                float *__restrict__ pose2, float *__restrict__ cs2, double *__restrict__ w2, int32_t *__restrict__ idx_out,
@@ -71,7 +72,7 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
                       nblk_global, stats, blockIdx.x, 0, smem);
     else
         likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, 1, tiles_x, tiles_y, blockIdx.x - n_res_blocks, 0,
-                            gridDim.x - n_res_blocks, smem);
+                            gridDim.x - n_res_blocks, smem, cnt_pending);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -101,21 +102,21 @@ void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticl
     pf->neff_folded = 0;
 }
 
-// apply the counts beside level 0 of the cumulative weights of the gathered population
-void gms_launch_apply_chunks(gms_pf *pf) {
+// block partials (SLAM.java:100-115) beside the apply pass the previous paired step left pending
+void gms_launch_partials_apply(gms_pf *pf, double *d_partials) {
     gms_map *m = pf->map;
-    ProfScope ps(m, GMS_K_APPLY);
+    if (!m->apply_pending || pf->n_maps != 1) { gms_launch_pf_partials(pf, d_partials); return; }
+    ProfScope ps(m, GMS_K_REDUCE);
+    const int64_t nblk = nblk_global_of(pf);
     const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
     const uint32_t n_apply = (uint32_t)(all < 2048 ? all : 2048);
-    const int64_t nch = nchunks_of(pf);
-    const uint32_t n_chunk = (uint32_t)nblk_global_of(pf);
     int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * 4;
-    hipLaunchKernelGGL(k_apply_chunks, dim3(n_apply + n_chunk), dim3(256), 0, m->stream, m->gd, m->d_log, m->d_cnt, cur, idle,
-                       n_chunk, pf->d_global, pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->d_p2, nblk_global_of(pf),
-                       pf->d_stats);
-    m->bbox_dirty = 1;
-    pf->chunks_ready = 1;
-    pf->neff_folded = 0;
+    hipLaunchKernelGGL(k_partials_apply, dim3((uint32_t)nblk + n_apply), dim3(256), 0, m->stream, pf->d_w, pf->d_logw, pf->d_pose,
+                       pf->n, pf->offset, nblk, d_partials,
+                       pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg, m->gd, m->d_log,
+                       m->d_cnt, cur, idle);
+    pf->pending_nseg = 0;
+    gms_apply_done(m);
 }
 
 // computeLikelihoodMap on the touched tiles (GridMap.java:233-250) beside resample() (SLAM.java:133-153)
@@ -142,7 +143,7 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lik_resample<KH>),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
         hipLaunchKernelGGL(k_lik_resample<KH>, dim3((uint32_t)blocks + n_res), dim3(256), smem, m->stream, m->gd, m->d_log, \
-                           m->d_lik, m->d_fac, m->fac_stride, m->d_taps, bb, tiles_x, tiles_y, n_res, pf->d_global, \
+                           m->d_lik, m->d_fac, m->fac_stride, m->d_taps, bb, tiles_x, tiles_y, m->d_cnt, n_res, pf->d_global, \
                            pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->r01_scalar, fraction, pf->n, pf->offset,     \
                            pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats);       \
     } while (0)

@@ -258,6 +258,7 @@ int gms_map_get_size(const gms_map *m, int32_t *W, int32_t *H, int32_t *n_maps) 
 
 int gms_map_set_stream(gms_map *m, void *hip_stream) {
     REQUIRE(m, "null map");
+    gms_flush_apply(m);
     HIPCHK(hipStreamSynchronize(m->stream));
     m->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : m->own_stream;
     return GMS_OK;
@@ -272,6 +273,7 @@ int gms_map_synchronize(gms_map *m) {
 int gms_map_reset(gms_map *m) {                                        // GridMap.java:129-132
     REQUIRE(m, "null map");
     HIPCHK(hipSetDevice(m->device));
+    gms_flush_apply(m);
     HIPCHK(hipMemsetAsync(m->d_log, 0, (size_t)m->gd.cells * m->n_maps * sizeof(double), m->stream));
     m->need_full_build = 1;
     return GMS_OK;
@@ -288,11 +290,13 @@ static int map_xfer(gms_map *m, void *dev, void *host, bool to_device) {
 
 int gms_map_upload_log(gms_map *m, const double *log_data) {
     REQUIRE(m && log_data, "null argument");
+    gms_flush_apply(m);
     m->need_full_build = 1;
     return map_xfer(m, m->d_log, const_cast<double *>(log_data), true);
 }
 int gms_map_download_log(gms_map *m, double *log_data) {
     REQUIRE(m && log_data, "null argument");
+    gms_flush_apply(m);
     return map_xfer(m, m->d_log, log_data, false);
 }
 int gms_map_upload_likelihood(gms_map *m, const double *lik) {
@@ -313,6 +317,8 @@ int gms_map_copy(gms_map *dst, const gms_map *src) {                  // GridMap
     REQUIRE(dst && src, "null argument");
     REQUIRE(dst->gd.W == src->gd.W && dst->gd.H == src->gd.H && dst->n_maps == src->n_maps, "gms_map_copy: shape mismatch");
     const size_t bytes = (size_t)src->gd.cells * src->n_maps * sizeof(double);
+    gms_flush_apply(const_cast<gms_map *>(src));
+    gms_flush_apply(dst);
     HIPCHK(hipStreamSynchronize(src->stream));
     HIPCHK(hipMemcpyAsync(dst->d_log, src->d_log, bytes, hipMemcpyDeviceToDevice, dst->stream));
     HIPCHK(hipMemcpyAsync(dst->d_lik, src->d_lik, bytes, hipMemcpyDeviceToDevice, dst->stream));
@@ -364,6 +370,7 @@ int gms_map_get_raw_at(gms_map *m, int32_t mi, int32_t x, int32_t y, double *raw
     // Java would throw ArrayIndexOutOfBounds (GridMap.java:135)
     REQUIRE(mi >= 0 && mi < m->n_maps && x >= 0 && x < m->gd.W && y >= 0 && y < m->gd.H, "gms_map_get_raw_at: index out of bounds");
     HIPCHK(hipSetDevice(m->device));
+    gms_flush_apply(m);
     gms_launch_get_raw(m, mi, x, y, m->d_scratch);
     double *h = reinterpret_cast<double *>(m->h_poses + (size_t)m->n_maps * 3);
     h = reinterpret_cast<double *>(((uintptr_t)h + 7) & ~(uintptr_t)7);
@@ -916,7 +923,9 @@ int gms_pf_resample_if(gms_pf *pf, const double *r01, double fraction) {   // Gr
     return do_resample(pf, r01, fraction, nullptr, nullptr);
 }
 
-// the tail of a paired scan step: dirty-tile likelihood rebuild beside the conditional resample
+// the tail of a paired scan step: dirty-tile likelihood rebuild beside the conditional resample.  The scan's counts
+// stay un-applied (the likelihood pass adds them on the fly): the apply pass runs beside the next step's weight
+// reduction, or when anything else touches the map (gms_flush_apply).
 static int paired_likelihood_resample(gms_pf *pf, const double *r01, double fraction) {
     gms_map *m = pf->map;
     if (fraction >= 0.0) {
@@ -925,11 +934,12 @@ static int paired_likelihood_resample(gms_pf *pf, const double *r01, double frac
         std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);
         pf->have_global = 0;
         pf->stats_current = 0;
-    } else {
-        gms_launch_likelihood(m, 1);
+        m->apply_pending = 1;
+        m->bbox_dirty = 0;
+    } else {                                // no resample to pair with: the immediate protocol
+        gms_launch_apply_counts(m);
+        return finish_likelihood(m, 1);
     }
-    m->bbox_cur = 1 - m->bbox_cur;        // the box is consumed; the other half was cleared by the apply pass
-    m->bbox_dirty = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
 }
@@ -949,11 +959,10 @@ int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *de
         // The weight branch and the map branch are independent once the partials exist: they share launches
         // (gms_fused_kernels.hip).  (Two streams were measured: the event fork/join costs more than it hides.)
         pf->d_global = pf->d_global_own;
-        gms_launch_pf_partials(pf, pf->d_partials);
-        gms_launch_norm_raycast(pf, pf->d_partials, pf->d_global, true, dev_beams, B);    // :100-124 | :93
+        gms_launch_partials_apply(pf, pf->d_partials);                                    // :100-115 | previous scan's :223
+        gms_launch_norm_raycast(pf, pf->d_partials, pf->d_global, true, dev_beams, B);    // :120-124 | :93
         pf->have_global = 1;
         pf->stats_current = 1;
-        gms_launch_apply_counts(m);
         return paired_likelihood_resample(pf, r01, resample_fraction);           // :105 | GridMapApp.java:185-186
     }
     if (!rc) rc = gms_pf_normalize(pf, nullptr);                                 // :100-124
@@ -1188,19 +1197,19 @@ int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xythet
     int rc = GMS_OK;
     rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B);                 // SLAM.java:90, :99
     if (!rc && integrate && gms_can_pair_launches(pf, B) && !c->pending) {
-        // partials -> all-reduce -> [normalise | ray cast] -> all-gather -> [apply | cumulative sums] ->
+        // [partials | previous apply] -> all-reduce -> [normalise | ray cast] -> all-gather -> cumulative sums ->
         // [likelihood | resample]: the gather is in line (nothing independent is left to put beside it)
         rc = check_shard(pf, c);
         if (rc) return rc;
         const size_t np = (size_t)nblk_of(pf->n_global) * GMS_PARTIAL_STRIDE;
         PackedParticle *own_slot = pf->d_global_own + pf->offset;
-        gms_launch_pf_partials(pf, pf->d_partials);
+        gms_launch_partials_apply(pf, pf->d_partials);
         RCCLCHK(g_rccl.AllReduce(pf->d_partials, pf->d_partials, np, RCCL_FLOAT64, RCCL_SUM, c->nccl, m->stream));
         gms_launch_norm_raycast(pf, pf->d_partials, own_slot, false, dev_beams, B);
         pf->stats_current = 1;
         RCCLCHK(g_rccl.AllGather(own_slot, pf->d_global_own, (size_t)pf->n * sizeof(PackedParticle), RCCL_INT8, c->nccl, m->stream));
         pf->d_global = pf->d_global_own;
-        gms_launch_apply_chunks(pf);
+        gms_launch_pf_after_gather(pf);
         pf->have_global = 1;
         return paired_likelihood_resample(pf, r01, resample_fraction);
     }

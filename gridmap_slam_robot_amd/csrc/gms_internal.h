@@ -88,6 +88,7 @@ struct gms_map {
     int32_t score_variant;    // 0: wavefront per particle; 1: lane per particle (k_score_b); 2: cache-blocked (k_score_c, default)
     int32_t score_segments;   // k_score_b beam segments per workgroup (0 = auto)
     int32_t need_full_build;  // likelihood field must be rebuilt everywhere (upload/reset/copy)
+    int32_t apply_pending;    // the last scan's counts are not in logData yet (deferred apply pass, gms_flush_apply)
     int32_t pair_launches;    // scan steps pair independent kernels in one launch (GMS_PAIR_LAUNCHES=0 turns it off)
     gms_beam *h_beams;    // pinned staging
     float *h_poses;       // pinned staging
@@ -170,10 +171,12 @@ void gms_launch_pf_motion(gms_pf *pf, double d_center, double d_theta, uint64_t 
 void gms_launch_pf_after_gather(gms_pf *pf);
 void gms_launch_pf_chunk_sums(gms_pf *pf);
 // paired launches (gms_fused_kernels.hip)
+void gms_flush_apply(gms_map *m);
+void gms_apply_done(gms_map *m);
+void gms_launch_partials_apply(gms_pf *pf, double *d_partials);
 bool gms_can_pair_launches(const gms_pf *pf, int32_t B);
 void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local, bool own,
                              const gms_beam *d_beams, int32_t B);
-void gms_launch_apply_chunks(gms_pf *pf);
 void gms_launch_lik_resample(gms_pf *pf, double fraction);
 void gms_launch_pf_fold_neff(gms_pf *pf);
 void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride,

@@ -278,7 +278,8 @@ template <int KH>   // KH > 0: compile-time half width; KH == 0: runtime g.khalf
 __device__ __forceinline__ void
 likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
                 int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
-                int32_t tiles_x, int32_t tiles_y, uint32_t bx, uint32_t by, uint32_t gdx, unsigned char *smem) {
+                int32_t tiles_x, int32_t tiles_y, uint32_t bx, uint32_t by, uint32_t gdx, unsigned char *smem,
+                const uint32_t *__restrict__ cnt_pending = nullptr) {
     const int32_t k = KH > 0 ? KH : g.khalf;
     const int32_t ntaps = 2 * k + 1;
     const int32_t RW = LK_TW + 2 * k, RH = LK_TH + 2 * k;     // staged columns / rows
@@ -290,6 +291,9 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
 
     const int32_t mi = (int32_t)by;
     const double *mlog = logd + (size_t)mi * g.cells;
+    // cnt_pending: the scan's counts have not been added to logData yet (the apply pass runs later, beside another
+    // kernel); a staged cell is logData + its increment, the expression of apply_body (GridMap.java:223), not stored
+    const uint32_t *mcnt = cnt_pending ? cnt_pending + (size_t)mi * g.cells : nullptr;
     double *mlik = lik + (size_t)mi * g.cells;
     double *mfac = fac + (size_t)mi * fac_stride;
     // tile rectangle to process: the whole map, or the tiles that intersect the touched box dilated
@@ -327,13 +331,18 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             constexpr int32_t CRW = LK_TW + 2 * (KH > 0 ? KH : 1), CRH = LK_TH + 2 * (KH > 0 ? KH : 1);
             constexpr int32_t P1 = (CRW * CRH + 255) / 256;
             double lv[P1];
+            uint32_t cv[P1];
 #pragma unroll
             for (int q = 0; q < P1; q++) {
                 const int32_t idx = (int32_t)threadIdx.x + q * 256;
                 const int32_t r = idx / CRW, c = idx - r * CRW;
                 const int32_t gy = min(max(ty0 - KH + r, 0), g.H - 1), gx = min(max(tx0 - KH + c, 0), g.W - 1);
                 lv[q] = mlog[(size_t)gy * g.W + gx];
+                cv[q] = mcnt ? mcnt[(size_t)gy * g.W + gx] : 0u;
             }
+#pragma unroll
+            for (int q = 0; q < P1; q++)
+                if (cv[q]) lv[q] = lv[q] + ((double)(cv[q] & 0xffffu) * g.l_free + (double)(cv[q] >> 16) * g.l_occ);
 #pragma unroll
             for (int q = 0; q < P1; q++) {
                 const int32_t idx = (int32_t)threadIdx.x + q * 256;
@@ -358,7 +367,9 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 const int32_t gy = ty0 - k + r, gx = tx0 - k + c;
                 double val = 0.0;
                 if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
-                    const double v = mlog[(size_t)gy * g.W + gx];
+                    double v = mlog[(size_t)gy * g.W + gx];
+                    const uint32_t cc = mcnt ? mcnt[(size_t)gy * g.W + gx] : 0u;
+                    if (cc) v = v + ((double)(cc & 0xffffu) * g.l_free + (double)(cc >> 16) * g.l_occ);
                     const int32_t code = v > 0.0 ? 2 : (v < 0.0 ? 0 : 1);             // GridMap.java:239-244
                     val = 0.5 * (double)code;
                     seen |= 1 << code;
@@ -541,6 +552,7 @@ static void rc_launch(gms_map *m, dim3 grid, const gms_beam *d_beams, int32_t B,
 
 void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
                         int32_t pose_stride) {
+    gms_flush_apply(m);
     ProfScope ps(m, GMS_K_RAYCAST);
     int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;
     if ((int64_t)B * m->n_maps > 4096)       // batched maps: throughput-bound, 16 lanes of the phase-A wavefront busy
@@ -566,6 +578,7 @@ void gms_launch_trace_ray(gms_map *m, float x0, float y0, float x1, float y1, in
 __global__ void k_store_ray(RayIn *dst, RayIn r) { *dst = r; }
 
 void gms_launch_apply_ray(gms_map *m, RayIn ray) {
+    gms_flush_apply(m);
     // the single ray travels through the beam staging buffer
     RayIn *d_ray = reinterpret_cast<RayIn *>(m->d_beams);
     hipLaunchKernelGGL(k_store_ray, dim3(1), dim3(1), 0, m->stream, d_ray, ray);
@@ -574,16 +587,37 @@ void gms_launch_apply_ray(gms_map *m, RayIn ray) {
                         m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, nullptr, nullptr, 0, nullptr);
 }
 
-void gms_launch_apply_counts(gms_map *m) {
+// The paired scan step leaves its counts un-applied (the likelihood pass adds them on the fly) so that the apply pass
+// can run beside the next step's weight reduction.  Anything else that reads or writes logData, the counts or the box
+// first brings the map to the state the immediate protocol would have left: counts applied and cleared, the idle half
+// of the box cleared, the box consumed.
+static void apply_launch(gms_map *m) {
     ProfScope ps(m, GMS_K_APPLY);
     const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
     dim3 grid(all < 2048 ? all : 2048, m->n_maps);
     int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4;
     hipLaunchKernelGGL(k_apply, grid, dim3(256), 0, m->stream, m->gd, m->d_log, m->d_cnt, cur, idle);
+}
+void gms_apply_done(gms_map *m) {          // host bookkeeping after a deferred apply pass has been enqueued
+    m->bbox_cur = 1 - m->bbox_cur;
+    m->bbox_dirty = 0;
+    m->apply_pending = 0;
+}
+void gms_flush_apply(gms_map *m) {
+    if (!m->apply_pending) return;
+    hipSetDevice(m->device);
+    apply_launch(m);
+    gms_apply_done(m);
+}
+
+void gms_launch_apply_counts(gms_map *m) {
+    gms_flush_apply(m);
+    apply_launch(m);
     m->bbox_dirty = 1;
 }
 
 void gms_launch_likelihood(gms_map *m, int32_t dirty_only) {
+    gms_flush_apply(m);
     ProfScope ps(m, GMS_K_LIKELIHOOD);
     const int32_t k = m->gd.khalf;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
@@ -615,6 +649,8 @@ void gms_launch_factors(gms_map *m) {
 }
 
 void gms_launch_combine(gms_map *src, gms_map *dst) {
+    gms_flush_apply(src);
+    gms_flush_apply(dst);
     hipLaunchKernelGGL(k_combine, dim3(2048), dim3(256), 0, dst->stream, src->d_log, src->n_maps, src->gd.cells, dst->d_log);
 }
 

@@ -638,13 +638,13 @@ k_fold_neff(const double *__restrict__ p2_all, int64_t nblk, PfStatsDev *__restr
 
 // phase 1: this shard's block partials at their global slots; blocks of other shards are zeroed so
 // that an all-reduce(SUM) assembles the full vector exactly.  grid = (nblk_global, n_maps).
-__global__ void __launch_bounds__(256)
-k_partials(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n,
-           int64_t offset, int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part,
-           int32_t part_nseg) {
+__device__ __forceinline__ void
+partials_body(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n,
+              int64_t offset, int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part,
+              int32_t part_nseg, uint32_t bx, uint32_t by) {
     __shared__ RedLds L;
-    const int32_t mi = blockIdx.y;
-    const int64_t gb = blockIdx.x;
+    const int32_t mi = (int32_t)by;
+    const int64_t gb = bx;
     const int64_t lb = gb - offset / GMS_BLOCK;                       // block index inside the shard
     const int64_t nlb = ((int64_t)n + GMS_BLOCK - 1) / GMS_BLOCK;
     double *p = partials + ((size_t)mi * nblk_global + gb) * GMS_PARTIAL_STRIDE;
@@ -658,6 +658,13 @@ k_partials(double *__restrict__ w, double *__restrict__ logw, const float *__res
                    part_nseg, lb * GMS_BLOCK);
     if (threadIdx.x == 0)
         for (int k = 0; k < GMS_PARTIAL_STRIDE; k++) p[k] = out[k];
+}
+
+__global__ void __launch_bounds__(256)
+k_partials(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n,
+           int64_t offset, int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part,
+           int32_t part_nseg) {
+    partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y);
 }
 
 // Level 0 of the cumulative weights: one wavefront = one 64-particle chunk, lane = particle, inclusive scan by

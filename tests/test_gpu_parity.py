@@ -590,3 +590,70 @@ def test_rccl_step_inside_library_equals_standalone_step():
     comm.close()
     for pf in pfs:
         pf.close()
+
+
+def test_paired_steps_back_to_back_equal_the_separate_calls():
+    """The fused scan step pairs independent kernels in single launches and defers the apply pass of scan t into scan
+    t+1's weight reduction (the likelihood pass adds the counts on the fly).  Many steps back to back, with nothing
+    touching the map in between, then map accessors and un-paired updates interleaved: always the same bits as the
+    separate entry points."""
+    import torch
+    dev = torch.device("cuda", 0)
+    tr = synth.make_trace(8.0, 0.05, 240, T=24, seed=9)
+    N = 2048
+    a = GridMap(8.0, 8.0, 0.05, (-4.0, -4.0)); b = GridMap(8.0, 8.0, 0.05, (-4.0, -4.0))
+    for m in (a, b):
+        for t in range(3):
+            m.update(tr.scans[t], tr.poses[t])
+    pa, pb = ParticleFilter(a, N), ParticleFilter(b, N)
+    rng = np.random.default_rng(3)
+
+    def inputs(t):
+        P = torch.from_numpy(synth.make_particles(tr.poses[t], N, seed=100 + t, sigma_xy=0.04, sigma_theta_deg=2.0)).to(dev)
+        beams = torch.from_numpy(tr.scans[t].view(np.uint8).copy()).to(dev)
+        return P, beams, len(tr.scans[t]), float(rng.random())
+
+    def separate(P, beams, B, r01, frac):
+        pb.set_poses_dev(P.data_ptr()); pb.score_dev(beams.data_ptr(), B); pb.normalize(fetch=False)
+        pb.resample_if(r01, frac); b.update_at_dev(beams.data_ptr(), B, pb)
+
+    def same():
+        assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights())
+        assert np.array_equal(a.download_likelihood(), b.download_likelihood())
+        assert np.array_equal(a.download_log(), b.download_log())
+
+    keep = []
+    for t in range(3, 12):                                     # nine paired steps, nothing in between
+        P, beams, B, r01 = inputs(t)
+        keep.append((P, beams))
+        pa.slam_update_dev(P.data_ptr(), beams.data_ptr(), B, r01, 0.9, True)
+        separate(P, beams, B, r01, 0.9)
+    same()
+    for t in range(12, 18):                                    # accessors and un-paired updates between paired steps
+        P, beams, B, r01 = inputs(t)
+        keep.append((P, beams))
+        pa.slam_update_dev(P.data_ptr(), beams.data_ptr(), B, r01, 0.9, True)
+        separate(P, beams, B, r01, 0.9)
+        if t % 3 == 0:
+            x, y = 80 + t, 80
+            assert a.get_raw_at(x, y) == b.get_raw_at(x, y)
+        elif t % 3 == 1:
+            a.update(tr.scans[t], tr.poses[t]); b.update(tr.scans[t], tr.poses[t])
+        else:
+            a.integrate_observation(tr.scans[t], tr.poses[t]); b.integrate_observation(tr.scans[t], tr.poses[t])      # no likelihood rebuild
+    a.compute_likelihood_map(); b.compute_likelihood_map()
+    same()
+    # a step without the map update, one without the resample, and a reset while an apply pass is pending
+    P, beams, B, r01 = inputs(18)
+    pa.slam_update_dev(P.data_ptr(), beams.data_ptr(), B, r01, 0.9, True); separate(P, beams, B, r01, 0.9)
+    pa.slam_update_dev(P.data_ptr(), beams.data_ptr(), B, r01, 0.9, False)
+    pb.set_poses_dev(P.data_ptr()); pb.score_dev(beams.data_ptr(), B); pb.normalize(fetch=False); pb.resample_if(r01, 0.9)
+    same()
+    pa.slam_update_dev(P.data_ptr(), beams.data_ptr(), B, r01, 0.9, True); separate(P, beams, B, r01, 0.9)
+    a.reset(); b.reset()
+    assert not a.download_log().any() and not b.download_log().any()
+    pa.slam_update_dev(P.data_ptr(), beams.data_ptr(), B, r01, 0.9, True); separate(P, beams, B, r01, 0.9)
+    same()
+    full = GridMap(8.0, 8.0, 0.05, (-4.0, -4.0))
+    full.upload_log(a.download_log()); full.compute_likelihood_map()
+    assert np.array_equal(full.download_likelihood(), a.download_likelihood())    # dirty-tile rebuilds == a full rebuild
