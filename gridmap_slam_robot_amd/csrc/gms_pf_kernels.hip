@@ -790,7 +790,7 @@ __global__ void k_pack(const double *__restrict__ w, const float *__restrict__ p
 // resampling.  Cumulative weights, fixed shape (depends on n_global only, so every rank of a sharded
 // filter computes the same values):
 //   level 0  chunk of SCAN_CHUNK = 64 weights: one wavefront's inclusive shuffle scan (block_chunk_scan);
-//   level 1  super-chunk of 64 chunks: one lane adds the chunk totals in order;
+//   level 1  super-chunk of 64 chunks: one wavefront's shuffle scan of the chunk totals;
 //   level 2  one lane adds the super-chunk totals in order.
 // offset[c] = level2[c / 64] + level1[c]; cumulative weight of particle i = offset[i / 64] + cum[i].
 // Levels 1 and 2 are a few hundred additions: every workgroup of k_resample redoes them in LDS.
@@ -815,16 +815,20 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
         const double *tot = chunk_off + (size_t)mi * (nchunks + 1);
         for (int64_t c = threadIdx.x; c < nchunks; c += blockDim.x) off[c] = tot[c];
         __syncthreads();
-        for (int64_t sidx = threadIdx.x; sidx < nsuper; sidx += blockDim.x) {     // level 1
-            double a1 = 0.0;
-            const int64_t c0 = sidx * 64, c1 = c0 + 64 < nchunks ? c0 + 64 : nchunks;
-#pragma unroll 8
-            for (int64_t c = c0; c < c1; c++) {
-                const double v = off[c];
-                off[c] = a1;
-                a1 = (c == c0) ? v : a1 + v;
+        // level 1: one wavefront per super-chunk of 64 chunk totals, exclusive scan by shuffles (a fixed shape)
+        for (int64_t sidx = threadIdx.x >> 6; sidx < nsuper; sidx += blockDim.x >> 6) {
+            const int32_t lane = threadIdx.x & 63;
+            const int64_t c = sidx * 64 + lane;
+            const double v = c < nchunks ? off[c] : 0.0;
+            double inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double up = __shfl_up(inc, o, GMS_WAVE);
+                if (lane >= o) inc += up;
             }
-            sup[sidx] = a1;
+            const double excl = __shfl_up(inc, 1, GMS_WAVE);
+            if (c < nchunks) off[c] = lane == 0 ? 0.0 : excl;
+            if (lane == 63) sup[sidx] = inc;
         }
         __syncthreads();
         if (threadIdx.x == 0) {                                                   // level 2
