@@ -286,7 +286,9 @@ def main() -> int:
         "filter": {"neff": st["neff"], "n_zero_weights": st["n_zero"], "weight_sum": st["weight_sum"]},
         "roofline": {
             "kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dominant),
+            "frac": achieved / HBM_PEAK_GBS,
+            # the committed PMC passes are of the default configuration: no figure for other modes
+            "traffic": pmc_traffic(dominant) if (args.config == "C3" and not args.full_rebuild and not args.particles) else None,
             "algorithmic_bytes_per_launch": alg / per_launch_scale,
             "avg_launch_us": dom_avg_s * 1e6 / per_launch_scale, "launches_timed": dom_n,
         },

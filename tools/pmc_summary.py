@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 PMC passes per kernel and writes profiles/<round>/pmc_traffic.json.
+
+Usage: pmc_summary.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <out dir> [prefix]
+Each input dir holds a `*_counter_collection.csv` of `rocprofv3 --kernel-trace --pmc <COUNTER> -- python3 bench.py ...`
+(separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes).  FETCH_SIZE / WRITE_SIZE are in KB;
+FETCH_SIZE is doubled for gfx950 (128-byte requests are tallied at 64 B).  Kernel classes are bench.py's."""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+CLASS_OF = [("k_score_c", "score"), ("k_score_b", "score"), ("k_score(", "score"), ("k_norm_raycast", "raycast"),
+            ("k_raycast<false", "raycast"), ("k_lik_resample", "likelihood"), ("k_likelihood", "likelihood"),
+            ("k_partials_apply", "reduce"), ("k_partials", "reduce"), ("k_normalize_pack", "reduce"), ("k_apply", "apply"),
+            ("k_chunk_sums", "resample"), ("k_resample", "resample"), ("k_pose_trig", "pose_trig")]
+
+
+def per_kernel(d):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+        acc[name].append(float(r["Counter_Value"]))
+    return {k: (len(v), sum(v) / len(v), min(v), max(v)) for k, v in acc.items()}
+
+
+def main():
+    fetch, write, out = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
+    prefix = sys.argv[4] if len(sys.argv) > 4 else "pmc"
+    os.makedirs(out, exist_ok=True)
+    for tag, d in (("fetch_size", fetch), ("write_size", write)):
+        with open(os.path.join(out, f"{prefix}_{tag}_per_kernel.csv"), "w") as fh:
+            fh.write("kernel,dispatches,mean_counter_kb,min,max\n")
+            for k, (n, mean, lo, hi) in d.items():
+                fh.write(f'"{k}",{n},{mean:.1f},{lo:.1f},{hi:.1f}\n')
+    classes = {}
+    for name in set(fetch) | set(write):
+        cls = next((c for pat, c in CLASS_OF if name.startswith(pat.rstrip("("))), None)
+        if cls is None or name.startswith("k_raycast<true"):
+            continue
+        n = max(fetch.get(name, (0,))[0], write.get(name, (0,))[0])
+        classes.setdefault(cls, []).append((n, name))
+    for cls, members in classes.items():
+        top = max(n for n, _ in members)
+        e = {"kernels": {}, "fetch_size_kb_raw": 0.0, "write_size_kb": 0.0}
+        for n, name in members:
+            if 2 * n < top:                  # a kernel of the class that ran only during set-up
+                continue
+            fk, wk = fetch.get(name, (0, 0.0))[1], write.get(name, (0, 0.0))[1]
+            e["kernels"][name] = {"fetch_kb": round(fk, 1), "write_kb": round(wk, 1), "dispatches": n}
+            e["fetch_size_kb_raw"] += fk
+            e["write_size_kb"] += wk
+        classes[cls] = e
+    res = {}
+    for cls, e in classes.items():
+        res[cls] = {"kernels": e["kernels"], "fetch_size_kb_raw": round(e["fetch_size_kb_raw"], 1),
+                    "write_size_kb": round(e["write_size_kb"], 1),
+                    "hbm_bytes_per_launch": int((2.0 * e["fetch_size_kb_raw"] + e["write_size_kb"]) * 1024)}
+    res["_note"] = ("per scan step and kernel class, C3 bench; separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes with "
+                    "--kernel-trace only; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM (gfx950 tallies 128-B requests at "
+                    "64 B for wide reads; for the 8-byte gathers of k_score_c the factor is uncalibrated, so its read side is an "
+                    "upper bound); Infinity-Cache hits are counted, not excluded.  Paired launches are booked under the class "
+                    "bench.py books them under (k_norm_raycast: raycast, k_lik_resample: likelihood, k_partials_apply: reduce).")
+    json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    for cls, e in res.items():
+        if not cls.startswith("_"):
+            print(cls, e["hbm_bytes_per_launch"], list(e["kernels"]))
+
+
+if __name__ == "__main__":
+    main()
