@@ -119,6 +119,7 @@ def load() -> C.CDLL:
     sig("gms_map_download_likelihood", C.c_int, vp, vp)
     sig("gms_map_copy", C.c_int, vp, vp)
     sig("gms_map_get_raw_at", C.c_int, vp, i32, i32, i32, vp, vp)
+    sig("gms_map_get_at_point", C.c_int, vp, i32, C.c_float, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_double))
     sig("gms_map_combine", C.c_int, vp, vp)
     sig("gms_map_deskew", C.c_int, vp, vp, vp, vp, i32, f64, f64, vp, vp)
     sig("gms_map_integrate", C.c_int, vp, vp, i32, vp)

@@ -381,6 +381,36 @@ int gms_map_get_raw_at(gms_map *m, int32_t mi, int32_t x, int32_t y, double *raw
     return GMS_OK;
 }
 
+// Java (int) of a float (Float.intValue(): saturating, NaN -> 0)
+static int32_t j_f2i_host(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)f;
+}
+
+int gms_map_get_at_point(gms_map *m, int32_t mi, float point_x, float point_y, double *raw, double *likelihood) {
+    REQUIRE(m, "null map");
+    REQUIRE(mi >= 0 && mi < m->n_maps, "gms_map_get_at_point: map index out of range");
+    // tmp = point; tmp -= position; tmp /= resolution  (float Vec2 arithmetic, GridMap.java:143-145)
+    const float tx = (point_x - m->prm.pos_x) / m->prm.resolution, ty = (point_y - m->prm.pos_y) / m->prm.resolution;
+    const int32_t ix = j_f2i_host(tx), iy = j_f2i_host(ty);
+    const int32_t idx = (int32_t)((uint32_t)ix + (uint32_t)iy * (uint32_t)m->gd.W);       // Java int arithmetic wraps
+    if (idx < 0 || (int64_t)idx >= m->gd.cells)
+        return fail(GMS_ERR_INVALID, "gms_map_get_at_point: index %d out of bounds (Java: ArrayIndexOutOfBoundsException)", idx);
+    HIPCHK(hipSetDevice(m->device));
+    gms_flush_apply(m);
+    double *h = reinterpret_cast<double *>(m->h_poses + (size_t)m->n_maps * 3);
+    h = reinterpret_cast<double *>(((uintptr_t)h + 7) & ~(uintptr_t)7);
+    const size_t o = (size_t)mi * m->gd.cells + idx;
+    HIPCHK(hipMemcpyAsync(h, m->d_log + o, sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(h + 1, m->d_lik + o, sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (raw) *raw = h[0];
+    if (likelihood) *likelihood = h[1];
+    return GMS_OK;
+}
+
 // beams [n_maps][B] (host) -> d_beams [n_maps][max_beams]
 static int stage_beams(gms_map *m, const gms_beam *beams, int32_t B) {
     REQUIRE(beams, "null beams");

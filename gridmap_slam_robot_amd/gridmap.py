@@ -202,6 +202,20 @@ class GridMap:
         return prob.value
 
     # -- the hot path -----------------------------------------------------------------------------
+    def get_raw_at_point(self, point, mi: int = 0) -> float:
+        """getRawAt(map, Vec2 point) (GridMap.java:142-148)."""
+        raw = C.c_double()
+        check(load().gms_map_get_at_point(self._h, mi, float(point[0]), float(point[1]), C.byref(raw), None))
+        return raw.value
+
+    def get_likelihood(self, point, mi: int = 0) -> float:
+        """getLikelihood(map, Vec2 point) (GridMap.java:150-156)."""
+        lik = C.c_double()
+        check(load().gms_map_get_at_point(self._h, mi, float(point[0]), float(point[1]), None, C.byref(lik)))
+        return lik.value
+
+    getLikelihood = get_likelihood
+
     def _beam_args(self, obs):
         b = _beams_of(obs)
         if self.n_maps > 1:

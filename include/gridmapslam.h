@@ -142,6 +142,11 @@ int gms_map_deskew(gms_map *m, const double *angle, const double *distance, cons
                    double d_center, double d_theta, gms_beam *beams_out, const gms_beam **dev_beams_out);
 /* getRawAt(map,x,y) / getProbAt (GridMap.java:134-140) for map index mi. */
 int gms_map_get_raw_at(gms_map *m, int32_t mi, int32_t x, int32_t y, double *raw, double *prob);
+/* getRawAt(map, Vec2 point) / getLikelihood(map, Vec2 point) (GridMap.java:142-156): the world point goes through
+ * the reference's float arithmetic, (point - position) / resolution, intValue(), index x + y*W -- only the flat
+ * index is range-checked there (ArrayIndexOutOfBounds -> GMS_ERR_INVALID here), so an x beyond the row reads the
+ * neighbouring row exactly as the Java does.  raw / likelihood may be NULL. */
+int gms_map_get_at_point(gms_map *m, int32_t mi, float point_x, float point_y, double *raw, double *likelihood);
 
 /* GridMap.integrateObservation(map, obs, pose) (GridMap.java:173-191): beams[n_maps][B],
  * poses[n_maps][3] = x,y,theta. */

@@ -99,6 +99,8 @@ public:
     void reset() { check(gms_map_reset(h_)); }                                               // :129-132
     double getRawAt(int x, int y) { double v; check(gms_map_get_raw_at(h_, 0, x, y, &v, nullptr)); return v; }   // :134
     double getProbAt(int x, int y) { double v; check(gms_map_get_raw_at(h_, 0, x, y, nullptr, &v)); return v; }  // :138
+    double getRawAt(float px, float py) { double v; check(gms_map_get_at_point(h_, 0, px, py, &v, nullptr)); return v; }      // :142 (Vec2 point)
+    double getLikelihood(float px, float py) { double v; check(gms_map_get_at_point(h_, 0, px, py, nullptr, &v)); return v; } // :150
     bool pointInMap(float px, float py) const {                                              // :164-170
         const float tx = (px - params_.pos_x) / params_.resolution, ty = (py - params_.pos_y) / params_.resolution;
         return !(tx < 0 || ty < 0 || tx >= (float)w_ || ty >= (float)hgt_);

@@ -488,3 +488,16 @@ void orc_deskew(const double *angle, const double *distance, const uint8_t *hit,
         out[i].hit = hit[i] ? 1 : 0;
     }
 }
+
+/* J/slam/GridMap.java:142-156 */
+static int32_t j_f2i(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)f;
+}
+int32_t orc_point_index(const orc_grid *g, float px, float py) {
+    const float tx = (px - g->pos_x) / g->resolution;      /* tmp.minusAssign(position); tmp.divAssign(resolution) */
+    const float ty = (py - g->pos_y) / g->resolution;
+    return (int32_t)((uint32_t)j_f2i(tx) + (uint32_t)j_f2i(ty) * (uint32_t)g->W);
+}

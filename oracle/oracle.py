@@ -106,6 +106,8 @@ def lib() -> C.CDLL:
         L.orc_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_philox_normals.restype = None
         L.orc_philox_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, dp, dp]
+        L.orc_point_index.restype = C.c_int32
+        L.orc_point_index.argtypes = [C.POINTER(OrcGrid), C.c_float, C.c_float]
         L.orc_pose_trig.restype = None
         L.orc_pose_trig.argtypes = [C.c_float, dp, dp]
         _lib = L
@@ -154,6 +156,10 @@ class Grid:
     @property
     def kernel(self) -> np.ndarray:
         return np.array(self.g.kernel[: self.g.ktaps], dtype=np.float64)
+
+    def point_index(self, px: float, py: float) -> int:
+        """flat index of getRawAt(map, Vec2) / getLikelihood(map, Vec2) (GridMap.java:142-156)"""
+        return int(lib().orc_point_index(C.byref(self.g), np.float32(px), np.float32(py)))
 
     def set_kernel(self, taps):
         taps = np.asarray(taps, dtype=np.float64)

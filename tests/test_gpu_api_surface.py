@@ -38,6 +38,14 @@ def test_create_map_data_copy_get_raw_prob_and_geometry():
     assert e.value.code == _lib.GMS_ERR_INVALID
     assert m.point_in_map((0.0, 0.0)) and not m.point_in_map((3.3, 0.0)) and not m.point_in_map((-3.21, 0.0))
     assert m.getWorldSize() == (float(np.float32(128) * np.float32(0.05)),) * 2
+    lik = m.download_likelihood()
+    for pt in [(0.0, 0.0), (1.234, -2.345), (-3.21, 0.1), (3.3, 0.0), (-1.0, 2.5)]:              # getRawAt / getLikelihood (Vec2)
+        idx = g.point_index(*pt)
+        assert m.get_raw_at_point(pt) == got.reshape(-1)[idx]                                   # (:142-148)
+        assert m.get_likelihood(pt) == lik.reshape(-1)[idx]                                     # (:150-156)
+    with pytest.raises(GmsError) as e:                           # flat index out of the array: Java throws
+        m.get_likelihood((0.0, -3.3))
+    assert e.value.code == _lib.GMS_ERR_INVALID
     m.reset()                                                    # reset (:129-132): logData only
     assert not m.download_log().any() and m.download_likelihood().any()
 

@@ -170,3 +170,20 @@ def test_trace_format_matches_dataoutputstream_layout(tmp_path):
         + struct.pack(">ddb", 0.1, 3.0, 1) + struct.pack(">ddb", 0.2, 10.0, 0)
     g = read_trace(p)[0]
     assert (g.time_stamp, g.d_center, g.d_theta) == (1.5, 0.25, -0.5) and g.hit.tolist() == [1, 0]
+
+
+def test_point_index_follows_the_float_vec2_arithmetic():
+    """getRawAt(map, Vec2) / getLikelihood(map, Vec2) (GridMap.java:142-156): (point - position) / resolution in float,
+    Float.intValue() (truncation toward zero, saturating), x + y*W -- only the flat index is range-checked."""
+    g = orc.Grid(6.4, 6.4, 0.05, -3.2, -3.2)
+    W = g.W
+    f = np.float32
+    for px, py in [(0.0, 0.0), (-3.2, -3.2), (3.19, 3.19), (1.234, -2.345), (-3.21, 0.0), (0.0, -3.26), (3.3, 0.0)]:
+        tx = (f(px) - f(-3.2)) / f(0.05)
+        ty = (f(py) - f(-3.2)) / f(0.05)
+        want = int(np.trunc(tx)) + int(np.trunc(ty)) * W
+        assert g.point_index(px, py) == want
+    assert g.point_index(-3.21, 0.0) == 64 * W          # x in (-1, 0) truncates to column 0: inside, as in Java
+    assert g.point_index(3.3, 0.0) == 64 * W + 130      # beyond the row end: the flat index is still valid
+    assert g.point_index(0.0, -3.26) < 0                # one row below the map: Java throws
+    assert g.point_index(float("nan"), 0.0) == 64 * W   # Float.intValue() of NaN is 0
