@@ -144,7 +144,20 @@ def main() -> int:
         pf = ops.pf
         # default: both exchanges enqueued by the library on its own RCCL communicator (one C-ABI call per scan);
         # --torch-collectives routes them through torch.distributed instead
-        comm = None if args.torch_collectives else RcclComm(local_rank)
+        comm = None
+        if not args.torch_collectives:
+            ok = 1
+            try:
+                comm = RcclComm(local_rank)
+            except Exception as e:            # keep the run alive: the torch.distributed exchange does the same job
+                print(f"bench.py: in-library RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+                ok = 0
+            if world > 1:                     # every rank must take the same path
+                t_ok = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+                if int(t_ok.item()) == 0 and comm is not None:
+                    comm.close()
+                    comm = None
     else:
         pf = ParticleFilter(m, n_local)
         spf = comm = None
