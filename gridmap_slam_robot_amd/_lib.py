@@ -169,6 +169,9 @@ def load() -> C.CDLL:
     sig("gms_pf_normalize_sharded_begin", C.c_int, vp, vp)
     sig("gms_pf_normalize_sharded_end", C.c_int, vp, vp)
     sig("gms_slam_update_sharded_dev", C.c_int, vp, vp, vp, vp, i32, vp, f64, i32)
+    sig("gms_slam_update_sharded_begin_dev", C.c_int, vp, vp, vp, i32)
+    sig("gms_pf_gather_buffers", C.c_int, vp, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(vp), C.POINTER(C.c_int64))
+    sig("gms_slam_update_sharded_end_dev", C.c_int, vp, vp, i32, vp, f64, i32)
     sig("gms_profile_enable", C.c_int, vp, i32)
     sig("gms_profile_reset", C.c_int, vp)
     sig("gms_profile_get", C.c_int, vp, i32, vp, vp)

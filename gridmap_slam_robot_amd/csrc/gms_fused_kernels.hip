@@ -56,6 +56,54 @@ k_partials_apply(double *__restrict__ w, double *__restrict__ logw, const float 
     else apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - (uint32_t)nblk_global, 0, gridDim.x - (uint32_t)nblk_global);
 }
 
+// ---- sharded filters, one all-gather per scan (gms_slam_update_sharded_*) ---------------------------------------
+// B': this shard's block partials and the raw pack of its particles (the two all-gather payloads)  |  previous apply
+__global__ void __launch_bounds__(256)
+k_partials_pack_apply(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n, int64_t offset,
+                      int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part, int32_t part_nseg,
+                      PackedParticle *__restrict__ packed_local, uint32_t n_local_blocks,
+                      GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
+                      int32_t *__restrict__ bbox_idle) {
+    if (blockIdx.x < n_local_blocks) {
+        partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, (uint32_t)(offset / GMS_BLOCK) + blockIdx.x, 0);
+        pack_raw_block(w, pose, n, blockIdx.x, packed_local);         // each thread re-reads the weight it stored itself
+    } else {
+        apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - n_local_blocks, 0, gridDim.x - n_local_blocks);
+    }
+}
+
+// A': ray cast at the weighted pose  |  normalise this shard's weights + statistics  |  level 0 of the cumulative
+// normalised weights of the gathered raw population.  All three only need the gathered partial vector.
+__global__ void __launch_bounds__(256)
+k_raycast_norm_chunks(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox,
+                      int32_t nw_max, uint32_t n_ray_blocks, uint32_t n_norm_blocks,
+                      const double *__restrict__ partials, int64_t nblk_global, double *__restrict__ w, const float *__restrict__ pose,
+                      int32_t n, int64_t offset, const PackedParticle *__restrict__ glob_raw, int64_t n_global, int64_t nchunks,
+                      double *__restrict__ cum, double *__restrict__ chunk_tot, double *__restrict__ p2,
+                      PfStatsDev *__restrict__ stats) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x < n_ray_blocks) {
+        __shared__ RedLds L;
+        __shared__ float s_pose[3];
+        const double sum = fold_sum(partials, nblk_global, COL_SUM, L.a);
+        const double xw = fold_sum(partials, nblk_global, COL_XW, L.a), yw = fold_sum(partials, nblk_global, COL_YW, L.a),
+                     tw = fold_sum(partials, nblk_global, COL_TW, L.a);
+        if (threadIdx.x == 0) {
+            s_pose[0] = (float)(xw / sum);                             // SLAM.java:176
+            s_pose[1] = (float)(yw / sum);
+            s_pose[2] = (float)(tw / sum);
+        }
+        __syncthreads();
+        raycast_body<false, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,
+                               smem, s_pose);
+    } else if (blockIdx.x < n_ray_blocks + n_norm_blocks) {
+        normalize_own_body(partials, nblk_global, w, pose, n, offset, glob_raw, stats, blockIdx.x - n_ray_blocks);
+    } else {
+        chunk_sums_raw_body(glob_raw, n_global, nchunks, cum, chunk_tot, p2, nblk_global, partials,
+                            blockIdx.x - n_ray_blocks - n_norm_blocks);
+    }
+}
+
 // ---- C: likelihood rebuild (dirty tiles)  |  resample ---------------------------------------------------------
 template <int KH>
 __global__ void __launch_bounds__(256)
@@ -65,11 +113,11 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
                const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nchunks, const double *__restrict__ cum,
                const double *__restrict__ chunk_off, double r01, double fraction, int32_t n, int64_t offset,
                float *__restrict__ pose2, float *__restrict__ cs2, double *__restrict__ w2, int32_t *__restrict__ idx_out,
-               const double *__restrict__ p2, int64_t nblk_global, PfStatsDev *__restrict__ stats) {
+               const double *__restrict__ p2, int64_t nblk_global, PfStatsDev *__restrict__ stats, int32_t raw_weights) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (blockIdx.x < n_res_blocks)                      // a multiple of 8 keeps the likelihood tiles' XCD round-robin aligned
         resample_body(glob, n_global, nchunks, cum, chunk_off, nullptr, r01, fraction, n, offset, pose2, cs2, w2, idx_out, p2,
-                      nblk_global, stats, blockIdx.x, 0, smem);
+                      nblk_global, stats, blockIdx.x, 0, smem, raw_weights != 0);
     else
         likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, 1, tiles_x, tiles_y, blockIdx.x - n_res_blocks, 0,
                             gridDim.x - n_res_blocks, smem, cnt_pending);
@@ -145,11 +193,53 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
         hipLaunchKernelGGL(k_lik_resample<KH>, dim3((uint32_t)blocks + n_res), dim3(256), smem, m->stream, m->gd, m->d_log, \
                            m->d_lik, m->d_fac, m->fac_stride, m->d_taps, bb, tiles_x, tiles_y, m->d_cnt, n_res, pf->d_global, \
                            pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->r01_scalar, fraction, pf->n, pf->offset,     \
-                           pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats);       \
+                           pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats,       \
+                           pf->global_raw);                                                                              \
     } while (0)
     if (k == 3) LR_LAUNCH(3);
     else if (k == 5) LR_LAUNCH(5);
     else LR_LAUNCH(0);
 #undef LR_LAUNCH
     pf->neff_folded = 1;
+}
+
+// ---- sharded filters, one all-gather per scan ----------------------------------------------------------------------
+// this shard's partials at their global slots of d_partials and its raw pack at its slot of d_global_own (the payloads
+// of the two all-gathers, both in place), beside the apply pass a previous paired step left pending
+void gms_launch_partials_pack_apply(gms_pf *pf) {
+    gms_map *m = pf->map;
+    ProfScope ps(m, GMS_K_REDUCE);
+    const uint32_t n_local = (uint32_t)((pf->n + GMS_BLOCK - 1) / GMS_BLOCK);
+    uint32_t n_apply = 0;
+    if (m->apply_pending) {
+        const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
+        n_apply = (uint32_t)(all < 2048 ? all : 2048);
+    }
+    int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * 4;
+    hipLaunchKernelGGL(k_partials_pack_apply, dim3(n_local + n_apply), dim3(256), 0, m->stream, pf->d_w, pf->d_logw, pf->d_pose,
+                       pf->n, pf->offset, nblk_global_of(pf), pf->d_partials,
+                       pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg,
+                       pf->d_global_own + pf->offset, n_local, m->gd, m->d_log, m->d_cnt, cur, idle);
+    pf->pending_nseg = 0;
+    if (n_apply) gms_apply_done(m);
+}
+
+// after the gathers: ray cast (optional) | normalise own + statistics | cumulative sums of the gathered raw population
+void gms_launch_raycast_norm_chunks(gms_pf *pf, const gms_beam *d_beams, int32_t B, bool raycast) {
+    gms_map *m = pf->map;
+    ProfScope ps(m, GMS_K_RAYCAST);
+    pf->d_global = pf->d_global_own;
+    pf->global_raw = 1;
+    const uint32_t n_ray = raycast ? (uint32_t)((B + 3) / 4) : 0u, n_norm = (uint32_t)((pf->n + 255) / 256);
+    const uint32_t n_chunk = (uint32_t)nblk_global_of(pf);
+    const size_t smem = rc_smem(m, 4);
+    int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * 4;
+    if (smem > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast_norm_chunks), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem);
+    hipLaunchKernelGGL(k_raycast_norm_chunks, dim3(n_ray + n_norm + n_chunk), dim3(256), smem, m->stream, m->gd, d_beams, B, m->d_cnt,
+                       bb, rc_nw_max(m), n_ray, n_norm, pf->d_partials, nblk_global_of(pf), pf->d_w, pf->d_pose, pf->n, pf->offset,
+                       pf->d_global_own, pf->n_global, nchunks_of(pf), pf->d_cum, pf->d_chunk_tot, pf->d_p2, pf->d_stats);
+    pf->chunks_ready = 1;
+    pf->neff_folded = 0;
 }

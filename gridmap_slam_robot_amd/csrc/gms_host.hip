@@ -1082,6 +1082,8 @@ static struct {
     int (*CommDestroy)(void *);
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t);
+    int (*GroupStart)();
+    int (*GroupEnd)();
     const char *(*GetErrorString)(int);
 } g_rccl;
 
@@ -1108,8 +1110,11 @@ int gms_comm_load(const char *librccl_path) {
     *(void **)&g_rccl.CommDestroy = dlsym(dl, "ncclCommDestroy");
     *(void **)&g_rccl.AllReduce = dlsym(dl, "ncclAllReduce");
     *(void **)&g_rccl.AllGather = dlsym(dl, "ncclAllGather");
+    *(void **)&g_rccl.GroupStart = dlsym(dl, "ncclGroupStart");
+    *(void **)&g_rccl.GroupEnd = dlsym(dl, "ncclGroupEnd");
     *(void **)&g_rccl.GetErrorString = dlsym(dl, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.AllGather)
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.AllGather ||
+        !g_rccl.GroupStart || !g_rccl.GroupEnd)
         return fail(GMS_ERR_STATE, "RCCL library lacks the collective entry points");
     g_rccl.dl = dl;
     return GMS_OK;
@@ -1219,35 +1224,81 @@ int gms_pf_normalize_sharded_end(gms_pf *pf, gms_comm *c) {
     return GMS_OK;
 }
 
-// One scan step of a sharded filter, collectives included: what gms_slam_update_dev is for a stand-alone one.
+// ---- sharded scan step with ONE exchange ------------------------------------------------------------------------
+// The ranks exchange RAW weights: each rank's block partials and its raw pack {w, x, y, theta} are both all-gather
+// payloads (the gathered partial vector is what the all-reduce used to assemble), so they travel in one grouped
+// launch, and everything after it is local: fold, normalise own, cumulative sums of the normalised global weights
+// (the owner's division, w / weightSum, repeated on the gathered copy: same operands, same bits), ray cast, resample.
+static int sharded_shape_ok(const gms_pf *pf) {
+    if (pf->n_maps != 1) return fail(GMS_ERR_STATE, "sharded filters hold one map per handle");
+    if (pf->n_global != pf->n && pf->n % GMS_BLOCK)
+        return fail(GMS_ERR_INVALID, "shard size %d must be a multiple of GMS_BLOCK=%d", pf->n, GMS_BLOCK);
+    if (pf->n_global % pf->n || pf->offset % pf->n)
+        return fail(GMS_ERR_INVALID, "equal shards in rank order are required (n_local %d, offset %lld, n_global %lld)", pf->n,
+                    (long long)pf->offset, (long long)pf->n_global);
+    return GMS_OK;
+}
+
+// poses := dev_xytheta (may be NULL), weights, this shard's block partials and raw pack in their slots of the
+// gather buffers (gms_pf_gather_buffers)
+int gms_slam_update_sharded_begin_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B) {
+    REQUIRE(pf && dev_beams, "null argument");
+    int rc = sharded_shape_ok(pf);
+    if (rc) return rc;
+    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B);                 // SLAM.java:90, :99
+    if (rc) return rc;
+    gms_launch_partials_pack_apply(pf);                                          // :100-115 | previous scan's GridMap.java:223
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_pf_gather_buffers(gms_pf *pf, void **dev_packed_global, int64_t *packed_bytes_per_rank, double **dev_partials_global,
+                          int64_t *partials_doubles_per_rank) {
+    REQUIRE(pf, "null filter");
+    if (dev_packed_global) *dev_packed_global = pf->d_global_own;
+    if (packed_bytes_per_rank) *packed_bytes_per_rank = (int64_t)pf->n * (int64_t)sizeof(PackedParticle);
+    if (dev_partials_global) *dev_partials_global = pf->d_partials;
+    if (partials_doubles_per_rank) *partials_doubles_per_rank = nblk_of(pf->n) * GMS_PARTIAL_STRIDE;
+    return GMS_OK;
+}
+
+// after both buffers have been all-gathered in place: statistics, normalisation, map update, conditional resample
+int gms_slam_update_sharded_end_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B, const double *r01,
+                                    double resample_fraction, int32_t integrate) {
+    REQUIRE(pf && dev_beams && r01, "null argument");
+    gms_map *m = pf->map;
+    int rc = sharded_shape_ok(pf);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(m->device));
+    const bool pair = integrate && gms_can_pair_launches(pf, B);
+    gms_launch_raycast_norm_chunks(pf, dev_beams, B, pair);                      // :93 | :120-124 | level 0 of :140-149
+    pf->have_global = 1;
+    pf->stats_current = 1;
+    HIPCHK(hipGetLastError());
+    if (pair) return paired_likelihood_resample(pf, r01, resample_fraction);     // :105 | GridMapApp.java:185-186
+    if (integrate) rc = gms_map_update_at_dev(m, dev_beams, B, pf, 0);
+    if (!rc && resample_fraction >= 0.0) rc = gms_pf_resample_if(pf, r01, resample_fraction);
+    return rc;
+}
+
+// One scan step of a sharded filter, the exchange included: what gms_slam_update_dev is for a stand-alone one.
 int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B,
                                 const double *r01, double resample_fraction, int32_t integrate) {
     REQUIRE(pf && c && dev_beams && r01, "null argument");
     gms_map *m = pf->map;
-    int rc = GMS_OK;
-    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B);                 // SLAM.java:90, :99
-    if (!rc && integrate && gms_can_pair_launches(pf, B) && !c->pending) {
-        // [partials | previous apply] -> all-reduce -> [normalise | ray cast] -> all-gather -> cumulative sums ->
-        // [likelihood | resample]: the gather is in line (nothing independent is left to put beside it)
-        rc = check_shard(pf, c);
-        if (rc) return rc;
-        const size_t np = (size_t)nblk_of(pf->n_global) * GMS_PARTIAL_STRIDE;
-        PackedParticle *own_slot = pf->d_global_own + pf->offset;
-        gms_launch_partials_apply(pf, pf->d_partials);
-        RCCLCHK(g_rccl.AllReduce(pf->d_partials, pf->d_partials, np, RCCL_FLOAT64, RCCL_SUM, c->nccl, m->stream));
-        gms_launch_norm_raycast(pf, pf->d_partials, own_slot, false, dev_beams, B);
-        pf->stats_current = 1;
-        RCCLCHK(g_rccl.AllGather(own_slot, pf->d_global_own, (size_t)pf->n * sizeof(PackedParticle), RCCL_INT8, c->nccl, m->stream));
-        pf->d_global = pf->d_global_own;
-        gms_launch_pf_after_gather(pf);
-        pf->have_global = 1;
-        return paired_likelihood_resample(pf, r01, resample_fraction);
-    }
-    if (!rc) rc = gms_pf_normalize_sharded_begin(pf, c);                         // :100-124
-    if (!rc && integrate) rc = gms_map_update_at_dev(m, dev_beams, B, pf, 0);    // :102-105, :93 on every replica
-    if (!rc) rc = gms_pf_normalize_sharded_end(pf, c);
-    if (!rc && resample_fraction >= 0.0) rc = gms_pf_resample_if(pf, r01, resample_fraction);   // GridMapApp.java:185-186
-    return rc;
+    int rc = check_shard(pf, c);
+    if (rc) return rc;
+    if (c->pending) return fail(GMS_ERR_STATE, "gms_pf_normalize_sharded_end has not been called for the previous exchange");
+    rc = gms_slam_update_sharded_begin_dev(pf, dev_xytheta, dev_beams, B);
+    if (rc) return rc;
+    const size_t np = (size_t)nblk_of(pf->n) * GMS_PARTIAL_STRIDE;               // doubles per rank
+    double *own_partials = pf->d_partials + (size_t)c->rank * np;
+    PackedParticle *own_slot = pf->d_global_own + pf->offset;
+    RCCLCHK(g_rccl.GroupStart());                                                // both gathers in one launch
+    RCCLCHK(g_rccl.AllGather(own_slot, pf->d_global_own, (size_t)pf->n * sizeof(PackedParticle), RCCL_INT8, c->nccl, m->stream));
+    RCCLCHK(g_rccl.AllGather(own_partials, pf->d_partials, np, RCCL_FLOAT64, c->nccl, m->stream));
+    RCCLCHK(g_rccl.GroupEnd());
+    return gms_slam_update_sharded_end_dev(pf, dev_beams, B, r01, resample_fraction, integrate);
 }
 
 }  // extern "C"

@@ -119,6 +119,7 @@ struct gms_pf {
     double *d_partials;             // [n_maps][nblk_global][GMS_PARTIAL_STRIDE]
     double *d_p2;                   // [n_maps][nblk_global][2] {sum wn, sum wn^2} of the normalised global population
     int32_t neff_folded;            // stats.sq_sum has been folded from d_p2 (d_p2 is produced with the chunk sums)
+    int32_t global_raw;             // d_global holds RAW weights (gathered before the normalisation): resample divides
     PackedParticle *d_global_own;   // the library's own buffer; d_global may alias a caller's all-gather result
     PackedParticle *d_global;       // [n_maps][n_global] source population (own copy when unsharded)
     double *d_chunk_tot;            // [n_maps][nchunks] scan chunk totals / offsets
@@ -178,6 +179,8 @@ bool gms_can_pair_launches(const gms_pf *pf, int32_t B);
 void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local, bool own,
                              const gms_beam *d_beams, int32_t B);
 void gms_launch_lik_resample(gms_pf *pf, double fraction);
+void gms_launch_partials_pack_apply(gms_pf *pf);
+void gms_launch_raycast_norm_chunks(gms_pf *pf, const gms_beam *d_beams, int32_t B, bool raycast);
 void gms_launch_pf_fold_neff(gms_pf *pf);
 void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride,
                          const float *d_pose_src = nullptr);   // d_pose_src: set the poses in the same launch

@@ -583,7 +583,8 @@ __device__ __forceinline__ void fold_argmax(const double *__restrict__ p, int64_
 
 // all statistics from the (all-reduced) partial vector; every thread of the workgroup must call
 __device__ __forceinline__ double fold_stats(const double *__restrict__ p, int64_t nblk, PfStatsDev *s, bool write,
-                                             const float *__restrict__ pose, int64_t pose_base, int64_t pose_n, RedLds &L) {
+                                             const float *__restrict__ pose, int64_t pose_base, int64_t pose_n, RedLds &L,
+                                             const PackedParticle *__restrict__ glob = nullptr) {
     const double sum = fold_sum(p, nblk, COL_SUM, L.a);
     if (!write) return sum;
     const double nz = fold_sum(p, nblk, COL_NZ, L.a);
@@ -604,7 +605,10 @@ __device__ __forceinline__ double fold_stats(const double *__restrict__ p, int64
         s->wpose[2] = (float)(tw / sum);
         // strongest particle's pose, when this shard holds it
         const int64_t st = (int64_t)s->strongest - pose_base;
-        if (pose && st >= 0 && st < pose_n) {
+        if (glob) {                                                    // the gathered population is at hand
+            const PackedParticle pp = glob[s->strongest];
+            s->spose[0] = pp.x; s->spose[1] = pp.y; s->spose[2] = pp.theta;
+        } else if (pose && st >= 0 && st < pose_n) {
             s->spose[0] = pose[3 * st]; s->spose[1] = pose[3 * st + 1]; s->spose[2] = pose[3 * st + 2];
         }
     }
@@ -764,6 +768,43 @@ k_chunk_sums(const PackedParticle *__restrict__ glob_all, int64_t n_global, int6
     chunk_sums_body(glob_all, n_global, nchunks, cum_all, chunk_tot, p2_all, nblk_global, stats, blockIdx.x, blockIdx.y);
 }
 
+// ---- sharded filters whose ranks exchange RAW weights (one all-gather per scan; gms_slam_update_sharded_*) ----
+// After the gather every rank holds all raw weights, poses and block partials.  This body is `weight /= weightSum`
+// (SLAM.java:120-121) for the rank's own particles plus the statistics; nothing is packed (the raw pack travelled).
+__device__ __forceinline__ void
+normalize_own_body(const double *__restrict__ partials, int64_t nblk_global, double *__restrict__ w, const float *__restrict__ pose,
+                   int32_t n, int64_t offset, const PackedParticle *__restrict__ glob_raw, PfStatsDev *__restrict__ stats,
+                   uint32_t bx) {
+    __shared__ RedLds L;
+    const double sum = fold_stats(partials, nblk_global, stats, bx == 0, pose, offset, n, L, glob_raw);
+    const int32_t i = (int32_t)bx * 256 + threadIdx.x;
+    if (i < n) w[i] = w[i] / sum;
+}
+
+// Level 0 of the cumulative NORMALISED weights of the gathered raw population: the division the owner performs
+// (same operands, same result), then the scan of block_chunk_scan.  Every workgroup folds the weight sum itself.
+__device__ __forceinline__ void
+chunk_sums_raw_body(const PackedParticle *__restrict__ glob_raw, int64_t n_global, int64_t nchunks, double *__restrict__ cum,
+                    double *__restrict__ chunk_tot, double *__restrict__ p2, int64_t nblk_global,
+                    const double *__restrict__ partials, uint32_t bx) {
+    __shared__ RedLds L;
+    const double sum = fold_sum(partials, nblk_global, COL_SUM, L.a);
+    const int64_t i = (int64_t)bx * 256 + threadIdx.x;
+    const double v = i < n_global ? glob_raw[i].w / sum : 0.0;
+    block_chunk_scan(v, i, n_global, bx, nchunks, cum, chunk_tot, p2 + (size_t)bx * 2);
+}
+
+// raw pack of one reduction block (the all-gather payload): weight as scored, pose
+__device__ __forceinline__ void pack_raw_block(const double *__restrict__ w, const float *__restrict__ pose, int32_t n, int64_t lb,
+                                               PackedParticle *__restrict__ packed_local) {
+    const int64_t i = lb * GMS_BLOCK + threadIdx.x;
+    if (i < n) {
+        PackedParticle pp;
+        pp.w = w[i]; pp.x = pose[3 * i]; pp.y = pose[3 * i + 1]; pp.theta = pose[3 * i + 2]; pp.pad = 0u;
+        packed_local[i] = pp;
+    }
+}
+
 // statistics only (getWeightedPose / calculateNeff on the current particles, nothing rewritten)
 __global__ void __launch_bounds__(256)
 k_stats_only(const double *__restrict__ partials_all, int64_t nblk_global, const float *__restrict__ pose, int32_t n,
@@ -801,7 +842,7 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
               const double *__restrict__ cum_all, const double *__restrict__ chunk_off, const double *__restrict__ r01,
               double r01_scalar, double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, float *__restrict__ cs2,
               double *__restrict__ w2, int32_t *__restrict__ idx_out, const double *__restrict__ p2_all, int64_t nblk_global,
-              PfStatsDev *__restrict__ stats, uint32_t bx, uint32_t by, unsigned char *smem) {
+              PfStatsDev *__restrict__ stats, uint32_t bx, uint32_t by, unsigned char *smem, bool raw_weights = false) {
     double *off = reinterpret_cast<double *>(smem);                    // [nchunks + 1]
     const int32_t mi = (int32_t)by;
     __shared__ RedLds L;
@@ -888,7 +929,9 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
     float tc, ts;
     pose_trig(pp.theta, tc, ts);                                        // keep cs[] in step with pose[]
     cs2[2 * o] = tc; cs2[2 * o + 1] = ts;
-    w2[o] = pp.w;                                                       // copies keep their weight (SLAM.java:42)
+    // copies keep their (normalised) weight (SLAM.java:42); a gathered RAW population is normalised here, by the
+    // division its owner performs
+    w2[o] = raw_weights ? pp.w / stats[mi].weight_sum : pp.w;
     if (idx_out) idx_out[o] = (int32_t)src;
     if (t == 0) stats[mi].did_resample = go ? 1 : 0;
 }
@@ -898,10 +941,10 @@ k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_
            const double *__restrict__ cum_all, const double *__restrict__ chunk_off, const double *__restrict__ r01,
            double r01_scalar, double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, float *__restrict__ cs2,
            double *__restrict__ w2, int32_t *__restrict__ idx_out, const double *__restrict__ p2_all, int64_t nblk_global,
-           PfStatsDev *__restrict__ stats) {
+           PfStatsDev *__restrict__ stats, int32_t raw_weights) {
     extern __shared__ __align__(16) unsigned char smem[];
     resample_body(glob_all, n_global, nchunks, cum_all, chunk_off, r01, r01_scalar, fraction, n, offset, pose2, cs2, w2, idx_out,
-                  p2_all, nblk_global, stats, blockIdx.x, blockIdx.y, smem);
+                  p2_all, nblk_global, stats, blockIdx.x, blockIdx.y, smem, raw_weights != 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1087,7 +1130,7 @@ void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedPa
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
     // a stand-alone filter packs straight into its own population and gets level 0 of the scan with it
-    if (own) pf->d_global = pf->d_global_own;
+    if (own) { pf->d_global = pf->d_global_own; pf->global_raw = 0; }
     hipLaunchKernelGGL(k_normalize_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, d_partials, nblk,
                        pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local, own ? pf->d_cum : (double *)nullptr,
                        own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf), own ? pf->d_p2 : (double *)nullptr, pf->d_stats);
@@ -1106,7 +1149,7 @@ void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed) {
     gms_map *m = pf->map;
     hipLaunchKernelGGL(k_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_pose,
                        pf->n, d_packed);
-    if (d_packed == pf->d_global) { pf->chunks_ready = 0; pf->neff_folded = 0; }
+    if (d_packed == pf->d_global) { pf->chunks_ready = 0; pf->neff_folded = 0; pf->global_raw = 0; }
 }
 
 // level 0 of the scan + {sum wn, sum wn^2} + strongest pose from d_global (paths that did not come through a
@@ -1130,6 +1173,7 @@ void gms_launch_pf_fold_neff(gms_pf *pf) {
 }
 
 void gms_launch_pf_after_gather(gms_pf *pf) {
+    pf->global_raw = 0;
     pf->chunks_ready = 0;
     pf->neff_folded = 0;
     gms_launch_pf_chunk_sums(pf);          // eagerly: it also publishes the strongest particle's pose
@@ -1147,7 +1191,7 @@ void gms_launch_pf_resample(gms_pf *pf, double fraction) {
     hipLaunchKernelGGL(k_resample, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), smem, m->stream, pf->d_global,
                        pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01,
                        pf->r01_scalar, fraction, pf->n, pf->offset,
-                       pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats);
+                       pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats, pf->global_raw);
     pf->neff_folded = 1;
 }
 

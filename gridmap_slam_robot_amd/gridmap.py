@@ -525,6 +525,20 @@ class ParticleFilter:
         check(load().gms_slam_update_sharded_dev(self._h, comm._h, C.c_void_p(dev_xytheta or 0), C.c_void_p(dev_beams), B,
                                                  ptr(r), fraction, 1 if integrate else 0))
 
+    def slam_update_sharded_begin_dev(self, dev_xytheta: int, dev_beams: int, B: int):
+        check(load().gms_slam_update_sharded_begin_dev(self._h, C.c_void_p(dev_xytheta or 0), C.c_void_p(dev_beams), B))
+
+    def gather_buffers(self):
+        """(packed_global ptr, bytes per rank, partials_global ptr, doubles per rank): both are all-gathered in place."""
+        a, b = C.c_void_p(), C.c_void_p()
+        na, nb = C.c_int64(), C.c_int64()
+        check(load().gms_pf_gather_buffers(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
+        return a.value, na.value, b.value, nb.value
+
+    def slam_update_sharded_end_dev(self, dev_beams: int, B: int, r01, fraction: float = 0.5, integrate: bool = True):
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(r01, dtype=np.float64), (self.n_maps,)))
+        check(load().gms_slam_update_sharded_end_dev(self._h, C.c_void_p(dev_beams), B, ptr(r), fraction, 1 if integrate else 0))
+
     getParticles = get_particles
     getWeightedPose = weighted_pose
 

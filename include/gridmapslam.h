@@ -284,9 +284,20 @@ int gms_pf_normalize_sharded_begin(gms_pf *pf, gms_comm *c);
 /* Joins the gather; the global population becomes the source of gms_pf_resample[_if]. */
 int gms_pf_normalize_sharded_end(gms_pf *pf, gms_comm *c);
 /* gms_slam_update_dev for a sharded filter: every rank calls it with its shard's motion-model samples and the
- * same scan and r01; both exchanges happen inside.  Results equal the stand-alone filter's bit for bit. */
+ * same scan and r01.  ONE exchange per scan: the ranks all-gather their RAW weights + poses and their block partials
+ * (one grouped RCCL launch); normalisation, statistics, map update and resample are local after that.  Results equal
+ * the stand-alone filter's bit for bit. */
 int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B,
                                 const double *r01, double resample_fraction, int32_t integrate);
+/* The same step for a host that brings its own collectives: _begin (poses, weights, this shard's payloads), then the
+ * caller all-gathers BOTH buffers of gms_pf_gather_buffers in place (rank r's payload sits at r * per-rank size;
+ * equal shards in rank order), then _end.  The buffers belong to the handle and keep their addresses until
+ * gms_pf_set_shard / destroy. */
+int gms_slam_update_sharded_begin_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B);
+int gms_pf_gather_buffers(gms_pf *pf, void **dev_packed_global, int64_t *packed_bytes_per_rank, double **dev_partials_global,
+                          int64_t *partials_doubles_per_rank);
+int gms_slam_update_sharded_end_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B, const double *r01,
+                                    double resample_fraction, int32_t integrate);
 
 /* ---- measurement ------------------------------------------------------------------------------- */
 enum {

@@ -657,3 +657,71 @@ def test_paired_steps_back_to_back_equal_the_separate_calls():
     full = GridMap(8.0, 8.0, 0.05, (-4.0, -4.0))
     full.upload_log(a.download_log()); full.compute_likelihood_map()
     assert np.array_equal(full.download_likelihood(), a.download_likelihood())    # dirty-tile rebuilds == a full rebuild
+
+
+def _hip_memcpy_dtod(dst: int, src: int, nbytes: int):
+    import ctypes as C
+    hip = C.CDLL(None)                                        # the HIP runtime the library and torch share
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 3) == 0      # hipMemcpyDeviceToDevice
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_single_exchange_sharded_step_equals_standalone(world):
+    """gms_slam_update_sharded_begin_dev -> all-gather of BOTH gather buffers -> _end_dev with `world` shards of one
+    population on one GPU (the gathers are device copies between the shards' buffers, what RCCL does over xGMI):
+    every shard's particles, weights, statistics and map replica equal the stand-alone filter's, bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    tr = synth.make_trace(8.0, 0.05, 200, T=16, seed=31)
+    n = 512
+    N = n * world
+    ref_map = GridMap(8.0, 8.0, 0.05, (-4.0, -4.0))
+    maps = [GridMap(8.0, 8.0, 0.05, (-4.0, -4.0)) for _ in range(world)]
+    for m in [ref_map] + maps:
+        for t in range(3):
+            m.update(tr.scans[t], tr.poses[t])
+    ref = ParticleFilter(ref_map, N)
+    pfs = []
+    for r, m in enumerate(maps):
+        pf = ParticleFilter(m, n)
+        pf.set_shard(r * n, N)
+        pfs.append(pf)
+    rng = np.random.default_rng(8)
+    for t in range(3, 10):
+        Ph = synth.make_particles(tr.poses[t], N, seed=200 + t, sigma_xy=0.04, sigma_theta_deg=2.0)
+        P = torch.from_numpy(Ph).to(dev)
+        beams = torch.from_numpy(tr.scans[t].view(np.uint8).copy()).to(dev)
+        B, r01 = len(tr.scans[t]), float(rng.random())
+        integrate = t != 6                                    # one step without the map update
+        frac = -1.0 if t == 8 else 0.9                        # one step without the resample
+        if frac >= 0:
+            ref.slam_update_dev(P.data_ptr(), beams.data_ptr(), B, r01, frac, integrate)
+        else:
+            ref.set_poses_dev(P.data_ptr()); ref.score_dev(beams.data_ptr(), B); ref.normalize(fetch=False)
+            if integrate:
+                ref_map.update_at_dev(beams.data_ptr(), B, ref)
+        for r, pf in enumerate(pfs):
+            pf.slam_update_sharded_begin_dev(P[r * n:(r + 1) * n].data_ptr(), beams.data_ptr(), B)
+        for m in maps:
+            m.synchronize()
+        bufs = [pf.gather_buffers() for pf in pfs]
+        for r in range(world):                                # all-gather, in place
+            for q in range(world):
+                if q != r:
+                    pk, nb, pt, nd = bufs[r]
+                    _hip_memcpy_dtod(pk + q * nb, bufs[q][0] + q * nb, nb)
+                    _hip_memcpy_dtod(pt + q * nd * 8, bufs[q][2] + q * nd * 8, nd * 8)
+        for r, pf in enumerate(pfs):
+            pf.slam_update_sharded_end_dev(beams.data_ptr(), B, r01, frac, integrate)
+        st = ref.stats()
+        poses, weights = ref.get_poses(), ref.get_weights()
+        for r, (pf, m) in enumerate(zip(pfs, maps)):
+            assert pf.stats() == st
+            assert np.array_equal(pf.get_poses(), poses[r * n:(r + 1) * n])
+            assert np.array_equal(pf.get_weights(), weights[r * n:(r + 1) * n])
+            assert np.array_equal(m.download_log(), ref_map.download_log())
+            assert np.array_equal(m.download_likelihood(), ref_map.download_likelihood())
+            assert np.array_equal(pf.weighted_pose(), ref.weighted_pose()) if frac < 0 else True
+    for pf in pfs + [ref]:
+        pf.close()

@@ -1,7 +1,8 @@
 """How the per-rank tail of a sharded scan step grows with the GLOBAL population (weak scaling), measured on one
-GPU: the shard stays at 16384 particles, n_global = world x 16384, the other ranks' slots of the gathered buffer
-hold a copy of this rank's packed particles (their content does not matter for the timing).  No collectives run:
-this isolates the redundant per-rank work (chunk sums over the global population, resample source search)."""
+GPU: the shard stays at 16384 particles, n_global = world x 16384, the other ranks' slots of the two gather buffers
+hold copies of this rank's payloads (their content does not matter for the timing).  No collective runs: this
+isolates the redundant per-rank work of gms_slam_update_sharded_begin_dev / _end_dev (fold of the longer partial
+vector, cumulative sums over the global population, resample source search)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,27 +20,27 @@ def main():
         m.update(tr.scans[t], tr.poses[t])
     beams = torch.from_numpy(tr.scans[32].view(np.uint8).copy()).to(dev)
     P = torch.from_numpy(synth.make_particles(tr.poses[32], n, seed=99)).to(dev)
+    import ctypes as C
+    hip = C.CDLL(None)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     for world in (1, 2, 4, 8):
         pf = ParticleFilter(m, n)
         pf.set_shard(0, n * world)
-        partials = torch.zeros(pf.partials_len(), dtype=torch.float64, device=dev)
-        glob = torch.zeros(3 * n * world, dtype=torch.float64, device=dev)
         def step(i):
-            pf.set_poses_dev(P.data_ptr())
-            pf.score_dev(beams.data_ptr(), B)
-            pf.local_partials(partials.data_ptr())
-            pf.apply_partials(partials.data_ptr(), glob.data_ptr())
-            m.update_at_dev(beams.data_ptr(), B, pf)
-            pf.import_global(glob.data_ptr())
-            pf.resample_if(0.37, 0.5)
-        step(0); torch.cuda.synchronize()
-        for r in range(1, world):                       # the other ranks' slots: copies of this rank's
-            glob[3 * n * r:3 * n * (r + 1)] = glob[:3 * n]
+            pf.slam_update_sharded_begin_dev(P.data_ptr(), beams.data_ptr(), B)
+            # (the all-gather would run here: the other ranks' slots hold copies of this rank's payloads)
+            pf.slam_update_sharded_end_dev(beams.data_ptr(), B, 0.37, 0.5, True)
+        pf.slam_update_sharded_begin_dev(P.data_ptr(), beams.data_ptr(), B)
+        torch.cuda.synchronize(); m.synchronize()
+        pk, nb, pt, nd = pf.gather_buffers()
+        for r in range(1, world):
+            assert hip.hipMemcpy(pk + r * nb, pk, nb, 3) == 0 and hip.hipMemcpy(pt + r * nd * 8, pt, nd * 8, 3) == 0
+        pf.slam_update_sharded_end_dev(beams.data_ptr(), B, 0.37, 0.5, True)
         for i in range(20): step(i)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        torch.cuda.synchronize(); m.synchronize(); t0 = time.perf_counter()
         K = 300
         for i in range(K): step(i)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+        torch.cuda.synchronize(); m.synchronize(); dt = (time.perf_counter() - t0) / K
         print(f"world {world}: n_global {n * world:7d}  {dt * 1e6:7.1f} us/step", flush=True)
         pf.close()
 
