@@ -288,7 +288,7 @@ def main() -> int:
                         f"full scan step (score+normalise+resample+ray-cast+likelihood rebuild)",
             "particles_total": n_global, "beams": B, "grid": [m.W, m.H], "resolution_m": res,
             "parallelism": f"particles sharded x{world}, map replicated" if world > 1 else "single GPU",
-            "exchange": None if spf is None else ("torch.distributed (RCCL)" if comm is None else "in-library RCCL: all-reduce + all-gather beside the map update"),
+            "exchange": None if spf is None else ("torch.distributed (RCCL)" if comm is None else "in-library RCCL: one grouped all-gather per scan (raw weights + block partials)"),
             "likelihood_rebuild": "full" if args.full_rebuild else "dirty-rect (bit-identical to full)",
             "inputs": "host buffers every step (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
         },
