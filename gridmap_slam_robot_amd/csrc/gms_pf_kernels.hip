@@ -832,7 +832,7 @@ __global__ void k_pack(const double *__restrict__ w, const float *__restrict__ p
 // filter computes the same values):
 //   level 0  chunk of SCAN_CHUNK = 64 weights: one wavefront's inclusive shuffle scan (block_chunk_scan);
 //   level 1  super-chunk of 64 chunks: one wavefront's shuffle scan of the chunk totals;
-//   level 2  one lane adds the super-chunk totals in order.
+//   level 2  wavefront 0 scans the super-chunk totals, 64 per pass, passes chained in order.
 // offset[c] = level2[c / 64] + level1[c]; cumulative weight of particle i = offset[i / 64] + cum[i].
 // Levels 1 and 2 are a few hundred additions: every workgroup of k_resample redoes them in LDS.
 // ---------------------------------------------------------------------------------------------
@@ -854,7 +854,13 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
     double *sup = off + nchunks + 1;                                   // [nsuper + 1]
     if (go) {
         const double *tot = chunk_off + (size_t)mi * (nchunks + 1);
-        for (int64_t c = threadIdx.x; c < nchunks; c += blockDim.x) off[c] = tot[c];
+        for (int64_t c0 = threadIdx.x; c0 < nchunks; c0 += 8 * (int64_t)blockDim.x) {  // eight loads in flight per thread
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int64_t c = c0 + k * (int64_t)blockDim.x; v[k] = c < nchunks ? tot[c] : 0.0; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int64_t c = c0 + k * (int64_t)blockDim.x; if (c < nchunks) off[c] = v[k]; }
+        }
         __syncthreads();
         // level 1: one wavefront per super-chunk of 64 chunk totals, exclusive scan by shuffles (a fixed shape)
         for (int64_t sidx = threadIdx.x >> 6; sidx < nsuper; sidx += blockDim.x >> 6) {
@@ -872,14 +878,24 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
             if (lane == 63) sup[sidx] = inc;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {                                                   // level 2
-            double a2 = 0.0;
-            for (int64_t sidx = 0; sidx < nsuper; sidx++) {
-                const double v = sup[sidx];
-                sup[sidx] = a2;
-                a2 = (sidx == 0) ? v : a2 + v;
+        if (threadIdx.x < 64) {                                                   // level 2: wavefront 0, 64 totals per pass
+            const int32_t lane = threadIdx.x;
+            double carry = 0.0;
+            for (int64_t s0 = 0; s0 < nsuper; s0 += 64) {
+                const int64_t sidx = s0 + lane;
+                const double v = sidx < nsuper ? sup[sidx] : 0.0;
+                double inc = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const double up = __shfl_up(inc, o, GMS_WAVE);
+                    if (lane >= o) inc += up;
+                }
+                const double excl = __shfl_up(inc, 1, GMS_WAVE);
+                if (sidx < nsuper) sup[sidx] = s0 == 0 ? (lane == 0 ? 0.0 : excl) : carry + (lane == 0 ? 0.0 : excl);
+                const double tot = __shfl(inc, 63, GMS_WAVE);
+                carry = s0 == 0 ? tot : carry + tot;
             }
-            off[nchunks] = a2;                                                    // grand total
+            if (lane == 0) off[nchunks] = carry;                                  // grand total
         }
         __syncthreads();
         for (int64_t c = 64 + threadIdx.x; c < nchunks; c += blockDim.x) off[c] = sup[c >> 6] + off[c];   // super-chunk 0 adds nothing
