@@ -922,12 +922,21 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
         } else {
             const double base = off[lo];
             const int64_t i0 = lo * SCAN_CHUNK;
-            int64_t a = 0, b = min((int64_t)SCAN_CHUNK, n_global - i0);   // first j with !(U > c_j)
-            const int64_t len = b;
-            while (a < b) {
-                const int64_t mid = (a + b) >> 1;
-                if (U > base + cm[i0 + mid]) a = mid + 1; else b = mid;
-            }
+            // first j in the chunk with !(U > c_j): two 8-way steps, the eight candidates of a step loaded together
+            // (two dependent round trips to memory instead of six for a bisection; same answer on a sorted chunk)
+            const int64_t len = min((int64_t)SCAN_CHUNK, n_global - i0);
+            double cv[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) cv[k] = cm[i0 + min((int64_t)(8 * k + 7), len - 1)];
+            int32_t oct = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) oct += (8 * k + 7 < len && U > base + cv[k]) ? 1 : 0;
+            if (oct > 7) oct = 7;
+#pragma unroll
+            for (int k = 0; k < 8; k++) cv[k] = cm[i0 + min((int64_t)(8 * oct + k), len - 1)];
+            int64_t a = 8 * oct;
+#pragma unroll
+            for (int k = 0; k < 8; k++) a += (8 * oct + k < len && U > base + cv[k]) ? 1 : 0;
             src = i0 + (a < len ? a : len - 1);
             // boundary within rounding distance of U: a sequential scan may choose a neighbour
             const double tol = N * 4.5e-16 * fabs(off[nchunks]);
