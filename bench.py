@@ -175,18 +175,15 @@ def main() -> int:
         if comm is not None:
             pf.slam_update_sharded_dev(comm, pose_sets[s].data_ptr(), beams_ptr, B, r01[i % 4096], 0.5, True)
             return
+        if spf is not None:
+            # the same single-exchange step with the two all-gathers issued through torch.distributed
+            spf.scan_step((pose_sets[s].data_ptr(), beams_ptr, B, True), r01[i % 4096], 0.5)
+            return
+        # --full-rebuild: the separate entry points, likelihood field rebuilt everywhere as the reference does
         pf.set_poses_dev(pose_sets[s].data_ptr())
         pf.score_dev(beams_ptr, B)
-        if spf is None:
-            pf.normalize(fetch=False)
-            pf.resample_if(r01[i % 4096], 0.5)
-        else:
-            # the map update needs only the weighted pose: it runs beside the all-gather (RCCL's own stream)
-            spf.normalize_begin()
-            m.update_at_dev(beams_ptr, B, pf)
-            spf.normalize_end()
-            spf.resample(r01[i % 4096], 0.5)
-            return
+        pf.normalize(fetch=False)
+        pf.resample_if(r01[i % 4096], 0.5)
         if args.full_rebuild:
             m.integrate_at_dev(beams_ptr, B, pf)
             m.compute_likelihood_map()

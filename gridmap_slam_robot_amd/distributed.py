@@ -17,6 +17,14 @@ broadcasting 32 MiB).  Per scan:
 
 Both messages are small (18 KiB and 1.5 MiB at 65 536 particles): latency-bound, one RCCL call each.
 
+`ShardedParticleFilter.scan_step` is the protocol the product actually runs per scan, with ONE exchange: the ranks
+all-gather their RAW particles {w, x, y, theta} and their block partials (the gathered partial vector is what the
+all-reduce above assembles), both gathers issued together, and normalisation, statistics, map update and resample
+are local afterwards (the normalised weight of another rank's particle is the owner's division repeated on the
+gathered copy).  libgridmapslam.so does the same with RCCL inside (`gms_slam_update_sharded_dev` over an `RcclComm`:
+one C-ABI call per scan, no Python collective wrappers on the critical path); `scan_step` is the torch.distributed
+route and the one the gloo tests exercise.
+
 The collective logic is independent of where the shard kernels run: `ops` is the object that performs
 them.  The product uses HipShardOps (libgridmapslam.so, device pointers of torch CUDA tensors, the
 library running on torch's current stream).  There is no CPU implementation in this package; the gloo
@@ -34,6 +42,13 @@ import torch.distributed as dist
 
 from . import _lib
 from .gridmap import GridMap, ParticleFilter
+
+
+class _DeviceBuffer:
+    """A device allocation of the library as a 1-D float64 array for torch.as_tensor (no copy, no ownership)."""
+
+    def __init__(self, ptr: int, n_doubles: int):
+        self.__cuda_array_interface__ = {"shape": (int(n_doubles),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
 class HipShardOps:
@@ -71,6 +86,27 @@ class HipShardOps:
             self.pf.resample(r01)
         else:
             self.pf.resample_if(r01, fraction)
+
+    # -- single-exchange scan step (ShardedParticleFilter.scan_step): inputs = (dev_poses or 0, dev_beams, B, integrate)
+    def exchange_begin(self, inputs):
+        dev_poses, dev_beams, B, _ = inputs
+        self.pf.slam_update_sharded_begin_dev(dev_poses, dev_beams, B)
+
+    def gather_views(self):
+        """(packed_global, packed_local, partials_global, partials_local): torch tensors that ALIAS the handle's two
+        gather buffers (no copy); the local ones are this rank's slices, so the all-gathers run in place."""
+        if getattr(self, "_views", None) is None:
+            pk, nb, pt, nd = self.pf.gather_buffers()
+            world = self.pf.n_global // self.pf.n
+            rank = self.pf.offset // self.pf.n
+            g = torch.as_tensor(_DeviceBuffer(pk, world * nb // 8), device=self.device)
+            t = torch.as_tensor(_DeviceBuffer(pt, world * nd), device=self.device)
+            self._views = (g, g[rank * nb // 8:(rank + 1) * nb // 8], t, t[rank * nd:(rank + 1) * nd])
+        return self._views
+
+    def exchange_end(self, inputs, r01: float, fraction: Optional[float]):
+        _, dev_beams, B, integrate = inputs
+        self.pf.slam_update_sharded_end_dev(dev_beams, B, r01, -1.0 if fraction is None else fraction, integrate)
 
     def stats(self) -> dict:
         return self.pf.stats()
@@ -175,6 +211,26 @@ class ShardedParticleFilter:
     def normalize(self):
         self.normalize_begin()
         self.normalize_end()
+
+    def scan_step(self, inputs, r01: float, fraction: Optional[float] = 0.5):
+        """One scan (SLAM.update + conditional resample) with ONE exchange: every rank scores its shard and leaves its
+        block partials and its RAW particles {w, x, y, theta} in its slots of the two gather buffers; both buffers are
+        all-gathered (issued together); statistics, normalisation, map update and resample are local after that.
+        `inputs` is whatever the shard ops need (HipShardOps: (dev_poses, dev_beams, B, integrate)).  Every rank
+        passes the same scan and r01.  (libgridmapslam's gms_slam_update_sharded_dev is this with RCCL inside.)"""
+        self.ops.exchange_begin(inputs)
+        if self.world > 1 or self.force:
+            pg, pl, tg, tl = self.ops.gather_views()
+            works = []
+            for out, mine in ((pg, pl), (tg, tl)):
+                try:
+                    works.append(dist.all_gather_into_tensor(out, mine, group=self.group, async_op=True))
+                except (RuntimeError, NotImplementedError, TypeError):
+                    mine_c = mine.clone()             # list form (gloo): the input must not alias an output chunk
+                    works.append(dist.all_gather(list(out.chunk(self.world)), mine_c, group=self.group, async_op=True))
+            for wk in works:
+                wk.wait()
+        self.ops.exchange_end(inputs, r01, fraction)
 
     def resample(self, r01: float, fraction: Optional[float] = None):
         """SLAM.resample (SLAM.java:133-153); with `fraction`, only if neff < fraction*N

@@ -85,6 +85,27 @@ class NumpyShardOps:
     def weighted_pose(self):
         return self.st["wpose"]
 
+    # -- single-exchange protocol (ShardedParticleFilter.scan_step): raw payloads, everything else local
+    def exchange_begin(self, inputs):
+        self.t_glob = torch.zeros(self.nblk * STRIDE, dtype=torch.float64)
+        self.local_partials(self.t_glob)                      # own slots filled, the gather brings the rest
+        self.p_glob = torch.zeros(3 * self.n_global, dtype=torch.float64)
+        a = np.zeros(self.n, dtype=_lib.PACKED_DTYPE)
+        a["w"], a["x"], a["y"], a["theta"] = self.w, self.pose[:, 0], self.pose[:, 1], self.pose[:, 2]      # RAW weights
+        self.p_glob[3 * self.offset:3 * (self.offset + self.n)] = torch.from_numpy(a.view(np.float64))
+
+    def gather_views(self):
+        lo, hi = self.offset // BLOCK, (self.offset + self.n) // BLOCK
+        return (self.p_glob, self.p_glob[3 * self.offset:3 * (self.offset + self.n)],
+                self.t_glob, self.t_glob[lo * STRIDE:hi * STRIDE])
+
+    def exchange_end(self, inputs, r01, fraction):
+        s = self._fold(self.t_glob)
+        self.w = self.w / s                                   # weight /= weightSum for the own particles
+        self.glob = self.p_glob.numpy().view(_lib.PACKED_DTYPE).copy()
+        self.glob["w"] = self.glob["w"] / s                   # ... and the same division on the gathered raw copies
+        self.resample(r01, fraction)
+
 
 def make_inputs(n_global, seed=3):
     rng = np.random.default_rng(seed)
@@ -179,3 +200,46 @@ def test_hip_shard_ops_refuse_to_run_without_a_gpu(have_gpu):
     from gridmap_slam_robot_amd.distributed import HipShardOps
     with pytest.raises(RuntimeError):
         HipShardOps(None, BLOCK, 0, BLOCK)
+
+
+def run_single_exchange(rank, world, n_global, r01):
+    poses, w = make_inputs(n_global)
+    n, off = ShardedParticleFilter.shard_of(n_global, world, rank)
+    ops = NumpyShardOps(poses[off:off + n], w[off:off + n], off, n_global)
+    spf = ShardedParticleFilter(n_global, ops)
+    spf.scan_step(None, r01, None)
+    return dict(st=dict(ops.st), idx=ops.idx.copy(), pose=ops.pose.copy(), w=ops.w.copy(), glob_w=ops.glob["w"].copy())
+
+
+def _worker_single(rank, world, port, n_global, r01, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = run_single_exchange(rank, world, n_global, r01)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_exchange_step_two_ranks_reproduce_one_rank_and_the_two_collective_protocol():
+    """ShardedParticleFilter.scan_step: raw particles + block partials all-gathered, everything after it local.
+    Two ranks == one rank bit for bit, and both == the all-reduce / all-gather protocol above."""
+    n_global, r01, world = 4 * BLOCK, 0.371, 2
+    single = run_single_exchange(0, 1, n_global, r01)
+    old = run_filter(0, 1, n_global, r01)
+    assert single["st"]["weight_sum"] == old["st"]["weight_sum"] and single["st"]["strongest"] == old["st"]["strongest"]
+    assert np.array_equal(single["glob_w"], old["glob_w"]) and np.array_equal(single["idx"], old["idx"])
+    assert np.array_equal(single["pose"], old["pose"])
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_single, args=(world, _free_port(), n_global, r01, ret), nprocs=world, join=True)
+    n = n_global // world
+    for r in range(world):
+        out = ret[r]
+        for k in ("weight_sum", "strongest", "n_zero", "neff"):
+            assert out["st"][k] == single["st"][k]
+        assert np.array_equal(out["st"]["wpose"], single["st"]["wpose"])
+        assert np.array_equal(out["glob_w"], single["glob_w"])
+        assert np.array_equal(out["idx"], single["idx"][r * n:(r + 1) * n])
+        assert np.array_equal(out["pose"], single["pose"][r * n:(r + 1) * n])
+        assert np.array_equal(out["w"], single["w"][r * n:(r + 1) * n])

@@ -725,3 +725,34 @@ def test_single_exchange_sharded_step_equals_standalone(world):
             assert np.array_equal(pf.weighted_pose(), ref.weighted_pose()) if frac < 0 else True
     for pf in pfs + [ref]:
         pf.close()
+
+
+def test_scan_step_through_the_python_sharding_layer_equals_standalone():
+    """distributed.ShardedParticleFilter.scan_step over HipShardOps (the torch.distributed route of the single-exchange
+    step; one rank here, so no collective runs): same bits as gms_slam_update_dev, and the gather buffers are visible
+    to torch without a copy."""
+    import torch
+    from gridmap_slam_robot_amd.distributed import HipShardOps, ShardedParticleFilter
+    dev = torch.device("cuda", 0)
+    tr = synth.make_trace(6.4, 0.05, 150, T=10, seed=13)
+    N = 768
+    a = GridMap(6.4, 6.4, 0.05, (-3.2, -3.2)); b = GridMap(6.4, 6.4, 0.05, (-3.2, -3.2))
+    for m in (a, b):
+        for t in range(3):
+            m.update(tr.scans[t], tr.poses[t])
+    ref = ParticleFilter(a, N)
+    ops = HipShardOps(b, N, 0, N)
+    spf = ShardedParticleFilter(N, ops)
+    for t in range(3, 7):
+        P = torch.from_numpy(synth.make_particles(tr.poses[t], N, seed=t, sigma_xy=0.03, sigma_theta_deg=1.5)).to(dev)
+        beams = torch.from_numpy(tr.scans[t].view(np.uint8).copy()).to(dev)
+        B, r01 = len(tr.scans[t]), 0.1 * t
+        ref.slam_update_dev(P.data_ptr(), beams.data_ptr(), B, r01, 0.9, True)
+        spf.scan_step((P.data_ptr(), beams.data_ptr(), B, True), r01, 0.9)
+        torch.cuda.synchronize()
+        assert ref.stats() == ops.pf.stats()
+        assert np.array_equal(ref.get_poses(), ops.pf.get_poses()) and np.array_equal(ref.get_weights(), ops.pf.get_weights())
+        assert np.array_equal(a.download_log(), b.download_log())
+    pg, pl, tg, tl = ops.gather_views()
+    assert pg.data_ptr() == ops.pf.gather_buffers()[0] and pl.data_ptr() == pg.data_ptr() and tl.numel() == 3 * 9
+    assert pg.numel() == 3 * N and bool(torch.isfinite(tg).all())
