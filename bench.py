@@ -83,6 +83,7 @@ def main() -> int:
     ap.add_argument("--cpu-scans", type=int, default=0, help="scans of the CPU baseline sample (0 = auto)")
     ap.add_argument("--full-rebuild", action="store_true", help="rebuild the whole likelihood field every scan")
     ap.add_argument("--host-inputs", action="store_true", help="hand poses and scans over as HOST buffers every step (PCIe-inclusive rate; never the headline value)")
+    ap.add_argument("--event-stride", type=int, default=8, help="timed region: HIP events around every n-th launch of the dominant kernel (a bracket costs microseconds of stream time)")
     ap.add_argument("--torch-collectives", action="store_true", help="sharded runs: exchange through torch.distributed instead of the library's own RCCL communicator")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (all-reduce / all-gather) code path even with one rank")
     args = ap.parse_args()
@@ -196,6 +197,8 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
+    bracket_us = m.profile_calibrate(200) * 1e3
+
     # ---- warmup, with every kernel class bracketed: find the dominant one -----------------------------
     m.profile(True)
     m.profile_reset()
@@ -212,6 +215,7 @@ def main() -> int:
 
     # ---- timed region: exactly K steps, only the dominant kernel bracketed by events -------------------
     m.profile_reset()
+    m.profile_sample(max(1, args.event_stride))
     m.profile(dom_bit)
     barrier()
     t0 = time.perf_counter()
@@ -222,6 +226,7 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
     dom_ms, dom_n = m.profile_get()[dominant]
     m.profile(False)
+    m.profile_sample(1)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -300,7 +305,10 @@ def main() -> int:
             # the committed PMC passes are of the default configuration: no figure for other modes
             "traffic": pmc_traffic(dominant) if (args.config == "C3" and not args.full_rebuild and not args.particles) else None,
             "algorithmic_bytes_per_launch": alg / per_launch_scale,
-            "avg_launch_us": dom_avg_s * 1e6 / per_launch_scale, "launches_timed": dom_n,
+            "avg_launch_us": dom_avg_s * 1e6 / per_launch_scale, "launches_timed": dom_n, "event_stride": max(1, args.event_stride),
+            # the same bracket around an empty kernel (dispatch latency + ~1 us): a kernel-trace profiler's duration
+            # for the dominant kernel is about avg_launch_us minus this (profiles/ holds that trace)
+            "event_bracket_empty_kernel_us": bracket_us,
         },
     }
 

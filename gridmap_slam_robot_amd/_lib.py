@@ -175,6 +175,8 @@ def load() -> C.CDLL:
     sig("gms_profile_enable", C.c_int, vp, i32)
     sig("gms_profile_reset", C.c_int, vp)
     sig("gms_profile_get", C.c_int, vp, i32, vp, vp)
+    sig("gms_profile_sample", C.c_int, vp, i32)
+    sig("gms_profile_calibrate", C.c_int, vp, i32, C.POINTER(C.c_double))
     sig("gms_debug_f32", C.c_int, vp, i32, vp, vp, i64)
     _lib = L
     return L

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <new>
+#include <vector>
 
 #include "gms_internal.h"
 
@@ -143,10 +144,15 @@ int gms_profile_enable(gms_map *m, int32_t on) {
     m->prof_on = on;          // bit k brackets kernel class k
     return GMS_OK;
 }
+int gms_profile_sample(gms_map *m, int32_t stride) {
+    REQUIRE(m && stride >= 1, "gms_profile_sample: stride must be >= 1");
+    m->prof_stride = stride;
+    return GMS_OK;
+}
 int gms_profile_reset(gms_map *m) {
     REQUIRE(m, "null map");
     prof_drain(m);
-    for (int k = 0; k < GMS_K_COUNT; k++) { m->prof_ms[k] = 0; m->prof_n[k] = 0; }
+    for (int k = 0; k < GMS_K_COUNT; k++) { m->prof_ms[k] = 0; m->prof_n[k] = 0; m->prof_seen[k] = 0; }
     return GMS_OK;
 }
 int gms_profile_get(gms_map *m, int32_t k, double *total_ms, int64_t *launches) {
@@ -154,6 +160,30 @@ int gms_profile_get(gms_map *m, int32_t k, double *total_ms, int64_t *launches) 
     prof_drain(m);
     if (total_ms) *total_ms = m->prof_ms[k];
     if (launches) *launches = m->prof_n[k];
+    return GMS_OK;
+}
+
+int gms_profile_calibrate(gms_map *m, int32_t reps, double *bracket_ms) {
+    REQUIRE(m && bracket_ms && reps > 0 && reps <= 4096, "gms_profile_calibrate: bad arguments");
+    HIPCHK(hipSetDevice(m->device));
+    // event, empty kernel, event, empty kernel, ... enqueued back to back (the queue never drains, as in a scan loop)
+    const int32_t skip = 8, n = reps + skip;
+    std::vector<hipEvent_t> ev(n + 1);
+    for (hipEvent_t &e : ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventRecord(ev[0], m->stream));
+    for (int32_t i = 0; i < n; i++) {
+        gms_launch_noop(m);
+        HIPCHK(hipEventRecord(ev[i + 1], m->stream));
+    }
+    HIPCHK(hipEventSynchronize(ev[n]));
+    double total = 0.0;
+    for (int32_t i = skip; i < n; i++) {
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        total += ms;
+    }
+    for (hipEvent_t &e : ev) hipEventDestroy(e);
+    *bracket_ms = total / reps;
     return GMS_OK;
 }
 
@@ -235,6 +265,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     m->score_variant = 2;
     if (const char *v = getenv("GMS_SCORE_VARIANT")) m->score_variant = atoi(v);
     m->pair_launches = 1;
+    m->prof_stride = 1;
     if (const char *v = getenv("GMS_PAIR_LAUNCHES")) m->pair_launches = atoi(v) != 0;
     if (const char *v = getenv("GMS_SCORE_SEGMENTS")) m->score_segments = atoi(v);
     *out = m;

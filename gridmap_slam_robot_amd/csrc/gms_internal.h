@@ -95,6 +95,8 @@ struct gms_map {
     int32_t *d_trace_cells; uint8_t *d_trace_cls; int32_t *d_trace_cnt; size_t trace_cap_bytes;
     // profiling
     int32_t prof_on;
+    int32_t prof_stride;      // every prof_stride-th launch of an enabled class is bracketed (>= 1)
+    int64_t prof_seen[GMS_K_COUNT];
     std::vector<ProfSlot> prof_pending;
     std::vector<ProfSlot> prof_free;
     double prof_ms[GMS_K_COUNT];
@@ -162,6 +164,7 @@ void gms_launch_combine(gms_map *src, gms_map *dst);
 void gms_launch_deskew(gms_map *m, const double *d_angle, const double *d_distance, const uint8_t *d_hit, int32_t length,
                        double d_center, double d_theta, gms_beam *d_out);
 void gms_launch_factors(gms_map *m);   // d_fac from d_lik (after an upload / copy)
+void gms_launch_noop(gms_map *m);
 void gms_launch_get_raw(gms_map *m, int32_t mi, int32_t x, int32_t y, double *d_out2);
 void gms_launch_debug_f32(gms_map *m, int32_t op, const float *d_a, float *d_out, int64_t n);
 
@@ -198,6 +201,8 @@ void gms_prof_end(gms_map *m);
 struct ProfScope {
     gms_map *m;
     bool on;
-    ProfScope(gms_map *mm, int32_t k) : m(mm), on((mm->prof_on >> k) & 1) { if (on) gms_prof_begin(m, k); }
+    ProfScope(gms_map *mm, int32_t k) : m(mm), on(((mm->prof_on >> k) & 1) && (mm->prof_seen[k]++ % mm->prof_stride) == 0) {
+        if (on) gms_prof_begin(m, k);
+    }
     ~ProfScope() { if (on) gms_prof_end(m); }
 };

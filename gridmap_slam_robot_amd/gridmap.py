@@ -319,6 +319,16 @@ class GridMap:
     def integrate_at_dev(self, dev_beams: int, B: int, pf: "ParticleFilter", strongest: bool = False):
         check(load().gms_map_integrate_at_dev(self._h, C.c_void_p(dev_beams), B, pf._h, 1 if strongest else 0))
 
+    def profile_sample(self, stride: int = 1):
+        """Bracket only every stride-th launch of the enabled kernel classes."""
+        check(load().gms_profile_sample(self._h, stride))
+
+    def profile_calibrate(self, reps: int = 200) -> float:
+        """Mean event-bracket time around an empty kernel, in milliseconds (what a bracket costs by itself)."""
+        v = C.c_double()
+        check(load().gms_profile_calibrate(self._h, reps, C.byref(v)))
+        return v.value
+
     def profile_reset(self):
         check(load().gms_profile_reset(self._h))
 

@@ -308,8 +308,15 @@ enum {
  * bit k of `mask` enables kernel class k (GMS_K_*); 0 turns profiling off. */
 int gms_profile_enable(gms_map *m, int32_t mask);
 int gms_profile_reset(gms_map *m);
+/* Bracket only every stride-th launch of an enabled class (default 1): the two event markers of a bracket cost
+ * microseconds on the stream, which a 70 us scan step notices. */
+int gms_profile_sample(gms_map *m, int32_t stride);
 /* Total device milliseconds and launch count of kernel class k since the last reset. */
 int gms_profile_get(gms_map *m, int32_t k, double *total_ms, int64_t *launches);
+/* What such a bracket costs by itself: the mean event-to-event time around an EMPTY kernel (dispatch latency + the
+ * ~1 us an empty kernel runs), over `reps` launches on the handle's stream.  A kernel-trace profiler reports the
+ * kernel's own duration, i.e. roughly the bracketed time minus this. */
+int gms_profile_calibrate(gms_map *m, int32_t reps, double *bracket_ms);
 
 /* ---- diagnostics ------------------------------------------------------------------------------- */
 /* The float-rounded device primitives the parity contract leans on, for tests: op 0 = (float)sqrt(a)
