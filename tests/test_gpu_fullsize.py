@@ -145,6 +145,19 @@ def test_edge_cases_empty_scan_single_particle_all_miss_ragged_grid():
         assert np.array_equal(pf.get_weights(), np.ones(5))
         st = pf.normalize()
         assert st["weight_sum"] == 5.0 and st["strongest"] == 0 and abs(st["neff"] - 5.0) < 1e-12
+        # the fused scan step (paired launches, deferred apply) on the same awkward inputs == the separate calls
+        twin = GridMap(*((3.3, 2.1) if mm is m else (3.0, 2.1)), 0.07, (0.0, 1.0))
+        twin.upload_log(mm.download_log()); twin.compute_likelihood_map(); mm.compute_likelihood_map()
+        for n_p in (1, 5, 300):
+            fa, fb = ParticleFilter(mm, n_p), ParticleFilter(twin, n_p)
+            for k, scan in enumerate((obs, miss, empty, obs)):
+                P = synth.make_particles(pose, n_p, seed=k, sigma_xy=0.05, sigma_theta_deg=2.0)
+                sa = fa.slam_update(P, scan, 0.6, 0.5, True, fetch=True)
+                fb.set_poses(P); fb.score(scan); sb = fb.normalize(); fb.resample_if(0.6, 0.5); twin.update_at(scan, fb)
+                assert sa == sb
+                assert np.array_equal(fa.get_poses(), fb.get_poses()) and np.array_equal(fa.get_weights(), fb.get_weights())
+            assert np.array_equal(mm.download_log(), twin.download_log())
+            assert np.array_equal(mm.download_likelihood(), twin.download_likelihood())
 
 
 def test_config5_slice_batched_against_the_oracle():
