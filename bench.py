@@ -199,6 +199,22 @@ def main() -> int:
 
     bracket_us = m.profile_calibrate(200) * 1e3
 
+    # ---- one untimed step first: if the in-library exchange cannot run here, every rank falls back together ----
+    if comm is not None:
+        ok = 1
+        try:
+            step(0)
+            torch.cuda.synchronize()
+        except Exception as e:
+            print(f"bench.py: in-library sharded step failed ({e}); using torch.distributed", file=sys.stderr)
+            ok = 0
+        if world > 1:
+            t_ok = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            ok = int(t_ok.item())
+        if not ok:
+            comm = None
+
     # ---- warmup, with every kernel class bracketed: find the dominant one -----------------------------
     m.profile(True)
     m.profile_reset()
