@@ -285,7 +285,23 @@ def main() -> int:
                 ab = None        # the dirty-rect rebuild touches a scan-dependent part of the 16 B/cell field
             kernels[k] = {"ms_per_step": round(ms / nb, 5), "launches_per_step": round(n / nb, 2),
                           "algorithmic_gb_per_s": (round(ab / (ms / nb * 1e-3) / 1e9, 1) if ab else None)}
-    map_update_ms = sum(kernels.get(k, {}).get("ms_per_step", 0.0) for k in ("raycast", "apply", "likelihood"))
+    # BASELINE metric (ii), map-update ms/scan = integrateObservation + computeLikelihoodMap: the map entry point by
+    # itself (ray cast, apply, likelihood rebuild as three kernels at a fixed device-resident pose), wall time
+    upd_pose = torch.from_numpy(np.ascontiguousarray(tr.poses[T // 2], dtype=np.float32)).to(dev)
+    def map_update(i):
+        bp = scans_dev[T // 2 + i % n_sets].data_ptr()
+        if args.full_rebuild:
+            m.integrate_dev(bp, B, upd_pose.data_ptr()); m.compute_likelihood_map()
+        else:
+            m.update_dev(bp, B, upd_pose.data_ptr())
+    for i in range(5):
+        map_update(i)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(nb):
+        map_update(i)
+    torch.cuda.synchronize()
+    map_update_ms = (time.perf_counter() - t1) / nb * 1e3
 
     out = {
         "metric": "particle-scan evals/sec",
