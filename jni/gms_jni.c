@@ -157,3 +157,23 @@ JNIEXPORT void JNICALL CLS(mapUpdateAt)(JNIEnv *env, jclass c, jlong m, jdoubleA
     if (!rc) rc = gms_map_update_at((gms_map *)(intptr_t)m, buf, B, (gms_pf *)(intptr_t)pf, 0);
     throw_gms(env, rc);
 }
+
+/* SLAM.update(z, u) (SLAM.java:80-131) + `if (neff < fraction * N) resample()` (GridMapApp.java:185-186) in ONE call:
+ * poses (may be null) are the motion-model samples drawn on the JVM; out3 = {weightSum, neff, strongest}.
+ * resampleFraction < 0 skips the resampling; integrate = false is the skipUpdate case (SLAM.java:82). */
+JNIEXPORT void JNICALL CLS(slamUpdate)(JNIEnv *env, jclass c, jlong pf, jfloatArray xyt, jdoubleArray beams, jint B, jdouble r01,
+                                       jdouble resampleFraction, jboolean integrate, jdoubleArray out3) {
+    gms_beam buf[2048];
+    if (B > 2048) { throw_gms(env, GMS_ERR_INVALID); return; }
+    int rc = beams_from(env, beams, B, buf);
+    if (rc) { throw_gms(env, rc); return; }
+    gms_pf_stats st;
+    jfloat *p = xyt ? (*env)->GetPrimitiveArrayCritical(env, xyt, NULL) : NULL;
+    rc = gms_slam_update((gms_pf *)(intptr_t)pf, p, buf, B, &r01, resampleFraction, integrate ? 1 : 0, &st);
+    if (p) (*env)->ReleasePrimitiveArrayCritical(env, xyt, p, JNI_ABORT);
+    if (!rc && out3) {
+        const jdouble v[3] = { st.weight_sum, st.neff, (jdouble)st.strongest };
+        (*env)->SetDoubleArrayRegion(env, out3, 0, 3, v);
+    }
+    throw_gms(env, rc);
+}

@@ -22,6 +22,9 @@ final class NativeSlam {
     static native void pfNormalize(long pf, double[] weightSumNeffStrongest);
     static native void pfResample(long pf, double r01);
     static native void pfWeightedPose(long pf, float[] out3);
+    /** SLAM.update + conditional resample in one native call (four kernel launches on the device). */
+    static native void slamUpdate(long pf, float[] xythetaOrNull, double[] beams, int B, double r01, double resampleFraction,
+                                  boolean integrate, double[] weightSumNeffStrongest);
 
     /** Observation -> double[4*B] {localX, localY, distance, wasHit} (Observation.java:37-41). */
     static double[] flatten(Observation obs) {
