@@ -145,7 +145,11 @@ class RcclComm:
             _lib.load().gms_comm_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the module globals may already be gone
+            pass
 
 
 class ShardedParticleFilter:
