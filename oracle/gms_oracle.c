@@ -306,6 +306,15 @@ void orc_score(const orc_grid *g, const double *lik, const orc_beam *beams, int3
     for (int32_t i = 0; i < N; i++) weights[i] = orc_probability_of(g, lik, beams, B, poses + 3 * (size_t)i);
 }
 
+/* the same over `threads` host threads (probabilityOf is a pure function of its arguments; the reference itself is
+ * single-threaded).  Reported beside the single-thread baseline, never used as a checker. */
+void orc_score_mt(const orc_grid *g, const double *lik, const orc_beam *beams, int32_t B, const float *poses, int32_t N,
+                  double *weights, int32_t threads) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int32_t i = 0; i < N; i++) weights[i] = orc_probability_of(g, lik, beams, B, poses + 3 * (size_t)i);
+}
+
 void orc_score_log(const orc_grid *g, const double *lik, const orc_beam *beams, int32_t B,
                    const float *poses, int32_t N, double *log_weights) {
     for (int32_t i = 0; i < N; i++) {

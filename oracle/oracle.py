@@ -84,6 +84,8 @@ def lib() -> C.CDLL:
         L.orc_probability_of.argtypes = [gp, dp, vp, C.c_int32, fp]
         L.orc_score.restype = None
         L.orc_score.argtypes = [gp, dp, vp, C.c_int32, fp, C.c_int32, dp]
+        L.orc_score_mt.restype = None
+        L.orc_score_mt.argtypes = [gp, dp, vp, C.c_int32, fp, C.c_int32, dp, C.c_int32]
         L.orc_score_log.restype = None
         L.orc_score_log.argtypes = [gp, dp, vp, C.c_int32, fp, C.c_int32, dp]
         L.orc_normalize.restype = C.c_double
@@ -216,6 +218,12 @@ class Grid:
         poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
         w = np.empty(len(poses), dtype=np.float64)
         lib().orc_score(C.byref(self.g), _dp(lik), beams.ctypes.data, len(beams), _fp(poses), len(poses), _dp(w))
+        return w
+
+    def score_mt(self, lik, beams, poses, threads: int) -> np.ndarray:
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        w = np.empty(len(poses), dtype=np.float64)
+        lib().orc_score_mt(C.byref(self.g), _dp(lik), beams.ctypes.data, len(beams), _fp(poses), len(poses), _dp(w), int(threads))
         return w
 
     def score_log(self, lik, beams, poses) -> np.ndarray:
