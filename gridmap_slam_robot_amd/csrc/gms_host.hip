@@ -1115,6 +1115,8 @@ static struct {
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t);
     int (*GroupStart)();
     int (*GroupEnd)();
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t);
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t);
     const char *(*GetErrorString)(int);
 } g_rccl;
 
@@ -1143,6 +1145,8 @@ int gms_comm_load(const char *librccl_path) {
     *(void **)&g_rccl.AllGather = dlsym(dl, "ncclAllGather");
     *(void **)&g_rccl.GroupStart = dlsym(dl, "ncclGroupStart");
     *(void **)&g_rccl.GroupEnd = dlsym(dl, "ncclGroupEnd");
+    *(void **)&g_rccl.Send = dlsym(dl, "ncclSend");
+    *(void **)&g_rccl.Recv = dlsym(dl, "ncclRecv");
     *(void **)&g_rccl.GetErrorString = dlsym(dl, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.AllGather ||
         !g_rccl.GroupStart || !g_rccl.GroupEnd)
@@ -1171,6 +1175,7 @@ int gms_comm_create(gms_comm **out, const void *id128, int32_t rank, int32_t wor
     // MI355X); an in-line gather costs its own latency.  Small groups gather little: in line up to 2 ranks.
     c->overlap = world > 2;
     if (const char *e = getenv("GMS_COMM_OVERLAP")) c->overlap = atoi(e) != 0;
+    if (const char *e = getenv("GMS_EXCHANGE")) c->p2p = strcmp(e, "p2p") == 0;
     rccl_unique_id id;
     memcpy(&id, id128, sizeof(id));
     int r = g_rccl.CommInitRank(&c->nccl, world, id, rank);        // blocks until every rank has joined
@@ -1325,9 +1330,22 @@ int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xythet
     const size_t np = (size_t)nblk_of(pf->n) * GMS_PARTIAL_STRIDE;               // doubles per rank
     double *own_partials = pf->d_partials + (size_t)c->rank * np;
     PackedParticle *own_slot = pf->d_global_own + pf->offset;
-    RCCLCHK(g_rccl.GroupStart());                                                // both gathers in one launch
-    RCCLCHK(g_rccl.AllGather(own_slot, pf->d_global_own, (size_t)pf->n * sizeof(PackedParticle), RCCL_INT8, c->nccl, m->stream));
-    RCCLCHK(g_rccl.AllGather(own_partials, pf->d_partials, np, RCCL_FLOAT64, c->nccl, m->stream));
+    const size_t pbytes = (size_t)pf->n * sizeof(PackedParticle);
+    RCCLCHK(g_rccl.GroupStart());                                                // the whole exchange is one launch
+    if (c->p2p && g_rccl.Send && g_rccl.Recv) {
+        // the same exchange as point-to-point transfers to and from every peer (direct xGMI links, no ring):
+        // GMS_EXCHANGE=p2p, for comparison on a multi-GPU node
+        for (int32_t peer = 0; peer < c->world; peer++) {
+            if (peer == c->rank) continue;
+            RCCLCHK(g_rccl.Send(own_slot, pbytes, RCCL_INT8, peer, c->nccl, m->stream));
+            RCCLCHK(g_rccl.Recv(pf->d_global_own + (size_t)peer * pf->n, pbytes, RCCL_INT8, peer, c->nccl, m->stream));
+            RCCLCHK(g_rccl.Send(own_partials, np, RCCL_FLOAT64, peer, c->nccl, m->stream));
+            RCCLCHK(g_rccl.Recv(pf->d_partials + (size_t)peer * np, np, RCCL_FLOAT64, peer, c->nccl, m->stream));
+        }
+    } else {
+        RCCLCHK(g_rccl.AllGather(own_slot, pf->d_global_own, pbytes, RCCL_INT8, c->nccl, m->stream));
+        RCCLCHK(g_rccl.AllGather(own_partials, pf->d_partials, np, RCCL_FLOAT64, c->nccl, m->stream));
+    }
     RCCLCHK(g_rccl.GroupEnd());
     return gms_slam_update_sharded_end_dev(pf, dev_beams, B, r01, resample_fraction, integrate);
 }

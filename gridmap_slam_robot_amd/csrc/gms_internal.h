@@ -144,6 +144,7 @@ struct gms_comm {
     int32_t rank = 0, world = 1, device = 0;
     int32_t overlap = 0;            // all-gather on the side stream (default: world > 2; GMS_COMM_OVERLAP=0/1 overrides)
     int32_t pending = 0;            // an all-gather is in flight
+    int32_t p2p = 0;                // GMS_EXCHANGE=p2p: the scan's exchange as grouped ncclSend/ncclRecv instead of all-gathers
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
