@@ -109,7 +109,7 @@ template <int KH>
 __global__ void __launch_bounds__(256)
 k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac, int64_t fac_stride,
                const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t tiles_x, int32_t tiles_y,
-               const uint32_t *__restrict__ cnt_pending, uint32_t n_res_blocks,
+               const uint32_t *__restrict__ cnt_pending, uint8_t *__restrict__ tile_state, uint32_t n_res_blocks,
                const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nchunks, const double *__restrict__ cum,
                const double *__restrict__ chunk_off, double r01, double fraction, int32_t n, int64_t offset,
                float *__restrict__ pose2, float *__restrict__ cs2, double *__restrict__ w2, int32_t *__restrict__ idx_out,
@@ -120,7 +120,7 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
                       nblk_global, stats, blockIdx.x, 0, smem, raw_weights != 0);
     else
         likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, 1, tiles_x, tiles_y, blockIdx.x - n_res_blocks, 0,
-                            gridDim.x - n_res_blocks, smem, cnt_pending);
+                            gridDim.x - n_res_blocks, smem, cnt_pending, tile_state);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -177,7 +177,7 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
     const size_t RH = LK_TH + 2 * k, RW = LK_TW + 2 * k;
     const size_t smem_l = (RH * (RW + 1) + RH * (LK_TW + 1) + (2 * k + 1)) * sizeof(double);
     int32_t blocks = tiles_x * tiles_y;
-    const int32_t cap = smem_l <= 40 * 1024 ? 1024 : 512;
+    const int32_t cap = smem_l <= 40 * 1024 ? 1024 : (smem_l <= 53 * 1024 ? 768 : 512);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~7;
     const int64_t nch = nchunks_of(pf);
@@ -191,7 +191,7 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lik_resample<KH>),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
         hipLaunchKernelGGL(k_lik_resample<KH>, dim3((uint32_t)blocks + n_res), dim3(256), smem, m->stream, m->gd, m->d_log, \
-                           m->d_lik, m->d_fac, m->fac_stride, m->d_taps, bb, tiles_x, tiles_y, m->d_cnt, n_res, pf->d_global, \
+                           m->d_lik, m->d_fac, m->fac_stride, m->d_taps, bb, tiles_x, tiles_y, m->d_cnt, m->d_tile_state, n_res, pf->d_global, \
                            pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->r01_scalar, fraction, pf->n, pf->offset,     \
                            pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats,       \
                            pf->global_raw);                                                                              \

@@ -192,7 +192,7 @@ static int map_free(gms_map *m) {
     if (!m) return GMS_OK;
     prof_drain(m);
     for (ProfSlot &s : m->prof_free) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
-    hipFree(m->d_log); hipFree(m->d_lik); hipFree(m->d_fac); hipFree(m->d_cnt); hipFree(m->d_bbox); hipFree(m->d_taps);
+    hipFree(m->d_log); hipFree(m->d_lik); hipFree(m->d_fac); hipFree(m->d_cnt); hipFree(m->d_bbox); hipFree(m->d_taps); hipFree(m->d_tile_state);
     hipFree(m->d_beams); hipFree(m->d_poses); hipFree(m->d_scratch);
     hipFree(m->d_trace_cells); hipFree(m->d_trace_cls); hipFree(m->d_trace_cnt);
     if (m->h_beams) hipHostFree(m->h_beams);
@@ -248,6 +248,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     ok = ok && hipMalloc(&m->d_cnt, cells * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_bbox, (size_t)m->n_maps * 8 * sizeof(int32_t)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_taps, GMS_MAX_TAPS * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_tile_state, (size_t)((g.W + 63) / 64) * ((g.H + 31) / 32) * m->n_maps) == hipSuccess;
     ok = ok && hipMalloc(&m->d_beams, (size_t)m->n_maps * m->max_beams * sizeof(gms_beam)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_poses, (size_t)m->n_maps * 3 * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_scratch, 64 * sizeof(double)) == hipSuccess;

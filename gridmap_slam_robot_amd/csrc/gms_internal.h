@@ -82,6 +82,7 @@ struct gms_map {
     int32_t bbox_cur;     // half in use
     int32_t bbox_dirty;   // an integrate ran since the last likelihood build
     double *d_taps;       // [ktaps]
+    uint8_t *d_tile_state;  // [n_maps][likelihood tiles]: 0 unknown, 1..3 the tile of d_lik/d_fac holds the constants of a uniform tile of code 0 / 0.5 / 1
     gms_beam *d_beams;    // [n_maps][max_beams] staging
     float *d_poses;       // [n_maps][3] staging
     double *d_scratch;    // small device scratch
@@ -166,6 +167,7 @@ void gms_launch_deskew(gms_map *m, const double *d_angle, const double *d_distan
                        double d_center, double d_theta, gms_beam *d_out);
 void gms_launch_factors(gms_map *m);   // d_fac from d_lik (after an upload / copy)
 void gms_launch_noop(gms_map *m);
+void gms_invalidate_tile_state(gms_map *m);
 void gms_launch_get_raw(gms_map *m, int32_t mi, int32_t x, int32_t y, double *d_out2);
 void gms_launch_debug_f32(gms_map *m, int32_t op, const float *d_a, float *d_out, int64_t n);
 

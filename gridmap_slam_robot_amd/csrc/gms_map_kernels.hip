@@ -279,7 +279,7 @@ __device__ __forceinline__ void
 likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
                 int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
                 int32_t tiles_x, int32_t tiles_y, uint32_t bx, uint32_t by, uint32_t gdx, unsigned char *smem,
-                const uint32_t *__restrict__ cnt_pending = nullptr) {
+                const uint32_t *__restrict__ cnt_pending = nullptr, uint8_t *__restrict__ tile_state = nullptr) {
     const int32_t k = KH > 0 ? KH : g.khalf;
     const int32_t ntaps = 2 * k + 1;
     const int32_t RW = LK_TW + 2 * k, RH = LK_TH + 2 * k;     // staged columns / rows
@@ -287,7 +287,8 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     double *in_s = reinterpret_cast<double *>(smem);          // [RH][PIN]
     double *hs = in_s + (size_t)RH * PIN;                     // [RH][PHS]
     double *taps_s = hs + (size_t)RH * PHS;                   // [ntaps] (generic path)
-    __shared__ int32_t s_mask;
+    __shared__ int32_t s_mask[3];
+    int32_t tile_iter = 0;
 
     const int32_t mi = (int32_t)by;
     const double *mlog = logd + (size_t)mi * g.cells;
@@ -312,34 +313,49 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     if (KH == 0)
         for (int32_t i = threadIdx.x; i < ntaps; i += blockDim.x) taps_s[i] = taps_g[i];
 
-    for (int32_t t = (int32_t)bx; t < ntiles; t += (int32_t)gdx) {
-        // XCD-aware order (full rebuild): workgroups b and b+8 share an XCD, so each XCD walks a
-        // contiguous band of tiles and the halo re-reads hit its own L2
-        int32_t tile = t;
-        if (!dirty_only && (ntiles & 7) == 0) tile = (t & 7) * (ntiles >> 3) + (t >> 3);
-        const int32_t tx0 = (qx0 + tile % qnx) * LK_TW, ty0 = (qy0 + tile / qnx) * LK_TH;
-
-        __syncthreads();                                       // previous tile's LDS reads are done
-        if (threadIdx.x == 0) s_mask = 0;
+    // XCD-aware order (full rebuild): workgroups b and b+8 share an XCD, so each XCD walks a
+    // contiguous band of tiles and the halo re-reads hit its own L2
+    auto tile_of = [&](int32_t t) { return (!dirty_only && (ntiles & 7) == 0) ? (t & 7) * (ntiles >> 3) + (t >> 3) : t; };
+    // The staged rectangle of a tile: every load is issued before the first one is consumed (addresses clamped into
+    // the map, so no load sits behind a branch: 13 dependent round trips otherwise), and the NEXT tile's loads are
+    // issued as soon as this tile's values are in LDS, so they fly during the barriers and the two blur passes.
+    constexpr int32_t CRW = LK_TW + 2 * (KH > 0 ? KH : 1), CRH = LK_TH + 2 * (KH > 0 ? KH : 1);
+    constexpr int32_t P1 = (CRW * CRH + 255) / 256;
+    double lv[P1];
+    uint32_t cv[P1];
+    auto issue_loads = [&](int32_t t) {
+        const int32_t tile = tile_of(t);
+        const int32_t ltx0 = (qx0 + tile % qnx) * LK_TW, lty0 = (qy0 + tile / qnx) * LK_TH;
+#pragma unroll
+        for (int q = 0; q < P1; q++) {
+            const int32_t idx = (int32_t)threadIdx.x + q * 256;
+            const int32_t r = idx / CRW, c = idx - r * CRW;
+            const int32_t gy = min(max(lty0 - KH + r, 0), g.H - 1), gx = min(max(ltx0 - KH + c, 0), g.W - 1);
+            lv[q] = mlog[(size_t)gy * g.W + gx];
+            cv[q] = mcnt ? mcnt[(size_t)gy * g.W + gx] : 0u;
+        }
+    };
+    if (KH > 0) {
+        if (threadIdx.x < 3) s_mask[threadIdx.x] = 0;
         __syncthreads();
+        if ((int32_t)bx < ntiles) issue_loads((int32_t)bx);
+    }
+
+    for (int32_t t = (int32_t)bx; t < ntiles; t += (int32_t)gdx) {
+        const int32_t tile = tile_of(t);
+        const int32_t tx0 = (qx0 + tile % qnx) * LK_TW, ty0 = (qy0 + tile / qnx) * LK_TH;
+        // what this tile of likelihoodData / the factor table holds: 0 unknown, 1..3 the constants of a uniform tile
+        uint8_t *tstate = tile_state ? tile_state + (size_t)mi * tiles_x * tiles_y + (size_t)(qy0 + tile / qnx) * tiles_x + (qx0 + tile % qnx)
+                                     : nullptr;
 
         // ---- phase 1
         int32_t seen = 0;                                      // bit c: a cell of code c; bit 3: outside the map
+        uint32_t codes = 0;                                    // KH > 0: 2 bits per staged cell of this thread (3 = outside)
+        int32_t *smask = &s_mask[0];
         if (KH > 0) {
-            // every load of the staged rectangle is issued before the first one is consumed: the addresses are
-            // clamped into the map so that no load sits behind a branch (13 dependent round trips otherwise)
-            constexpr int32_t CRW = LK_TW + 2 * (KH > 0 ? KH : 1), CRH = LK_TH + 2 * (KH > 0 ? KH : 1);
-            constexpr int32_t P1 = (CRW * CRH + 255) / 256;
-            double lv[P1];
-            uint32_t cv[P1];
-#pragma unroll
-            for (int q = 0; q < P1; q++) {
-                const int32_t idx = (int32_t)threadIdx.x + q * 256;
-                const int32_t r = idx / CRW, c = idx - r * CRW;
-                const int32_t gy = min(max(ty0 - KH + r, 0), g.H - 1), gx = min(max(tx0 - KH + c, 0), g.W - 1);
-                lv[q] = mlog[(size_t)gy * g.W + gx];
-                cv[q] = mcnt ? mcnt[(size_t)gy * g.W + gx] : 0u;
-            }
+            // The codes come out of registers; LDS is written only if the tile turns out not to be uniform (most of a
+            // map is), and the mask word rotates through three slots so that a uniform tile costs one barrier.
+            smask = &s_mask[tile_iter % 3];
 #pragma unroll
             for (int q = 0; q < P1; q++)
                 if (cv[q]) lv[q] = lv[q] + ((double)(cv[q] & 0xffffu) * g.l_free + (double)(cv[q] >> 16) * g.l_occ);
@@ -349,18 +365,20 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 const int32_t r = idx / CRW, c = idx - r * CRW;
                 const int32_t gy = ty0 - KH + r, gx = tx0 - KH + c;
                 if (idx < CRW * CRH) {
-                    double val = 0.0;
+                    int32_t code = 3;
                     if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
-                        const int32_t code = lv[q] > 0.0 ? 2 : (lv[q] < 0.0 ? 0 : 1);     // GridMap.java:239-244
-                        val = 0.5 * (double)code;
+                        code = lv[q] > 0.0 ? 2 : (lv[q] < 0.0 ? 0 : 1);                    // GridMap.java:239-244
                         seen |= 1 << code;
                     } else {
                         seen |= 8;
                     }
-                    in_s[r * PIN + c] = val;
+                    codes |= (uint32_t)code << (2 * q);
                 }
             }
         } else {
+            __syncthreads();                                   // previous tile's LDS reads are done
+            if (threadIdx.x == 0) *smask = 0;
+            __syncthreads();
 #pragma unroll 4
             for (int32_t idx = threadIdx.x; idx < RH * RW; idx += blockDim.x) {
                 const int32_t r = idx / RW, c = idx - r * RW;
@@ -381,12 +399,35 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) seen |= __shfl_xor(seen, o, GMS_WAVE);
-        if ((threadIdx.x & 63) == 0) atomicOr(&s_mask, seen);
+        if ((threadIdx.x & 63) == 0) atomicOr(smask, seen);
         __syncthreads();
-        const int32_t mask = s_mask;
+        const int32_t mask = *smask;
+        if (KH > 0) {
+            // Re-arm the slot of the PREVIOUS tile (every thread read it before arriving at this barrier); it is used
+            // again two tiles from now, after the next barrier.  (Re-arming the next tile's slot here would race with
+            // a wavefront that is already OR-ing into it.)
+            if (threadIdx.x == 0) s_mask[(tile_iter + 2) % 3] = 0;
+            tile_iter++;
+            const bool uniform = mask == 1 || mask == 2 || mask == 4;
+            if (!uniform) {
+                // stage {0, 0.5, 1} (outside the map: 0.0).  Every thread passed the barrier above, so the previous
+                // tile's reads of in_s and hs are over.
+#pragma unroll
+                for (int q = 0; q < P1; q++) {
+                    const int32_t idx = (int32_t)threadIdx.x + q * 256;
+                    const int32_t r = idx / CRW, c = idx - r * CRW;
+                    const uint32_t code = (codes >> (2 * q)) & 3u;
+                    if (idx < CRW * CRH) in_s[r * PIN + c] = code == 3u ? 0.0 : 0.5 * (double)code;
+                }
+            }
+            if (t + (int32_t)gdx < ntiles) issue_loads(t + (int32_t)gdx);      // in flight during the rest of this tile
+            if (!uniform) __syncthreads();
+        }
 
         if (mask == 1 || mask == 2 || mask == 4) {
             // ---- uniform tile: every in-order sum sees the same inputs
+            const uint8_t want = mask == 1 ? 1 : (mask == 2 ? 2 : 3);
+            if (tstate && *tstate == want) continue;           // the tile already holds exactly these constants: no store
             const double cval = mask == 1 ? 0.0 : (mask == 2 ? 0.5 : 1.0);
             double hc = 0.0;
             for (int32_t i = 0; i < ntaps; i++) hc += taps_g[i] * cval;           // Util.java:393-401
@@ -399,8 +440,10 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 mlik[o] = vc;
                 mfac[o] = fc;
             }
+            if (tstate && threadIdx.x == 0) *tstate = want;
             continue;
         }
+        if (tstate && threadIdx.x == 0) *tstate = 0;
 
         if (KH > 0) {
             // ---- phase 2: strips of LK_STRIP outputs along x
@@ -465,10 +508,10 @@ template <int KH>
 __global__ void __launch_bounds__(256)
 k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
              int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
-             int32_t tiles_x, int32_t tiles_y) {
+             int32_t tiles_x, int32_t tiles_y, uint8_t *__restrict__ tile_state) {
     extern __shared__ __align__(16) unsigned char smem[];
     likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, dirty_only, tiles_x, tiles_y, blockIdx.x, blockIdx.y,
-                        gridDim.x, smem);
+                        gridDim.x, smem, nullptr, tile_state);
 }
 
 // scoring factors from an existing likelihood field (upload / copy); entry [cells] = neutral 1.0
@@ -625,7 +668,8 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only) {
     const size_t smem = (RH * (RW + 1) + RH * (LK_TW + 1) + (2 * k + 1)) * sizeof(double);
     // persistent workgroups: 4 per CU when LDS allows, each walks tiles blockIdx.x, += gridDim.x
     int32_t blocks = tiles_x * tiles_y;
-    const int32_t cap = (smem <= 40 * 1024 ? 1024 : 512) / (m->n_maps > 4 ? 4 : m->n_maps);
+    // persistent workgroups per CU by LDS: 4 up to 40 KiB each, 3 up to 53 KiB (KH = 5: 47 KiB), else 2
+    const int32_t cap = (smem <= 40 * 1024 ? 1024 : (smem <= 53 * 1024 ? 768 : 512)) / (m->n_maps > 4 ? 4 : m->n_maps);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~7;                      // keep the XCD round-robin aligned
     dim3 grid(blocks, m->n_maps);
@@ -636,7 +680,7 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only) {
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_likelihood<KH>),                           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                       \
         hipLaunchKernelGGL(k_likelihood<KH>, grid, dim3(256), smem, m->stream, m->gd, m->d_log, m->d_lik,     \
-                           m->d_fac, m->fac_stride, m->d_taps, bb, dirty_only, tiles_x, tiles_y);                                      \
+                           m->d_fac, m->fac_stride, m->d_taps, bb, dirty_only, tiles_x, tiles_y, m->d_tile_state);                                      \
     } while (0)
     if (k == 3) LK_LAUNCH(3);
     else if (k == 5) LK_LAUNCH(5);
@@ -647,7 +691,15 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only) {
 __global__ void k_noop() {}
 void gms_launch_noop(gms_map *m) { hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, m->stream); }
 
+// likelihoodData / the factor table were written by something other than the likelihood kernel: nothing is known
+// about their tiles any more
+void gms_invalidate_tile_state(gms_map *m) {
+    const size_t tiles = (size_t)((m->gd.W + LK_TW - 1) / LK_TW) * ((m->gd.H + LK_TH - 1) / LK_TH);
+    hipMemsetAsync(m->d_tile_state, 0, tiles * m->n_maps, m->stream);
+}
+
 void gms_launch_factors(gms_map *m) {
+    gms_invalidate_tile_state(m);
     hipLaunchKernelGGL(k_factors, dim3(1024, m->n_maps), dim3(256), 0, m->stream, m->gd, m->d_lik, m->d_fac, m->fac_stride);
 }
 
