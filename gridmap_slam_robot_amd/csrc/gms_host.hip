@@ -187,6 +187,37 @@ int gms_profile_calibrate(gms_map *m, int32_t reps, double *bracket_ms) {
     return GMS_OK;
 }
 
+// ---- pinned staging rings -----------------------------------------------------------------------------
+static int ring_alloc(StageRing &r, size_t bytes) {
+    for (int i = 0; i < GMS_STAGE_SLOTS; i++) {
+        HIPCHK(hipHostMalloc(&r.slot[i], bytes));
+        HIPCHK(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+    }
+    return GMS_OK;
+}
+static void ring_free(StageRing &r) {
+    for (int i = 0; i < GMS_STAGE_SLOTS; i++) {
+        if (r.slot[i]) hipHostFree(r.slot[i]);
+        if (r.ev[i]) hipEventDestroy(r.ev[i]);
+        r.slot[i] = nullptr; r.ev[i] = nullptr; r.busy[i] = false;
+    }
+}
+// next slot, free to be overwritten by the host (waits only for the copy that used it GMS_STAGE_SLOTS calls ago)
+static int ring_acquire(StageRing &r, void **out) {
+    const int i = r.next;
+    if (r.busy[i]) { HIPCHK(hipEventSynchronize(r.ev[i])); r.busy[i] = false; }
+    *out = r.slot[i];
+    return GMS_OK;
+}
+// call after enqueueing the asynchronous copy out of the acquired slot
+static int ring_commit(StageRing &r, hipStream_t stream) {
+    const int i = r.next;
+    HIPCHK(hipEventRecord(r.ev[i], stream));
+    r.busy[i] = true;
+    r.next = (i + 1) % GMS_STAGE_SLOTS;
+    return GMS_OK;
+}
+
 // ---- GridMap --------------------------------------------------------------------------------------
 static int map_free(gms_map *m) {
     if (!m) return GMS_OK;
@@ -196,6 +227,8 @@ static int map_free(gms_map *m) {
     hipFree(m->d_beams); hipFree(m->d_poses); hipFree(m->d_scratch);
     hipFree(m->d_trace_cells); hipFree(m->d_trace_cls); hipFree(m->d_trace_cnt);
     if (m->h_beams) hipHostFree(m->h_beams);
+    ring_free(m->beam_ring);
+    if (m->pose_copy_ev_set) hipEventDestroy(m->pose_copy_ev);
     if (m->h_poses) hipHostFree(m->h_poses);
     if (m->own_stream) hipStreamDestroy(m->own_stream);
 
@@ -250,9 +283,10 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     ok = ok && hipMalloc(&m->d_taps, GMS_MAX_TAPS * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_tile_state, (size_t)((g.W + 63) / 64) * ((g.H + 31) / 32) * m->n_maps) == hipSuccess;
     ok = ok && hipMalloc(&m->d_beams, (size_t)m->n_maps * m->max_beams * sizeof(gms_beam)) == hipSuccess;
-    ok = ok && hipMalloc(&m->d_poses, (size_t)m->n_maps * 3 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_poses, (size_t)m->n_maps * 3 * sizeof(float) + 16) == hipSuccess;   // (+16: copied in 16-byte units)
     ok = ok && hipMalloc(&m->d_scratch, 64 * sizeof(double)) == hipSuccess;
     ok = ok && hipHostMalloc(&m->h_beams, (size_t)m->n_maps * m->max_beams * sizeof(gms_beam)) == hipSuccess;
+    ok = ok && ring_alloc(m->beam_ring, (size_t)m->n_maps * m->max_beams * sizeof(gms_beam)) == GMS_OK;
     ok = ok && hipHostMalloc(&m->h_poses, (size_t)m->n_maps * 3 * sizeof(float) + 64 * sizeof(double)) == hipSuccess;
     if (!ok) { map_free(m); return fail(GMS_ERR_NOMEM, "device allocation failed (%zu cells x %d maps)", (size_t)g.cells, m->n_maps); }
     hipMemcpyAsync(m->d_taps, p->kernel, p->ktaps * sizeof(double), hipMemcpyHostToDevice, m->stream);
@@ -448,22 +482,27 @@ static int stage_beams(gms_map *m, const gms_beam *beams, int32_t B) {
     REQUIRE(beams, "null beams");
     REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
     HIPCHK(hipSetDevice(m->device));
-    // the pinned staging buffer may still feed an earlier copy
-    HIPCHK(hipStreamSynchronize(m->stream));
+    void *slot = nullptr;
+    int rc = ring_acquire(m->beam_ring, &slot);
+    if (rc) return rc;
+    gms_beam *h = static_cast<gms_beam *>(slot);
     for (int32_t mi = 0; mi < m->n_maps; mi++)
-        memcpy(m->h_beams + (size_t)mi * m->max_beams, beams + (size_t)mi * B, (size_t)B * sizeof(gms_beam));
-    if (m->n_maps == 1)
-        HIPCHK(hipMemcpyAsync(m->d_beams, m->h_beams, (size_t)B * sizeof(gms_beam), hipMemcpyHostToDevice, m->stream));
-    else
-        HIPCHK(hipMemcpyAsync(m->d_beams, m->h_beams, (size_t)m->n_maps * m->max_beams * sizeof(gms_beam),
-                              hipMemcpyHostToDevice, m->stream));
-    return GMS_OK;
+        memcpy(h + (size_t)mi * m->max_beams, beams + (size_t)mi * B, (size_t)B * sizeof(gms_beam));
+    // (the device-side staging buffer is safe to overwrite in stream order: earlier kernels that read it come first;
+    // sizeof(gms_beam) is a multiple of 16, so the copy kernel's granularity fits)
+    gms_launch_copy(m, m->d_beams, h, (m->n_maps == 1 ? (size_t)B : (size_t)m->n_maps * m->max_beams) * sizeof(gms_beam));
+    return ring_commit(m->beam_ring, m->stream);
 }
 
 static int stage_poses(gms_map *m, const float *poses) {
     REQUIRE(poses, "null poses");
+    // 12 bytes per map: passed through the beam ring's slot-sized buffers would be wasteful; the previous copy out
+    // of h_poses is awaited instead (it is long done unless calls come back to back)
+    if (m->pose_copy_ev_set) HIPCHK(hipEventSynchronize(m->pose_copy_ev));
     memcpy(m->h_poses, poses, (size_t)m->n_maps * 3 * sizeof(float));
-    HIPCHK(hipMemcpyAsync(m->d_poses, m->h_poses, (size_t)m->n_maps * 3 * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    gms_launch_copy(m, m->d_poses, m->h_poses, (size_t)m->n_maps * 3 * sizeof(float));
+    if (!m->pose_copy_ev_set) { HIPCHK(hipEventCreateWithFlags(&m->pose_copy_ev, hipEventDisableTiming)); m->pose_copy_ev_set = 1; }
+    HIPCHK(hipEventRecord(m->pose_copy_ev, m->stream));
     return GMS_OK;
 }
 
@@ -675,6 +714,7 @@ int gms_pf_destroy(gms_pf *pf) {
     pf_free_global(pf);
     if (pf->h_stats) hipHostFree(pf->h_stats);
     if (pf->h_stage) hipHostFree(pf->h_stage);
+    ring_free(pf->pose_ring);
     delete pf;
     return GMS_OK;
 }
@@ -701,6 +741,7 @@ int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // Partic
     ok = ok && hipMalloc(&pf->d_idx, T * 4) == hipSuccess;
     ok = ok && hipHostMalloc(&pf->h_stats, (size_t)m->n_maps * sizeof(PfStatsDev) + (size_t)m->n_maps * 8) == hipSuccess;
     ok = ok && hipHostMalloc(&pf->h_stage, T * 3 * sizeof(float)) == hipSuccess;
+    ok = ok && ring_alloc(pf->pose_ring, T * 3 * sizeof(float)) == GMS_OK;
     if (!ok || pf_alloc_global(pf) != GMS_OK) { gms_pf_destroy(pf); return fail(GMS_ERR_NOMEM, "device allocation failed for %d particles", n); }
     hipMemsetAsync(pf->d_stats, 0, (size_t)m->n_maps * 2 * sizeof(PfStatsDev), m->stream);
     gms_launch_pf_init(pf);
@@ -721,15 +762,25 @@ int gms_pf_set_shard(gms_pf *pf, int64_t offset, int64_t n_global) {
     return pf_alloc_global(pf);
 }
 
+// host poses -> a pinned ring slot -> the filter (k_pose_trig reads the slot over PCIe: copy + trig in one launch; no
+// stream synchronisation, no hipMemcpyAsync)
+static int upload_poses(gms_pf *pf, const float *xytheta) {
+    gms_map *m = pf->map;
+    const size_t bytes = (size_t)pf->n * pf->n_maps * 3 * sizeof(float);
+    void *slot = nullptr;
+    int rc = ring_acquire(pf->pose_ring, &slot);
+    if (rc) return rc;
+    memcpy(slot, xytheta, bytes);
+    gms_launch_pf_pose_trig(pf, static_cast<const float *>(slot));
+    return ring_commit(pf->pose_ring, m->stream);
+}
+
 int gms_pf_set_poses(gms_pf *pf, const float *xytheta) {
     REQUIRE(pf && xytheta, "null argument");
     gms_map *m = pf->map;
     HIPCHK(hipSetDevice(m->device));
-    HIPCHK(hipStreamSynchronize(m->stream));          // the pinned staging buffer may still feed an earlier copy
-    const size_t bytes = (size_t)pf->n * pf->n_maps * 3 * sizeof(float);
-    memcpy(pf->h_stage, xytheta, bytes);
-    HIPCHK(hipMemcpyAsync(pf->d_pose, pf->h_stage, bytes, hipMemcpyHostToDevice, m->stream));
-    gms_launch_pf_pose_trig(pf, pf->d_pose);
+    int rc = upload_poses(pf, xytheta);
+    if (rc) return rc;
     pf->have_global = 0;
     pf->stats_current = 0;
     return GMS_OK;
@@ -1041,10 +1092,10 @@ int gms_slam_update(gms_pf *pf, const float *xytheta, const gms_beam *beams, int
     if (pf->offset != 0 || pf->n_global != pf->n)
         return fail(GMS_ERR_STATE, "sharded filter: the collectives belong to the caller (see distributed.py)");
     int rc = GMS_OK;
+    const int32_t stride_ok = (m->n_maps == 1) || (B == m->max_beams);
     if (xytheta) rc = gms_pf_set_poses(pf, xytheta);
     if (!rc) rc = stage_beams(m, beams, B);
     const gms_beam *d = m->d_beams;
-    const int32_t stride_ok = (m->n_maps == 1) || (B == m->max_beams);
     if (!rc && !stride_ok) {
         // batched handles stage [n_maps][max_beams]; the *_dev entry points expect [n_maps][B]: go through the
         // staging-stride launchers instead

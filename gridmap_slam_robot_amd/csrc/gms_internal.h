@@ -63,6 +63,16 @@ struct ProfSlot {
     int32_t k;
 };
 
+// Pinned host staging for inputs that arrive as host buffers: a small ring, so that copying the next scan's inputs
+// never waits for the stream to drain -- only (rarely) for the copy that last used the same slot.
+#define GMS_STAGE_SLOTS 4
+struct StageRing {
+    void *slot[GMS_STAGE_SLOTS] = {};
+    hipEvent_t ev[GMS_STAGE_SLOTS] = {};
+    bool busy[GMS_STAGE_SLOTS] = {};
+    int32_t next = 0;
+};
+
 struct gms_map {
     gms_params prm;
     GridDev gd;
@@ -91,8 +101,11 @@ struct gms_map {
     int32_t need_full_build;  // likelihood field must be rebuilt everywhere (upload/reset/copy)
     int32_t apply_pending;    // the last scan's counts are not in logData yet (deferred apply pass, gms_flush_apply)
     int32_t pair_launches;    // scan steps pair independent kernels in one launch (GMS_PAIR_LAUNCHES=0 turns it off)
-    gms_beam *h_beams;    // pinned staging
+    gms_beam *h_beams;    // pinned staging (de-skew inputs, single-ray entry)
+    StageRing beam_ring;  // pinned staging of scans handed over as host buffers
     float *h_poses;       // pinned staging
+    hipEvent_t pose_copy_ev;  // the last copy out of h_poses
+    int32_t pose_copy_ev_set;
     int32_t *d_trace_cells; uint8_t *d_trace_cls; int32_t *d_trace_cnt; size_t trace_cap_bytes;
     // profiling
     int32_t prof_on;
@@ -133,7 +146,8 @@ struct gms_pf {
     double *d_r01;                  // [n_maps] (batched maps; a single map passes r01 as a kernel argument)
     double r01_scalar;
     int32_t *d_idx;                 // [n_maps][n]
-    float *h_stage;                 // pinned staging for poses
+    float *h_stage;                 // pinned staging for poses (read-back)
+    StageRing pose_ring;            // pinned staging of pose proposals handed over as host buffers
     int32_t have_global;            // d_global holds the current normalised population
     int32_t chunks_ready;           // d_cum / d_chunk_tot hold level 0 of the scan of d_global
     int32_t pending_nseg;           // > 0: d_w is stale, the weights are still d_part's segment products
@@ -167,6 +181,7 @@ void gms_launch_deskew(gms_map *m, const double *d_angle, const double *d_distan
                        double d_center, double d_theta, gms_beam *d_out);
 void gms_launch_factors(gms_map *m);   // d_fac from d_lik (after an upload / copy)
 void gms_launch_noop(gms_map *m);
+void gms_launch_copy(gms_map *m, void *dst, const void *src, size_t nbytes);   // src may be pinned host memory
 void gms_invalidate_tile_state(gms_map *m);
 void gms_launch_get_raw(gms_map *m, int32_t mi, int32_t x, int32_t y, double *d_out2);
 void gms_launch_debug_f32(gms_map *m, int32_t op, const float *d_a, float *d_out, int64_t n);

@@ -688,6 +688,20 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only) {
 #undef LK_LAUNCH
 }
 
+// pinned host memory -> device memory, 16 bytes per lane (nbytes rounded up by the caller's buffers).  A kernel rather
+// than hipMemcpyAsync: enqueueing an asynchronous host-to-device copy costs ~45 us of HOST time on this stack
+// (tools/host_path_probe.py), a launch ~5 us.
+__global__ void k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void gms_launch_copy(gms_map *m, void *dst, const void *src, size_t nbytes) {
+    const int64_t n16 = (int64_t)((nbytes + 15) / 16);
+    if (n16 == 0) return;
+    const int64_t blocks = (n16 + 255) / 256;
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, m->stream,
+                       reinterpret_cast<uint4 *>(dst), reinterpret_cast<const uint4 *>(src), n16);
+}
+
 __global__ void k_noop() {}
 void gms_launch_noop(gms_map *m) { hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, m->stream); }
 
