@@ -236,8 +236,10 @@ int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B);
  * (SLAM.java:82).  r01[n_maps] is read on the host.  Nothing is read back. */
 int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, const double *r01,
                         double resample_fraction, int32_t integrate);
-/* The same scan step with HOST inputs (what a JNI caller holds): poses (may be NULL) and the scan are staged once;
- * stats (may be NULL; when given the call synchronises) receives SLAM.update's return values. */
+/* The same scan step with HOST inputs (what a JNI caller holds): poses (may be NULL) and the scan are copied into
+ * pinned staging rings before the call returns (the caller may reuse its buffers at once) and pulled in by the
+ * device without a stream synchronise; stats (may be NULL; when given the call synchronises) receives SLAM.update's
+ * return values. */
 int gms_slam_update(gms_pf *pf, const float *xytheta, const gms_beam *beams, int32_t B, const double *r01,
                     double resample_fraction, int32_t integrate, gms_pf_stats *stats);
 
