@@ -715,6 +715,7 @@ int gms_pf_destroy(gms_pf *pf) {
     if (pf->h_stats) hipHostFree(pf->h_stats);
     if (pf->h_stage) hipHostFree(pf->h_stage);
     ring_free(pf->pose_ring);
+    ring_free(pf->r01_ring);
     delete pf;
     return GMS_OK;
 }
@@ -737,7 +738,8 @@ int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // Partic
     ok = ok && hipMalloc(&pf->d_nhit, (size_t)m->n_maps * 4) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_part, T * GMS_SCORE_MAXSEG * 8) == hipSuccess;
     ok = ok && hipMalloc(&pf->d_stats, (size_t)m->n_maps * 2 * sizeof(PfStatsDev)) == hipSuccess;
-    ok = ok && hipMalloc(&pf->d_r01, (size_t)m->n_maps * 8) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_r01, (size_t)m->n_maps * 8 + 16) == hipSuccess;          // (+16: copied in 16-byte units)
+    ok = ok && ring_alloc(pf->r01_ring, (size_t)m->n_maps * 8 + 16) == GMS_OK;
     ok = ok && hipMalloc(&pf->d_idx, T * 4) == hipSuccess;
     ok = ok && hipHostMalloc(&pf->h_stats, (size_t)m->n_maps * sizeof(PfStatsDev) + (size_t)m->n_maps * 8) == hipSuccess;
     ok = ok && hipHostMalloc(&pf->h_stage, T * 3 * sizeof(float)) == hipSuccess;
@@ -1005,10 +1007,13 @@ static int do_resample(gms_pf *pf, const double *r01, double fraction, int32_t *
     if (pf->n_maps == 1) {
         pf->r01_scalar = r01[0];                       // travels as a kernel argument: no copy, no synchronisation
     } else {
-        HIPCHK(hipStreamSynchronize(m->stream));       // h_stats tail doubles as the r01 staging area
-        double *h_r = reinterpret_cast<double *>(reinterpret_cast<char *>(pf->h_stats) + (size_t)pf->n_maps * sizeof(PfStatsDev));
-        memcpy(h_r, r01, (size_t)pf->n_maps * sizeof(double));
-        HIPCHK(hipMemcpyAsync(pf->d_r01, h_r, (size_t)pf->n_maps * sizeof(double), hipMemcpyHostToDevice, m->stream));
+        void *slot = nullptr;                          // one draw per map: pinned ring slot -> copy kernel, no synchronise
+        int rr = ring_acquire(pf->r01_ring, &slot);
+        if (rr) return rr;
+        memcpy(slot, r01, (size_t)pf->n_maps * sizeof(double));
+        gms_launch_copy(m, pf->d_r01, slot, (size_t)pf->n_maps * sizeof(double));
+        rr = ring_commit(pf->r01_ring, m->stream);
+        if (rr) return rr;
     }
     gms_launch_pf_resample(pf, fraction);
     std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);

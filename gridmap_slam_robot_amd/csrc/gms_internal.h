@@ -148,6 +148,7 @@ struct gms_pf {
     int32_t *d_idx;                 // [n_maps][n]
     float *h_stage;                 // pinned staging for poses (read-back)
     StageRing pose_ring;            // pinned staging of pose proposals handed over as host buffers
+    StageRing r01_ring;             // pinned staging of the per-map resampling draws (n_maps > 1)
     int32_t have_global;            // d_global holds the current normalised population
     int32_t chunks_ready;           // d_cum / d_chunk_tot hold level 0 of the scan of d_global
     int32_t pending_nseg;           // > 0: d_w is stale, the weights are still d_part's segment products
