@@ -52,8 +52,10 @@ k_partials_apply(double *__restrict__ w, double *__restrict__ logw, const float 
                  int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part, int32_t part_nseg,
                  GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
                  int32_t *__restrict__ bbox_idle) {
-    if (blockIdx.x < (uint32_t)nblk_global) partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, 0);
-    else apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - (uint32_t)nblk_global, 0, gridDim.x - (uint32_t)nblk_global);
+    if (blockIdx.x < (uint32_t)nblk_global)
+        partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y);
+    else
+        apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - (uint32_t)nblk_global, blockIdx.y, gridDim.x - (uint32_t)nblk_global);
 }
 
 // ---- sharded filters, one all-gather per scan (gms_slam_update_sharded_*) ---------------------------------------
@@ -111,16 +113,17 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
                const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t tiles_x, int32_t tiles_y,
                const uint32_t *__restrict__ cnt_pending, uint8_t *__restrict__ tile_state, uint32_t n_res_blocks,
                const PackedParticle *__restrict__ glob, int64_t n_global, int64_t nchunks, const double *__restrict__ cum,
-               const double *__restrict__ chunk_off, double r01, double fraction, int32_t n, int64_t offset,
+               const double *__restrict__ chunk_off, const double *__restrict__ r01_maps, double r01, double fraction,
+               int32_t n, int64_t offset,
                float *__restrict__ pose2, float *__restrict__ cs2, double *__restrict__ w2, int32_t *__restrict__ idx_out,
                const double *__restrict__ p2, int64_t nblk_global, PfStatsDev *__restrict__ stats, int32_t raw_weights) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (blockIdx.x < n_res_blocks)                      // a multiple of 8 keeps the likelihood tiles' XCD round-robin aligned
-        resample_body(glob, n_global, nchunks, cum, chunk_off, nullptr, r01, fraction, n, offset, pose2, cs2, w2, idx_out, p2,
-                      nblk_global, stats, blockIdx.x, 0, smem, raw_weights != 0);
+        resample_body(glob, n_global, nchunks, cum, chunk_off, r01_maps, r01, fraction, n, offset, pose2, cs2, w2, idx_out, p2,
+                      nblk_global, stats, blockIdx.x, blockIdx.y, smem, raw_weights != 0);
     else
-        likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, 1, tiles_x, tiles_y, blockIdx.x - n_res_blocks, 0,
-                            gridDim.x - n_res_blocks, smem, cnt_pending, tile_state);
+        likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, 1, tiles_x, tiles_y, blockIdx.x - n_res_blocks,
+                            blockIdx.y, gridDim.x - n_res_blocks, smem, cnt_pending, tile_state);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -153,14 +156,14 @@ void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticl
 // block partials (SLAM.java:100-115) beside the apply pass the previous paired step left pending
 void gms_launch_partials_apply(gms_pf *pf, double *d_partials) {
     gms_map *m = pf->map;
-    if (!m->apply_pending || pf->n_maps != 1) { gms_launch_pf_partials(pf, d_partials); return; }
+    if (!m->apply_pending) { gms_launch_pf_partials(pf, d_partials); return; }
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
     const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
     const uint32_t n_apply = (uint32_t)(all < 2048 ? all : 2048);
-    int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * 4;
-    hipLaunchKernelGGL(k_partials_apply, dim3((uint32_t)nblk + n_apply), dim3(256), 0, m->stream, pf->d_w, pf->d_logw, pf->d_pose,
-                       pf->n, pf->offset, nblk, d_partials,
+    int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4;
+    hipLaunchKernelGGL(k_partials_apply, dim3((uint32_t)nblk + n_apply, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw,
+                       pf->d_pose, pf->n, pf->offset, nblk, d_partials,
                        pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg, m->gd, m->d_log,
                        m->d_cnt, cur, idle);
     pf->pending_nseg = 0;
@@ -177,22 +180,23 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
     const size_t RH = LK_TH + 2 * k, RW = LK_TW + 2 * k;
     const size_t smem_l = (RH * (RW + 1) + RH * (LK_TW + 1) + (2 * k + 1)) * sizeof(double);
     int32_t blocks = tiles_x * tiles_y;
-    const int32_t cap = smem_l <= 40 * 1024 ? 1024 : (smem_l <= 53 * 1024 ? 768 : 512);
+    const int32_t cap = (smem_l <= 40 * 1024 ? 1024 : (smem_l <= 53 * 1024 ? 768 : 512)) / (m->n_maps > 4 ? 4 : m->n_maps);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~7;
     const int64_t nch = nchunks_of(pf);
     const size_t smem_r = (size_t)(nch + 1 + (nch + 63) / 64 + 1) * sizeof(double);
     const size_t smem = smem_l > smem_r ? smem_l : smem_r;
     const uint32_t n_res = (uint32_t)((pf->n + 255) / 256);
-    const int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * 4;
+    const int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;
+    const double *r01_maps = pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01;
 #define LR_LAUNCH(KH)                                                                                                     \
     do {                                                                                                                  \
         if (smem > 48 * 1024)                                                                                             \
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lik_resample<KH>),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
-        hipLaunchKernelGGL(k_lik_resample<KH>, dim3((uint32_t)blocks + n_res), dim3(256), smem, m->stream, m->gd, m->d_log, \
+        hipLaunchKernelGGL(k_lik_resample<KH>, dim3((uint32_t)blocks + n_res, pf->n_maps), dim3(256), smem, m->stream, m->gd, m->d_log, \
                            m->d_lik, m->d_fac, m->fac_stride, m->d_taps, bb, tiles_x, tiles_y, m->d_cnt, m->d_tile_state, n_res, pf->d_global, \
-                           pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->r01_scalar, fraction, pf->n, pf->offset,     \
+                           pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, r01_maps, pf->r01_scalar, fraction, pf->n, pf->offset, \
                            pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats,       \
                            pf->global_raw);                                                                              \
     } while (0)

@@ -998,23 +998,29 @@ int gms_pf_weighted_pose(gms_pf *pf, float *out) {                      // SLAM.
     return GMS_OK;
 }
 
+// Math.random() of SLAM.java:136, one draw per map, to where the resample kernel reads it
+static int stage_r01(gms_pf *pf, const double *r01) {
+    gms_map *m = pf->map;
+    if (pf->n_maps == 1) {
+        pf->r01_scalar = r01[0];                       // travels as a kernel argument: no copy, no synchronisation
+        return GMS_OK;
+    }
+    void *slot = nullptr;                              // pinned ring slot -> copy kernel, no synchronise
+    int rc = ring_acquire(pf->r01_ring, &slot);
+    if (rc) return rc;
+    memcpy(slot, r01, (size_t)pf->n_maps * sizeof(double));
+    gms_launch_copy(m, pf->d_r01, slot, (size_t)pf->n_maps * sizeof(double));
+    return ring_commit(pf->r01_ring, m->stream);
+}
+
 static int do_resample(gms_pf *pf, const double *r01, double fraction, int32_t *indices, int32_t *n_ambiguous) {
     REQUIRE(pf && r01, "null argument");
     gms_map *m = pf->map;
     HIPCHK(hipSetDevice(m->device));
     int rc = ensure_global(pf);
     if (rc) return rc;
-    if (pf->n_maps == 1) {
-        pf->r01_scalar = r01[0];                       // travels as a kernel argument: no copy, no synchronisation
-    } else {
-        void *slot = nullptr;                          // one draw per map: pinned ring slot -> copy kernel, no synchronise
-        int rr = ring_acquire(pf->r01_ring, &slot);
-        if (rr) return rr;
-        memcpy(slot, r01, (size_t)pf->n_maps * sizeof(double));
-        gms_launch_copy(m, pf->d_r01, slot, (size_t)pf->n_maps * sizeof(double));
-        rr = ring_commit(pf->r01_ring, m->stream);
-        if (rr) return rr;
-    }
+    rc = stage_r01(pf, r01);
+    if (rc) return rc;
     gms_launch_pf_resample(pf, fraction);
     std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);
     pf->have_global = 0;
@@ -1047,7 +1053,8 @@ int gms_pf_resample_if(gms_pf *pf, const double *r01, double fraction) {   // Gr
 static int paired_likelihood_resample(gms_pf *pf, const double *r01, double fraction) {
     gms_map *m = pf->map;
     if (fraction >= 0.0) {
-        pf->r01_scalar = r01[0];
+        int rc = stage_r01(pf, r01);
+        if (rc) return rc;
         gms_launch_lik_resample(pf, fraction);
         std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);
         pf->have_global = 0;
@@ -1082,6 +1089,17 @@ int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *de
         pf->have_global = 1;
         pf->stats_current = 1;
         return paired_likelihood_resample(pf, r01, resample_fraction);           // :105 | GridMapApp.java:185-186
+    }
+    if (!rc && integrate && pf->n_maps > 1 && B > 0 && !m->need_full_build && m->pair_launches) {
+        // batched maps: the ray cast runs 16 rays per workgroup (1024 threads), so only the other two pairs apply:
+        // [partials | previous apply] -> normalise -> ray cast -> [likelihood | resample]
+        pf->d_global = pf->d_global_own;
+        gms_launch_partials_apply(pf, pf->d_partials);
+        gms_launch_pf_apply_partials(pf, pf->d_partials, pf->d_global, true);
+        pf->have_global = 1;
+        pf->stats_current = 1;
+        gms_launch_raycast(m, dev_beams, B, B, stats_pose_ptr(pf, 0), (int32_t)(sizeof(PfStatsDev) / sizeof(float)));
+        return paired_likelihood_resample(pf, r01, resample_fraction);
     }
     if (!rc) rc = gms_pf_normalize(pf, nullptr);                                 // :100-124
     if (!rc && resample_fraction >= 0.0) rc = gms_pf_resample_if(pf, r01, resample_fraction);   // GridMapApp.java:185-186

@@ -756,3 +756,36 @@ def test_scan_step_through_the_python_sharding_layer_equals_standalone():
     pg, pl, tg, tl = ops.gather_views()
     assert pg.data_ptr() == ops.pf.gather_buffers()[0] and pl.data_ptr() == pg.data_ptr() and tl.numel() == 3 * 9
     assert pg.numel() == 3 * N and bool(torch.isfinite(tg).all())
+
+
+def test_batched_fused_steps_equal_the_separate_calls():
+    """n_maps > 1: the fused scan step pairs [partials | previous apply] and [likelihood | resample] (the batched ray cast
+    keeps its own launch) and defers the apply pass; several steps back to back == the separate entry points, per map."""
+    import torch
+    dev = torch.device("cuda", 0)
+    M, N, B = 3, 700, 150
+    ext, res = 6.4, 0.05
+    traces = [synth.make_trace(ext, res, B, T=12, seed=40 + i) for i in range(M)]
+    a = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M); b = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M)
+    for m in (a, b):
+        for t in range(3):
+            m.update(np.stack([tr.scans[t] for tr in traces]), np.stack([tr.poses[t] for tr in traces]))
+    pa, pb = ParticleFilter(a, N), ParticleFilter(b, N)
+    rng = np.random.default_rng(12)
+    for t in range(3, 9):
+        P = np.stack([synth.make_particles(traces[i].poses[t], N, seed=10 * t + i, sigma_xy=0.04, sigma_theta_deg=2.0) for i in range(M)])
+        Pd = torch.from_numpy(P).to(dev)
+        scans = np.stack([tr.scans[t] for tr in traces])
+        sd = torch.from_numpy(scans.view(np.uint8).copy()).to(dev)
+        r01 = rng.random(M)
+        frac = -1.0 if t == 6 else 0.9
+        pa.slam_update_dev(Pd.data_ptr(), sd.data_ptr(), B, r01, frac, True)
+        pb.set_poses_dev(Pd.data_ptr()); pb.score_dev(sd.data_ptr(), B); pb.normalize(fetch=False)
+        if frac >= 0:
+            pb.resample_if(r01, frac)
+        b.update_at_dev(sd.data_ptr(), B, pb)
+        if t in (5, 8):
+            assert pa.stats() == pb.stats()
+            assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights())
+            assert np.array_equal(a.download_likelihood(), b.download_likelihood())
+            assert np.array_equal(a.download_log(), b.download_log())
