@@ -160,7 +160,7 @@ void gms_launch_partials_apply(gms_pf *pf, double *d_partials) {
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
     const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
-    const uint32_t n_apply = (uint32_t)(all < 2048 ? all : 2048);
+    const uint32_t n_apply = (uint32_t)(all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS);
     int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4;
     hipLaunchKernelGGL(k_partials_apply, dim3((uint32_t)nblk + n_apply, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw,
                        pf->d_pose, pf->n, pf->offset, nblk, d_partials,
@@ -217,7 +217,7 @@ void gms_launch_partials_pack_apply(gms_pf *pf) {
     uint32_t n_apply = 0;
     if (m->apply_pending) {
         const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
-        n_apply = (uint32_t)(all < 2048 ? all : 2048);
+        n_apply = (uint32_t)(all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS);
     }
     int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * 4;
     hipLaunchKernelGGL(k_partials_pack_apply, dim3(n_local + n_apply), dim3(256), 0, m->stream, pf->d_w, pf->d_logw, pf->d_pose,

@@ -206,6 +206,9 @@ __global__ void k_trace_ray(int32_t W, int32_t H, float x0, float y0, float x1, 
 
 // log += n_free*l_free + n_occ*l_occ on the touched box; counts cleared.  Persistent workgroups
 // enumerate only the 256 x 4 cell tiles that intersect the box; a lane owns 4 consecutive cells.
+#ifndef GMS_APPLY_BLOCKS
+#define GMS_APPLY_BLOCKS 2048   // persistent workgroups of the apply pass (per map)
+#endif
 #define APPLY_TW 256
 #define APPLY_TH 4
 __device__ __forceinline__ void
@@ -637,7 +640,7 @@ void gms_launch_apply_ray(gms_map *m, RayIn ray) {
 static void apply_launch(gms_map *m) {
     ProfScope ps(m, GMS_K_APPLY);
     const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
-    dim3 grid(all < 2048 ? all : 2048, m->n_maps);
+    dim3 grid(all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS, m->n_maps);
     int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4;
     hipLaunchKernelGGL(k_apply, grid, dim3(256), 0, m->stream, m->gd, m->d_log, m->d_cnt, cur, idle);
 }
