@@ -3,6 +3,8 @@ it finishes in seconds (it does: the C port scores 16 384 x 720 in ~0.1 s), plus
 properties the domain offers -- order independence of two scans, dirty rebuild == full rebuild, count
 checksum of the ray cast, permutation equivariance of the weights, sortedness and copy counts of the
 systematic resample -- and the edge cases (empty scan, one particle, all-miss scan, ragged grid)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -187,3 +189,37 @@ def test_config5_slice_batched_against_the_oracle():
         want = g.score(lik, traces[i].scans[3], P[i])
         ok = want > 1e-290
         assert rel_err(w[i][ok], want[ok]) <= 1e-11
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("GMS_FUZZ_SEEDS", "16")))))
+def test_fused_step_random_shapes_equal_the_separate_calls(seed):
+    """Random map sizes / resolutions (both blur half-widths and the generic one), beam and particle counts, resample
+    thresholds: a few fused scan steps back to back must leave exactly what the separate entry points leave."""
+    rng = np.random.default_rng(1000 + seed)
+    res = float(rng.choice([0.05, 0.02, 0.1, 0.035]))
+    W = int(rng.integers(40, 400)); H = int(rng.integers(40, 400))
+    ext_x, ext_y = W * res * 0.999, H * res * 0.999
+    pos = (-ext_x / 2 + float(rng.uniform(-0.3, 0.3)), -ext_y / 2 + float(rng.uniform(-0.3, 0.3)))
+    B = int(rng.integers(1, 400)); N = int(rng.integers(1, 3000))
+    a, b = GridMap(ext_x, ext_y, res, pos), GridMap(ext_x, ext_y, res, pos)
+    pa, pb = ParticleFilter(a, N), ParticleFilter(b, N)
+    for step in range(5):
+        ang = rng.uniform(-np.pi, np.pi, B)
+        dist = rng.uniform(0.1, 0.6 * max(ext_x, ext_y), B)
+        hits = rng.uniform(0, 1, B) < 0.8
+        obs = Observation.from_polar(ang, np.where(hits, dist, 10.0), hits)
+        centre = np.array([pos[0] + ext_x / 2, pos[1] + ext_y / 2, 0.0], dtype=np.float32)
+        P = synth.make_particles(centre + rng.normal(0, 0.05, 3).astype(np.float32), N, seed=step, sigma_xy=0.05, sigma_theta_deg=3.0)
+        r01, frac = float(rng.random()), float(rng.choice([0.5, 0.9, 2.0, -1.0]))
+        integrate = bool(rng.uniform() < 0.85)
+        sa = pa.slam_update(P, obs, r01, frac, integrate, fetch=True)
+        pb.set_poses(P); pb.score(obs); sb = pb.normalize()
+        if frac >= 0:
+            pb.resample_if(r01, frac)
+        if integrate:
+            b.update_at(obs, pb)
+        assert all(sa[k] == sb[k] or (sa[k] != sa[k] and sb[k] != sb[k]) for k in sa)      # (NaN Neff when every weight is 0)
+        if step in (2, 4):
+            assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights(), equal_nan=True)
+            assert np.array_equal(a.download_log(), b.download_log())
+            assert np.array_equal(a.download_likelihood(), b.download_likelihood())
