@@ -223,3 +223,49 @@ def test_fused_step_random_shapes_equal_the_separate_calls(seed):
             assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights(), equal_nan=True)
             assert np.array_equal(a.download_log(), b.download_log())
             assert np.array_equal(a.download_likelihood(), b.download_likelihood())
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("GMS_FUZZ_SEEDS", "8")))))
+def test_random_shapes_against_the_oracle(seed):
+    """The same random shapes against the CPU oracle: ray-cast map (cells touched bit-exact, log-odds <= 1e-12 rel.),
+    likelihood field (==), weights (<= 1e-10 rel. where representable), strongest, resample indices."""
+    rng = np.random.default_rng(5000 + seed)
+    res = float(rng.choice([0.05, 0.02, 0.1, 0.035]))
+    W = int(rng.integers(40, 300)); H = int(rng.integers(40, 300))
+    ext_x, ext_y = W * res * 0.999, H * res * 0.999
+    pos = (-ext_x / 2 + float(rng.uniform(-0.3, 0.3)), -ext_y / 2 + float(rng.uniform(-0.3, 0.3)))
+    B = int(rng.integers(1, 300)); N = int(rng.integers(1, 1500))
+    m = GridMap(ext_x, ext_y, res, pos)
+    g = orc.Grid(ext_x, ext_y, res, pos[0], pos[1])
+    assert (m.W, m.H) == (g.W, g.H)
+    log = g.new_log()
+    centre = np.array([pos[0] + ext_x / 2, pos[1] + ext_y / 2, 0.0], dtype=np.float32)
+    for step in range(3):
+        ang = rng.uniform(-np.pi, np.pi, B)
+        dist = rng.uniform(0.1, 0.6 * max(ext_x, ext_y), B)
+        hits = rng.uniform(0, 1, B) < 0.8
+        obs = Observation.from_polar(ang, np.where(hits, dist, 10.0), hits)
+        pose = (centre + np.array([rng.normal(0, 0.2), rng.normal(0, 0.2), rng.uniform(-3, 3)])).astype(np.float32)
+        g.integrate(log, obs.beams, pose)
+        m.update(obs, pose)
+    got = m.download_log().reshape(-1)
+    assert np.array_equal(got != 0, log != 0)
+    nz = log != 0
+    assert not nz.any() or np.max(np.abs(got[nz] - log[nz]) / np.abs(log[nz])) <= 1e-12
+    lik = g.build_likelihood(got)
+    assert np.array_equal(m.download_likelihood().reshape(-1), lik)
+    P = synth.make_particles(centre, N, seed=seed, sigma_xy=0.08, sigma_theta_deg=4.0)
+    pf = ParticleFilter(m, N)
+    pf.set_poses(P); pf.score(obs)
+    st = pf.normalize()
+    w = g.score(lik, obs.beams, P)
+    ws, strongest = orc.normalize(w)
+    if ws > 1e-280:
+        gw = pf.get_weights()
+        ok = w > 1e-290
+        assert np.max(np.abs(gw[ok] - w[ok]) / w[ok]) <= 1e-10
+        assert st["strongest"] == strongest or w[st["strongest"]] == w[strongest]
+        r01 = float(rng.random())
+        idx, amb = pf.resample(r01, want_indices=True)
+        want, _ = orc.resample_indices(gw, r01)
+        assert amb > 0 or np.array_equal(idx, want)
