@@ -666,15 +666,14 @@ def _hip_memcpy_dtod(dst: int, src: int, nbytes: int):
     assert hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 3) == 0      # hipMemcpyDeviceToDevice
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_single_exchange_sharded_step_equals_standalone(world):
+@pytest.mark.parametrize("world,n", [(2, 512), (4, 512), (3, 256), (8, 256), (2, 1280)])
+def test_single_exchange_sharded_step_equals_standalone(world, n):
     """gms_slam_update_sharded_begin_dev -> all-gather of BOTH gather buffers -> _end_dev with `world` shards of one
     population on one GPU (the gathers are device copies between the shards' buffers, what RCCL does over xGMI):
     every shard's particles, weights, statistics and map replica equal the stand-alone filter's, bit for bit."""
     import torch
     dev = torch.device("cuda", 0)
     tr = synth.make_trace(8.0, 0.05, 200, T=16, seed=31)
-    n = 512
     N = n * world
     ref_map = GridMap(8.0, 8.0, 0.05, (-4.0, -4.0))
     maps = [GridMap(8.0, 8.0, 0.05, (-4.0, -4.0)) for _ in range(world)]
