@@ -163,6 +163,8 @@ def main() -> int:
         pf = ParticleFilter(m, n_local)
         spf = comm = None
 
+    two_collectives = [False]
+
     def step(i: int):
         s = i % n_sets
         t = T // 2 + s
@@ -176,9 +178,18 @@ def main() -> int:
         if comm is not None:
             pf.slam_update_sharded_dev(comm, pose_sets[s].data_ptr(), beams_ptr, B, r01[i % 4096], 0.5, True)
             return
-        if spf is not None:
+        if spf is not None and not two_collectives[0]:
             # the same single-exchange step with the two all-gathers issued through torch.distributed
             spf.scan_step((pose_sets[s].data_ptr(), beams_ptr, B, True), r01[i % 4096], 0.5)
+            return
+        if spf is not None:
+            # last resort: all-reduce of the partials, all-gather of the normalised particles (distributed.py)
+            pf.set_poses_dev(pose_sets[s].data_ptr())
+            pf.score_dev(beams_ptr, B)
+            spf.normalize_begin()
+            m.update_at_dev(beams_ptr, B, pf)
+            spf.normalize_end()
+            spf.resample(r01[i % 4096], 0.5)
             return
         # --full-rebuild: the separate entry points, likelihood field rebuilt everywhere as the reference does
         pf.set_poses_dev(pose_sets[s].data_ptr())
@@ -199,21 +210,35 @@ def main() -> int:
 
     bracket_us = m.profile_calibrate(200) * 1e3
 
-    # ---- one untimed step first: if the in-library exchange cannot run here, every rank falls back together ----
-    if comm is not None:
-        ok = 1
-        try:
-            step(0)
-            torch.cuda.synchronize()
-        except Exception as e:
-            print(f"bench.py: in-library sharded step failed ({e}); using torch.distributed", file=sys.stderr)
-            ok = 0
+    # ---- one untimed step first: if an exchange route cannot run here, every rank falls back together -----------
+    # in-library RCCL (one grouped all-gather) -> torch.distributed scan_step (same protocol) -> the two-collective
+    # protocol over torch.distributed
+    def agree(ok: int) -> int:
         if world > 1:
             t_ok = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-            ok = int(t_ok.item())
-        if not ok:
-            comm = None
+            return int(t_ok.item())
+        return ok
+
+    if spf is not None:
+        for route in ("in-library", "torch-single", "torch-two"):
+            if route == "in-library" and comm is None:
+                continue
+            if route == "torch-single":
+                comm = None
+            if route == "torch-two":
+                comm, two_collectives[0] = None, True
+            ok = 1
+            try:
+                step(0)
+                torch.cuda.synchronize()
+            except Exception as e:
+                print(f"bench.py: sharded step via {route} failed ({e})", file=sys.stderr)
+                ok = 0
+            if agree(ok):
+                break
+        else:
+            raise RuntimeError("no exchange route works on this node")
 
     # ---- warmup, with every kernel class bracketed: find the dominant one -----------------------------
     m.profile(True)
@@ -322,7 +347,7 @@ def main() -> int:
                         f"full scan step (score+normalise+resample+ray-cast+likelihood rebuild)",
             "particles_total": n_global, "beams": B, "grid": [m.W, m.H], "resolution_m": res,
             "parallelism": f"particles sharded x{world}, map replicated" if world > 1 else "single GPU",
-            "exchange": None if spf is None else ("torch.distributed (RCCL)" if comm is None else "in-library RCCL: one grouped all-gather per scan (raw weights + block partials)"),
+            "exchange": None if spf is None else (("torch.distributed, all-reduce + all-gather" if two_collectives[0] else "torch.distributed (RCCL), one exchange") if comm is None else "in-library RCCL: one grouped all-gather per scan (raw weights + block partials)"),
             "likelihood_rebuild": "full" if args.full_rebuild else "dirty-rect (bit-identical to full)",
             "inputs": "host buffers every step (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
         },
