@@ -84,6 +84,8 @@ def main() -> int:
     ap.add_argument("--full-rebuild", action="store_true", help="rebuild the whole likelihood field every scan")
     ap.add_argument("--host-inputs", action="store_true", help="hand poses and scans over as HOST buffers every step (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--event-stride", type=int, default=8, help="timed region: HIP events around every n-th launch of the dominant kernel (a bracket costs microseconds of stream time)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "in-library", "torch-single", "torch-two"],
+                    help="sharded runs: first exchange route to try (auto = in-library RCCL; later routes are fall-backs)")
     ap.add_argument("--torch-collectives", action="store_true", help="sharded runs: exchange through torch.distributed instead of the library's own RCCL communicator")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (all-reduce / all-gather) code path even with one rank")
     args = ap.parse_args()
@@ -221,7 +223,10 @@ def main() -> int:
         return ok
 
     if spf is not None:
-        for route in ("in-library", "torch-single", "torch-two"):
+        routes = ["in-library", "torch-single", "torch-two"]
+        if args.exchange != "auto":
+            routes = routes[routes.index(args.exchange):]
+        for route in routes:
             if route == "in-library" and comm is None:
                 continue
             if route == "torch-single":

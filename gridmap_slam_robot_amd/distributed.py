@@ -61,7 +61,14 @@ class HipShardOps:
         self.pf = ParticleFilter(grid_map, n_local)
         self.pf.set_shard(offset, n_global)
         self.device = torch.device("cuda", torch.cuda.current_device())
-        grid_map.set_stream(torch.cuda.current_stream().cuda_stream)
+        # The library and the torch.distributed collectives must share ONE real stream: c10d orders a collective
+        # against torch's current stream, and the default stream's handle is 0, which the library reads as "use your
+        # own stream" -- two unrelated streams then, and a collective can start before the kernels that fill its
+        # buffer have run (seen as diverging filters after a few scans).  So: the current stream if it is a real one,
+        # else a stream of our own, made current around every collective (ShardedParticleFilter._on_stream).
+        cur = torch.cuda.current_stream()
+        self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(device=self.device)
+        grid_map.set_stream(self.stream.cuda_stream)
 
     def new_buffer(self, n_doubles: int) -> torch.Tensor:
         return torch.zeros(n_doubles, dtype=torch.float64, device=self.device)
@@ -180,6 +187,19 @@ class ShardedParticleFilter:
         return n, rank * n
 
     # ------------------------------------------------------------------------------------------
+    def _on_stream(self):
+        """Context in which the collectives are issued: the shard ops' stream made current (so that c10d orders them
+        after the library's kernels and the library's next kernels after them); inputs produced on the stream that
+        was current before are waited for first.  A no-op for CPU stand-ins."""
+        st = getattr(self.ops, "stream", None)
+        if st is None:
+            import contextlib
+            return contextlib.nullcontext()
+        prev = torch.cuda.current_stream()
+        if prev.cuda_stream != st.cuda_stream:
+            st.wait_stream(prev)
+        return torch.cuda.stream(st)
+
     def _all_gather_start(self):
         """Start the all-gather of the packed particles; returns a work handle (None = already complete)."""
         if self.world == 1 and not self.force:
@@ -197,20 +217,22 @@ class ShardedParticleFilter:
         after this), and the START of the all-gather of the packed normalised particles.  Work that needs
         only the weighted pose (the map update) can be enqueued between normalize_begin and normalize_end:
         RCCL runs the all-gather on its own stream beside it."""
-        self.ops.local_partials(self.partials)
-        if self.world > 1 or self.force:
-            dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
-        self.ops.apply_partials(self.partials, self.packed_local)
-        self._pending = self._all_gather_start()
+        with self._on_stream():
+            self.ops.local_partials(self.partials)
+            if self.world > 1 or self.force:
+                dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
+            self.ops.apply_partials(self.partials, self.packed_local)
+            self._pending = self._all_gather_start()
 
     def normalize_end(self):
         """Second half: wait for the all-gather (the current stream waits, not the host) and hand the global
         population to the shard (resampling source)."""
-        work = getattr(self, "_pending", None)
-        if work is not None:
-            work.wait()
-        self._pending = None
-        self.ops.import_global(self.packed_global)
+        with self._on_stream():
+            work = getattr(self, "_pending", None)
+            if work is not None:
+                work.wait()
+            self._pending = None
+            self.ops.import_global(self.packed_global)
 
     def normalize(self):
         self.normalize_begin()
@@ -222,19 +244,20 @@ class ShardedParticleFilter:
         all-gathered (issued together); statistics, normalisation, map update and resample are local after that.
         `inputs` is whatever the shard ops need (HipShardOps: (dev_poses, dev_beams, B, integrate)).  Every rank
         passes the same scan and r01.  (libgridmapslam's gms_slam_update_sharded_dev is this with RCCL inside.)"""
-        self.ops.exchange_begin(inputs)
-        if self.world > 1 or self.force:
-            pg, pl, tg, tl = self.ops.gather_views()
-            works = []
-            for out, mine in ((pg, pl), (tg, tl)):
-                try:
-                    works.append(dist.all_gather_into_tensor(out, mine, group=self.group, async_op=True))
-                except (RuntimeError, NotImplementedError, TypeError):
-                    mine_c = mine.clone()             # list form (gloo): the input must not alias an output chunk
-                    works.append(dist.all_gather(list(out.chunk(self.world)), mine_c, group=self.group, async_op=True))
-            for wk in works:
-                wk.wait()
-        self.ops.exchange_end(inputs, r01, fraction)
+        with self._on_stream():
+            self.ops.exchange_begin(inputs)
+            if self.world > 1 or self.force:
+                pg, pl, tg, tl = self.ops.gather_views()
+                works = []
+                for out, mine in ((pg, pl), (tg, tl)):
+                    try:
+                        works.append(dist.all_gather_into_tensor(out, mine, group=self.group, async_op=True))
+                    except (RuntimeError, NotImplementedError, TypeError):
+                        mine_c = mine.clone()             # list form (gloo): the input must not alias an output chunk
+                        works.append(dist.all_gather(list(out.chunk(self.world)), mine_c, group=self.group, async_op=True))
+                for wk in works:
+                    wk.wait()
+            self.ops.exchange_end(inputs, r01, fraction)
 
     def resample(self, r01: float, fraction: Optional[float] = None):
         """SLAM.resample (SLAM.java:133-153); with `fraction`, only if neff < fraction*N
@@ -244,10 +267,11 @@ class ShardedParticleFilter:
     def refresh_stats(self):
         """Weighted pose / Neff of the CURRENT (e.g. resampled) particles: one more all-reduce of the
         partial vector, nothing rewritten (getWeightedPose after resample, J/app/GridMapApp.java:192)."""
-        self.ops.local_partials(self.partials)
-        if self.world > 1:
-            dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
-        self.ops.stats_from_partials(self.partials)
+        with self._on_stream():
+            self.ops.local_partials(self.partials)
+            if self.world > 1:
+                dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
+            self.ops.stats_from_partials(self.partials)
 
     def stats(self) -> dict:
         return self.ops.stats()

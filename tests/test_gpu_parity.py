@@ -788,3 +788,40 @@ def test_batched_fused_steps_equal_the_separate_calls():
             assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights())
             assert np.array_equal(a.download_likelihood(), b.download_likelihood())
             assert np.array_equal(a.download_log(), b.download_log())
+
+
+def test_torch_routes_share_one_stream_with_the_library():
+    """Regression: with torch's DEFAULT stream current (handle 0) the library used to fall back to its own stream while
+    the torch.distributed side worked on the default one; without a host synchronise between the phases the two-collective
+    route then diverged from the stand-alone filter after a few scans.  Many scans, no synchronise in between, both torch
+    routes (a one-rank group is enough: the copy that stands in for the all-gather is a torch op)."""
+    import torch
+    from gridmap_slam_robot_amd.distributed import HipShardOps, ShardedParticleFilter
+    assert torch.cuda.current_stream().cuda_stream == 0
+    dev = torch.device("cuda", 0)
+    ext, res, B, N = 10.24, 0.02, 240, 2048
+    tr = synth.make_trace(ext, res, B, T=24, seed=77)
+    maps = [GridMap(ext, ext, res, (-ext / 2, -ext / 2)) for _ in range(3)]
+    for m in maps:
+        for t in range(8):
+            m.update(tr.scans[t], tr.poses[t])
+    ref = ParticleFilter(maps[0], N)
+    two = ShardedParticleFilter(N, HipShardOps(maps[1], N, 0, N))
+    one = ShardedParticleFilter(N, HipShardOps(maps[2], N, 0, N))
+    sets = [torch.from_numpy(synth.make_particles(tr.poses[8 + s], N, seed=9 + s)).to(dev) for s in range(8)]
+    scans = torch.from_numpy(tr.scans.view(np.uint8).reshape(len(tr.scans), -1).copy()).to(dev)
+    r01 = np.random.default_rng(2).random(256)
+    torch.cuda.synchronize()
+    for i in range(120):
+        s = i % 8
+        bp = scans[8 + s].data_ptr()
+        ref.slam_update_dev(sets[s].data_ptr(), bp, B, float(r01[i]), 0.5, True)
+        pf = two.ops.pf
+        pf.set_poses_dev(sets[s].data_ptr()); pf.score_dev(bp, B)
+        two.normalize_begin(); maps[1].update_at_dev(bp, B, pf); two.normalize_end(); two.resample(float(r01[i]), 0.5)
+        one.scan_step((sets[s].data_ptr(), bp, B, True), float(r01[i]), 0.5)
+    torch.cuda.synchronize()
+    for spf, m in ((two, maps[1]), (one, maps[2])):
+        assert spf.ops.pf.stats() == ref.stats()
+        assert np.array_equal(spf.ops.pf.get_poses(), ref.get_poses()) and np.array_equal(spf.ops.pf.get_weights(), ref.get_weights())
+        assert np.array_equal(m.download_log(), maps[0].download_log())
