@@ -142,6 +142,8 @@ class GridMap:
 
     # -- stream / sync ---------------------------------------------------------------------------
     def set_stream(self, hip_stream: Optional[int]):
+        """Run on an existing HIP stream (e.g. torch.cuda.Stream().cuda_stream).  None / 0 = the handle's own stream --
+        note that torch's DEFAULT stream has handle 0, so passing it does not put the library on torch's stream."""
         check(load().gms_map_set_stream(self._h, C.c_void_p(hip_stream or 0)))
 
     def synchronize(self):

@@ -116,8 +116,9 @@ double gms_inv_log_odds(double l);
 int gms_map_create(const gms_params *p, gms_map **out);
 int gms_map_destroy(gms_map *m);
 int gms_map_get_size(const gms_map *m, int32_t *W, int32_t *H, int32_t *n_maps);
-/* Run this handle's work on an existing hipStream_t (e.g. torch's current stream); NULL restores
- * the handle's own stream. */
+/* Run this handle's work on an existing hipStream_t (e.g. a torch stream); NULL restores the handle's own stream.
+ * NB the legacy default stream's handle IS NULL: a host whose other work runs on the default stream gets the handle's
+ * own stream here, unrelated to it -- give both sides one real stream when they exchange device buffers. */
 int gms_map_set_stream(gms_map *m, void *hip_stream);
 int gms_map_synchronize(gms_map *m);
 /* GridMap.reset (GridMap.java:129-132): logData := logOdds(0.5) = 0 (likelihoodData is left alone,
