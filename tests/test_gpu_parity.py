@@ -825,3 +825,33 @@ def test_torch_routes_share_one_stream_with_the_library():
         assert spf.ops.pf.stats() == ref.stats()
         assert np.array_equal(spf.ops.pf.get_poses(), ref.get_poses()) and np.array_equal(spf.ops.pf.get_weights(), ref.get_weights())
         assert np.array_equal(m.download_log(), maps[0].download_log())
+
+
+def test_host_input_steps_back_to_back_equal_device_input_steps():
+    """gms_slam_update stages poses and scan through pinned rings (4 slots) read by kernels later in stream order; many
+    steps without a synchronise (so slots are reused while earlier steps may still be queued), each with different
+    inputs and the caller's arrays overwritten right after the call: same bits as the device-input step."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ext, res, B, N = 10.24, 0.02, 300, 3000
+    tr = synth.make_trace(ext, res, B, T=24, seed=5)
+    a, b = GridMap(ext, ext, res, (-ext / 2, -ext / 2)), GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    for m in (a, b):
+        for t in range(6):
+            m.update(tr.scans[t], tr.poses[t])
+    pa, pb = ParticleFilter(a, N), ParticleFilter(b, N)
+    sets = [synth.make_particles(tr.poses[6 + s], N, seed=30 + s) for s in range(6)]
+    sets_dev = [torch.from_numpy(p).to(dev) for p in sets]
+    scans_dev = torch.from_numpy(tr.scans.view(np.uint8).reshape(len(tr.scans), -1).copy()).to(dev)
+    r01 = np.random.default_rng(6).random(64)
+    P_host = np.empty_like(sets[0]); scan_host = np.empty_like(tr.scans[0])
+    torch.cuda.synchronize()
+    for i in range(60):
+        s = i % 6
+        P_host[:] = sets[s]; scan_host[:] = tr.scans[6 + s]
+        pa.slam_update(P_host, scan_host, float(r01[i]), 0.5, True)
+        P_host[:] = -7.0; scan_host["local_x"][:] = 1e9            # the call has taken its copy
+        pb.slam_update_dev(sets_dev[s].data_ptr(), scans_dev[6 + s].data_ptr(), B, float(r01[i]), 0.5, True)
+    assert pa.stats() == pb.stats()
+    assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights())
+    assert np.array_equal(a.download_log(), b.download_log())
