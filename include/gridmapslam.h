@@ -224,7 +224,10 @@ int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B);
 /* ---- device-resident inputs ---------------------------------------------------------------------
  * The same entry points for callers whose scans / poses already live in HBM (a trace staged once, a
  * torch tensor, the output of a device-side motion model).  dev_beams is [n_maps][B] gms_beam,
- * dev_poses [n_maps][3], dev_xytheta [n_maps][n][3]; all are read on the handle's stream. */
+ * dev_poses [n_maps][3], dev_xytheta [n_maps][n][3]; all are read on the handle's stream, asynchronously: the call
+ * returns before the kernels run, so the buffers must stay valid and unmodified until the stream has passed them
+ * (gms_map_synchronize, or an event of the caller's on that stream) -- in particular, memory handed back to a caching
+ * allocator that serves another stream may be reused too early. */
 int gms_map_integrate_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, const float *dev_poses);
 int gms_map_integrate_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, gms_pf *pf, int32_t which);
 int gms_map_update_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, const float *dev_poses);
