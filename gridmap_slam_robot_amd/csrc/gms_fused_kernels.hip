@@ -131,7 +131,7 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 bool gms_can_pair_launches(const gms_pf *pf, int32_t B) {
     const gms_map *m = pf->map;
-    return pf->n_maps == 1 && B > 0 && B <= 4096 && !m->need_full_build && m->pair_launches;
+    return pf->n_maps == 1 && B > 0 && B <= GMS_MAX_BEAMS && !m->need_full_build && m->pair_launches;
 }
 
 // normalise (SLAM.java:120-124) beside integrateObservation at the weighted pose (:93, GridMap.java:173-191)
@@ -139,7 +139,7 @@ void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticl
                              const gms_beam *d_beams, int32_t B) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_RAYCAST);
-    if (own) pf->d_global = pf->d_global_own;
+    if (own) { pf->d_global = pf->d_global_own; pf->global_raw = 0; }     // normalised weights are packed (as apply_partials does)
     const uint32_t n_ray = (uint32_t)((B + 3) / 4), n_norm = (uint32_t)((pf->n + 255) / 256);
     const size_t smem = rc_smem(m, 4);
     int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * 4;

@@ -241,6 +241,12 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     *out = nullptr;
     REQUIRE(p->resolution > 0.0f && p->n_maps >= 1 && p->n_maps <= 1024, "gms_map_create: bad resolution / n_maps");
     REQUIRE(p->ktaps >= 1 && (p->ktaps & 1) && p->ktaps <= GMS_MAX_TAPS, "gms_map_create: ktaps must be odd and <= GMS_MAX_TAPS");
+    // One scan holds at most GMS_MAX_BEAMS beams: the scoring kernel stages 128 beams per segment product and keeps at
+    // most GMS_SCORE_MAXSEG of them, and the per-scan cell counts are 16-bit halves (a cell is visited at most
+    // (1 + extra_steps) times per ray -- a zero-length ray emits its cell n = 1 + extra times, RayIterator.java:75 --
+    // so (1 + extra_steps) * beams must stay below 65536).
+    REQUIRE(p->max_beams >= 0 && p->max_beams <= GMS_MAX_BEAMS, "gms_map_create: max_beams exceeds GMS_MAX_BEAMS");
+    REQUIRE(p->extra_steps >= 0 && (int64_t)(1 + p->extra_steps) * GMS_MAX_BEAMS <= 65535, "gms_map_create: extra_steps too large for the 16-bit per-scan cell counts");
     int32_t W, H;
     gms_grid_size(p, &W, &H);
     REQUIRE(W > 0 && H > 0 && (int64_t)W * H < (1ll << 31), "gms_map_create: grid size out of range");
@@ -309,6 +315,8 @@ int gms_map_create(const gms_params *p, gms_map **out) {
 
 int gms_map_destroy(gms_map *m) {
     if (!m) return GMS_OK;
+    // a filter keeps a pointer to its map (stream, device, grids): destroy the filters first
+    if (m->n_filters > 0) return fail(GMS_ERR_STATE, "gms_map_destroy: %d particle filter(s) still bound to this map", m->n_filters);
     hipSetDevice(m->device);
     hipStreamSynchronize(m->stream);
     return map_free(m);
@@ -540,7 +548,7 @@ int gms_map_integrate(gms_map *m, const gms_beam *beams, int32_t B, const float 
 
 int gms_map_integrate_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, const float *dev_poses) {
     REQUIRE(m && dev_beams && dev_poses, "null argument");
-    REQUIRE(B >= 0 && B <= 16384, "beam count out of range");
+    REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
     HIPCHK(hipSetDevice(m->device));
     if (B > 0) {
         gms_launch_raycast(m, dev_beams, B, B, dev_poses, 3);
@@ -553,7 +561,7 @@ int gms_map_integrate_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, cons
 int gms_map_integrate_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, gms_pf *pf, int32_t which) {
     REQUIRE(m && dev_beams && pf && pf->map == m, "gms_map_integrate_at_dev: bad arguments");
     REQUIRE(which == 0 || which == 1, "which must be 0 (weighted pose) or 1 (strongest particle)");
-    REQUIRE(B >= 0 && B <= 16384, "beam count out of range");
+    REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
     HIPCHK(hipSetDevice(m->device));
     if (B > 0) {
         gms_launch_raycast(m, dev_beams, B, B, stats_pose_ptr(pf, which), (int32_t)(sizeof(PfStatsDev) / sizeof(float)));
@@ -588,15 +596,19 @@ int gms_map_apply_ray(gms_map *m, float sx, float sy, float ex, float ey, float 
 }
 
 static int ensure_trace(gms_map *m, size_t cells, size_t counts) {
-    const size_t need = cells * 9 + counts * 4;
-    if (need <= m->trace_cap_bytes) return GMS_OK;
+    // the three buffers have capacities of their own: a call with fewer cells but more counts than the last one
+    // must still grow the count buffer
+    if (cells <= m->trace_cap_cells && counts <= m->trace_cap_counts) return GMS_OK;
     HIPCHK(hipStreamSynchronize(m->stream));
+    if (cells < m->trace_cap_cells) cells = m->trace_cap_cells;
+    if (counts < m->trace_cap_counts) counts = m->trace_cap_counts;
     hipFree(m->d_trace_cells); hipFree(m->d_trace_cls); hipFree(m->d_trace_cnt);
-    m->d_trace_cells = nullptr; m->d_trace_cls = nullptr; m->d_trace_cnt = nullptr; m->trace_cap_bytes = 0;
+    m->d_trace_cells = nullptr; m->d_trace_cls = nullptr; m->d_trace_cnt = nullptr;
+    m->trace_cap_cells = 0; m->trace_cap_counts = 0;
     HIPCHK(hipMalloc(&m->d_trace_cells, cells * 2 * sizeof(int32_t)));
     HIPCHK(hipMalloc(&m->d_trace_cls, cells));
     HIPCHK(hipMalloc(&m->d_trace_cnt, counts * sizeof(int32_t)));
-    m->trace_cap_bytes = need;
+    m->trace_cap_cells = cells; m->trace_cap_counts = counts;
     return GMS_OK;
 }
 
@@ -708,6 +720,7 @@ int gms_pf_destroy(gms_pf *pf) {
     if (!pf) return GMS_OK;
     hipSetDevice(pf->map->device);
     hipStreamSynchronize(pf->map->stream);
+    pf->map->n_filters--;
     hipFree(pf->d_pose); hipFree(pf->d_pose2); hipFree(pf->d_part); hipFree(pf->d_cs2);
     hipFree(pf->d_w); hipFree(pf->d_w2); hipFree(pf->d_logw); hipFree(pf->d_cs); hipFree(pf->d_hitbeams);
     hipFree(pf->d_nhit); hipFree(pf->d_stats); hipFree(pf->d_r01); hipFree(pf->d_idx);
@@ -728,6 +741,7 @@ int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // Partic
     gms_pf *pf = new (std::nothrow) gms_pf();
     if (!pf) return fail(GMS_ERR_NOMEM, "out of host memory");
     pf->map = m; pf->n = n; pf->offset = 0; pf->n_global = n; pf->n_maps = m->n_maps;
+    m->n_filters++;
     const size_t T = (size_t)n * m->n_maps;
     bool ok = true;
     ok = ok && hipMalloc(&pf->d_pose, T * 12) == hipSuccess && hipMalloc(&pf->d_pose2, T * 12) == hipSuccess;
@@ -818,11 +832,13 @@ int gms_pf_set_weights(gms_pf *pf, const double *w) {
 }
 int gms_pf_get_weights(gms_pf *pf, double *w) {
     REQUIRE(pf && w, "null argument");
+    HIPCHK(hipSetDevice(pf->map->device));
     gms_launch_pf_combine(pf);
     return pf_copy_f64(pf, pf->d_w, w, false);
 }
 int gms_pf_get_log_weights(gms_pf *pf, double *lw) {
     REQUIRE(pf && lw, "null argument");
+    HIPCHK(hipSetDevice(pf->map->device));
     gms_launch_pf_combine(pf);
     return pf_copy_f64(pf, pf->d_logw, lw, false);
 }
@@ -1157,6 +1173,23 @@ int gms_pf_did_resample(gms_pf *pf, int32_t *flags) {
     return GMS_OK;
 }
 
+int gms_pf_last_step(gms_pf *pf, float *weighted_pose, float *strongest_pose, int32_t *did_resample, int32_t *n_ambiguous) {
+    REQUIRE(pf, "null filter");
+    HIPCHK(hipSetDevice(pf->map->device));
+    int rc = pull_stats(pf);
+    if (rc) return rc;
+    for (int32_t mi = 0; mi < pf->n_maps; mi++) {
+        const PfStatsDev &s = pf->h_stats[mi];
+        for (int k = 0; k < 3; k++) {
+            if (weighted_pose) weighted_pose[3 * mi + k] = s.wpose[k];
+            if (strongest_pose) strongest_pose[3 * mi + k] = s.spose[k];
+        }
+        if (did_resample) did_resample[mi] = s.did_resample;
+        if (n_ambiguous) n_ambiguous[mi] = s.n_ambiguous;
+    }
+    return GMS_OK;
+}
+
 int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B) {   // GridMap.java:319-346
     REQUIRE(pf, "null filter");
     gms_map *m = pf->map;
@@ -1299,6 +1332,7 @@ int gms_pf_normalize_sharded_begin(gms_pf *pf, gms_comm *c) {
     if (rc) return rc;
     gms_map *m = pf->map;
     HIPCHK(hipSetDevice(m->device));
+    if (c->broken) return fail(GMS_ERR_STATE, "communicator is broken (an earlier exchange failed): destroy it");
     if (c->pending) return fail(GMS_ERR_STATE, "gms_pf_normalize_sharded_end has not been called for the previous exchange");
     const size_t np = (size_t)nblk_of(pf->n_global) * GMS_PARTIAL_STRIDE;
     gms_launch_pf_partials(pf, pf->d_partials);
@@ -1399,6 +1433,7 @@ int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xythet
     gms_map *m = pf->map;
     int rc = check_shard(pf, c);
     if (rc) return rc;
+    if (c->broken) return fail(GMS_ERR_STATE, "communicator is broken (an earlier exchange failed): destroy it");
     if (c->pending) return fail(GMS_ERR_STATE, "gms_pf_normalize_sharded_end has not been called for the previous exchange");
     rc = gms_slam_update_sharded_begin_dev(pf, dev_xytheta, dev_beams, B);
     if (rc) return rc;
@@ -1407,21 +1442,36 @@ int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xythet
     PackedParticle *own_slot = pf->d_global_own + pf->offset;
     const size_t pbytes = (size_t)pf->n * sizeof(PackedParticle);
     RCCLCHK(g_rccl.GroupStart());                                                // the whole exchange is one launch
+    // Inside the bracket an error must not return: the thread's RCCL group depth would stay at 1 and every later
+    // collective of this process (torch.distributed shares this librccl) would queue behind a group that never closes.
+    // The first error is kept, GroupEnd always runs, and the communicator is marked broken.
+    int first = 0;
+    const char *what = "";
+#define RCCL_IN_GROUP(expr) do { if (!first) { first = (expr); if (first) what = #expr; } } while (0)
     if (c->p2p && g_rccl.Send && g_rccl.Recv) {
         // the same exchange as point-to-point transfers to and from every peer (direct xGMI links, no ring):
         // GMS_EXCHANGE=p2p, for comparison on a multi-GPU node
         for (int32_t peer = 0; peer < c->world; peer++) {
             if (peer == c->rank) continue;
-            RCCLCHK(g_rccl.Send(own_slot, pbytes, RCCL_INT8, peer, c->nccl, m->stream));
-            RCCLCHK(g_rccl.Recv(pf->d_global_own + (size_t)peer * pf->n, pbytes, RCCL_INT8, peer, c->nccl, m->stream));
-            RCCLCHK(g_rccl.Send(own_partials, np, RCCL_FLOAT64, peer, c->nccl, m->stream));
-            RCCLCHK(g_rccl.Recv(pf->d_partials + (size_t)peer * np, np, RCCL_FLOAT64, peer, c->nccl, m->stream));
+            RCCL_IN_GROUP(g_rccl.Send(own_slot, pbytes, RCCL_INT8, peer, c->nccl, m->stream));
+            RCCL_IN_GROUP(g_rccl.Recv(pf->d_global_own + (size_t)peer * pf->n, pbytes, RCCL_INT8, peer, c->nccl, m->stream));
+            RCCL_IN_GROUP(g_rccl.Send(own_partials, np, RCCL_FLOAT64, peer, c->nccl, m->stream));
+            RCCL_IN_GROUP(g_rccl.Recv(pf->d_partials + (size_t)peer * np, np, RCCL_FLOAT64, peer, c->nccl, m->stream));
         }
     } else {
-        RCCLCHK(g_rccl.AllGather(own_slot, pf->d_global_own, pbytes, RCCL_INT8, c->nccl, m->stream));
-        RCCLCHK(g_rccl.AllGather(own_partials, pf->d_partials, np, RCCL_FLOAT64, c->nccl, m->stream));
+        RCCL_IN_GROUP(g_rccl.AllGather(own_slot, pf->d_global_own, pbytes, RCCL_INT8, c->nccl, m->stream));
+        RCCL_IN_GROUP(g_rccl.AllGather(own_partials, pf->d_partials, np, RCCL_FLOAT64, c->nccl, m->stream));
     }
-    RCCLCHK(g_rccl.GroupEnd());
+#undef RCCL_IN_GROUP
+    const int end = g_rccl.GroupEnd();
+    if (first || end) {
+        c->broken = 1;
+        // the begin half may have consumed a deferred apply pass; bring the map to a defined state for the fallback route
+        gms_flush_apply(m);
+        const int r_ = first ? first : end;
+        return fail(GMS_ERR_HIP, "%s: %s (communicator marked broken)", first ? what : "ncclGroupEnd",
+                    g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error");
+    }
     return gms_slam_update_sharded_end_dev(pf, dev_beams, B, r01, resample_fraction, integrate);
 }
 

@@ -49,6 +49,8 @@ struct PfStatsDev {
 };
 
 #define GMS_SCORE_MAXSEG 32
+#define GMS_SCORE_SEGLEN 45     // beams per segment product of the default scoring kernel (see gms_launch_pf_score)
+static_assert(128 * GMS_SCORE_MAXSEG >= GMS_MAX_BEAMS, "a scan must fit GMS_SCORE_MAXSEG segments of 128 beams");
 #define GMS_PARTIAL_STRIDE 9   // per block: sum w, max w, first argmax, n_zero, max logw, sum w^2, sum x*w, sum y*w, sum th*w
 
 // packed particle exchanged by the all-gather (24 B)
@@ -79,6 +81,7 @@ struct gms_map {
     int32_t n_maps;
     int32_t device;
     int32_t max_beams;
+    int32_t n_filters;        // live gms_pf handles bound to this map (gms_map_destroy refuses while > 0)
     hipStream_t own_stream;
     hipStream_t stream;
     double *d_log;        // [n_maps][H][W]
@@ -106,7 +109,8 @@ struct gms_map {
     float *h_poses;       // pinned staging
     hipEvent_t pose_copy_ev;  // the last copy out of h_poses
     int32_t pose_copy_ev_set;
-    int32_t *d_trace_cells; uint8_t *d_trace_cls; int32_t *d_trace_cnt; size_t trace_cap_bytes;
+    int32_t *d_trace_cells; uint8_t *d_trace_cls; int32_t *d_trace_cnt;
+    size_t trace_cap_cells, trace_cap_counts;   // capacities of d_trace_cells/d_trace_cls (cells) and d_trace_cnt (counts)
     // profiling
     int32_t prof_on;
     int32_t prof_stride;      // every prof_stride-th launch of an enabled class is bracketed (>= 1)
@@ -160,6 +164,7 @@ struct gms_comm {
     int32_t rank = 0, world = 1, device = 0;
     int32_t overlap = 0;            // all-gather on the side stream (default: world > 2; GMS_COMM_OVERLAP=0/1 overrides)
     int32_t pending = 0;            // an all-gather is in flight
+    int32_t broken = 0;             // an exchange failed: every later call on this communicator fails fast
     int32_t p2p = 0;                // GMS_EXCHANGE=p2p: the scan's exchange as grouped ncclSend/ncclRecv instead of all-gathers
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -1092,13 +1092,18 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
     if (m->score_variant == 2) {
         const int32_t threads = pf->n >= 1024 ? 1024 : ((pf->n + 63) / 64) * 64;
         const int64_t groups = ((int64_t)pf->n + threads - 1) / threads;
-        int64_t nseg = 256 / (groups * pf->n_maps);                   // ~1 workgroup of 16 wavefronts per CU (measured best at C3)
-        const int64_t min_seg = ((int64_t)B + 127) / 128;             // <= 128 factors per segment product
-        if (nseg > GMS_SCORE_MAXSEG) nseg = GMS_SCORE_MAXSEG;
+        // Beam segments: a function of B ONLY.  The segmentation decides how the product of the factors is associated
+        // (in order inside a segment, segment products in segment order), so it must not depend on how many particles
+        // this handle holds: a shard of a sharded filter and the stand-alone filter of the whole population have to
+        // round alike (tests/test_gpu_configs.py caught 8 x 8192 vs 65536 differing in the last bit when it did).
+        // 45 beams per segment = the 16 segments measured best at C3 (720 beams, one 16-wavefront workgroup per CU);
+        // <= 128 beams per segment (the LDS beam table; also keeps a segment product >= 0.01^128, a normal double).
+        int64_t nseg = ((int64_t)B + GMS_SCORE_SEGLEN - 1) / GMS_SCORE_SEGLEN;
+        if (m->score_segments > 0) nseg = m->score_segments;          // GMS_SCORE_SEGMENTS: experiments (every handle alike)
+        const int64_t min_seg = ((int64_t)B + 127) / 128;
         if (nseg < min_seg) nseg = min_seg;
         if (nseg < 1) nseg = 1;
-        if (m->score_segments > 0) nseg = m->score_segments < min_seg ? min_seg : m->score_segments;
-        if (nseg > GMS_SCORE_MAXSEG) nseg = GMS_SCORE_MAXSEG;
+        if (nseg > GMS_SCORE_MAXSEG) nseg = GMS_SCORE_MAXSEG;         // B <= GMS_MAX_BEAMS = 128 * GMS_SCORE_MAXSEG
         hipLaunchKernelGGL(k_score_c, dim3((unsigned)groups, (unsigned)nseg, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
                            m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
                            pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pf->d_pose, pf->d_cs);

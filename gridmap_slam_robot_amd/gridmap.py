@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -102,11 +103,14 @@ class GridMap:
         W, H, M = C.c_int32(), C.c_int32(), C.c_int32()
         check(L.gms_map_get_size(self._h, C.byref(W), C.byref(H), C.byref(M)))
         self.W, self.H, self.n_maps = W.value, H.value, M.value
+        self._filters = weakref.WeakSet()         # ParticleFilters bound to this map: they are closed before it
 
     # -- lifetime -------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            load().gms_map_destroy(self._h)
+            for pf in list(getattr(self, "_filters", ())):      # gms_map_destroy refuses while filters are alive
+                pf.close()
+            check(load().gms_map_destroy(self._h))
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -369,6 +373,7 @@ class ParticleFilter:
         self._h = C.c_void_p()
         check(load().gms_pf_create(grid_map._h, n, C.byref(self._h)))
         self.offset, self.n_global = 0, n
+        grid_map._filters.add(self)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -492,6 +497,18 @@ class ParticleFilter:
         f = np.empty(self.n_maps, dtype=np.int32)
         check(load().gms_pf_did_resample(self._h, ptr(f)))
         return bool(f[0]) if self.n_maps == 1 else f.astype(bool)
+
+    def last_step(self) -> dict:
+        """Device-side record of the last normalise / scan step: the weighted pose of the SCORED population (what a
+        fused scan step integrated the scan at), the strongest particle's pose, did_resample, n_ambiguous."""
+        wp = np.empty((self.n_maps, 3), dtype=np.float32)
+        sp = np.empty((self.n_maps, 3), dtype=np.float32)
+        did = np.empty(self.n_maps, dtype=np.int32)
+        amb = np.empty(self.n_maps, dtype=np.int32)
+        check(load().gms_pf_last_step(self._h, ptr(wp), ptr(sp), ptr(did), ptr(amb)))
+        if self.n_maps == 1:
+            return dict(weighted_pose=wp[0], strongest_pose=sp[0], did_resample=bool(did[0]), n_ambiguous=int(amb[0]))
+        return dict(weighted_pose=wp, strongest_pose=sp, did_resample=did.astype(bool), n_ambiguous=amb)
 
     def sample_motion(self, d_center: float, d_theta: float, seed: int, sequence: int):
         """pose[i] = sampleMotionModel(pose[i], u) (SLAM.java:155-163 -> Odometry.apply, Odometry.java:77-96)."""

@@ -41,6 +41,7 @@ extern "C" {
 
 #define GMS_MAX_TAPS 129        /* likelihood kernel taps (odd) */
 #define GMS_BLOCK 256           /* particles per reduction block; shard offsets are multiples of it */
+#define GMS_MAX_BEAMS 4096      /* beams per scan (per map): gms_params.max_beams may not exceed it */
 
 enum {
     GMS_OK = 0,
@@ -78,7 +79,7 @@ typedef struct gms_params {
     float hit_tolerance;        /* inverseSensorModel hitTolerance, 2 */
     double z_hit, z_random;     /* 0.9, 1 - 0.9 */
     float max_range;            /* SensorModel.SENSOR_MAX_RANGE, 10 */
-    int32_t max_beams;          /* capacity per scan (per map); 0 = 2048 */
+    int32_t max_beams;          /* capacity per scan (per map); 0 = 2048; at most GMS_MAX_BEAMS */
 } gms_params;
 
 typedef struct gms_map gms_map;      /* GridMap + GridMapData (n_maps of them) */
@@ -114,6 +115,7 @@ double gms_inv_log_odds(double l);
 /* ---- GridMap / GridMapData --------------------------------------------------------------------- */
 /* new GridMap(width,height,resolution,position) + createMapData(null)  (GridMap.java:80,106). */
 int gms_map_create(const gms_params *p, gms_map **out);
+/* GMS_ERR_STATE while particle filters created on this map are alive: destroy those first. */
 int gms_map_destroy(gms_map *m);
 int gms_map_get_size(const gms_map *m, int32_t *W, int32_t *H, int32_t *n_maps);
 /* Run this handle's work on an existing hipStream_t (e.g. a torch stream); NULL restores the handle's own stream.
@@ -211,6 +213,11 @@ int gms_pf_resample(gms_pf *pf, const double *r01, int32_t *indices, int32_t *n_
 int gms_pf_resample_if(gms_pf *pf, const double *r01, double fraction);
 /* flags[n_maps]: whether the last gms_pf_resample / gms_pf_resample_if replaced the particles. */
 int gms_pf_did_resample(gms_pf *pf, int32_t *flags);
+/* What the last normalise / scan step left on the device, per map (any pointer may be NULL): the weighted pose
+ * (SLAM.getWeightedPose of the SCORED population, i.e. before a resample replaced it: the pose a fused scan step
+ * integrated the scan at), the strongest particle's pose (SLAM.getStrongestParticle), whether the conditional
+ * resample ran, and how many of its slots were ambiguous (see gms_pf_resample).  Synchronises the stream. */
+int gms_pf_last_step(gms_pf *pf, float *weighted_pose, float *strongest_pose, int32_t *did_resample, int32_t *n_ambiguous);
 /* SLAM.sampleMotionModel -> Odometry.apply(pose) for every particle (J/slam/SLAM.java:155-163,
  * J/slam/Odometry.java:60-96): Gaussian step and heading change with the reference's standard deviations
  * ((0.01 + 0.05|dCenter|)/2 and 5 deg + 0.1|dTheta|).  The reference's random stream is unseeded and
