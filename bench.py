@@ -6,29 +6,35 @@ One "step" = one LIDAR scan through the whole path, inputs already resident in H
   -> normalise / Neff / weighted pose -> resample if neff < N/2 -> ray-cast the scan into the
   log-odds map at the weighted pose -> rebuild the likelihood field where it changed.
 
-Workload at 1 GPU = BASELINE.json configs[2] ("C3"): 16384 particles, 720 beams, 2048x2048 grid @ 2 cm,
-the configuration the metric is quoted on.  At N GPUs the particles are sharded, 16384 per GPU (weak
-scaling; configs[3] is the 4-GPU point of that series), with an RCCL all-reduce for the weight
-normaliser and an all-gather for resampling; every rank keeps a replica of the map.
+Workload at 1 GPU = BASELINE.json configs[2] ("C3"): 16384 particles, 720 beams, 2048x2048 grid @ 2 cm, the
+configuration the metric is quoted on.  At N GPUs the particles are sharded, 16384 per GPU (weak scaling; configs[3],
+"C4", is the 4-GPU point of that series), one grouped RCCL all-gather per scan (raw weights + block partials); every
+rank keeps a replica of the map.  --config C5 is the batched-map throughput mode (64 maps x 4096 particles x 1080
+beams in one handle; at N GPUs every rank runs its own 64 maps, no collective); --config C2 the small single-map case.
+The default 1-GPU run also reports C5 and C2 in a "secondary" block (shorter runs of the same measurement).
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
          bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  value = total particles x steps / max-over-ranks wall time of the K
-steps.  roofline = the dominant kernel's algorithmic bytes per launch / its average launch duration
-(HIP events on the library's stream, recorded inside the timed region).  cpu_baseline = the C oracle
-(a port of the reference's Java loops; the reference itself cannot run here) on a bounded sample of
-the same workload, one host thread.
+Rank 0 prints ONE JSON line.  value = total particles x steps / max-over-ranks wall time of the K steps.
+roofline = the dominant kernel's algorithmic bytes per launch / its average launch duration (HIP events on the
+library's stream, recorded inside the timed region; the stride is chosen so that at least 16 launches are bracketed).
+cpu_baseline = the C oracle (a port of the reference's Java loops; the reference itself cannot run here) on a bounded
+sample of the same workload, one host thread.  At N > 1 the run first VERIFIES itself: one untimed step on the sharded
+filter and, on rank 0, on a stand-alone filter of the whole population; "sharded_equals_standalone" reports whether
+every rank's particles, weights, statistics and map came out bit-identical.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import math
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -36,369 +42,520 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+GATHER_CEILING_LANES_PER_S = 818e9   # tools/microbench/gather8.hip on MI355X: independent 8-byte look-ups whose patch stays in L1
+MIN_BRACKETED_LAUNCHES = 16
 
 
-def algorithmic_bytes(kind: str, *, n_particles=0, n_hit=0, n_beams=0, cells=0, visits=0) -> float:
-    """SURVEY.md section 8(d) per-unit figures x the units one launch processes."""
-    if kind == "score":        # 8 B per beam-eval + (12 B pose + 8 B weight) per particle + 17 B per beam once
-        return 8.0 * n_particles * n_hit + 20.0 * n_particles + 17.0 * n_beams
-    if kind == "likelihood":   # 16 B per cell (read log-odds, write likelihood)
-        return 16.0 * cells
-    if kind == "raycast":      # 16 B per visited cell (fp64 read + write)
-        return 16.0 * visits
-    if kind == "reduce":       # 16 B per particle
-        return 16.0 * n_particles
-    if kind == "resample":     # 8 B weight + 12 B pose read + 12 B pose write
-        return 32.0 * n_particles
-    if kind == "apply":
-        return 16.0 * visits
-    return 0.0
+# ---------------------------------------------------------------------------------------------------------------------
+# algorithmic bytes (SURVEY.md section 8(d) per-unit figures x the units one launch processes)
+# ---------------------------------------------------------------------------------------------------------------------
+def algorithmic_bytes(kind: str, *, n_particles=0, n_hit=0, n_beams=0, cells=0, visits=0, dirty_cells=0, n_maps=1,
+                      paired=True, full_rebuild=False) -> float:
+    """Per launch.  A paired launch (gms_fused_kernels.hip) does the work of both members; `paired` adds the partner's
+    bytes to the class the launch is booked under (reduce: + previous scan's apply; raycast: + normalise;
+    likelihood: + resample)."""
+    score = 8.0 * n_particles * n_hit + 20.0 * n_particles + 17.0 * n_beams   # 8 B/beam-eval + pose+weight/particle + beam table
+    reduce_ = 16.0 * n_particles                                              # 16 B per particle
+    apply_ = 16.0 * visits                                                    # 16 B per visited cell (fp64 read + write)
+    raycast = 16.0 * visits
+    resample = 32.0 * n_particles                                             # 8 B weight + 12 B pose read + 12 B pose write
+    lik = 16.0 * (cells if full_rebuild else dirty_cells)                     # 16 B per cell rebuilt
+    per_map = {"score": score, "reduce": reduce_ + (apply_ if paired else 0.0), "apply": apply_,
+               "raycast": raycast + (reduce_ if paired else 0.0), "likelihood": lik + (resample if paired else 0.0),
+               "resample": resample}.get(kind, 0.0)
+    return per_map * n_maps
 
 
-def pmc_traffic(kernel_class: str):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/*/pmc_traffic.json: separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of this
-    command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None when not collected."""
-    import glob
+def pmc_traffic(config: str, kernel_class: str):
+    """HBM-side bytes per launch from the committed PMC passes (profiles/*/pmc_traffic*.json: separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950); None when not collected for this configuration.  The newest round wins."""
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic*.json"))):
         try:
             d = json.load(open(f))
-            if kernel_class in d:
-                best = d[kernel_class].get("hbm_bytes_per_launch")
         except Exception:
-            pass
+            continue
+        d = d.get(config, d if config == "C3" and "score" in d else {})      # r01's file is C3 only, un-keyed
+        if kernel_class in d:
+            best = d[kernel_class].get("hbm_bytes_per_launch")
     return best
 
 
-def main() -> int:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="C3", help="C2 | C3 (per-GPU particles/beams/grid)")
-    ap.add_argument("--particles", type=int, default=0, help="override particles per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scans", type=int, default=0, help="scans of the CPU baseline sample (0 = auto)")
-    ap.add_argument("--full-rebuild", action="store_true", help="rebuild the whole likelihood field every scan")
-    ap.add_argument("--host-inputs", action="store_true", help="hand poses and scans over as HOST buffers every step (PCIe-inclusive rate; never the headline value)")
-    ap.add_argument("--event-stride", type=int, default=8, help="timed region: HIP events around every n-th launch of the dominant kernel (a bracket costs microseconds of stream time)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "in-library", "torch-single", "torch-two"],
-                    help="sharded runs: first exchange route to try (auto = in-library RCCL; later routes are fall-backs)")
-    ap.add_argument("--torch-collectives", action="store_true", help="sharded runs: exchange through torch.distributed instead of the library's own RCCL communicator")
-    ap.add_argument("--force-sharded", action="store_true", help="run the sharded (all-reduce / all-gather) code path even with one rank")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """One BASELINE configuration on this rank: map pre-built from the first half of a synthetic trace, pose sets
+    resident in HBM, the filter (stand-alone, or this rank's shard)."""
 
-    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner on C stdout when a
-    # communicator is created, so everything but the result goes to stderr
-    sys.stdout.flush()
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
-
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus N > 1 must be launched with torch.distributed.run", file=sys.stderr)
-            return 2
-    torch.cuda.set_device(local_rank)
-    if world > 1 or (args.force_sharded and "RANK" in os.environ):
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from gridmap_slam_robot_amd import GridMap, ParticleFilter, _lib, synth
-    from gridmap_slam_robot_amd.distributed import HipShardOps, RcclComm, ShardedParticleFilter
-
-    cfg = dict(synth.CONFIGS[args.config])
-    n_local = args.particles or cfg["particles"]
-    n_global = n_local * world
-    B, ext, res = cfg["beams"], cfg["extent"], cfg["resolution"]
-    T = 64
-    dev = torch.device("cuda", local_rank)
-
-    # ---- inputs (identical on every rank: same seeds) ------------------------------------------------
-    tr = synth.make_trace(ext, res, B, T=T, seed=1234)
-    m = GridMap(ext, ext, res, (-ext / 2, -ext / 2), device=local_rank, max_beams=max(2048, B))
-    m.set_stream(torch.cuda.current_stream().cuda_stream)
-    for t in range(T // 2):                      # pre-built map: likelihoods are informative
-        m.update(tr.scans[t], tr.poses[t])
-    m.synchronize()
-    log0 = m.download_log().reshape(-1).copy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-
-    n_sets = 8
-    scans_dev = torch.from_numpy(tr.scans.view(np.uint8).reshape(T, -1).copy()).to(dev)
-    pose_sets = []
-    for s in range(n_sets):
-        t = T // 2 + s
-        allp = synth.make_particles(tr.poses[t], n_global, seed=99 + s)      # sigma 0.10 m / 5 deg
-        pose_sets.append(torch.from_numpy(allp[rank * n_local:(rank + 1) * n_local].copy()).to(dev))
-    pose_sets_host = [p.cpu().numpy() for p in pose_sets] if args.host_inputs else None
-    n_hit = int(tr.scans[T // 2]["hit"].sum())
-    r01 = np.random.default_rng(7).random(4096)
-
-    if world > 1 or args.force_sharded:
-        ops = HipShardOps(m, n_local, rank * n_local, n_global)
-        spf = ShardedParticleFilter(n_global, ops)
-        pf = ops.pf
-        # default: both exchanges enqueued by the library on its own RCCL communicator (one C-ABI call per scan);
-        # --torch-collectives routes them through torch.distributed instead
-        comm = None
-        if not args.torch_collectives:
-            ok = 1
-            try:
-                comm = RcclComm(local_rank)
-            except Exception as e:            # keep the run alive: the torch.distributed exchange does the same job
-                print(f"bench.py: in-library RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
-                ok = 0
-            if world > 1:                     # every rank must take the same path
-                t_ok = torch.tensor([ok], dtype=torch.int32, device=dev)
-                dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-                if int(t_ok.item()) == 0 and comm is not None:
-                    comm.close()
-                    comm = None
-    else:
-        pf = ParticleFilter(m, n_local)
-        spf = comm = None
-
-    two_collectives = [False]
-
-    def step(i: int):
-        s = i % n_sets
-        t = T // 2 + s
-        beams_ptr = scans_dev[t].data_ptr()
-        if args.host_inputs and spf is None:
-            pf.slam_update(pose_sets_host[s], tr.scans[t], r01[i % 4096], 0.5, True)
-            return
-        if spf is None and not args.full_rebuild:
-            pf.slam_update_dev(pose_sets[s].data_ptr(), beams_ptr, B, r01[i % 4096], 0.5, True)   # one C-ABI call per scan
-            return
-        if comm is not None:
-            pf.slam_update_sharded_dev(comm, pose_sets[s].data_ptr(), beams_ptr, B, r01[i % 4096], 0.5, True)
-            return
-        if spf is not None and not two_collectives[0]:
-            # the same single-exchange step with the two all-gathers issued through torch.distributed
-            spf.scan_step((pose_sets[s].data_ptr(), beams_ptr, B, True), r01[i % 4096], 0.5)
-            return
-        if spf is not None:
-            # last resort: all-reduce of the partials, all-gather of the normalised particles (distributed.py)
-            pf.set_poses_dev(pose_sets[s].data_ptr())
-            pf.score_dev(beams_ptr, B)
-            spf.normalize_begin()
-            m.update_at_dev(beams_ptr, B, pf)
-            spf.normalize_end()
-            spf.resample(r01[i % 4096], 0.5)
-            return
-        # --full-rebuild: the separate entry points, likelihood field rebuilt everywhere as the reference does
-        pf.set_poses_dev(pose_sets[s].data_ptr())
-        pf.score_dev(beams_ptr, B)
-        pf.normalize(fetch=False)
-        pf.resample_if(r01[i % 4096], 0.5)
-        if args.full_rebuild:
-            m.integrate_at_dev(beams_ptr, B, pf)
-            m.compute_likelihood_map()
+    def __init__(self, name, args, torch, dist, rank, world, local_rank, sharded, keep_log=False):
+        from gridmap_slam_robot_amd import GridMap, ParticleFilter, synth
+        self.name, self.args, self.torch, self.dist = name, args, torch, dist
+        self.rank, self.world = rank, world
+        cfg = dict(synth.CONFIGS["C3" if name == "C4" else name])
+        self.M = cfg["n_maps"]
+        self.n_local = args.particles or cfg["particles"]
+        self.batched = self.M > 1
+        self.sharded = sharded and not self.batched
+        self.n_global = self.n_local * (world if self.sharded else 1)
+        self.B, self.ext, self.res = cfg["beams"], cfg["extent"], cfg["resolution"]
+        self.T = T = 64 if not self.batched else 16
+        self.dev = dev = torch.device("cuda", local_rank)
+        self.n_sets = 8 if not self.batched else 4
+        ext, res, B, M = self.ext, self.res, self.B, self.M
+        self.synth = synth
+        if not self.batched:
+            self.tr = tr = synth.make_trace(ext, res, B, T=T, seed=1234)
+            self.m = m = GridMap(ext, ext, res, (-ext / 2, -ext / 2), device=local_rank, max_beams=max(2048, B))
+            self.stream = torch.cuda.current_stream()
+            m.set_stream(self.stream.cuda_stream)
+            for t in range(T // 2):                  # pre-built map: likelihoods are informative
+                m.update(tr.scans[t], tr.poses[t])
+            m.synchronize()
+            self.log0 = m.download_log().reshape(-1).copy() if keep_log else None
+            self.scans_dev = torch.from_numpy(tr.scans.view(np.uint8).reshape(T, -1).copy()).to(dev)
+            self.pose_sets, self.pose_sets_host = [], []
+            for s in range(self.n_sets):
+                allp = synth.make_particles(tr.poses[T // 2 + s], self.n_global, seed=99 + s)      # sigma 0.10 m / 5 deg
+                mine = allp[rank * self.n_local:(rank + 1) * self.n_local] if self.sharded else allp
+                self.pose_sets.append(torch.from_numpy(np.ascontiguousarray(mine)).to(dev))
+                self.pose_sets_host.append(np.ascontiguousarray(mine))
+                if s == 0:
+                    self.global_set0 = allp
+            self.n_hit = int(tr.scans[T // 2]["hit"].sum())
+            self.scan0 = tr.scans[T // 2]
+            self.pose0 = tr.poses[T // 2]
         else:
-            m.update_at_dev(beams_ptr, B, pf)
+            nt = min(M, 8)
+            self.traces = trs = [synth.make_trace(ext, res, B, T=T, seed=100 + i) for i in range(nt)]
+            self.m = m = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M, device=local_rank, max_beams=max(2048, B))
+            self.stream = torch.cuda.current_stream()
+            m.set_stream(self.stream.cuda_stream)
+            for t in range(T // 2):
+                m.update(np.stack([trs[i % nt].scans[t] for i in range(M)]), np.stack([trs[i % nt].poses[t] for i in range(M)]))
+            m.synchronize()
+            self.log0 = None
+            self.scans_dev = [torch.from_numpy(np.stack([trs[i % nt].scans[t] for i in range(M)]).view(np.uint8).copy()).to(dev)
+                              for t in range(T)]
+            self.pose_sets = []
+            for s in range(self.n_sets):
+                t = T // 2 + s
+                P = np.stack([synth.make_particles(trs[i % nt].poses[t], self.n_local, seed=7 + i + 64 * s) for i in range(M)])
+                self.pose_sets.append(torch.from_numpy(P).to(dev))
+            self.n_hit = int(trs[0].scans[T // 2]["hit"].sum())
+            self.scan0 = trs[0].scans[T // 2]
+            self.pose0 = trs[0].poses[T // 2]
+        self.r01 = np.random.default_rng(7).random((4096, M))
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        self.spf = self.comm = self.ops = None
+        self.route = None
+        self.two_collectives = False
+        if self.sharded:
+            from gridmap_slam_robot_amd.distributed import HipShardOps, RcclComm, ShardedParticleFilter
+            self.ops = HipShardOps(m, self.n_local, rank * self.n_local, self.n_global)
+            self.stream = self.ops.stream
+            self.spf = ShardedParticleFilter(self.n_global, self.ops)
+            self.pf = self.ops.pf
+            if args.exchange in ("auto", "in-library"):
+                ok = 1
+                try:
+                    self.comm = RcclComm(local_rank)
+                except Exception as e:            # keep the run alive: the torch.distributed exchange does the same job
+                    print(f"bench.py: in-library RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+                    ok = 0
+                if not self.agree(ok) and self.comm is not None:
+                    self.comm.close()
+                    self.comm = None
+        else:
+            self.pf = ParticleFilter(m, self.n_local)
 
-    bracket_us = m.profile_calibrate(200) * 1e3
-
-    # ---- one untimed step first: if an exchange route cannot run here, every rank falls back together -----------
-    # in-library RCCL (one grouped all-gather) -> torch.distributed scan_step (same protocol) -> the two-collective
-    # protocol over torch.distributed
-    def agree(ok: int) -> int:
-        if world > 1:
-            t_ok = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+    # -- helpers ------------------------------------------------------------------------------------------------------
+    def agree(self, ok: int) -> int:
+        """every rank must take the same path"""
+        if self.world > 1 and self.dist.is_initialized():
+            t_ok = self.torch.tensor([ok], dtype=self.torch.int32, device=self.dev)
+            self.dist.all_reduce(t_ok, op=self.dist.ReduceOp.MIN)
             return int(t_ok.item())
         return ok
 
-    if spf is not None:
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1 and self.dist.is_initialized():
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def beams_ptr(self, t):
+        return self.scans_dev[t].data_ptr()
+
+    # -- one scan step ------------------------------------------------------------------------------------------------
+    def step(self, i: int):
+        a, pf, m, B = self.args, self.pf, self.m, self.B
+        s = i % self.n_sets
+        t = self.T // 2 + s
+        bp = self.beams_ptr(t)
+        r01 = self.r01[i % 4096]
+        if self.batched:
+            pf.slam_update_dev(self.pose_sets[s].data_ptr(), bp, B, r01, 0.5, True)      # one C-ABI call per batched scan
+            return
+        r01 = float(r01[0])
+        if a.host_inputs and self.spf is None:
+            pf.slam_update(self.pose_sets_host[s], self.tr.scans[t], r01, 0.5, True)
+            return
+        if self.spf is None and not a.full_rebuild:
+            pf.slam_update_dev(self.pose_sets[s].data_ptr(), bp, B, r01, 0.5, True)       # one C-ABI call per scan
+            return
+        if self.comm is not None:
+            pf.slam_update_sharded_dev(self.comm, self.pose_sets[s].data_ptr(), bp, B, r01, 0.5, True)
+            return
+        if self.spf is not None and not self.two_collectives:
+            # the same single-exchange step with the two all-gathers issued through torch.distributed
+            self.spf.scan_step((self.pose_sets[s].data_ptr(), bp, B, True), r01, 0.5)
+            return
+        if self.spf is not None:
+            # last resort: all-reduce of the partials, all-gather of the normalised particles (distributed.py)
+            pf.set_poses_dev(self.pose_sets[s].data_ptr())
+            pf.score_dev(bp, B)
+            self.spf.normalize_begin()
+            m.update_at_dev(bp, B, pf)
+            self.spf.normalize_end()
+            self.spf.resample(r01, 0.5)
+            return
+        # --full-rebuild: the separate entry points, likelihood field rebuilt everywhere as the reference does
+        pf.set_poses_dev(self.pose_sets[s].data_ptr())
+        pf.score_dev(bp, B)
+        pf.normalize(fetch=False)
+        pf.resample_if(r01, 0.5)
+        m.integrate_at_dev(bp, B, pf)
+        m.compute_likelihood_map()
+
+    # -- exchange route (sharded runs): one untimed step; if a route cannot run here every rank falls back together ---
+    def pick_route(self):
+        if self.spf is None:
+            return
         routes = ["in-library", "torch-single", "torch-two"]
-        if args.exchange != "auto":
-            routes = routes[routes.index(args.exchange):]
+        if self.args.exchange != "auto":
+            routes = routes[routes.index(self.args.exchange):]
         for route in routes:
-            if route == "in-library" and comm is None:
+            if route == "in-library" and self.comm is None:
                 continue
             if route == "torch-single":
-                comm = None
+                self.comm = None
             if route == "torch-two":
-                comm, two_collectives[0] = None, True
+                self.comm, self.two_collectives = None, True
             ok = 1
             try:
-                step(0)
-                torch.cuda.synchronize()
+                self.step(0)
+                self.torch.cuda.synchronize()
             except Exception as e:
                 print(f"bench.py: sharded step via {route} failed ({e})", file=sys.stderr)
                 ok = 0
-            if agree(ok):
-                break
-        else:
-            raise RuntimeError("no exchange route works on this node")
+            if self.agree(ok):
+                self.route = route
+                return
+        raise RuntimeError("no exchange route works on this node")
 
-    # ---- warmup, with every kernel class bracketed: find the dominant one -----------------------------
+    def exchange_text(self):
+        if self.spf is None:
+            return None
+        return {"in-library": "in-library RCCL: one grouped all-gather per scan (raw weights + block partials)",
+                "torch-single": "torch.distributed (RCCL), one exchange: two all-gathers issued together",
+                "torch-two": "torch.distributed (RCCL), all-reduce of the partials + all-gather of the normalised particles"}[self.route]
+
+    # -- N > 1: is the sharded filter the stand-alone filter? ---------------------------------------------------------
+    def verify_against_standalone(self):
+        """One untimed step on the sharded filter (every rank) and on a stand-alone filter of the whole population
+        (rank 0, its own map replica copied from the pre-built one).  Every rank reports its particles, weights,
+        statistics and map checksums; rank 0 compares them with the stand-alone filter's, bit for bit."""
+        from gridmap_slam_robot_amd import GridMap, ParticleFilter
+        torch, dist = self.torch, self.dist
+        ext, res, B = self.ext, self.res, self.B
+        t0 = self.T // 2
+        r01 = float(self.r01[0][0])
+        ref = None
+        if self.rank == 0:
+            m2 = GridMap(ext, ext, res, (-ext / 2, -ext / 2), device=self.dev.index, max_beams=max(2048, B))
+            m2.set_stream(self.stream.cuda_stream)
+            m2.copy_from(self.m)
+            pf2 = ParticleFilter(m2, self.n_global)
+            P = torch.from_numpy(np.ascontiguousarray(self.global_set0)).to(self.dev)
+            with torch.cuda.stream(self.stream):
+                pf2.slam_update_dev(P.data_ptr(), self.beams_ptr(t0), B, r01, 0.5, True)
+            torch.cuda.synchronize()
+            ref = dict(stats=pf2.stats(), poses=pf2.get_poses(), weights=pf2.get_weights(),
+                       log_crc=zlib.crc32(m2.download_log().tobytes()), lik_crc=zlib.crc32(m2.download_likelihood().tobytes()))
+            pf2.close(); m2.close()
+        self.step(0)                                    # set 0, scan t0, r01[0]: the same inputs
+        torch.cuda.synchronize()
+        mine = dict(rank=self.rank, stats=self.pf.stats(), poses=self.pf.get_poses(), weights=self.pf.get_weights(),
+                    log_crc=zlib.crc32(self.m.download_log().tobytes()), lik_crc=zlib.crc32(self.m.download_likelihood().tobytes()))
+        rccl_ranks = None
+        if self.comm is not None:
+            import ctypes as C
+            from gridmap_slam_robot_amd import _lib
+            r, w = C.c_int32(), C.c_int32()
+            _lib.check(_lib.load().gms_comm_rank(self.comm._h, C.byref(r), C.byref(w)))
+            rccl_ranks = int(w.value)
+            mine["comm_rank"] = int(r.value)
+        if self.world > 1:
+            box = [None] * self.world
+            dist.all_gather_object(box, mine)
+        else:
+            box = [mine]
+        if self.rank != 0:
+            return None
+        n = self.n_local
+        detail = {}
+        ok = True
+        for e in box:
+            r = e["rank"]
+            checks = dict(stats=e["stats"] == ref["stats"],
+                          poses=bool(np.array_equal(e["poses"], ref["poses"][r * n:(r + 1) * n])),
+                          weights=bool(np.array_equal(e["weights"], ref["weights"][r * n:(r + 1) * n])),
+                          log=e["log_crc"] == ref["log_crc"], likelihood=e["lik_crc"] == ref["lik_crc"])
+            if "comm_rank" in e:
+                checks["comm_rank"] = e["comm_rank"] == r
+            if not all(checks.values()):
+                ok = False
+                detail[f"rank{r}"] = [k for k, v in checks.items() if not v]
+        return {"sharded_equals_standalone": ok, "mismatches": detail or None, "rccl_ranks": rccl_ranks,
+                "route_verified": self.route, "population": self.n_global}
+
+    # -- what one scan touches (algorithmic bytes of the map kernels) -------------------------------------------------
+    def scan_footprint(self):
+        """visited cells of one scan and the cells of the likelihood tiles a dirty rebuild covers (map 0)."""
+        from gridmap_slam_robot_amd import GridMap
+        probe = self.m
+        if self.batched:        # trace_scan works on map 0 of a handle: a one-map handle of the same geometry
+            probe = GridMap(self.ext, self.ext, self.res, (-self.ext / 2, -self.ext / 2), device=self.dev.index, max_beams=max(2048, self.B))
+        cells, cls, counts = probe.trace_scan(self.scan0, self.pose0)
+        visits = int(counts.sum())
+        k = (probe.params.ktaps - 1) // 2
+        sel = np.zeros(cls.shape, dtype=bool)
+        for b in range(len(counts)):
+            sel[b, :counts[b]] = cls[b, :counts[b]] != 1
+        if sel.any():
+            xs, ys = cells[..., 0][sel], cells[..., 1][sel]
+            x0, x1 = max(int(xs.min()) - k, 0), min(int(xs.max()) + k, probe.W - 1)
+            y0, y1 = max(int(ys.min()) - k, 0), min(int(ys.max()) + k, probe.H - 1)
+            dirty = (x1 // 64 - x0 // 64 + 1) * (y1 // 32 - y0 // 32 + 1) * 64 * 32
+        else:
+            dirty = 0
+        if probe is not self.m:
+            probe.close()
+        return visits, int(dirty)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def measure(wl: Workload, steps: int, warmup: int):
+    """warm-up (every kernel class bracketed: find the dominant one), the timed region (exactly `steps` steps, only the
+    dominant class bracketed, every stride-th launch), a second informational pass with every class bracketed."""
+    from gridmap_slam_robot_amd import _lib
+    m, torch, dist = wl.m, wl.torch, wl.dist
+    bracket_us = m.profile_calibrate(200) * 1e3
     m.profile(True)
     m.profile_reset()
-    for i in range(args.warmup):
-        step(i)
-    barrier()
+    for i in range(warmup):
+        wl.step(i)
+    wl.barrier()
     warm = m.profile_get()
     m.profile(False)
-    if args.warmup > 0:
-        dominant = max((k for k in warm if warm[k][1] > 0), key=lambda k: warm[k][0], default="score")
-    else:
-        dominant = "score"
+    compute = [k for k in warm if warm[k][1] > 0 and k != "exchange"]
+    dominant = max(compute, key=lambda k: warm[k][0], default="score") if warmup > 0 else "score"
     dom_bit = 1 << _lib.KERNEL_NAMES.index(dominant)
+    per_step = max(1.0, warm[dominant][1] / warmup) if warmup > 0 and warm[dominant][1] else 1.0
+    # a bracket costs microseconds of stream time (two marker commands): as few as give >= 16 bracketed launches
+    stride = wl.args.event_stride or max(1, int(steps * per_step) // MIN_BRACKETED_LAUNCHES)
 
-    # ---- timed region: exactly K steps, only the dominant kernel bracketed by events -------------------
     m.profile_reset()
-    m.profile_sample(max(1, args.event_stride))
+    m.profile_sample(stride)
     m.profile(dom_bit)
-    barrier()
+    wl.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        wl.step(warmup + i)
     issue = time.perf_counter() - t0          # host time to enqueue K steps (the GPU must not be waiting on it)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    wl.barrier()
+    elapsed_rank = elapsed = time.perf_counter() - t0
     dom_ms, dom_n = m.profile_get()[dominant]
     m.profile(False)
     m.profile_sample(1)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    per_rank = [elapsed_rank]
+    if wl.world > 1 and dist.is_initialized():
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=wl.dev)
+        allt = [torch.zeros_like(tt) for _ in range(wl.world)]
+        dist.all_gather(allt, tt)
+        per_rank = [float(x.item()) for x in allt]
+        elapsed = max(per_rank)
 
-    # ---- per-kernel breakdown (second pass, all classes bracketed; informational) ----------------------
     m.profile(True)
     m.profile_reset()
-    nb = min(args.steps, 50)
+    nb = max(1, min(steps, 50))
     for i in range(nb):
-        step(args.warmup + args.steps + i)
-    barrier()
+        wl.step(warmup + steps + i)
+    wl.barrier()
     prof = m.profile_get()
     m.profile(False)
-    st = pf.stats()
-    visits = None
-    if rank == 0:
-        cells, cls, counts = m.trace_scan(tr.scans[T // 2], tr.poses[T // 2])
-        visits = int(counts.sum())
+    return dict(elapsed=elapsed, issue=issue, per_rank=per_rank, dominant=dominant, dom_ms=dom_ms, dom_n=dom_n, stride=stride,
+                prof=prof, nb=nb, bracket_us=bracket_us)
 
-    if rank != 0:
-        if dist.is_initialized():
-            dist.barrier()
-            dist.destroy_process_group()
-        return 0
 
-    steps = args.steps
-    value = n_global * steps / elapsed
-    dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
-    launches_per_step = {k: (prof[k][1] / nb if nb else 0) for k in prof}
-    alg = algorithmic_bytes(dominant, n_particles=n_local, n_hit=n_hit, n_beams=B, cells=m.W * m.H, visits=visits or 0)
-    # a class may launch several kernels per scan (reduce, resample): the figure is per scan step
-    per_launch_scale = max(1.0, launches_per_step.get(dominant, 1.0))
-    achieved = alg / per_launch_scale / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+def report(wl: Workload, meas: dict, steps: int, warmup: int):
+    """the JSON fields of one configuration (rank 0)."""
+    a = wl.args
+    visits, dirty = wl.scan_footprint()
+    m = wl.m
+    n_total = wl.n_global * wl.M * (wl.world if (wl.batched and wl.world > 1) else 1)
+    elapsed = meas["elapsed"]
+    value = n_total * steps / elapsed
+    paired = not a.full_rebuild and not a.host_inputs or wl.batched
+    kw = dict(n_particles=wl.n_local, n_hit=wl.n_hit, n_beams=wl.B, cells=m.W * m.H, visits=visits, dirty_cells=dirty, n_maps=wl.M,
+              paired=bool(paired), full_rebuild=a.full_rebuild)
+    nb, prof = meas["nb"], meas["prof"]
     kernels = {}
     for k, (ms, n) in prof.items():
-        if n:
-            ab = algorithmic_bytes(k, n_particles=n_local, n_hit=n_hit, n_beams=B, cells=m.W * m.H, visits=visits or 0)
-            if k == "likelihood" and not args.full_rebuild:
-                ab = None        # the dirty-rect rebuild touches a scan-dependent part of the 16 B/cell field
-            kernels[k] = {"ms_per_step": round(ms / nb, 5), "launches_per_step": round(n / nb, 2),
-                          "algorithmic_gb_per_s": (round(ab / (ms / nb * 1e-3) / 1e9, 1) if ab else None)}
-    # BASELINE metric (ii), map-update ms/scan = integrateObservation + computeLikelihoodMap: the map entry point by
-    # itself (ray cast, apply, likelihood rebuild as three kernels at a fixed device-resident pose), wall time
-    upd_pose = torch.from_numpy(np.ascontiguousarray(tr.poses[T // 2], dtype=np.float32)).to(dev)
-    def map_update(i):
-        bp = scans_dev[T // 2 + i % n_sets].data_ptr()
-        if args.full_rebuild:
+        if not n:
+            continue
+        lps = n / nb
+        ab = algorithmic_bytes(k, **kw) / max(1.0, lps) if k != "exchange" else None
+        us = ms / n * 1e3
+        tr = pmc_traffic(wl.name, k) if not (a.full_rebuild or a.particles or a.host_inputs) else None
+        e = {"launches_per_step": round(lps, 2), "avg_launch_us": round(us, 2), "ms_per_step": round(ms / nb, 5)}
+        if ab:
+            e.update({"algorithmic_bytes_per_launch": int(ab), "algorithmic_gb_per_s": round(ab / (us * 1e-6) / 1e9, 1),
+                      "hbm_frac": round(ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
+            if tr:
+                e.update({"traffic_bytes_per_launch": int(tr), "traffic_over_algorithmic": round(tr / ab, 2)})
+        kernels[k] = e
+    dom = meas["dominant"]
+    lps_dom = max(1.0, prof[dom][1] / nb) if prof[dom][1] else 1.0
+    alg = algorithmic_bytes(dom, **kw) / lps_dom
+    dom_avg_s = (meas["dom_ms"] / max(meas["dom_n"], 1)) * 1e-3
+    achieved = alg / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+    net_s = max(dom_avg_s - meas["bracket_us"] * 1e-6, 1e-9)
+    roof = {
+        "kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": pmc_traffic(wl.name, dom) if not (a.full_rebuild or a.particles or a.host_inputs) else None,
+        "algorithmic_bytes_per_launch": alg, "avg_launch_us": dom_avg_s * 1e6, "launches_timed": meas["dom_n"],
+        "event_stride": meas["stride"],
+        # the same bracket around an empty kernel (dispatch latency + ~1 us): a kernel-trace profiler's duration for the
+        # dominant kernel is about avg_launch_us minus this (profiles/ holds that trace)
+        "event_bracket_empty_kernel_us": meas["bracket_us"],
+        "avg_launch_us_minus_bracket": net_s * 1e6, "frac_minus_bracket": alg / net_s / 1e9 / HBM_PEAK_GBS,
+    }
+    if dom == "score":
+        # what the counters say bounds this kernel (profiles/: the factor table is L2/Infinity-Cache resident, traffic is
+        # a fraction of the algorithmic bytes; TA_BUSY per look-up instruction = distinct 128-byte lines per wavefront)
+        roof["bound_measured"] = "l1-gather (texture-address pipe: one 128-byte line per clock)"
+        lookups = wl.n_local * wl.n_hit * wl.M
+        roof["lookups_per_s"] = lookups / dom_avg_s
+        roof["gather_ceiling_frac"] = lookups / dom_avg_s / GATHER_CEILING_LANES_PER_S
+    st = wl.pf.stats()
+    st0 = st[0] if isinstance(st, list) else st
+    out = {
+        "ms_per_step": elapsed / steps * 1e3,
+        "timed_region_s": elapsed,
+        "host_issue_ms_per_step": meas["issue"] / steps * 1e3,
+        "config": {
+            "workload": (f"{wl.name}: {wl.M} maps x {m.W}x{m.H} @ {wl.res} m x {wl.n_local} particles x {wl.B} beams ({wl.n_hit} hits), batched handle, "
+                         if wl.batched else
+                         f"{wl.name}: {wl.n_local} particles/GPU x {wl.B} beams ({wl.n_hit} hits), {m.W}x{m.H} grid @ {wl.res} m, ")
+                        + "full scan step (score+normalise+resample+ray-cast+likelihood rebuild)",
+            "particles_total": n_total, "beams": wl.B, "grid": [m.W, m.H], "resolution_m": wl.res, "maps": wl.M,
+            "parallelism": ("single GPU" if wl.world == 1 else
+                            (f"{wl.M} independent maps per rank x{wl.world}, no collective" if wl.batched else
+                             f"particles sharded x{wl.world}, map replicated")),
+            "exchange": wl.exchange_text(),
+            "likelihood_rebuild": "full" if a.full_rebuild else "dirty-rect (bit-identical to full)",
+            "inputs": "host buffers every step (PCIe-inclusive)" if a.host_inputs else "resident in HBM",
+        },
+        "value": value,
+        "beam_evals_per_s": value * wl.n_hit,
+        "scans_per_s": steps * wl.M * (wl.world if wl.batched else 1) / elapsed,
+        "kernels": kernels,
+        "filter": {"neff": st0["neff"], "n_zero_weights": st0["n_zero"], "weight_sum": st0["weight_sum"],
+                   "note": "the reference's plain product of <= 720 factors: most raw weights underflow at this cloud (reproduced, "
+                           "counted); max_log_weight is the underflow-free companion", "max_log_weight": st0["max_log_weight"]},
+        "roofline": roof,
+        "scan_footprint": {"visited_cells": visits, "dirty_rebuild_cells": dirty},
+    }
+    return out
+
+
+def map_update_ms(wl: Workload, nb: int) -> float:
+    """BASELINE metric (ii), map-update ms/scan = integrateObservation + computeLikelihoodMap: the map entry point by
+    itself (ray cast, apply, likelihood rebuild as three kernels at a fixed device-resident pose), wall time."""
+    torch, m, B = wl.torch, wl.m, wl.B
+    if wl.batched:
+        return None
+    upd_pose = torch.from_numpy(np.ascontiguousarray(wl.pose0, dtype=np.float32)).to(wl.dev)
+
+    def one(i):
+        bp = wl.beams_ptr(wl.T // 2 + i % wl.n_sets)
+        if wl.args.full_rebuild:
             m.integrate_dev(bp, B, upd_pose.data_ptr()); m.compute_likelihood_map()
         else:
             m.update_dev(bp, B, upd_pose.data_ptr())
     for i in range(5):
-        map_update(i)
+        one(i)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for i in range(nb):
-        map_update(i)
+        one(i)
     torch.cuda.synchronize()
-    map_update_ms = (time.perf_counter() - t1) / nb * 1e3
+    return (time.perf_counter() - t1) / nb * 1e3
 
-    out = {
-        "metric": "particle-scan evals/sec",
-        "value": value,
-        "unit": "particle-scan evals/s",
-        "n_gpus": world,
-        "steps": steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / steps * 1e3,
-        "host_issue_ms_per_step": issue / steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {
-            "workload": f"{args.config}: {n_local} particles/GPU x {B} beams ({n_hit} hits), {m.W}x{m.H} grid @ {res} m, "
-                        f"full scan step (score+normalise+resample+ray-cast+likelihood rebuild)",
-            "particles_total": n_global, "beams": B, "grid": [m.W, m.H], "resolution_m": res,
-            "parallelism": f"particles sharded x{world}, map replicated" if world > 1 else "single GPU",
-            "exchange": None if spf is None else (("torch.distributed, all-reduce + all-gather" if two_collectives[0] else "torch.distributed (RCCL), one exchange") if comm is None else "in-library RCCL: one grouped all-gather per scan (raw weights + block partials)"),
-            "likelihood_rebuild": "full" if args.full_rebuild else "dirty-rect (bit-identical to full)",
-            "inputs": "host buffers every step (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
-        },
-        "beam_evals_per_s": value * n_hit,
-        "scans_per_s": steps / elapsed,
-        "map_update_ms_per_scan": map_update_ms,
-        "kernels": kernels,
-        "filter": {"neff": st["neff"], "n_zero_weights": st["n_zero"], "weight_sum": st["weight_sum"]},
-        "roofline": {
-            "kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            # the committed PMC passes are of the default configuration: no figure for other modes
-            "traffic": pmc_traffic(dominant) if (args.config == "C3" and not args.full_rebuild and not args.particles) else None,
-            "algorithmic_bytes_per_launch": alg / per_launch_scale,
-            "avg_launch_us": dom_avg_s * 1e6 / per_launch_scale, "launches_timed": dom_n, "event_stride": max(1, args.event_stride),
-            # the same bracket around an empty kernel (dispatch latency + ~1 us): a kernel-trace profiler's duration
-            # for the dominant kernel is about avg_launch_us minus this (profiles/ holds that trace)
-            "event_bracket_empty_kernel_us": bracket_us,
-        },
-    }
 
-    # ---- CPU baseline: the oracle (port of the Java loops), one thread, bounded sample ------------------
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as orc
-        g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
-        log = log0
+def cpu_baseline(wl: Workload, budget_s: float, with_score_sweep: bool):
+    """the oracle (port of the Java loops), one thread, bounded sample of the same workload (map 0 of a batch)."""
+    from oracle import oracle as orc
+    synth = wl.synth
+    ext, res, B, T, n_sets = wl.ext, wl.res, wl.B, wl.T, wl.n_sets
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    if wl.batched:
+        tr = wl.traces[0]
+        log = g.new_log()
+        for t in range(T // 2):
+            g.integrate(log, tr.scans[t], tr.poses[t])
+    else:
+        tr = wl.tr
+        log = wl.log0.copy()
+    lik = g.build_likelihood(log)
+    n_cpu = wl.n_local
+    P = synth.make_particles(tr.poses[T // 2], n_cpu, seed=99)
+    r01 = wl.r01[:, 0]
+    # (ii) map update alone: integrateObservation + computeLikelihoodMap (GridMap.java:173-250), full rebuild as the reference does
+    reps, u0 = 0, time.perf_counter()
+    log_u = log.copy()
+    while reps < 3 or (time.perf_counter() - u0 < 0.15 * budget_s and reps < 64):
+        g.integrate(log_u, tr.scans[T // 2 + reps % n_sets], tr.poses[T // 2 + reps % n_sets])
+        g.build_likelihood(log_u)
+        reps += 1
+    upd_ms = (time.perf_counter() - u0) / reps * 1e3
+    c0 = time.perf_counter()
+    done = 0
+    for i in range(10 ** 6):
+        t = T // 2 + (i % n_sets)
+        w = g.score(lik, tr.scans[t], P)
+        ws, strongest = orc.normalize(w)
+        ne = orc.neff(w) if ws > 0 else float("nan")
+        if ws > 0 and ne < n_cpu / 2:
+            orc.resample_indices(w, float(r01[i % 4096]))
+        wp = orc.weighted_pose(P, w) if ws > 0 else tr.poses[t]
+        g.integrate(log, tr.scans[t], wp)
         lik = g.build_likelihood(log)
-        n_cpu = n_local
-        scans_cpu = args.cpu_scans or 10 ** 6          # bounded by time: ~12 s of single-thread CPU work
-        P = synth.make_particles(tr.poses[T // 2], n_global, seed=99)[:n_cpu]
-        c0 = time.perf_counter()
-        done = 0
-        for i in range(scans_cpu):
-            t = T // 2 + (i % n_sets)
-            w = g.score(lik, tr.scans[t], P)
-            ws, strongest = orc.normalize(w)
-            ne = orc.neff(w) if ws > 0 else float("nan")
-            if ws > 0 and ne < n_cpu / 2:
-                orc.resample_indices(w, float(r01[i]))
-            wp = orc.weighted_pose(P, w) if ws > 0 else tr.poses[t]
-            g.integrate(log, tr.scans[t], wp)
-            lik = g.build_likelihood(log)
-            done += 1
-            if time.perf_counter() - c0 > (30.0 if args.cpu_scans else 12.0):
-                break
-        cpu_s = time.perf_counter() - c0
+        done += 1
+        if time.perf_counter() - c0 > budget_s:
+            break
+    cpu_s = time.perf_counter() - c0
+    out = {
+        "value": n_cpu * done / cpu_s, "unit": "particle-scan evals/s", "cores": 1, "kind": "port",
+        "sample": f"{done} scan steps of the same trace" + (" (map 0 of the batch)" if wl.batched else "") + f", all {n_cpu} particles "
+                  f"(C oracle, gcc -O2 -ffp-contract=off, single thread; full likelihood rebuild per scan as the reference does)",
+        "seconds": cpu_s,
+        "map_update_ms_per_scan": upd_ms,
+        "map_update_sample": f"{reps} x (integrateObservation + computeLikelihoodMap), C oracle, single thread",
+    }
+    if with_score_sweep:
         # extra information: scoring alone (a pure function) over host threads with OpenMP; the thread count that does
         # best is reported (containers often expose more CPUs than they may use)
         try:
@@ -424,18 +581,130 @@ def main() -> int:
             w_st = g.score(lik, tr.scans[T // 2], P)
             st_s = min(st_s, time.perf_counter() - s0)
         assert np.array_equal(w_mt, w_st)
-        out["cpu_baseline"] = {
-            "value": n_cpu * done / cpu_s, "unit": "particle-scan evals/s", "cores": 1, "kind": "port",
-            "sample": f"{done} scan steps of the same trace, all {n_cpu} particles "
-                      f"(C oracle, gcc -O2 -ffp-contract=off, single thread; full likelihood rebuild per scan as the reference does)",
-            "seconds": cpu_s,
-            "score_only": {"single_thread_particle_evals_per_s": n_cpu / st_s, "openmp_particle_evals_per_s": n_cpu / mt_s,
-                           "openmp_threads": ncore, "cpus_visible": navail,
-                           "note": "probabilityOf over all particles only (no map update, no likelihood rebuild); the GPU scoring "
-                                   "kernel alone does particles / kernels.score.ms_per_step"},
-        }
+        out["score_only"] = {"single_thread_particle_evals_per_s": n_cpu / st_s, "openmp_particle_evals_per_s": n_cpu / mt_s,
+                             "openmp_threads": ncore, "cpus_visible": navail,
+                             "note": "probabilityOf over all particles only (no map update, no likelihood rebuild); the GPU scoring "
+                                     "kernel alone does particles / kernels.score.ms_per_step"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C3", help="C3 (default; C4 = the same per-GPU shape at 4 GPUs) | C2 | C5 (64 batched maps)")
+    ap.add_argument("--particles", type=int, default=0, help="override particles per GPU (per map)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C5 / C2 block of the default 1-GPU run")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline's scan-step loop")
+    ap.add_argument("--full-rebuild", action="store_true", help="rebuild the whole likelihood field every scan")
+    ap.add_argument("--host-inputs", action="store_true", help="hand poses and scans over as HOST buffers every step (PCIe-inclusive rate; never the headline value)")
+    ap.add_argument("--event-stride", type=int, default=0, help="timed region: HIP events around every n-th launch of the dominant kernel (0 = as few as give >= 16 bracketed launches)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "in-library", "torch-single", "torch-two"],
+                    help="sharded runs: first exchange route to try (auto = in-library RCCL; later routes are fall-backs)")
+    ap.add_argument("--force-sharded", action="store_true", help="run the sharded (all-gather) code path even with one rank")
+    ap.add_argument("--no-verify", action="store_true", help="sharded runs: skip the sharded == stand-alone check")
+    args = ap.parse_args()
+    if args.config not in ("C2", "C3", "C4", "C5"):
+        print("bench.py: --config must be C2, C3, C4 or C5", file=sys.stderr)
+        return 2
+
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner on C stdout when a
+    # communicator is created, so everything but the result goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    if world > 1 or (args.force_sharded and "RANK" in os.environ):
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    sharded = world > 1 or args.force_sharded
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    wl = Workload(args.config, args, torch, dist, rank, world, local_rank, sharded, keep_log=(want_cpu and rank == 0))
+    verify = None
+    if wl.spf is not None:
+        wl.pick_route()
+        if not args.no_verify:
+            try:
+                verify = wl.verify_against_standalone()
+            except Exception as e:      # the check must never take the measurement down with it
+                print(f"bench.py: sharded-vs-standalone check failed to run: {e!r}", file=sys.stderr)
+                verify = {"sharded_equals_standalone": None, "error": repr(e)} if rank == 0 else None
+                wl.agree(0)
+
+    meas = measure(wl, args.steps, args.warmup)
+    if rank != 0:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
+    rep = report(wl, meas, args.steps, args.warmup)
+    out = {
+        "metric": "particle-scan evals/sec",
+        "value": rep.pop("value"),
+        "unit": "particle-scan evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": rep.pop("ms_per_step"),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+    }
+    out.update(rep)
+    mu = map_update_ms(wl, meas["nb"])
+    if mu is not None:
+        out["map_update_ms_per_scan"] = mu
+    if world > 1 or wl.spf is not None:
+        out["per_rank_ms_per_step"] = [round(t / args.steps * 1e3, 5) for t in meas["per_rank"]]
+        ex = out["kernels"].get("exchange")
+        out["exchange_latency_us"] = ex["avg_launch_us"] if ex else None     # the L of DESIGN.md section 7 (event-bracketed, in-library route)
+        if verify is not None:
+            out["verify"] = verify
+            out["sharded_equals_standalone"] = verify.get("sharded_equals_standalone")
+            out["rccl_ranks"] = verify.get("rccl_ranks")
+
+    if want_cpu:
+        out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds, with_score_sweep=True)
     else:
         out["cpu_baseline"] = None
+
+    # ---- the other single-GPU configurations, shorter runs of the same measurement ------------------------------------
+    if world == 1 and not args.no_secondary and args.config == "C3" and not (args.full_rebuild or args.host_inputs or args.particles or args.force_sharded):
+        sec = {}
+        for name, (k_steps, k_warm) in (("C5", (20, 3)), ("C2", (100, 10))):
+            try:
+                w2 = Workload(name, args, torch, dist, 0, 1, local_rank, False, keep_log=want_cpu)
+                m2 = measure(w2, k_steps, k_warm)
+                r2 = report(w2, m2, k_steps, k_warm)
+                r2["steps"], r2["warmup"] = k_steps, k_warm
+                mu2 = map_update_ms(w2, m2["nb"])
+                if mu2 is not None:
+                    r2["map_update_ms_per_scan"] = mu2
+                if want_cpu:
+                    r2["cpu_baseline"] = cpu_baseline(w2, 3.0, with_score_sweep=False)
+                sec[name] = r2
+                w2.pf.close(); w2.m.close()
+                del w2
+            except Exception as e:
+                sec[name] = {"error": repr(e)}
+        out["secondary"] = sec
 
     os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():

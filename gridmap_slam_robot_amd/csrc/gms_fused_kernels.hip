@@ -27,13 +27,13 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
     if (blockIdx.x < n_ray_blocks) {
         __shared__ RedLds L;
         __shared__ float s_pose[3];
-        const double sum = fold_sum(partials, nblk_global, COL_SUM, L.a);
-        const double xw = fold_sum(partials, nblk_global, COL_XW, L.a), yw = fold_sum(partials, nblk_global, COL_YW, L.a),
-                     tw = fold_sum(partials, nblk_global, COL_TW, L.a);
+        const int cols[4] = { COL_SUM, COL_XW, COL_YW, COL_TW };
+        double f[4];
+        fold_sums<4>(partials, nblk_global, cols, f, L);               // one round trip, one barrier pair
         if (threadIdx.x == 0) {
-            s_pose[0] = (float)(xw / sum);                             // SLAM.java:176
-            s_pose[1] = (float)(yw / sum);
-            s_pose[2] = (float)(tw / sum);
+            s_pose[0] = (float)(f[1] / f[0]);                          // SLAM.java:176
+            s_pose[1] = (float)(f[2] / f[0]);
+            s_pose[2] = (float)(f[3] / f[0]);
         }
         __syncthreads();
         raycast_body<false, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,
@@ -87,13 +87,13 @@ k_raycast_norm_chunks(GridDev g, const gms_beam *__restrict__ beams, int32_t B, 
     if (blockIdx.x < n_ray_blocks) {
         __shared__ RedLds L;
         __shared__ float s_pose[3];
-        const double sum = fold_sum(partials, nblk_global, COL_SUM, L.a);
-        const double xw = fold_sum(partials, nblk_global, COL_XW, L.a), yw = fold_sum(partials, nblk_global, COL_YW, L.a),
-                     tw = fold_sum(partials, nblk_global, COL_TW, L.a);
+        const int cols[4] = { COL_SUM, COL_XW, COL_YW, COL_TW };
+        double f[4];
+        fold_sums<4>(partials, nblk_global, cols, f, L);               // one round trip, one barrier pair
         if (threadIdx.x == 0) {
-            s_pose[0] = (float)(xw / sum);                             // SLAM.java:176
-            s_pose[1] = (float)(yw / sum);
-            s_pose[2] = (float)(tw / sum);
+            s_pose[0] = (float)(f[1] / f[0]);                          // SLAM.java:176
+            s_pose[1] = (float)(f[2] / f[0]);
+            s_pose[2] = (float)(f[3] / f[0]);
         }
         __syncthreads();
         raycast_body<false, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,

@@ -1441,12 +1441,14 @@ int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xythet
     double *own_partials = pf->d_partials + (size_t)c->rank * np;
     PackedParticle *own_slot = pf->d_global_own + pf->offset;
     const size_t pbytes = (size_t)pf->n * sizeof(PackedParticle);
+    int first = 0, end = 0;
+    const char *what = "";
+    {
+    ProfScope ps(m, GMS_K_EXCHANGE);                                             // event-bracketed when asked for: the L of DESIGN.md section 7
     RCCLCHK(g_rccl.GroupStart());                                                // the whole exchange is one launch
     // Inside the bracket an error must not return: the thread's RCCL group depth would stay at 1 and every later
     // collective of this process (torch.distributed shares this librccl) would queue behind a group that never closes.
     // The first error is kept, GroupEnd always runs, and the communicator is marked broken.
-    int first = 0;
-    const char *what = "";
 #define RCCL_IN_GROUP(expr) do { if (!first) { first = (expr); if (first) what = #expr; } } while (0)
     if (c->p2p && g_rccl.Send && g_rccl.Recv) {
         // the same exchange as point-to-point transfers to and from every peer (direct xGMI links, no ring):
@@ -1463,7 +1465,8 @@ int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xythet
         RCCL_IN_GROUP(g_rccl.AllGather(own_partials, pf->d_partials, np, RCCL_FLOAT64, c->nccl, m->stream));
     }
 #undef RCCL_IN_GROUP
-    const int end = g_rccl.GroupEnd();
+    end = g_rccl.GroupEnd();
+    }
     if (first || end) {
         c->broken = 1;
         // the begin half may have consumed a deferred apply pass; bring the map to a defined state for the fallback route

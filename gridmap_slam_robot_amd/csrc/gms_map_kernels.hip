@@ -30,11 +30,11 @@ __device__ __forceinline__ void bbox_decode(const int32_t *bb, int32_t W, int32_
 // `error` recurrence that decides "y step or x step"; everything else (cell coordinates, distance,
 // sensor class, map update) is a function of how many y steps precede step k.
 //   phase A  one lane per ray runs just that recurrence (compare, select, add: the exact float
-//            operations of the reference, in order) and records the decisions as bit words in LDS,
-//            with the running count of y steps per word.
-//   phase B  one wavefront per ray: lane j of iteration i owns step k = 64 i + j, rebuilds
-//            (x_k, y_k) from a popcount, and does the per-cell work of GridMap.applyMeasurement
-//            (GridMap.java:215-223) in parallel.
+//            operations of the reference, in order) and publishes the decisions as bit words in LDS,
+//            with the running count of y steps per word, every 32 steps.
+//   phase B  a wavefront per 64-step block: lane j owns step k = 64 i + j, rebuilds (x_k, y_k) from a
+//            popcount, and does the per-cell work of GridMap.applyMeasurement (GridMap.java:215-223)
+//            in parallel -- while phase A is still walking the rest of the ray.
 // (Tried and measured slower at C3: gathering the decisions by wave ballot and packing them on the scalar
 // unit -- 3 VALU per step instead of 5, but the scalar packing does not overlap the recurrence: 19.3-20.6 us
 // against 18.1 us for the per-lane words below.)
@@ -51,49 +51,97 @@ struct RayMeta {
     float sx, sy, measured;
 };
 
-// phase A for one ray: meta + decision words (word w of ray slot `slot` at words[w * stride + slot])
-__device__ __forceinline__ RayMeta ray_phase_a(const GridDev &g, const RayIn &ray, uint32_t *__restrict__ words,
-                                               uint32_t *__restrict__ ybase, int32_t stride, int32_t slot) {
+// Decision words travel from the phase-A wavefront to the phase-B wavefronts through LDS slots of 8 bytes,
+// (RC_VALID | number of y steps before the word) << 32 | decision word: one ds_write_b64, so a reader sees a slot either
+// empty (cleared at kernel start) or complete.  Slot of word w of ray `slot`: slots[w * stride + slot].
+#define RC_VALID 0x80000000u
+
+// The slots are written and polled with explicit DS instructions: through a generic pointer the compiler emits flat
+// accesses, and marking them volatile adds a full wait after every one (the producer would stall on each publish).
+// LDS executes a wavefront's DS instructions in order, a 64-bit access is a single one, and the "memory" clobber
+// keeps the compiler from caching or reordering around them.
+typedef __attribute__((address_space(3))) uint64_t gms_lds_u64;
+__device__ __forceinline__ uint32_t lds_offset(const uint64_t *p) { return (uint32_t)(uintptr_t)(const gms_lds_u64 *)p; }
+__device__ __forceinline__ void lds_publish_u64(uint64_t *p, uint64_t v) {
+    asm volatile("ds_write_b64 %0, %1" : : "v"(lds_offset(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_poll_2xu64(const uint64_t *p0, const uint64_t *p1, uint64_t &a, uint64_t &c) {
+    asm volatile("ds_read_b64 %0, %2\n\t"
+                 "ds_read_b64 %1, %3\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(c) : "v"(lds_offset(p0)), "v"(lds_offset(p1)) : "memory");
+}
+
+// ray_init + the parts of the walk that do not depend on the recurrence
+__device__ __forceinline__ RayMeta ray_meta(const GridDev &g, const RayIn &ray, RayDev &r) {
     RayMeta mt;
-    RayDev r;
     ray_init(r, ray.sx + 0.5f, ray.sy + 0.5f, ray.ex + 0.5f, ray.ey + 0.5f, g.extra);   // GridMap.java:210
     mt.x0 = r.x; mt.y0 = r.y; mt.x_inc = r.x_inc; mt.y_inc = r.y_inc;
     mt.sx = ray.sx; mt.sy = ray.sy; mt.measured = ray.measured; mt.hit = ray.hit;
     const bool inb0 = !(r.x < 0 || r.x >= g.W || r.y < 0 || r.y >= g.H);
     mt.n_eff = (inb0 && r.n > 0) ? min(r.n, g.W + g.H + 1) : 0;
-    float err = r.error;
-    const float ndx = -r.dx, dy = r.dy;
-    const int32_t nwords = (mt.n_eff + 31) >> 5;
-    uint32_t ycount = 0;
-    for (int32_t w = 0; w < nwords; ++w) {
-        uint32_t word = 0;
-#pragma unroll
-        for (int32_t j = 0; j < 32; ++j) {
-            const bool c = err > 0.0f;                 // RayIterator.java:117
-            word |= (c ? 1u : 0u) << j;
-            err = err + (c ? ndx : dy);                // :119 / :122 (a - b == a + (-b) exactly)
-        }
-        words[w * stride + slot] = word;
-        ybase[w * stride + slot] = ycount;
-        ycount += __popc(word);
-    }
     return mt;
 }
 
-// phase B for one ray, executed by one wavefront; returns the number of cells visited (lane 0's count)
+// phase A for one ray: the float `error` recurrence, 32 decisions per published slot
+__device__ __forceinline__ void ray_phase_a(const RayDev &r, int32_t n_eff, uint64_t *__restrict__ slots, int32_t stride, int32_t slot) {
+    float err = r.error;
+    float ndx = -r.dx, dy = r.dy;
+    // Plain registers (no |x| / -x source modifiers folded in): v_cndmask then keeps its e32 form with the implicit vcc,
+    // which needs no wait states after v_cmp (the e64 form the compiler picked cost an s_nop 1 per step).
+    asm volatile("" : "+v"(ndx), "+v"(dy));
+    const int32_t nwords = (n_eff + 31) >> 5;
+    uint32_t ycount = 0;
+    for (int32_t w = 0; w < nwords; ++w) {
+        uint32_t word = 0;
+        float t;
+#pragma unroll
+        for (int32_t j = 0; j < 32; ++j) {
+            // one step of RayIterator.next (RayIterator.java:117-123) in four VALU instructions, the wavefront's issue
+            // rate being the limit (one lane per ray, one phase-A wavefront per SIMD):
+            //   vcc  = 0 < err                       c = error > 0                               (:117)
+            //   t    = vcc ? -dx : dy
+            //   err  = err + t                       error -= dx  /  error += dy                 (:119 / :122; a - b == a + (-b))
+            //   word = word + word + vcc             shift the decision in (bit 31 - j after 32 steps)
+            asm volatile("v_cmp_lt_f32_e32 vcc, 0, %0\n\t"
+                         "v_cndmask_b32_e32 %2, %3, %4, vcc\n\t"
+                         "v_add_f32_e32 %0, %0, %2\n\t"
+                         "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+                         : "+v"(err), "+v"(word), "=&v"(t)
+                         : "v"(dy), "v"(ndx)
+                         : "vcc");
+        }
+        word = __brev(word);                           // decision j at bit j
+        lds_publish_u64(&slots[w * stride + slot], ((uint64_t)(RC_VALID | ycount) << 32) | (uint64_t)word);
+        ycount += __popc(word);
+    }
+}
+
+// phase B for 64 consecutive steps [64 blk, 64 blk + 64) of one ray, executed by one wavefront: lane j owns step
+// k = 64 blk + j, rebuilds (x_k, y_k) from a popcount, and does the per-cell work of GridMap.applyMeasurement
+// (GridMap.java:215-223).  Waits (LDS polling) until phase A has published the two words it needs.  Returns the
+// number of cells of the block that are inside the map.
 template <bool TRACE>
-__device__ __forceinline__ int32_t ray_phase_b(const GridDev &g, const RayMeta &mt, const uint32_t *__restrict__ words,
-                                               const uint32_t *__restrict__ ybase, int32_t stride, int32_t slot, int32_t lane,
-                                               uint32_t *__restrict__ mcnt, int32_t bb[4], int32_t b, int32_t *__restrict__ t_cells,
-                                               uint8_t *__restrict__ t_cls, int32_t cap) {
-    int32_t count = 0;
-    for (int32_t k = lane; k < mt.n_eff; k += 64) {
-        const int32_t w = k >> 5, j = k & 31;
-        const uint32_t word = words[w * stride + slot];
-        const int32_t ny = (int32_t)(ybase[w * stride + slot] + __popc(word & ((1u << j) - 1u)));
+__device__ __forceinline__ int32_t ray_phase_b(const GridDev &g, const RayMeta &mt, const uint64_t *__restrict__ slots, int32_t stride,
+                                               int32_t slot, int32_t blk, int32_t lane, uint32_t *__restrict__ mcnt, int32_t bb[4],
+                                               int32_t b, int32_t *__restrict__ t_cells, uint8_t *__restrict__ t_cls, int32_t cap) {
+    const int32_t nwords = (mt.n_eff + 31) >> 5;
+    const int32_t w0 = 2 * blk, w1 = min(2 * blk + 1, nwords - 1);
+    uint64_t a, c;
+    for (;;) {                                         // wave-uniform: every lane reads the same two slots
+        lds_poll_2xu64(&slots[w0 * stride + slot], &slots[w1 * stride + slot], a, c);
+        if (((a & c) >> 63) != 0u) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    const int32_t k = blk * 64 + lane;
+    bool valid = false;
+    if (k < mt.n_eff) {
+        const uint64_t sl = lane < 32 ? a : c;
+        const int32_t j = lane & 31;
+        const int32_t ny = (int32_t)(((uint32_t)(sl >> 32) & ~RC_VALID) + __popc((uint32_t)sl & ((1u << j) - 1u)));
         const int32_t nx = k - ny;
         const int32_t cx = mt.x0 + mt.x_inc * nx, cy = mt.y0 + mt.y_inc * ny;
-        const bool valid = !(cx < 0 || cx >= g.W || cy < 0 || cy >= g.H);                 // :108
+        valid = !(cx < 0 || cx >= g.W || cy < 0 || cy >= g.H);                            // RayIterator.java:108
         if (valid) {
             const float d = cell_distance(mt.sx, mt.sy, cx, cy);                          // GridMap.java:215-217
             const int32_t cls = sensor_class(d, mt.measured, mt.hit, g.half_tol);         // :223
@@ -109,9 +157,8 @@ __device__ __forceinline__ int32_t ray_phase_b(const GridDev &g, const RayMeta &
                 bb[2] = max(bb[2], cx + 1);       bb[3] = max(bb[3], cy + 1);
             }
         }
-        count += __popcll(__ballot(valid));
     }
-    return count;
+    return __popcll(__ballot(valid));
 }
 
 // workgroup-level max of the encoded box in LDS, then at most four global atomics per workgroup, and only
@@ -132,7 +179,11 @@ __device__ __forceinline__ void bbox_commit(int32_t bb[4], int32_t lane, int32_t
     }
 }
 
-// fused form: one workgroup = RC_RAYS rays, phase A by wave 0, phase B by one wavefront per ray, words in LDS
+// One workgroup = RC_RAYS rays, RC_RAYS wavefronts.  Wavefront 0 is the producer: lane r runs phase A of ray r and
+// publishes a slot every 32 steps.  The other RC_RAYS - 1 wavefronts are consumers: they take the 64-step blocks of
+// all rays round-robin (block-major, the order in which the producer publishes them) and run phase B as soon as a
+// block's words are there, so the cell work -- distance, sensor class, count atomics -- hides under the recurrence
+// instead of following it (measured at C3: 17.4 -> see DESIGN.md).  The producer never waits for a consumer.
 // (bx, by) = workgroup / map index and `smem` = the dynamic LDS: the body is shared by k_raycast and by the
 // launch that runs the ray cast beside the weight normalisation (gms_fused_kernels.hip); pose_lds, when given,
 // replaces poses[] (a pose the workgroup has just folded itself).
@@ -143,13 +194,18 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
              uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox, int32_t *__restrict__ t_cells,
              uint8_t *__restrict__ t_cls, int32_t cap, int32_t *__restrict__ t_counts, int32_t nw_max,
              uint32_t bx, uint32_t by, unsigned char *smem, const float *pose_lds) {
-    uint32_t *s_words = reinterpret_cast<uint32_t *>(smem);            // [nw_max][RC_RAYS]
-    uint32_t *s_ybase = s_words + (size_t)nw_max * RC_RAYS;            // [nw_max][RC_RAYS]
+    uint64_t *s_slots = reinterpret_cast<uint64_t *>(smem);            // [nw_max][RC_RAYS]
     __shared__ RayMeta s_meta[RC_RAYS];
     __shared__ int32_t s_bb[4];
+    __shared__ int32_t s_count[RC_RAYS];
 
     const int32_t mi = (int32_t)by;
-    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t lane = threadIdx.x & 63;
+    const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int32_t i = threadIdx.x; i < nw_max * RC_RAYS; i += RC_RAYS * 64) s_slots[i] = 0ull;
+    RayDev r;
+    r.dx = r.dy = r.error = 0.0f; r.x = r.y = r.x_inc = r.y_inc = r.n = 0;
+    int32_t my_n_eff = 0;
     if (wave == 0 && lane < RC_RAYS) {
         const int32_t b = (int32_t)bx * RC_RAYS + lane;
         RayMeta mt;
@@ -158,21 +214,34 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
             RayIn ray;
             if (single) ray = *single;
             else ray = make_ray(g, beams[(size_t)mi * beam_stride + b], pose_lds ? pose_lds : poses + (size_t)pose_stride * mi);
-            mt = ray_phase_a(g, ray, s_words, s_ybase, RC_RAYS, lane);
+            mt = ray_meta(g, ray, r);
         }
+        my_n_eff = mt.n_eff;
         s_meta[lane] = mt;
+        s_count[lane] = 0;
     }
     __syncthreads();
-#ifdef GMS_EXP_NO_PHASE_B
-    if (s_meta[0].n_eff >= 0) return;
-#endif
-    const int32_t b = (int32_t)bx * RC_RAYS + wave;
-    const RayMeta mt = s_meta[wave];
     int32_t bb[4] = { 0, 0, 0, 0 };
-    const int32_t count = ray_phase_b<TRACE>(g, mt, s_words, s_ybase, RC_RAYS, wave, lane,
-                                             TRACE ? nullptr : cnt + (size_t)mi * g.cells, bb, b, t_cells, t_cls, cap);
+    if (wave == 0) {
+        if (lane < RC_RAYS) ray_phase_a(r, my_n_eff, s_slots, RC_RAYS, lane);
+    } else {
+        int32_t nblk_max = 0;
+#pragma unroll
+        for (int q = 0; q < RC_RAYS; q++) nblk_max = max(nblk_max, (s_meta[q].n_eff + 63) >> 6);
+        constexpr int32_t NC = RC_RAYS - 1;
+        for (int32_t q = wave - 1; q < nblk_max * RC_RAYS; q += NC) {
+            const int32_t blk = q / RC_RAYS, ray = q - blk * RC_RAYS;
+            const RayMeta mt = s_meta[ray];
+            if (blk * 64 >= mt.n_eff) continue;
+            const int32_t n = ray_phase_b<TRACE>(g, mt, s_slots, RC_RAYS, ray, blk, lane, TRACE ? nullptr : cnt + (size_t)mi * g.cells, bb,
+                                                 (int32_t)bx * RC_RAYS + ray, t_cells, t_cls, cap);
+            if (TRACE && lane == 0) atomicAdd(&s_count[ray], n);
+        }
+    }
     if (TRACE) {
-        if (lane == 0 && b < B && t_counts) t_counts[b] = count;
+        __syncthreads();
+        const int32_t b = (int32_t)bx * RC_RAYS + (int32_t)threadIdx.x;
+        if (threadIdx.x < RC_RAYS && b < B && t_counts) t_counts[b] = s_count[threadIdx.x];
     } else {
         bbox_commit(bb, lane, bbox + 4 * mi, s_bb);
     }
@@ -582,7 +651,7 @@ __global__ void k_debug_f32(int32_t op, const float *__restrict__ a, float *__re
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline int32_t rc_nw_max(const gms_map *m) { return (m->gd.W + m->gd.H + 1 + 31) / 32; }
-static inline size_t rc_smem(const gms_map *m, int rays) { return (size_t)rc_nw_max(m) * rays * 2 * sizeof(uint32_t); }
+static inline size_t rc_smem(const gms_map *m, int rays) { return (size_t)rc_nw_max(m) * rays * sizeof(uint64_t); }
 
 template <bool TRACE, int RAYS>
 static void rc_launch(gms_map *m, dim3 grid, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,

@@ -570,6 +570,37 @@ __device__ __forceinline__ double fold_sum(const double *__restrict__ p, int64_t
     return group_sum(acc, lds);
 }
 
+// NC columns at once: the loads of all columns are in flight together and the reductions share ONE barrier pair
+// (a fold_sum per column is a dependent memory round trip + two barriers each: 2-3 us of pure latency for the four
+// columns the ray-cast workgroups need).  Per column the arithmetic is fold_sum's, operation for operation: the
+// per-thread strided sum, the wave butterfly, ((w0 + w1) + w2) + w3 over the group's waves -- same bits.
+template <int NC>
+__device__ __forceinline__ void fold_sums(const double *__restrict__ p, int64_t nblk, const int (&col)[NC], double (&out)[NC],
+                                          RedLds &L) {
+    static_assert(NC <= GMS_PARTIAL_STRIDE, "RedLds::m has GMS_PARTIAL_STRIDE rows");
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] = 0.0;
+    for (int64_t b = threadIdx.x & (GRP - 1); b < nblk; b += GRP) {
+        double v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) v[c] = p[b * GMS_PARTIAL_STRIDE + col[c]];
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc[c] += v[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] = wave_sum_f64(acc[c]);
+    const int32_t wave = threadIdx.x >> 6, g4 = (wave >> 2) << 2;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) L.m[c][wave] = acc[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; c++) out[c] = ((L.m[c][g4] + L.m[c][g4 + 1]) + L.m[c][g4 + 2]) + L.m[c][g4 + 3];
+}
+
 __device__ __forceinline__ void fold_argmax(const double *__restrict__ p, int64_t nblk, int colv, int coli, double &mv,
                                             double &mx, RedLds &L) {
     mv = -INFINITY; mx = 9.0e15;
@@ -585,10 +616,11 @@ __device__ __forceinline__ void fold_argmax(const double *__restrict__ p, int64_
 __device__ __forceinline__ double fold_stats(const double *__restrict__ p, int64_t nblk, PfStatsDev *s, bool write,
                                              const float *__restrict__ pose, int64_t pose_base, int64_t pose_n, RedLds &L,
                                              const PackedParticle *__restrict__ glob = nullptr) {
-    const double sum = fold_sum(p, nblk, COL_SUM, L.a);
-    if (!write) return sum;
-    const double nz = fold_sum(p, nblk, COL_NZ, L.a);
-    const double xw = fold_sum(p, nblk, COL_XW, L.a), yw = fold_sum(p, nblk, COL_YW, L.a), tw = fold_sum(p, nblk, COL_TW, L.a);
+    if (!write) return fold_sum(p, nblk, COL_SUM, L.a);
+    const int cols[5] = { COL_SUM, COL_NZ, COL_XW, COL_YW, COL_TW };
+    double f[5];
+    fold_sums<5>(p, nblk, cols, f, L);
+    const double sum = f[0], nz = f[1], xw = f[2], yw = f[3], tw = f[4];
     double mv, mx, ml, mli;
     fold_argmax(p, nblk, COL_MAX, COL_ARG, mv, mx, L);
     fold_argmax(p, nblk, COL_MLW, -1, ml, mli, L);
