@@ -306,6 +306,12 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     m->score_variant = 2;
     if (const char *v = getenv("GMS_SCORE_VARIANT")) m->score_variant = atoi(v);
     m->pair_launches = 1;
+    {   // the tiled batched ray cast: 8 KiB of slots + a 64 KiB tile + static LDS
+        int lds_max = 0;
+        if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, m->device) != hipSuccess) lds_max = 64 * 1024;
+        m->raycast_tile = lds_max >= 80 * 1024;
+        if (const char *v = getenv("GMS_RAYCAST_TILE")) m->raycast_tile = m->raycast_tile && atoi(v) != 0;
+    }
     m->prof_stride = 1;
     if (const char *v = getenv("GMS_PAIR_LAUNCHES")) m->pair_launches = atoi(v) != 0;
     if (const char *v = getenv("GMS_SCORE_SEGMENTS")) m->score_segments = atoi(v);

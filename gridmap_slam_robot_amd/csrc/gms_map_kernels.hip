@@ -61,6 +61,7 @@ struct RayMeta {
 // LDS executes a wavefront's DS instructions in order, a 64-bit access is a single one, and the "memory" clobber
 // keeps the compiler from caching or reordering around them.
 typedef __attribute__((address_space(3))) uint64_t gms_lds_u64;
+typedef __attribute__((address_space(3))) uint32_t gms_lds_u32;
 __device__ __forceinline__ uint32_t lds_offset(const uint64_t *p) { return (uint32_t)(uintptr_t)(const gms_lds_u64 *)p; }
 __device__ __forceinline__ void lds_publish_u64(uint64_t *p, uint64_t v) {
     asm volatile("ds_write_b64 %0, %1" : : "v"(lds_offset(p)), "v"(v) : "memory");
@@ -83,16 +84,25 @@ __device__ __forceinline__ RayMeta ray_meta(const GridDev &g, const RayIn &ray, 
     return mt;
 }
 
-// phase A for one ray: the float `error` recurrence, 32 decisions per published slot
-__device__ __forceinline__ void ray_phase_a(const RayDev &r, int32_t n_eff, uint64_t *__restrict__ slots, int32_t stride, int32_t slot) {
-    float err = r.error;
-    float ndx = -r.dx, dy = r.dy;
+// phase A for one ray: the float `error` recurrence, 32 decisions per published slot.  Resumable: words [w0, w1) are
+// produced (slot index w - w0), `err` and `ycount` carry the state from one call to the next.
+struct RayWalk {
+    float err, ndx, dy;
+    uint32_t ycount;
+};
+__device__ __forceinline__ RayWalk ray_walk_begin(const RayDev &r) {
+    RayWalk k;
+    k.err = r.error; k.ndx = -r.dx; k.dy = r.dy; k.ycount = 0;
     // Plain registers (no |x| / -x source modifiers folded in): v_cndmask then keeps its e32 form with the implicit vcc,
     // which needs no wait states after v_cmp (the e64 form the compiler picked cost an s_nop 1 per step).
-    asm volatile("" : "+v"(ndx), "+v"(dy));
-    const int32_t nwords = (n_eff + 31) >> 5;
-    uint32_t ycount = 0;
-    for (int32_t w = 0; w < nwords; ++w) {
+    asm volatile("" : "+v"(k.ndx), "+v"(k.dy));
+    return k;
+}
+__device__ __forceinline__ void ray_phase_a(RayWalk &k, int32_t w0, int32_t w1, uint64_t *__restrict__ slots, int32_t stride, int32_t slot) {
+    float err = k.err;
+    const float ndx = k.ndx, dy = k.dy;
+    uint32_t ycount = k.ycount;
+    for (int32_t w = w0; w < w1; ++w) {
         uint32_t word = 0;
         float t;
 #pragma unroll
@@ -112,21 +122,28 @@ __device__ __forceinline__ void ray_phase_a(const RayDev &r, int32_t n_eff, uint
                          : "vcc");
         }
         word = __brev(word);                           // decision j at bit j
-        lds_publish_u64(&slots[w * stride + slot], ((uint64_t)(RC_VALID | ycount) << 32) | (uint64_t)word);
+        lds_publish_u64(&slots[(w - w0) * stride + slot], ((uint64_t)(RC_VALID | ycount) << 32) | (uint64_t)word);
         ycount += __popc(word);
     }
+    k.err = err; k.ycount = ycount;
 }
 
 // phase B for 64 consecutive steps [64 blk, 64 blk + 64) of one ray, executed by one wavefront: lane j owns step
 // k = 64 blk + j, rebuilds (x_k, y_k) from a popcount, and does the per-cell work of GridMap.applyMeasurement
 // (GridMap.java:215-223).  Waits (LDS polling) until phase A has published the two words it needs.  Returns the
 // number of cells of the block that are inside the map.
+struct CountTile {         // per-workgroup accumulation tile in LDS (batched maps): cells [x0, x0 + w) x [y0, y0 + h); w == 0: none.
+    uint32_t *cells;       // a cell is 16 bits, n_free | n_occ << 8 (at most 64 rays x (1 + extra) visits per workgroup), two per word
+    int32_t x0, y0, w, h;
+};
+
 template <bool TRACE>
 __device__ __forceinline__ int32_t ray_phase_b(const GridDev &g, const RayMeta &mt, const uint64_t *__restrict__ slots, int32_t stride,
                                                int32_t slot, int32_t blk, int32_t lane, uint32_t *__restrict__ mcnt, int32_t bb[4],
-                                               int32_t b, int32_t *__restrict__ t_cells, uint8_t *__restrict__ t_cls, int32_t cap) {
+                                               int32_t b, int32_t *__restrict__ t_cells, uint8_t *__restrict__ t_cls, int32_t cap,
+                                               const CountTile tile = CountTile{nullptr, 0, 0, 0, 0}, int32_t w_base = 0) {
     const int32_t nwords = (mt.n_eff + 31) >> 5;
-    const int32_t w0 = 2 * blk, w1 = min(2 * blk + 1, nwords - 1);
+    const int32_t w0 = 2 * blk - w_base, w1 = min(2 * blk + 1, nwords - 1) - w_base;
     uint64_t a, c;
     for (;;) {                                         // wave-uniform: every lane reads the same two slots
         lds_poll_2xu64(&slots[w0 * stride + slot], &slots[w1 * stride + slot], a, c);
@@ -152,9 +169,17 @@ __device__ __forceinline__ int32_t ray_phase_b(const GridDev &g, const RayMeta &
                     if (t_cls) t_cls[o] = (uint8_t)cls;
                 }
             } else if (cls != 1) {
-                atomicAdd(&mcnt[(size_t)cy * g.W + cx], cls == 0 ? 1u : 0x10000u);
-                bb[0] = max(bb[0], g.W - 1 - cx); bb[1] = max(bb[1], g.H - 1 - cy);
-                bb[2] = max(bb[2], cx + 1);       bb[3] = max(bb[3], cy + 1);
+                const uint32_t inc = cls == 0 ? 1u : 0x10000u;
+                const uint32_t ux = (uint32_t)(cx - tile.x0), uy = (uint32_t)(cy - tile.y0);
+                if (ux < (uint32_t)tile.w && uy < (uint32_t)tile.h) {                         // (w == 0: no tile)
+                    const uint32_t ci = uy * (uint32_t)tile.w + ux;                           // LDS; flushed row by row afterwards
+                    __hip_atomic_fetch_add((gms_lds_u32 *)(tile.cells) + (ci >> 1), (cls == 0 ? 1u : 0x100u) << ((ci & 1u) << 4),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    atomicAdd(&mcnt[(size_t)cy * g.W + cx], inc);
+                    bb[0] = max(bb[0], g.W - 1 - cx); bb[1] = max(bb[1], g.H - 1 - cy);
+                    bb[2] = max(bb[2], cx + 1);       bb[3] = max(bb[3], cy + 1);
+                }
             }
         }
     }
@@ -223,7 +248,10 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
     __syncthreads();
     int32_t bb[4] = { 0, 0, 0, 0 };
     if (wave == 0) {
-        if (lane < RC_RAYS) ray_phase_a(r, my_n_eff, s_slots, RC_RAYS, lane);
+        if (lane < RC_RAYS) {
+            RayWalk wk = ray_walk_begin(r);
+            ray_phase_a(wk, 0, (my_n_eff + 31) >> 5, s_slots, RC_RAYS, lane);
+        }
     } else {
         int32_t nblk_max = 0;
 #pragma unroll
@@ -256,6 +284,118 @@ k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam
     extern __shared__ __align__(16) unsigned char smem[];
     raycast_body<TRACE, RC_RAYS>(g, beams, B, beam_stride, poses, pose_stride, single, cnt, bbox, t_cells, t_cls, cap, t_counts,
                                  nw_max, blockIdx.x, blockIdx.y, smem, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched maps (config 5: tens of thousands of rays per launch): the scattered u32 atomics on the count grid are the
+// floor of k_raycast there -- device-scope atomics execute at the memory side, and a wave-instruction whose 64 lanes
+// land in 64 different 64-byte segments runs ~17x below the rate of 256 contiguous bytes (MI355X_MICROARCH.md).
+// Here a workgroup takes 64 CONSECUTIVE beams of one map (a wedge of the scan: all rays leave the same cell), keeps
+// the counts of the wedge's bounding box in an LDS tile (ds_add_u32), and flushes the tile row by row afterwards:
+// one global atomic per touched cell and workgroup instead of one per visit, consecutive lanes on consecutive cells.
+// Same counts in d_cnt as k_raycast (integer adds commute); a wedge whose box does not fit the tile, or a cell
+// outside it, falls back to the direct atomics.
+// ---------------------------------------------------------------------------------------------
+#define RCT_RAYS 64
+#define RCT_THREADS 512
+#define RCT_WORDS 16                    // decision words per ray and round (512 steps); longer walks take more rounds
+#define RCT_TILE_CELLS 32768            // 64 KiB of 16-bit cells
+#define RCT_LDS_BYTES (RCT_WORDS * RCT_RAYS * 8 + RCT_TILE_CELLS * 2)
+
+__global__ void __launch_bounds__(RCT_THREADS)
+k_raycast_tile(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride, const float *__restrict__ poses,
+               int32_t pose_stride, uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *s_slots = reinterpret_cast<uint64_t *>(smem);            // [RCT_WORDS][RCT_RAYS]
+    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_slots + RCT_WORDS * RCT_RAYS);         // [RCT_TILE_CELLS / 2]
+    __shared__ RayMeta s_meta[RCT_RAYS];
+    __shared__ int32_t s_bb[4];
+    __shared__ int32_t s_box[5];                                        // wedge box x0, y0, x1, y1 (inclusive); longest walk in words
+
+    const int32_t mi = blockIdx.y;
+    const int32_t lane = threadIdx.x & 63;
+    const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    RayDev r;
+    r.dx = r.dy = r.error = 0.0f; r.x = r.y = r.x_inc = r.y_inc = r.n = 0;
+    int32_t my_nwords = 0;
+    if (wave == 0) {
+        const int32_t b = (int32_t)blockIdx.x * RCT_RAYS + lane;
+        RayMeta mt;
+        mt.n_eff = 0; mt.x0 = mt.y0 = mt.x_inc = mt.y_inc = mt.hit = 0; mt.sx = mt.sy = mt.measured = 0.0f;
+        int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
+        if (b < B) {
+            const RayIn ray = make_ray(g, beams[(size_t)mi * beam_stride + b], poses + (size_t)pose_stride * mi);
+            mt = ray_meta(g, ray, r);
+            if (mt.n_eff > 0) {
+                // The walk is monotonic in x and in y and ends n - 1 steps from the start cell; the end point's cell plus
+                // the additional steps (RayIterator.java:75,83,96; one more for a near-tie decided by float rounding)
+                // bounds it tighter.  A cell outside the box would take the direct-atomic path: the box is a hint.
+                const int32_t xe = mt.x0 + mt.x_inc * (mt.n_eff - 1), ye = mt.y0 + mt.y_inc * (mt.n_eff - 1);
+                const int32_t xt = (int32_t)floorf(ray.ex + 0.5f), yt = (int32_t)floorf(ray.ey + 0.5f);
+                const int32_t ex = mt.x_inc > 0 ? min(xe, xt + g.extra + 1) : (mt.x_inc < 0 ? max(xe, xt - g.extra - 1) : mt.x0);
+                const int32_t ey = mt.y_inc > 0 ? min(ye, yt + g.extra + 1) : (mt.y_inc < 0 ? max(ye, yt - g.extra - 1) : mt.y0);
+                bx0 = max(min(mt.x0, ex), 0); bx1 = min(max(mt.x0, ex), g.W - 1);
+                by0 = max(min(mt.y0, ey), 0); by1 = min(max(mt.y0, ey), g.H - 1);
+            }
+        }
+        my_nwords = (mt.n_eff + 31) >> 5;
+        s_meta[lane] = mt;
+        int32_t nwm = my_nwords;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            bx0 = min(bx0, __shfl_xor(bx0, o, GMS_WAVE)); by0 = min(by0, __shfl_xor(by0, o, GMS_WAVE));
+            bx1 = max(bx1, __shfl_xor(bx1, o, GMS_WAVE)); by1 = max(by1, __shfl_xor(by1, o, GMS_WAVE));
+            nwm = max(nwm, __shfl_xor(nwm, o, GMS_WAVE));
+        }
+        if (lane == 0) { s_box[0] = bx0; s_box[1] = by0; s_box[2] = bx1; s_box[3] = by1; s_box[4] = nwm; }
+    }
+    __syncthreads();
+    CountTile tile;
+    tile.cells = s_tile; tile.x0 = s_box[0]; tile.y0 = s_box[1];
+    tile.w = s_box[2] >= s_box[0] ? s_box[2] - s_box[0] + 1 : 0;
+    tile.h = s_box[3] >= s_box[1] ? s_box[3] - s_box[1] + 1 : 0;
+    // 8 bits per count: RCT_RAYS * (1 + extra) visits of one cell at most
+    if ((int64_t)tile.w * tile.h > RCT_TILE_CELLS || RCT_RAYS * (1 + g.extra) > 255) tile.w = tile.h = 0;     // direct atomics
+    const int32_t tcells = tile.w * tile.h;
+    const int32_t nwords_max = s_box[4];
+    for (int32_t i = threadIdx.x; i < (tcells + 1) / 2; i += RCT_THREADS) s_tile[i] = 0u;
+    int32_t bb[4] = { 0, 0, 0, 0 };
+    RayWalk wk = ray_walk_begin(r);
+    for (int32_t wb = 0; wb < nwords_max; wb += RCT_WORDS) {           // one round = up to 512 steps of every ray
+        for (int32_t i = threadIdx.x; i < RCT_WORDS * RCT_RAYS; i += RCT_THREADS) s_slots[i] = 0ull;
+        __syncthreads();                                                // (also: the tile is cleared, the previous round consumed)
+        if (wave == 0) {
+            if (wb < my_nwords) ray_phase_a(wk, wb, min(my_nwords, wb + RCT_WORDS), s_slots, RCT_RAYS, lane);
+        } else {
+            constexpr int32_t NC = RCT_THREADS / 64 - 1;
+            const int32_t blk0 = wb >> 1, nblk = min(RCT_WORDS / 2, (nwords_max - wb + 1) >> 1);
+            for (int32_t q = wave - 1; q < nblk * RCT_RAYS; q += NC) {
+                const int32_t blk = blk0 + q / RCT_RAYS, ray = q % RCT_RAYS;
+                const RayMeta mt = s_meta[ray];
+                if (blk * 64 >= mt.n_eff) continue;
+                ray_phase_b<false>(g, mt, s_slots, RCT_RAYS, ray, blk, lane, cnt + (size_t)mi * g.cells, bb, 0, nullptr, nullptr, 0,
+                                   tile, wb);
+            }
+        }
+        __syncthreads();
+    }
+    if (nwords_max == 0) __syncthreads();
+    // flush: one atomic per touched cell, lanes on consecutive cells of a row
+    uint32_t *mcnt = cnt + (size_t)mi * g.cells;
+    for (int32_t ry = wave; ry < tile.h; ry += RCT_THREADS / 64) {     // a wavefront per tile row: no division per cell
+        const int32_t cy = tile.y0 + ry, rbase = ry * tile.w;
+        for (int32_t rx = lane; rx < tile.w; rx += 64) {
+            const int32_t i = rbase + rx;
+            const uint32_t v = (s_tile[i >> 1] >> ((i & 1) << 4)) & 0xffffu;
+            if (v) {
+                const int32_t cx = tile.x0 + rx;
+                atomicAdd(&mcnt[(size_t)cy * g.W + cx], (v & 0xffu) | ((v >> 8) << 16));
+                bb[0] = max(bb[0], g.W - 1 - cx); bb[1] = max(bb[1], g.H - 1 - cy);
+                bb[2] = max(bb[2], cx + 1);       bb[3] = max(bb[3], cy + 1);
+            }
+        }
+    }
+    bbox_commit(bb, lane, bbox + 4 * mi, s_bb);
 }
 
 // plain RayIterator walk (gms_map_trace_ray)
@@ -670,7 +810,13 @@ void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t 
     gms_flush_apply(m);
     ProfScope ps(m, GMS_K_RAYCAST);
     int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;
-    if ((int64_t)B * m->n_maps > 4096)       // batched maps: throughput-bound, 16 lanes of the phase-A wavefront busy
+    if ((int64_t)B * m->n_maps > 4096 && m->raycast_tile) {
+        // batched maps: throughput-bound; 64 consecutive beams per workgroup, counts accumulated in an LDS tile
+        const size_t smem = RCT_LDS_BYTES;
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast_tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k_raycast_tile, dim3((B + RCT_RAYS - 1) / RCT_RAYS, m->n_maps), dim3(RCT_THREADS), smem, m->stream, m->gd,
+                           d_beams, B, beam_stride, d_poses, pose_stride, m->d_cnt, bb);
+    } else if ((int64_t)B * m->n_maps > 4096)       // (GMS_RAYCAST_TILE=0, or not enough LDS: 16 rays per workgroup, direct atomics)
         rc_launch<false, 16>(m, dim3((B + 15) / 16, m->n_maps), d_beams, B, beam_stride, d_poses, pose_stride, nullptr, m->d_cnt, bb,
                              nullptr, nullptr, 0, nullptr);
     else
