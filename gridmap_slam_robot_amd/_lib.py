@@ -155,6 +155,7 @@ def load() -> C.CDLL:
     sig("gms_pf_did_resample", C.c_int, vp, vp)
     sig("gms_pf_refine_poses", C.c_int, vp, vp, i32)
     sig("gms_pf_last_step", C.c_int, vp, vp, vp, vp, vp)
+    sig("gms_pf_set_refine", C.c_int, vp, i32)
     sig("gms_pf_sample_motion", C.c_int, vp, f64, f64, C.c_uint64, C.c_uint64)
     sig("gms_pf_partials_len", C.c_int, vp, vp)
     sig("gms_pf_local_partials", C.c_int, vp, vp)

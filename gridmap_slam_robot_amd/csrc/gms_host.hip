@@ -861,12 +861,18 @@ int gms_pf_score(gms_pf *pf, const gms_beam *beams, int32_t B) {       // GridMa
     return GMS_OK;
 }
 
-// poses := dev_xytheta (may be NULL: keep the current ones), then weights: one launch with the default scoring kernel
-static int set_poses_and_score_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B) {
+// poses := dev_xytheta (may be NULL: keep the current ones), then weights: one launch with the default scoring kernel.
+// refine: the poses are replaced by findBestPose's argmax first (SLAM.java:96-97), which takes launches of its own.
+static int set_poses_and_score_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, bool refine = false) {
     REQUIRE(pf && dev_beams, "null argument");
     gms_map *m = pf->map;
     REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
     HIPCHK(hipSetDevice(m->device));
+    if (refine) {
+        if (dev_xytheta) gms_launch_pf_pose_trig(pf, dev_xytheta);                // SLAM.java:90
+        gms_launch_pf_refine(pf, dev_beams, B, B);                                // :96-97
+        dev_xytheta = nullptr;
+    }
     gms_launch_pf_score(pf, dev_beams, B, B, dev_xytheta);
     pf->have_global = 0;
     pf->stats_current = 0;
@@ -1101,7 +1107,7 @@ int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *de
     if (pf->offset != 0 || pf->n_global != pf->n)
         return fail(GMS_ERR_STATE, "sharded filter: the collectives belong to the caller (see distributed.py)");
     int rc = GMS_OK;
-    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B);                 // SLAM.java:90, :99
+    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B, pf->refine != 0);   // SLAM.java:90, :96-97, :99
     if (!rc && integrate && gms_can_pair_launches(pf, B)) {
         // The weight branch and the map branch are independent once the partials exist: they share launches
         // (gms_fused_kernels.hip).  (Two streams were measured: the event fork/join costs more than it hides.)
@@ -1144,6 +1150,7 @@ int gms_slam_update(gms_pf *pf, const float *xytheta, const gms_beam *beams, int
     if (!rc && !stride_ok) {
         // batched handles stage [n_maps][max_beams]; the *_dev entry points expect [n_maps][B]: go through the
         // staging-stride launchers instead
+        if (pf->refine) gms_launch_pf_refine(pf, m->d_beams, B, m->max_beams);
         gms_launch_pf_score(pf, m->d_beams, B, m->max_beams);
         pf->have_global = 0; pf->stats_current = 0;
         rc = gms_pf_normalize(pf, nullptr);
@@ -1176,6 +1183,12 @@ int gms_pf_did_resample(gms_pf *pf, int32_t *flags) {
     int rc = pull_stats(pf);
     if (rc) return rc;
     for (int32_t mi = 0; mi < pf->n_maps; mi++) flags[mi] = pf->h_stats[mi].did_resample;
+    return GMS_OK;
+}
+
+int gms_pf_set_refine(gms_pf *pf, int32_t on) {                          // SLAM.java:96-97
+    REQUIRE(pf, "null filter");
+    pf->refine = on != 0;
     return GMS_OK;
 }
 
@@ -1396,7 +1409,7 @@ int gms_slam_update_sharded_begin_dev(gms_pf *pf, const float *dev_xytheta, cons
     REQUIRE(pf && dev_beams, "null argument");
     int rc = sharded_shape_ok(pf);
     if (rc) return rc;
-    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B);                 // SLAM.java:90, :99
+    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B, pf->refine != 0);   // SLAM.java:90, :96-97, :99
     if (rc) return rc;
     gms_launch_partials_pack_apply(pf);                                          // :100-115 | previous scan's GridMap.java:223
     HIPCHK(hipGetLastError());

@@ -156,6 +156,7 @@ struct gms_pf {
     StageRing r01_ring;             // pinned staging of the per-map resampling draws (n_maps > 1)
     int32_t have_global;            // d_global holds the current normalised population
     int32_t chunks_ready;           // d_cum / d_chunk_tot hold level 0 of the scan of d_global
+    int32_t refine;                 // scan steps run findBestPose on every particle before weighting (gms_pf_set_refine)
     int32_t pending_nseg;           // > 0: d_w is stale, the weights are still d_part's segment products
 };
 

@@ -1053,7 +1053,10 @@ k_refine(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, cons
         double prod = 1.0;
         for (int32_t j = lane; j < nb; j += 64) {
             const double2 bm = sb[j];
-            prod *= fac[beam_cell(g, t, bm.x, bm.y)];
+            bool guard = false;
+            uint32_t cell = beam_cell_fast(g, t, bm.x, bm.y, guard);          // no division in the common case (see j_cell_fast)
+            if (__builtin_expect(guard, 0)) cell = beam_cell(g, t, bm.x, bm.y);
+            prod *= fac[cell];
         }
         int e;
         double mnt = frexp(prod, &e);

@@ -514,6 +514,10 @@ class ParticleFilter:
         """pose[i] = sampleMotionModel(pose[i], u) (SLAM.java:155-163 -> Odometry.apply, Odometry.java:77-96)."""
         check(load().gms_pf_sample_motion(self._h, d_center, d_theta, seed, sequence))
 
+    def set_refine(self, on: bool = True):
+        """scan steps (slam_update*) run findBestPose on every particle before weighting it (SLAM.java:96-97)."""
+        check(load().gms_pf_set_refine(self._h, 1 if on else 0))
+
     def refine_poses(self, obs):
         """pose[i] = findBestPose(map, obs, pose[i]) (GridMap.java:319-346)."""
         b, B = self.map._beam_args(obs)

@@ -228,6 +228,13 @@ int gms_pf_sample_motion(gms_pf *pf, double d_center, double d_theta, uint64_t s
  * (GridMap.java:319-346): poses are replaced by the argmax pose. */
 int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B);
 
+/* SLAM.update refines every particle's pose before weighting it (J/slam/SLAM.java:96-97; the reference calls
+ * findBestPoseOptim there, whose objective is broken -- SURVEY.md section 3.1 -- and keeps the lattice search
+ * findBestPose commented out beside it).  on != 0: gms_slam_update / gms_slam_update_dev / the sharded scan steps run
+ * gms_pf_refine_poses' lattice search (GridMap.java:319-346) on the motion-model samples before scoring them.
+ * Default off (the search is 1210 probabilityOf evaluations per particle). */
+int gms_pf_set_refine(gms_pf *pf, int32_t on);
+
 /* ---- device-resident inputs ---------------------------------------------------------------------
  * The same entry points for callers whose scans / poses already live in HBM (a trace staged once, a
  * torch tensor, the output of a device-side motion model).  dev_beams is [n_maps][B] gms_beam,

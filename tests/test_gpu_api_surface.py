@@ -216,3 +216,31 @@ def test_map_outlives_its_filters():
     pf2.close()
     assert L.gms_map_destroy(m2._h) == _lib.GMS_OK
     m2._h.value = None
+
+
+def test_scan_step_with_pose_refinement_equals_the_separate_calls():
+    """gms_pf_set_refine: SLAM.update refines every pose before weighting it (SLAM.java:96-97) -- the fused step with
+    the flag set == set_poses -> refine_poses (findBestPose, GridMap.java:319-346) -> score -> normalise -> resample ->
+    map update, and the refined poses equal the oracle's lattice argmax."""
+    tr, m, g, log = small_case()
+    twin = GridMap(6.4, 6.4, 0.05, (-3.2, -3.2)); twin.copy_from(m); twin.compute_likelihood_map(); m.compute_likelihood_map()
+    N = 96
+    P = synth.make_particles(tr.poses[5], N, seed=11, sigma_xy=0.06, sigma_theta_deg=4.0)
+    a, b = ParticleFilter(m, N), ParticleFilter(twin, N)
+    a.set_refine(True)
+    lik = m.download_likelihood().reshape(-1)
+    sa = a.slam_update(P, tr.scans[5], 0.4, -1.0, True, fetch=True)          # no resample: the refined poses stay visible
+    b.set_poses(P); b.refine_poses(tr.scans[5]); b.score(tr.scans[5]); sb = b.normalize(); twin.update_at(tr.scans[5], b)
+    assert sa == sb
+    assert np.array_equal(a.get_poses(), b.get_poses()) and np.array_equal(a.get_weights(), b.get_weights())
+    assert np.array_equal(m.download_log(), twin.download_log())
+    got = a.get_poses()
+    moved = 0
+    for i in range(0, N, 7):
+        best, prob, n_eval = g.find_best_pose(lik, tr.scans[5], P[i])
+        assert n_eval == 1210 and np.array_equal(got[i], best)
+        moved += int(not np.array_equal(best, P[i]))
+    assert moved > 0
+    a.set_refine(False)
+    a.slam_update(P, tr.scans[5], 0.4, -1.0, False)
+    assert np.array_equal(a.get_poses(), P)

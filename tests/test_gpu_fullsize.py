@@ -269,3 +269,36 @@ def test_random_shapes_against_the_oracle(seed):
         idx, amb = pf.resample(r01, want_indices=True)
         want, _ = orc.resample_indices(gw, r01)
         assert amb > 0 or np.array_equal(idx, want)
+
+
+def dense_log(W, H, seed=0):
+    """Worst case for the likelihood kernel: every 64 x 32 tile holds all three codes (an 8 x 8 checkerboard of
+    occupied / free cells with unexplored specks), so no tile takes the uniform short cut."""
+    y, x = np.mgrid[0:H, 0:W]
+    log = np.where(((x >> 3) + (y >> 3)) & 1, 2.197224312426715, -0.8472978036208759)
+    rng = np.random.default_rng(seed)
+    log[rng.random((H, W)) < 0.02] = 0.0
+    return log.reshape(-1)
+
+
+def test_likelihood_full_rebuild_on_a_dense_map_equals_the_oracle():
+    """2048^2, all 4096 tiles non-uniform: the kernel's worst case (the synthetic room leaves ~90 % of the tiles uniform).
+    Compared with == against the oracle; then a dirty rebuild after one more scan == a full rebuild."""
+    c = synth.CONFIGS["C3"]
+    ext, res, B = c["extent"], c["resolution"], c["beams"]
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    m = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    log = dense_log(m.W, m.H)
+    m.upload_log(log)
+    m.compute_likelihood_map()
+    want = g.build_likelihood(log)
+    assert np.array_equal(m.download_likelihood().reshape(-1), want)
+    m.compute_likelihood_map()                                     # idempotent (tile states stay "not uniform")
+    assert np.array_equal(m.download_likelihood().reshape(-1), want)
+    tr = synth.make_trace(ext, res, B, T=16, seed=3, n_scans=1)
+    m.update(tr.scans[0], tr.poses[0])                             # dirty rebuild on top of the dense field
+    log2 = log.copy()
+    g.integrate(log2, tr.scans[0], tr.poses[0])
+    got = m.download_log().reshape(-1)
+    assert np.max(np.abs(got - log2)) <= 1e-12
+    assert np.array_equal(m.download_likelihood().reshape(-1), g.build_likelihood(got))

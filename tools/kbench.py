@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--particles", type=int, default=0)
     ap.add_argument("--sigma", type=float, default=0.10)
     ap.add_argument("--beams", type=int, default=0, help="override beams per scan")
+    ap.add_argument("--dense", action="store_true", help="likelihood mode only: replace the map by the dense worst case (every 64x32 tile non-uniform) first")
     ap.add_argument("--sort", default="", help="order the particles on the host first: theta | cluster:<deg>:<m> (locality experiment)")
     args = ap.parse_args()
     import torch
@@ -87,7 +88,13 @@ def main():
     if want("update"):
         run("update(dirty)", lambda: m.update_dev(scans_dev[t].data_ptr(), B, poses_dev[t].data_ptr()))
     if want("likelihood"):
-        run("likelihood(full)", lambda: m.compute_likelihood_map())
+        if args.dense:
+            y, x = np.mgrid[0:m.H, 0:m.W]
+            log = np.where(((x >> 3) + (y >> 3)) & 1, 2.197224312426715, -0.8472978036208759)
+            log[np.random.default_rng(0).random((m.H, m.W)) < 0.02] = 0.0
+            m.upload_log(log)
+            m.compute_likelihood_map()
+        run("likelihood(full, dense map)" if args.dense else "likelihood(full)", lambda: m.compute_likelihood_map())
     print(json.dumps(out))
 
 if __name__ == "__main__":
