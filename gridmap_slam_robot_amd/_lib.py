@@ -171,6 +171,7 @@ def load() -> C.CDLL:
     sig("gms_pf_normalize_sharded_begin", C.c_int, vp, vp)
     sig("gms_pf_normalize_sharded_end", C.c_int, vp, vp)
     sig("gms_slam_update_sharded_dev", C.c_int, vp, vp, vp, vp, i32, vp, f64, i32)
+    sig("gms_slam_update_sharded", C.c_int, vp, vp, vp, vp, i32, vp, f64, i32, sp)
     sig("gms_slam_update_sharded_begin_dev", C.c_int, vp, vp, vp, i32)
     sig("gms_pf_gather_buffers", C.c_int, vp, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(vp), C.POINTER(C.c_int64))
     sig("gms_slam_update_sharded_end_dev", C.c_int, vp, vp, i32, vp, f64, i32)

@@ -1497,4 +1497,17 @@ int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xythet
     return gms_slam_update_sharded_end_dev(pf, dev_beams, B, r01, resample_fraction, integrate);
 }
 
+int gms_slam_update_sharded(gms_pf *pf, gms_comm *c, const float *xytheta, const gms_beam *beams, int32_t B, const double *r01,
+                            double resample_fraction, int32_t integrate, gms_pf_stats *stats) {
+    REQUIRE(pf && c && beams && r01, "null argument");
+    gms_map *m = pf->map;
+    REQUIRE(m->n_maps == 1, "sharded filters hold one map per handle");
+    int rc = GMS_OK;
+    if (xytheta) rc = gms_pf_set_poses(pf, xytheta);
+    if (!rc) rc = stage_beams(m, beams, B);
+    if (!rc) rc = gms_slam_update_sharded_dev(pf, c, nullptr, m->d_beams, B, r01, resample_fraction, integrate);
+    if (!rc && stats) rc = gms_pf_get_stats(pf, stats);
+    return rc;
+}
+
 }  // extern "C"

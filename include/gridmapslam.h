@@ -309,6 +309,11 @@ int gms_pf_normalize_sharded_end(gms_pf *pf, gms_comm *c);
  * the stand-alone filter's bit for bit. */
 int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B,
                                 const double *r01, double resample_fraction, int32_t integrate);
+/* The same with HOST inputs (what a JNI caller holds; see gms_slam_update): this rank's shard of the motion-model samples
+ * (may be NULL) and the scan are staged through the pinned rings; stats (may be NULL; synchronises) receives
+ * SLAM.update's return values, identical on every rank. */
+int gms_slam_update_sharded(gms_pf *pf, gms_comm *c, const float *xytheta, const gms_beam *beams, int32_t B, const double *r01,
+                            double resample_fraction, int32_t integrate, gms_pf_stats *stats);
 /* The same step for a host that brings its own collectives: _begin (poses, weights, this shard's payloads), then the
  * caller all-gathers BOTH buffers of gms_pf_gather_buffers in place (rank r's payload sits at r * per-rank size;
  * equal shards in rank order), then _end.  The buffers belong to the handle and keep their addresses until

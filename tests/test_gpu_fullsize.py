@@ -300,5 +300,7 @@ def test_likelihood_full_rebuild_on_a_dense_map_equals_the_oracle():
     log2 = log.copy()
     g.integrate(log2, tr.scans[0], tr.poses[0])
     got = m.download_log().reshape(-1)
-    assert np.max(np.abs(got - log2)) <= 1e-12
+    # (counts times constant vs. up to ~700 sequential additions near the robot: relative bar, 1e-5 in north_star)
+    assert np.max(np.abs(got - log2) / np.maximum(np.abs(log2), 1.0)) <= 1e-12
+    assert np.array_equal(np.sign(got), np.sign(log2))
     assert np.array_equal(m.download_likelihood().reshape(-1), g.build_likelihood(got))
