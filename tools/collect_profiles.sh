@@ -1,0 +1,50 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): rocprofv3 kernel-trace statistics and the separate FETCH_SIZE / WRITE_SIZE counter passes
+# of bench.py (C3 default, C5) and of the dense-map likelihood rebuild; raw output under gpurun_out/prof/, the summaries
+# that are kept go to profiles/<round>/ afterwards (tools/kstats.py, tools/pmc_summary.py).
+# usage: collect_profiles.sh <round dir name, e.g. r02>
+R=${1:-r02}
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$ROOT/gpurun_out/prof_$R"
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+stats() {   # name, command...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- "$@" > "$OUT/$name.stdout" 2> "$OUT/$name.stderr"
+  local f; f=$(find "$OUT/$name" -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/${name}_kernel_stats.csv"
+}
+pmc() {     # name, counter, command...
+  local name=$1 ctr=$2; shift 2
+  rocprofv3 --kernel-trace --pmc "$ctr" --output-format csv -d "$OUT/${name}_$ctr" -- "$@" > /dev/null 2> "$OUT/${name}_$ctr.stderr"
+}
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-secondary"
+stats c3_bench $B --steps 200 --warmup 20
+pmc c3 FETCH_SIZE $B --steps 50 --warmup 5
+pmc c3 WRITE_SIZE $B --steps 50 --warmup 5
+stats c5_bench $B --config C5 --steps 20 --warmup 3
+pmc c5 FETCH_SIZE $B --config C5 --steps 10 --warmup 2
+pmc c5 WRITE_SIZE $B --config C5 --steps 10 --warmup 2
+K="python3 $ROOT/tools/kbench.py --only likelihood --dense --iters 50"
+stats dense_likelihood $K
+pmc dense FETCH_SIZE $K
+pmc dense WRITE_SIZE $K
+stats c3_full_rebuild $B --full-rebuild --steps 100 --warmup 10
+cd "$ROOT"
+mkdir -p "$OUT/keep"
+for n in c3_bench c5_bench dense_likelihood c3_full_rebuild; do
+  cp "$OUT/${n}_kernel_stats.csv" "$OUT/keep/" 2>/dev/null
+  cp "$OUT/$n.stdout" "$OUT/keep/${n}_under_rocprof.json" 2>/dev/null
+done
+python3 tools/pmc_summary.py "$OUT/c3_FETCH_SIZE" "$OUT/c3_WRITE_SIZE" "$OUT/keep" c3_pmc C3
+python3 tools/pmc_summary.py "$OUT/c5_FETCH_SIZE" "$OUT/c5_WRITE_SIZE" "$OUT/keep" c5_pmc C5
+python3 tools/pmc_summary.py "$OUT/dense_FETCH_SIZE" "$OUT/dense_WRITE_SIZE" "$OUT/keep" dense_pmc dense_likelihood
+# un-profiled bench lines
+python3 bench.py > "$OUT/keep/bench.json" 2> "$OUT/bench.stderr"
+python3 bench.py --force-sharded --no-cpu-baseline --no-secondary > "$OUT/keep/bench_sharded_one_rank.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --host-inputs --no-cpu-baseline --no-secondary > "$OUT/keep/bench_host_inputs.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --full-rebuild --no-cpu-baseline --no-secondary > "$OUT/keep/bench_full_rebuild.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --config C5 --steps 50 --warmup 5 > "$OUT/keep/bench_c5.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$OUT/keep/bench_steps20.json" 2>> "$OUT/bench.stderr"
+ls -la "$OUT/keep"
+for f in "$OUT"/keep/*_kernel_stats.csv; do echo "== $f"; python3 tools/kstats.py "$f" | head -8; done

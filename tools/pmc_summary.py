@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 PMC passes per kernel and writes profiles/<round>/pmc_traffic.json.
 
-Usage: pmc_summary.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <out dir> [prefix]
+Usage: pmc_summary.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <out dir> [prefix] [config]
+With a config name (C3, C5, ...) the classes are merged into <out dir>/pmc_traffic.json under that key (bench.py reads
+roofline.traffic per configuration from there); without one the file is the classes themselves (round-1 layout).
 Each input dir holds a `*_counter_collection.csv` of `rocprofv3 --kernel-trace --pmc <COUNTER> -- python3 bench.py ...`
 (separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes).  FETCH_SIZE / WRITE_SIZE are in KB;
 FETCH_SIZE is doubled for gfx950 (128-byte requests are tallied at 64 B).  Kernel classes are bench.py's."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
-CLASS_OF = [("k_score_c", "score"), ("k_score_b", "score"), ("k_score(", "score"), ("k_norm_raycast", "raycast"),
+CLASS_OF = [("k_raycast_tile", "raycast"), ("k_raycast<false, 16>", "raycast"), ("k_score_c", "score"), ("k_score_b", "score"), ("k_score(", "score"), ("k_norm_raycast", "raycast"),
             ("k_raycast<false", "raycast"), ("k_lik_resample", "likelihood"), ("k_likelihood", "likelihood"),
             ("k_partials_apply", "reduce"), ("k_partials", "reduce"), ("k_normalize_pack", "reduce"), ("k_apply", "apply"),
             ("k_chunk_sums", "resample"), ("k_resample", "resample"), ("k_pose_trig", "pose_trig")]
@@ -26,6 +28,7 @@ def per_kernel(d):
 def main():
     fetch, write, out = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
     prefix = sys.argv[4] if len(sys.argv) > 4 else "pmc"
+    config = sys.argv[5] if len(sys.argv) > 5 else None
     os.makedirs(out, exist_ok=True)
     for tag, d in (("fetch_size", fetch), ("write_size", write)):
         with open(os.path.join(out, f"{prefix}_{tag}_per_kernel.csv"), "w") as fh:
@@ -55,12 +58,23 @@ def main():
         res[cls] = {"kernels": e["kernels"], "fetch_size_kb_raw": round(e["fetch_size_kb_raw"], 1),
                     "write_size_kb": round(e["write_size_kb"], 1),
                     "hbm_bytes_per_launch": int((2.0 * e["fetch_size_kb_raw"] + e["write_size_kb"]) * 1024)}
-    res["_note"] = ("per scan step and kernel class, C3 bench; separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes with "
+    res["_note"] = ("per scan step and kernel class, bench.py; separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes with "
                     "--kernel-trace only; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM (gfx950 tallies 128-B requests at "
                     "64 B for wide reads; for the 8-byte gathers of k_score_c the factor is uncalibrated, so its read side is an "
                     "upper bound); Infinity-Cache hits are counted, not excluded.  Paired launches are booked under the class "
                     "bench.py books them under (k_norm_raycast: raycast, k_lik_resample: likelihood, k_partials_apply: reduce).")
-    json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    path = os.path.join(out, "pmc_traffic.json")
+    if config:
+        allc = {}
+        if os.path.exists(path):
+            try:
+                allc = json.load(open(path))
+            except Exception:
+                allc = {}
+        allc[config] = res
+        json.dump(allc, open(path, "w"), indent=1)
+    else:
+        json.dump(res, open(path, "w"), indent=1)
     for cls, e in res.items():
         if not cls.startswith("_"):
             print(cls, e["hbm_bytes_per_launch"], list(e["kernels"]))
