@@ -363,8 +363,11 @@ def measure(wl: Workload, steps: int, warmup: int):
     dominant = max(compute, key=lambda k: warm[k][0], default="score") if warmup > 0 else "score"
     dom_bit = 1 << _lib.KERNEL_NAMES.index(dominant)
     per_step = max(1.0, warm[dominant][1] / warmup) if warmup > 0 and warm[dominant][1] else 1.0
-    # a bracket costs microseconds of stream time (two marker commands): as few as give >= 16 bracketed launches
-    stride = wl.args.event_stride or max(1, int(steps * per_step) // MIN_BRACKETED_LAUNCHES)
+    # A bracket costs microseconds of stream time (two marker commands, 3-7 us per bracketed launch at C3): as few as
+    # give >= 16 bracketed launches -- but never every launch: at the driver's --steps 20 that alone would cost 12 % of
+    # `value`; every second launch is the floor (10 launches at 20 steps; the all-classes pass after the timed region
+    # brackets every launch of min(steps, 50) further steps: kernels.<class>.avg_launch_us).
+    stride = wl.args.event_stride or max(2, int(steps * per_step) // MIN_BRACKETED_LAUNCHES)
 
     m.profile_reset()
     m.profile_sample(stride)
@@ -451,6 +454,15 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
         roof["gather_ceiling_frac"] = lookups / dom_avg_s / GATHER_CEILING_LANES_PER_S
     st = wl.pf.stats()
     st0 = st[0] if isinstance(st, list) else st
+    # Neff recomputed on the host from the LOG-weights of the same scored population (no underflow there): if the raw
+    # product's underflow cost the filter anything, the two would differ.  They do not: the particles whose product
+    # underflows carry < 1e-150 of the weight.  (A tempered likelihood would keep more particles alive; the reference
+    # has none, and none is added.)
+    neff_log = None
+    if wl.spf is None:                      # (a shard holds only its own log-weights)
+        lw = np.asarray(wl.pf.get_log_weights(), dtype=np.float64).reshape(wl.M, -1)[0]
+        sm = np.exp(lw - lw.max())
+        neff_log = float(sm.sum() ** 2 / (sm * sm).sum())
     out = {
         "ms_per_step": elapsed / steps * 1e3,
         "timed_region_s": elapsed,
@@ -474,7 +486,8 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
         "kernels": kernels,
         "filter": {"neff": st0["neff"], "n_zero_weights": st0["n_zero"], "weight_sum": st0["weight_sum"],
                    "note": "the reference's plain product of <= 720 factors: most raw weights underflow at this cloud (reproduced, "
-                           "counted); max_log_weight is the underflow-free companion", "max_log_weight": st0["max_log_weight"]},
+                           "counted); max_log_weight is the underflow-free companion", "max_log_weight": st0["max_log_weight"],
+                   "neff_from_log_weights": neff_log},
         "roofline": roof,
         "scan_footprint": {"visited_cells": visits, "dirty_rebuild_cells": dirty},
     }
