@@ -188,7 +188,7 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
     const size_t smem = smem_l > smem_r ? smem_l : smem_r;
     const uint32_t n_res = (uint32_t)((pf->n + 255) / 256);
     const int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;
-    const double *r01_maps = pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01;
+    const double *r01_maps = pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01_src;
 #define LR_LAUNCH(KH)                                                                                                     \
     do {                                                                                                                  \
         if (smem > 48 * 1024)                                                                                             \

@@ -1026,19 +1026,25 @@ int gms_pf_weighted_pose(gms_pf *pf, float *out) {                      // SLAM.
     return GMS_OK;
 }
 
-// Math.random() of SLAM.java:136, one draw per map, to where the resample kernel reads it
+// Math.random() of SLAM.java:136, one draw per map, to where the resample kernel reads it.  Batched handles: the draws
+// go into a pinned ring slot that the kernel reads in place (one 8-byte read per workgroup over PCIe, hidden beside the
+// likelihood tiles; a copy kernel in front of it was a 16 us PCIe round trip on the stream's critical path).  The slot is
+// released by commit_r01 once the resample launch is enqueued.
 static int stage_r01(gms_pf *pf, const double *r01) {
-    gms_map *m = pf->map;
     if (pf->n_maps == 1) {
         pf->r01_scalar = r01[0];                       // travels as a kernel argument: no copy, no synchronisation
         return GMS_OK;
     }
-    void *slot = nullptr;                              // pinned ring slot -> copy kernel, no synchronise
+    void *slot = nullptr;
     int rc = ring_acquire(pf->r01_ring, &slot);
     if (rc) return rc;
     memcpy(slot, r01, (size_t)pf->n_maps * sizeof(double));
-    gms_launch_copy(m, pf->d_r01, slot, (size_t)pf->n_maps * sizeof(double));
-    return ring_commit(pf->r01_ring, m->stream);
+    pf->d_r01_src = static_cast<const double *>(slot);
+    return GMS_OK;
+}
+static int commit_r01(gms_pf *pf) {
+    if (pf->n_maps == 1) return GMS_OK;
+    return ring_commit(pf->r01_ring, pf->map->stream);
 }
 
 static int do_resample(gms_pf *pf, const double *r01, double fraction, int32_t *indices, int32_t *n_ambiguous) {
@@ -1050,6 +1056,8 @@ static int do_resample(gms_pf *pf, const double *r01, double fraction, int32_t *
     rc = stage_r01(pf, r01);
     if (rc) return rc;
     gms_launch_pf_resample(pf, fraction);
+    rc = commit_r01(pf);
+    if (rc) return rc;
     std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);
     pf->have_global = 0;
     pf->stats_current = 0;
@@ -1084,6 +1092,8 @@ static int paired_likelihood_resample(gms_pf *pf, const double *r01, double frac
         int rc = stage_r01(pf, r01);
         if (rc) return rc;
         gms_launch_lik_resample(pf, fraction);
+        rc = commit_r01(pf);
+        if (rc) return rc;
         std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);
         pf->have_global = 0;
         pf->stats_current = 0;

@@ -148,7 +148,8 @@ struct gms_pf {
     PfStatsDev *d_stats;            // [2][n_maps]: [0] of the last normalise, [1] of the current particles (recomputed on demand)
     int32_t stats_current;          // d_stats[0] still describes the current particles
     PfStatsDev *h_stats;            // pinned
-    double *d_r01;                  // [n_maps] (batched maps; a single map passes r01 as a kernel argument)
+    double *d_r01;                  // [n_maps] (unused since the kernels read the pinned ring slot; kept for the allocation's alignment slack)
+    const double *d_r01_src;        // [n_maps] where the resample kernel reads the draws: the current pinned ring slot (batched maps)
     double r01_scalar;
     int32_t *d_idx;                 // [n_maps][n]
     float *h_stage;                 // pinned staging for poses (read-back)

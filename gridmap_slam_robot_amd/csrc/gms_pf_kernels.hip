@@ -1254,7 +1254,7 @@ void gms_launch_pf_resample(gms_pf *pf, double fraction) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resample), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
     hipLaunchKernelGGL(k_resample, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), smem, m->stream, pf->d_global,
-                       pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01,
+                       pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01_src,
                        pf->r01_scalar, fraction, pf->n, pf->offset,
                        pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats, pf->global_raw);
     pf->neff_folded = 1;
