@@ -297,7 +297,7 @@ k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam
 // outside it, falls back to the direct atomics.
 // ---------------------------------------------------------------------------------------------
 #define RCT_RAYS 64
-#define RCT_THREADS 512
+#define RCT_THREADS 1024                // 1 producer + 15 consumer wavefronts: phase B (~70 VALU per 64 cells) is the longer side here (256 threads: 125 us, 512: 73, 1024: 57 at C5)
 #define RCT_WORDS 16                    // decision words per ray and round (512 steps); longer walks take more rounds
 #define RCT_TILE_CELLS 32768            // 64 KiB of 16-bit cells
 #define RCT_LDS_BYTES (RCT_WORDS * RCT_RAYS * 8 + RCT_TILE_CELLS * 2)
