@@ -271,31 +271,39 @@ class Workload:
         ext, res, B = self.ext, self.res, self.B
         t0 = self.T // 2
         r01 = float(self.r01[0][0])
-        ref = None
+        # Every rank reaches the one collective of this check (all_gather_object) whatever happens locally: a rank that
+        # failed reports the error instead of its results, so a local failure cannot leave the ranks' collectives mismatched.
+        ref, ref_err = None, None
         if self.rank == 0:
-            m2 = GridMap(ext, ext, res, (-ext / 2, -ext / 2), device=self.dev.index, max_beams=max(2048, B))
-            m2.set_stream(self.stream.cuda_stream)
-            m2.copy_from(self.m)
-            pf2 = ParticleFilter(m2, self.n_global)
-            P = torch.from_numpy(np.ascontiguousarray(self.global_set0)).to(self.dev)
-            with torch.cuda.stream(self.stream):
-                pf2.slam_update_dev(P.data_ptr(), self.beams_ptr(t0), B, r01, 0.5, True)
-            torch.cuda.synchronize()
-            ref = dict(stats=pf2.stats(), poses=pf2.get_poses(), weights=pf2.get_weights(),
-                       log_crc=zlib.crc32(m2.download_log().tobytes()), lik_crc=zlib.crc32(m2.download_likelihood().tobytes()))
-            pf2.close(); m2.close()
-        self.step(0)                                    # set 0, scan t0, r01[0]: the same inputs
+            try:
+                m2 = GridMap(ext, ext, res, (-ext / 2, -ext / 2), device=self.dev.index, max_beams=max(2048, B))
+                m2.set_stream(self.stream.cuda_stream)
+                m2.copy_from(self.m)
+                pf2 = ParticleFilter(m2, self.n_global)
+                P = torch.from_numpy(np.ascontiguousarray(self.global_set0)).to(self.dev)
+                with torch.cuda.stream(self.stream):
+                    pf2.slam_update_dev(P.data_ptr(), self.beams_ptr(t0), B, r01, 0.5, True)
+                torch.cuda.synchronize()
+                ref = dict(stats=pf2.stats(), poses=pf2.get_poses(), weights=pf2.get_weights(),
+                           log_crc=zlib.crc32(m2.download_log().tobytes()), lik_crc=zlib.crc32(m2.download_likelihood().tobytes()))
+                pf2.close(); m2.close()
+            except Exception as e:
+                ref_err = repr(e)
+        self.step(0)                                    # set 0, scan t0, r01[0]: the same inputs (collective inside: every rank)
         torch.cuda.synchronize()
-        mine = dict(rank=self.rank, stats=self.pf.stats(), poses=self.pf.get_poses(), weights=self.pf.get_weights(),
-                    log_crc=zlib.crc32(self.m.download_log().tobytes()), lik_crc=zlib.crc32(self.m.download_likelihood().tobytes()))
         rccl_ranks = None
-        if self.comm is not None:
-            import ctypes as C
-            from gridmap_slam_robot_amd import _lib
-            r, w = C.c_int32(), C.c_int32()
-            _lib.check(_lib.load().gms_comm_rank(self.comm._h, C.byref(r), C.byref(w)))
-            rccl_ranks = int(w.value)
-            mine["comm_rank"] = int(r.value)
+        try:
+            mine = dict(rank=self.rank, stats=self.pf.stats(), poses=self.pf.get_poses(), weights=self.pf.get_weights(),
+                        log_crc=zlib.crc32(self.m.download_log().tobytes()), lik_crc=zlib.crc32(self.m.download_likelihood().tobytes()))
+            if self.comm is not None:
+                import ctypes as C
+                from gridmap_slam_robot_amd import _lib
+                r, w = C.c_int32(), C.c_int32()
+                _lib.check(_lib.load().gms_comm_rank(self.comm._h, C.byref(r), C.byref(w)))
+                rccl_ranks = int(w.value)
+                mine["comm_rank"] = int(r.value)
+        except Exception as e:
+            mine = dict(rank=self.rank, error=repr(e))
         if self.world > 1:
             box = [None] * self.world
             dist.all_gather_object(box, mine)
@@ -303,11 +311,18 @@ class Workload:
             box = [mine]
         if self.rank != 0:
             return None
+        if ref is None:
+            return {"sharded_equals_standalone": None, "error": f"stand-alone filter on rank 0: {ref_err}", "rccl_ranks": rccl_ranks,
+                    "route_verified": self.route, "population": self.n_global}
         n = self.n_local
         detail = {}
         ok = True
         for e in box:
             r = e["rank"]
+            if "error" in e:
+                ok = False
+                detail[f"rank{r}"] = [e["error"]]
+                continue
             checks = dict(stats=e["stats"] == ref["stats"],
                           poses=bool(np.array_equal(e["poses"], ref["poses"][r * n:(r + 1) * n])),
                           weights=bool(np.array_equal(e["weights"], ref["weights"][r * n:(r + 1) * n])),
@@ -656,7 +671,6 @@ def main() -> int:
             except Exception as e:      # the check must never take the measurement down with it
                 print(f"bench.py: sharded-vs-standalone check failed to run: {e!r}", file=sys.stderr)
                 verify = {"sharded_equals_standalone": None, "error": repr(e)} if rank == 0 else None
-                wl.agree(0)
 
     meas = measure(wl, args.steps, args.warmup)
     if rank != 0:
