@@ -431,6 +431,7 @@ apply_body(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ c
     const int32_t qx0 = x0 / APPLY_TW, qy0 = y0 / APPLY_TH;
     const int32_t qnx = (x1 - 1) / APPLY_TW - qx0 + 1, qny = (y1 - 1) / APPLY_TH - qy0 + 1;
     const bool vec = (g.W & 3) == 0;
+    const bool lazy_log = gridDim.y > 1;                 // batched maps (uniform)
     for (int32_t t = (int32_t)bx; t < qnx * qny; t += (int32_t)gdx) {
         const int32_t tx0 = (qx0 + t % qnx) * APPLY_TW, ty0 = (qy0 + t / qnx) * APPLY_TH;
         const int32_t y = ty0 + (threadIdx.x >> 6);
@@ -440,9 +441,13 @@ apply_body(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ c
         if (vec) {                                       // rows are 16-byte aligned: one 16-byte count load
             // the log-odds travel with the counts (two round trips per tile instead of three; untouched cells
             // are read for nothing, which costs bandwidth this kernel does not use)
+            // Batched handles (many maps' boxes: ~200 MB at config 5) are bandwidth-bound instead: there the log-odds of
+            // an untouched quad are not read (the extra dependent round trip is hidden by the other tiles in flight).
             const uint4 c = *reinterpret_cast<const uint4 *>(cnt + o);
-            const double2 la = *reinterpret_cast<const double2 *>(logd + o), lb = *reinterpret_cast<const double2 *>(logd + o + 2);
+            double2 la, lb;
+            if (!lazy_log) { la = *reinterpret_cast<const double2 *>(logd + o); lb = *reinterpret_cast<const double2 *>(logd + o + 2); }
             if ((c.x | c.y | c.z | c.w) == 0u) continue;
+            if (lazy_log) { la = *reinterpret_cast<const double2 *>(logd + o); lb = *reinterpret_cast<const double2 *>(logd + o + 2); }
             const uint32_t cc[4] = { c.x, c.y, c.z, c.w };
             const double lv[4] = { la.x, la.y, lb.x, lb.y };
 #pragma unroll
