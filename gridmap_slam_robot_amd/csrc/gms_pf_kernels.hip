@@ -17,7 +17,7 @@
 
 #define SCAN_CHUNK 64
 #ifndef SCORE_U
-#define SCORE_U 2     // likelihood look-ups in flight per lane in the scoring loops (measured at C3: 2 -> 21.2 us, 4 -> 23.0, 8 -> 22.4)
+#define SCORE_U 1     // likelihood look-ups in flight per lane in the scoring loops beside the software pipeline (k_score_c at C3 / C2 / C5: 1 -> 20.3 / 17.1 / 327 us, 2 -> 21.2 / 18.4 / 332, 4 -> 21.0 / 17.8)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -1131,9 +1131,14 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
         // (in order inside a segment, segment products in segment order), so it must not depend on how many particles
         // this handle holds: a shard of a sharded filter and the stand-alone filter of the whole population have to
         // round alike (tests/test_gpu_configs.py caught 8 x 8192 vs 65536 differing in the last bit when it did).
-        // 45 beams per segment = the 16 segments measured best at C3 (720 beams, one 16-wavefront workgroup per CU);
+        // 45 beams per segment = the 16 segments measured best at C3 (720 beams x 16 particle groups: one 16-wavefront
+        // workgroup per CU; 23 / 30 / 36 / 60 / 90 beams per segment: 21.6 / 24.8 / 27.7 / 25.3 / 34.5 us against 21.2) and
+        // at C5 (1080 beams: 332 us against 343-346 for 23 or 12).  Short scans (<= 384 beams: the reference's own 360, C2)
+        // come with small filters, where the launch is a handful of workgroups and the time is one workgroup's walk
+        // through its segment: 12 beams per segment (C2: 18.4 -> 8.4 us).  Either way a function of B only.
         // <= 128 beams per segment (the LDS beam table; also keeps a segment product >= 0.01^128, a normal double).
-        int64_t nseg = ((int64_t)B + GMS_SCORE_SEGLEN - 1) / GMS_SCORE_SEGLEN;
+        const int32_t seglen = B <= GMS_SCORE_SHORT_SCAN ? GMS_SCORE_SEGLEN_SHORT : GMS_SCORE_SEGLEN;
+        int64_t nseg = ((int64_t)B + seglen - 1) / seglen;
         if (m->score_segments > 0) nseg = m->score_segments;          // GMS_SCORE_SEGMENTS: experiments (every handle alike)
         const int64_t min_seg = ((int64_t)B + 127) / 128;
         if (nseg < min_seg) nseg = min_seg;
