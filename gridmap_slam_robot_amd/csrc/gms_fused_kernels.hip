@@ -14,6 +14,11 @@
 #include "gms_map_kernels.hip"
 #include "gms_pf_kernels.hip"
 
+// rays per 256-thread workgroup of the paired launches (one producer wavefront, three consumers)
+#ifndef RCF_RAYS
+#define RCF_RAYS 4
+#endif
+
 // ---- A: normalise + pack  |  ray cast at the weighted pose --------------------------------------------------
 // The ray-cast workgroups fold the weighted pose from the partial vector themselves (the arithmetic of
 // fold_stats: SLAM.java:165-178), because the workgroup that publishes it runs beside them.
@@ -36,7 +41,7 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
             s_pose[2] = (float)(f[3] / f[0]);
         }
         __syncthreads();
-        raycast_body<false, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,
+        raycast_body<false, RCF_RAYS, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,
                                smem, s_pose);
     } else {
         normalize_pack_body(partials, nblk_global, w, pose, n, offset, packed, cum, chunk_tot, nchunks, p2, stats,
@@ -96,7 +101,7 @@ k_raycast_norm_chunks(GridDev g, const gms_beam *__restrict__ beams, int32_t B, 
             s_pose[2] = (float)(f[3] / f[0]);
         }
         __syncthreads();
-        raycast_body<false, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,
+        raycast_body<false, RCF_RAYS, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,
                                smem, s_pose);
     } else if (blockIdx.x < n_ray_blocks + n_norm_blocks) {
         normalize_own_body(partials, nblk_global, w, pose, n, offset, glob_raw, stats, blockIdx.x - n_ray_blocks);
@@ -140,8 +145,8 @@ void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticl
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_RAYCAST);
     if (own) { pf->d_global = pf->d_global_own; pf->global_raw = 0; }     // normalised weights are packed (as apply_partials does)
-    const uint32_t n_ray = (uint32_t)((B + 3) / 4), n_norm = (uint32_t)((pf->n + 255) / 256);
-    const size_t smem = rc_smem(m, 4);
+    const uint32_t n_ray = (uint32_t)((B + RCF_RAYS - 1) / RCF_RAYS), n_norm = (uint32_t)((pf->n + 255) / 256);
+    const size_t smem = rc_smem(m, RCF_RAYS);
     int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * 4;
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_norm_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -234,9 +239,9 @@ void gms_launch_raycast_norm_chunks(gms_pf *pf, const gms_beam *d_beams, int32_t
     ProfScope ps(m, GMS_K_RAYCAST);
     pf->d_global = pf->d_global_own;
     pf->global_raw = 1;
-    const uint32_t n_ray = raycast ? (uint32_t)((B + 3) / 4) : 0u, n_norm = (uint32_t)((pf->n + 255) / 256);
+    const uint32_t n_ray = raycast ? (uint32_t)((B + RCF_RAYS - 1) / RCF_RAYS) : 0u, n_norm = (uint32_t)((pf->n + 255) / 256);
     const uint32_t n_chunk = (uint32_t)nblk_global_of(pf);
-    const size_t smem = rc_smem(m, 4);
+    const size_t smem = rc_smem(m, RCF_RAYS);
     int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * 4;
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast_norm_chunks), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -204,15 +204,15 @@ __device__ __forceinline__ void bbox_commit(int32_t bb[4], int32_t lane, int32_t
     }
 }
 
-// One workgroup = RC_RAYS rays, RC_RAYS wavefronts.  Wavefront 0 is the producer: lane r runs phase A of ray r and
-// publishes a slot every 32 steps.  The other RC_RAYS - 1 wavefronts are consumers: they take the 64-step blocks of
+// One workgroup = RC_RAYS rays, NWAVES wavefronts.  Wavefront 0 is the producer: lane r runs phase A of ray r and
+// publishes a slot every 32 steps.  The other NWAVES - 1 wavefronts are consumers: they take the 64-step blocks of
 // all rays round-robin (block-major, the order in which the producer publishes them) and run phase B as soon as a
 // block's words are there, so the cell work -- distance, sensor class, count atomics -- hides under the recurrence
 // instead of following it (measured at C3: 17.4 -> see DESIGN.md).  The producer never waits for a consumer.
 // (bx, by) = workgroup / map index and `smem` = the dynamic LDS: the body is shared by k_raycast and by the
 // launch that runs the ray cast beside the weight normalisation (gms_fused_kernels.hip); pose_lds, when given,
 // replaces poses[] (a pose the workgroup has just folded itself).
-template <bool TRACE, int RC_RAYS>
+template <bool TRACE, int RC_RAYS, int NWAVES = RC_RAYS>
 __device__ __forceinline__ void
 raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride,
              const float *__restrict__ poses, int32_t pose_stride, const RayIn *__restrict__ single,
@@ -227,7 +227,7 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
     const int32_t mi = (int32_t)by;
     const int32_t lane = threadIdx.x & 63;
     const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int32_t i = threadIdx.x; i < nw_max * RC_RAYS; i += RC_RAYS * 64) s_slots[i] = 0ull;
+    for (int32_t i = threadIdx.x; i < nw_max * RC_RAYS; i += NWAVES * 64) s_slots[i] = 0ull;
     RayDev r;
     r.dx = r.dy = r.error = 0.0f; r.x = r.y = r.x_inc = r.y_inc = r.n = 0;
     int32_t my_n_eff = 0;
@@ -256,7 +256,7 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
         int32_t nblk_max = 0;
 #pragma unroll
         for (int q = 0; q < RC_RAYS; q++) nblk_max = max(nblk_max, (s_meta[q].n_eff + 63) >> 6);
-        constexpr int32_t NC = RC_RAYS - 1;
+        constexpr int32_t NC = NWAVES - 1;
         for (int32_t q = wave - 1; q < nblk_max * RC_RAYS; q += NC) {
             const int32_t blk = q / RC_RAYS, ray = q - blk * RC_RAYS;
             const RayMeta mt = s_meta[ray];
