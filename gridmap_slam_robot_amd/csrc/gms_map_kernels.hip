@@ -564,6 +564,11 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
         // what this tile of likelihoodData / the factor table holds: 0 unknown, 1..3 the constants of a uniform tile
         uint8_t *tstate = tile_state ? tile_state + (size_t)mi * tiles_x * tiles_y + (size_t)(qy0 + tile / qnx) * tiles_x + (qx0 + tile % qnx)
                                      : nullptr;
+        // Read by EVERY thread here, before this tile's first barrier: thread 0 rewrites the state after that barrier, and a
+        // wavefront that read it later could see the new value and skip its share of a uniform tile's stores (round 1 read
+        // it at the point of use: one wavefront's 8 rows of a far-away tile were left stale about once in forty full-size
+        // multi-map runs; found by tests/test_gpu_configs.py).
+        const uint8_t tstate_old = tstate ? *reinterpret_cast<volatile uint8_t *>(tstate) : (uint8_t)0;
 
         // ---- phase 1
         int32_t seen = 0;                                      // bit c: a cell of code c; bit 3: outside the map
@@ -644,7 +649,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
         if (mask == 1 || mask == 2 || mask == 4) {
             // ---- uniform tile: every in-order sum sees the same inputs
             const uint8_t want = mask == 1 ? 1 : (mask == 2 ? 2 : 3);
-            if (tstate && *tstate == want) continue;           // the tile already holds exactly these constants: no store
+            if (tstate && tstate_old == want) continue;        // the tile already holds exactly these constants: no store
             const double cval = mask == 1 ? 0.0 : (mask == 2 ? 0.5 : 1.0);
             double hc = 0.0;
             for (int32_t i = 0; i < ntaps; i++) hc += taps_g[i] * cval;           // Util.java:393-401

@@ -295,7 +295,27 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
           const float *__restrict__ pose_src, float *__restrict__ pose_dst, float *__restrict__ cs_dst) {
     __shared__ double2 s_beam[128 + SCORE_U];        // this segment's beams with wasHit, in order
     __shared__ int32_t s_nb;
-    const int32_t mi = blockIdx.z, seg = blockIdx.y;
+    // Workgroup -> (beam segment, particle group), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs
+    // (each with an L2 of its own), so id & 7 picks the XCD and every XCD gets nseg / 8 ADJACENT segments for all particle
+    // groups: its L2 then holds the windows of a few neighbouring beams instead of the whole scan's (C3: 23.8 -> 22.3 us
+    // for segment-major order, -> see DESIGN.md for the adjacent-segment form; C5: 335 -> 326 us).
+    const int32_t mi = blockIdx.z;
+    int32_t seg, grp;
+    {
+        const int32_t i = blockIdx.x, ngrp = gridDim.x / nseg;
+#ifndef GMS_EXP_NO_XCD_ADJ
+        if ((nseg & 7) == 0) {
+            const int32_t spx = nseg >> 3, j = i >> 3;
+            seg = (i & 7) * spx + j % spx;
+            grp = j / spx;
+        } else
+#endif
+        {
+            seg = i % nseg;
+            grp = i / nseg;
+        }
+        (void)ngrp;
+    }
     const int32_t L = (B + nseg - 1) / nseg;          // <= 128 (launcher)
     const int32_t j0 = seg * L, j1 = min(B, j0 + L);
     const gms_beam *mb = beams + (size_t)mi * beam_stride;
@@ -315,7 +335,7 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     // pose_src: the poses enter the filter through this launch (SLAM.java:90): every segment's workgroup takes its
     // particles' trig itself -- the arithmetic hides under the first wavefront's beam compaction -- and segment 0
     // stores pose and trig where the other kernels expect them (what k_pose_trig does in a launch of its own)
-    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t p = grp * blockDim.x + threadIdx.x;
     const size_t gi = (size_t)mi * n + (p < n ? p : 0);
     XformDev t;
     if (pose_src) {
@@ -1144,7 +1164,7 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
         if (nseg < min_seg) nseg = min_seg;
         if (nseg < 1) nseg = 1;
         if (nseg > GMS_SCORE_MAXSEG) nseg = GMS_SCORE_MAXSEG;         // B <= GMS_MAX_BEAMS = 128 * GMS_SCORE_MAXSEG
-        hipLaunchKernelGGL(k_score_c, dim3((unsigned)groups, (unsigned)nseg, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
+        hipLaunchKernelGGL(k_score_c, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
                            m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
                            pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pf->d_pose, pf->d_cs);
         if (nseg > 1) pf->pending_nseg = (int32_t)nseg;               // combined by the next consumer of the weights
