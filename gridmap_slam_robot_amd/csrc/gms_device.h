@@ -51,8 +51,10 @@ __device__ __forceinline__ float j_sqrtf(float s) { return __builtin_sqrtf(s); }
 // Transform.fromRobotToWorld's trig: (double)(float) FastMath.cos((double) theta)
 // (J/math/Transform.java:15-16 via J/math/MathUtil.java:30-40).
 __device__ __forceinline__ void pose_trig(float theta, float &c, float &s) {
-    c = (float)cos((double)theta);
-    s = (float)sin((double)theta);
+    double sd, cd;
+    sincos((double)theta, &sd, &cd);                 // one argument reduction for both; same values as sin() and cos()
+    c = (float)cd;                                   // (tests/test_gpu_parity.py::test_device_sqrt_and_trig_round_like_the_oracle)
+    s = (float)sd;
 }
 
 // Transform.transformX / transformY (J/math/Transform.java:23,28): double, no FMA.

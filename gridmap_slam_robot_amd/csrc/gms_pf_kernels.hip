@@ -1145,7 +1145,7 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
     ProfScope ps(m, GMS_K_SCORE);
     pf->pending_nseg = 0;
     if (m->score_variant == 2) {
-        const int32_t threads = pf->n >= 1024 ? 1024 : ((pf->n + 63) / 64) * 64;
+        const int32_t threads = pf->n >= 1024 ? 1024 : ((pf->n + 63) / 64) * 64;     // (512-thread workgroups: the same time at C3; 768: +40 %)
         const int64_t groups = ((int64_t)pf->n + threads - 1) / threads;
         // Beam segments: a function of B ONLY.  The segmentation decides how the product of the factors is associated
         // (in order inside a segment, segment products in segment order), so it must not depend on how many particles
