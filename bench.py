@@ -654,10 +654,19 @@ def main() -> int:
     if args.gpus != world and world == 1 and args.gpus > 1:
         print("bench.py: --gpus N > 1 must be launched with torch.distributed.run", file=sys.stderr)
         return 2
+    # Test hooks (tests/test_gpu_bench_two_ranks.py): several ranks on ONE GPU with gloo collectives, to exercise the
+    # N > 1 control flow (route fall-back, self-verification, per-rank timing) where no multi-GPU node exists.  RCCL
+    # refuses two ranks on one device, so such a run takes the torch.distributed route by construction.
+    backend = os.environ.get("GMS_BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("GMS_BENCH_SHARE_DEVICE", "") not in ("", "0"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or (args.force_sharded and "RANK" in os.environ):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     sharded = world > 1 or args.force_sharded
     want_cpu = world == 1 and not args.no_cpu_baseline

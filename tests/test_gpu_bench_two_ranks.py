@@ -1,0 +1,41 @@
+"""bench.py's N > 1 control flow on ONE GPU: two ranks launched exactly as the driver launches them
+(python -m torch.distributed.run ... bench.py --gpus 2), sharing device 0, collectives over gloo (test hooks
+GMS_BENCH_DIST_BACKEND / GMS_BENCH_SHARE_DEVICE).  RCCL refuses two ranks on one device, so the in-library route must FAIL
+on both ranks, every rank must fall back together to the torch.distributed exchange, the self-verification must run
+(sharded == stand-alone on rank 0, bit for bit) and rank 0 must print one well-formed JSON line.  The first real RCCL
+world > 1 run happens on the driver's multi-GPU node; this is everything around it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_with_two_ranks_on_one_gpu_falls_back_verifies_and_reports():
+    env = dict(os.environ, GMS_BENCH_DIST_BACKEND="gloo", GMS_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--config", "C2", "--particles", "1024"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak"
+    assert d["config"]["particles_total"] == 2048 and "sharded x2" in d["config"]["parallelism"]
+    assert d["config"]["exchange"].startswith("torch.distributed")          # the in-library route cannot run here
+    assert d["sharded_equals_standalone"] is True, d.get("verify")
+    assert d["verify"]["population"] == 2048 and d["verify"]["mismatches"] is None
+    assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
+    assert d["value"] > 0 and d["roofline"]["launches_timed"] >= 1 and d["cpu_baseline"] is None
