@@ -898,6 +898,13 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
     double *off = reinterpret_cast<double *>(smem);                    // [nchunks + 1]
     const int32_t mi = (int32_t)by;
     __shared__ RedLds L;
+    // The chunk totals are loaded BEFORE the Neff fold decides whether the resample runs (they sit in registers meanwhile):
+    // one global round trip fewer on the critical path of the paired launch.  (More than 8 * blockDim chunks: the rest in
+    // the loop below.)
+    const double *tot = chunk_off + (size_t)mi * (nchunks + 1);
+    double tv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int64_t c = (int64_t)threadIdx.x + k * (int64_t)blockDim.x; tv[k] = c < nchunks ? tot[c] : 0.0; }
     double norm_sum, sq_sum;
     fold_neff(p2_all + (size_t)mi * nblk_global * 2, nblk_global, norm_sum, sq_sum, L.a);   // calculateNeff (SLAM.java:180-190)
     if (bx == 0 && threadIdx.x == 0) { stats[mi].norm_sum = norm_sum; stats[mi].sq_sum = sq_sum; }
@@ -905,8 +912,9 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
     const int64_t nsuper = (nchunks + 63) / 64;
     double *sup = off + nchunks + 1;                                   // [nsuper + 1]
     if (go) {
-        const double *tot = chunk_off + (size_t)mi * (nchunks + 1);
-        for (int64_t c0 = threadIdx.x; c0 < nchunks; c0 += 8 * (int64_t)blockDim.x) {  // eight loads in flight per thread
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int64_t c = (int64_t)threadIdx.x + k * (int64_t)blockDim.x; if (c < nchunks) off[c] = tv[k]; }
+        for (int64_t c0 = (int64_t)threadIdx.x + 8 * (int64_t)blockDim.x; c0 < nchunks; c0 += 8 * (int64_t)blockDim.x) {  // eight loads in flight per thread
             double v[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) { const int64_t c = c0 + k * (int64_t)blockDim.x; v[k] = c < nchunks ? tot[c] : 0.0; }
