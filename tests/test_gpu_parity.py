@@ -855,3 +855,39 @@ def test_host_input_steps_back_to_back_equal_device_input_steps():
     assert pa.stats() == pb.stats()
     assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights())
     assert np.array_equal(a.download_log(), b.download_log())
+
+
+def test_batched_tile_raycast_with_long_rays_equals_the_single_map_ray_cast():
+    """k_raycast_tile beyond its comfortable case: 2048^2 maps @ 2 cm, where a 64-beam wedge of 10 m rays does not fit the
+    64 KiB tile (direct-atomic fall-back inside the kernel) and a walk is up to ~1000 steps (two rounds of 512).  Six maps
+    x 720 beams = 4320 rays (> 4096: the batched path) against six single-map handles (k_raycast<4>) and the oracle."""
+    c = synth.CONFIGS["C3"]
+    ext, res, B = c["extent"], c["resolution"], c["beams"]
+    M = 6
+    traces = [synth.make_trace(ext, res, B, T=8, seed=40 + i, n_scans=2) for i in range(M)]
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    mb = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M)
+    for t in range(2):
+        mb.update(np.stack([tr.scans[t] for tr in traces]), np.stack([tr.poses[t] for tr in traces]))
+    lb = mb.download_log().reshape(M, -1)
+    kb = mb.download_likelihood().reshape(M, -1)
+    for i in range(M):
+        single = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+        log = g.new_log()
+        for t in range(2):
+            single.update(traces[i].scans[t], traces[i].poses[t])
+            g.integrate(log, traces[i].scans[t], traces[i].poses[t])
+        assert np.array_equal(lb[i], single.download_log().reshape(-1))          # same integer counts, same arithmetic
+        assert np.array_equal(kb[i], single.download_likelihood().reshape(-1))
+        assert np.array_equal(lb[i] != 0, log != 0)
+        nz = log != 0
+        assert rel_err(lb[i][nz], log[nz]) <= 1e-13
+        single.close()
+    # a ray far longer than the sensor range (API misuse, still exact): 30 m across the map, > 2 rounds, through the batch
+    far = Observation.from_polar(np.linspace(-3, 3, B), np.full(B, 30.0), np.ones(B, dtype=bool))
+    pose = np.array([-15.0, -15.0, 0.6], dtype=np.float32)
+    mb.update(np.stack([far.beams] * M), np.stack([pose] * M))
+    single = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    single.upload_log(lb[0].copy()); single.compute_likelihood_map()
+    single.update(far, pose)
+    assert np.array_equal(mb.download_log().reshape(M, -1)[0], single.download_log().reshape(-1))
