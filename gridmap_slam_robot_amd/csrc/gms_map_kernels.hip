@@ -2,8 +2,11 @@
 //
 //   k_raycast     GridMap.integrateObservation / applyMeasurement + RayIterator + SensorModel
 //                 (J/slam/GridMap.java:173-228, J/slam/RayIterator.java:65-130,
-//                  J/slam/SensorModel.java:31-41): one lane per ray walks the 4-connected DDA and
-//                 accumulates per-cell (n_free, n_occ) counts with 32-bit atomics.
+//                  J/slam/SensorModel.java:31-41): a producer wavefront runs the serial float recurrence of the
+//                 4-connected DDA, one lane per ray; consumer wavefronts turn the published decision words into
+//                 per-cell (n_free, n_occ) counts with 32-bit atomics meanwhile.
+//   k_raycast_tile  the same for batched maps: 64 consecutive beams per workgroup, counts accumulated in an LDS
+//                 tile of the wedge's bounding box and flushed row by row.
 //   k_apply       log += n_free*l_free + n_occ*l_occ over the touched bounding box (the three
 //                 possible increments of GridMap.java:223 are constants: J/app/Util.java:35-37).
 //   k_likelihood  GridMap.computeLikelihoodMap (GridMap.java:233-250) + Util.doGaussianBlurdSeparable
