@@ -1034,7 +1034,13 @@ k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_
 
 // ---------------------------------------------------------------------------------------------
 // GridMap.findBestPose (J/slam/GridMap.java:319-346): lattice search around every particle.
-// One workgroup per particle; waves take lattice poses round-robin; lanes stride the beams.
+// One workgroup per particle, ONE LANE PER LATTICE POSE (1210 poses over 256 lanes): every lane walks the hit beams in
+// order and multiplies its factors sequentially -- the reference's own order and its plain double product
+// (GridMap.java:262-288), with no cross-lane reduction per pose -- then one argmax over the lattice with the reference's
+// rule: strict `>` against maxProb = 0 in loop order, i.e. the first maximum wins (:334).  The 64 end points of a
+// wave-instruction are one beam seen from 64 neighbouring lattice poses: a compact, L1-resident patch.
+// (Round 1 gave a whole wavefront to each lattice pose: the trig of the pose was computed 64 times over and every pose
+// paid a 6-step shuffle product: 1.26 ms for 1024 particles x 360 beams against 0.62 ms for this form, 7e11 beam-evals/s.)
 // ---------------------------------------------------------------------------------------------
 #define REFINE_MAX_STEPS 16
 __global__ void __launch_bounds__(256)
@@ -1071,31 +1077,29 @@ k_refine(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, cons
     const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double best = 0.0;            // maxProb = 0 (:321)
     int32_t besti = -1;           // -1 = keep the start pose (:320)
-    for (int32_t q = wave; q < total; q += 4) {
+    for (int32_t q = threadIdx.x; q < total; q += 256) {               // q = loop order of the reference: theta fastest (:328-330)
         const int32_t it = q % nt, iy = (q / nt) % ny, ix = q / (nt * ny);
         const float cx = x0 + s_dx[ix], cy = y0 + s_dy[iy], ct = t0 + s_dt[it];       // :332
-        float c, s;
-        pose_trig(ct, c, s);
+        float c, sn;
+        pose_trig(ct, c, sn);
         XformDev t;
-        t.c = (double)c; t.s = (double)s; t.px = (double)cx; t.py = (double)cy;
-        double prod = 1.0;
-        for (int32_t j = lane; j < nb; j += 64) {
-            const double2 bm = sb[j];
+        t.c = (double)c; t.s = (double)sn; t.px = (double)cx; t.py = (double)cy;
+        double prod = 1.0;                                             // GridMap.java:262
+        for (int32_t j = 0; j < nb; j++) {                             // beams in order, sequential product (:267-288)
+            const double2 bm = sb[j];                                  // same address in every lane: LDS broadcast
             bool guard = false;
-            uint32_t cell = beam_cell_fast(g, t, bm.x, bm.y, guard);          // no division in the common case (see j_cell_fast)
+            uint32_t cell = beam_cell_fast(g, t, bm.x, bm.y, guard);   // no division in the common case (see j_cell_fast)
             if (__builtin_expect(guard, 0)) cell = beam_cell(g, t, bm.x, bm.y);
             prod *= fac[cell];
         }
-        int e;
-        double mnt = frexp(prod, &e);
+        if (prod > best) { best = prod; besti = q; }                   // :334 (q ascending per lane)
+    }
+    // first maximum over the lattice: larger probability wins, equal probabilities the smaller q
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double m2 = __shfl_xor(mnt, o, GMS_WAVE);
-            const int32_t e2 = __shfl_xor(e, o, GMS_WAVE);
-            mx_mul(mnt, e, m2, e2);
-        }
-        const double prob = ldexp(mnt, e);
-        if (prob > best) { best = prob; besti = q; }                                   // :334 (q ascending per wave)
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(best, o, GMS_WAVE);
+        const int32_t i2 = __shfl_xor(besti, o, GMS_WAVE);
+        if (i2 >= 0 && (besti < 0 || v2 > best || (v2 == best && i2 < besti))) { best = v2; besti = i2; }
     }
     if (lane == 0) { s_best[wave] = best; s_besti[wave] = besti; }
     __syncthreads();
@@ -1103,7 +1107,7 @@ k_refine(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, cons
         double b = 0.0; int32_t bi = -1;
         for (int k = 0; k < 4; k++) {
             const double v = s_best[k]; const int32_t vi = s_besti[k];
-            if (vi >= 0 && (v > b || (v == b && bi >= 0 && vi < bi))) { b = v; bi = vi; }
+            if (vi >= 0 && (bi < 0 || v > b || (v == b && vi < bi))) { b = v; bi = vi; }
         }
         if (bi >= 0) {
             const int32_t it = bi % nt, iy = (bi / nt) % ny, ix = bi / (nt * ny);
