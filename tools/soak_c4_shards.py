@@ -4,7 +4,7 @@ This is what found the tile-state race of the likelihood kernel (a wavefront ski
 here, invisible in single-map tests): 80 clean runs since the fix.  usage: soak_c4_shards.py [runs]"""
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gridmap_slam_robot_amd import GridMap, ParticleFilter, synth
 
