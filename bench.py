@@ -61,9 +61,10 @@ def algorithmic_bytes(kind: str, *, n_particles=0, n_hit=0, n_beams=0, cells=0, 
     raycast = 16.0 * visits
     resample = 32.0 * n_particles                                             # 8 B weight + 12 B pose read + 12 B pose write
     lik = 16.0 * (cells if full_rebuild else dirty_cells)                     # 16 B per cell rebuilt
+    order = 52.0 * n_particles                                                # 12 B pose read, 20 B pose+trig and 20 B ordered copy + index written
     per_map = {"score": score, "reduce": reduce_ + (apply_ if paired else 0.0), "apply": apply_,
                "raycast": raycast + (reduce_ if paired else 0.0), "likelihood": lik + (resample if paired else 0.0),
-               "resample": resample}.get(kind, 0.0)
+               "resample": resample, "order": order}.get(kind, 0.0)
     return per_map * n_maps
 
 
@@ -141,6 +142,8 @@ class Workload:
             for s in range(self.n_sets):
                 t = T // 2 + s
                 P = np.stack([synth.make_particles(trs[i % nt].poses[t], self.n_local, seed=7 + i + 64 * s) for i in range(M)])
+                if os.environ.get("GMS_EXP_SORT_CLOUD"):     # experiment: what a locality order of the particles would buy
+                    P = np.stack([q[np.lexsort((q[:, 0] // (2 * res), q[:, 1] // (2 * res), q[:, 2] // np.radians(0.5)))] for q in P])
                 self.pose_sets.append(torch.from_numpy(P).to(dev))
             self.n_hit = int(trs[0].scans[T // 2]["hit"].sum())
             self.scan0 = trs[0].scans[T // 2]

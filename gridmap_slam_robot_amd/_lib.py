@@ -21,7 +21,7 @@ PACKED_BYTES = 24
 
 GMS_OK, GMS_ERR_INVALID, GMS_ERR_NO_DEVICE, GMS_ERR_HIP, GMS_ERR_NOMEM, GMS_ERR_STATE = 0, -1, -2, -3, -4, -5
 K_RAYCAST, K_APPLY, K_LIKELIHOOD, K_SCORE, K_REDUCE, K_RESAMPLE, K_REFINE, K_EXCHANGE, K_COUNT = range(9)
-KERNEL_NAMES = ["raycast", "apply", "likelihood", "score", "reduce", "resample", "refine", "exchange"]
+KERNEL_NAMES = ["raycast", "apply", "likelihood", "score", "reduce", "resample", "refine", "exchange", "order"]
 
 BEAM_DTYPE = np.dtype(
     [("local_x", "<f8"), ("local_y", "<f8"), ("distance", "<f8"), ("hit", "u1"), ("pad_", "u1", (7,))]

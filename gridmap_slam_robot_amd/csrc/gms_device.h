@@ -123,6 +123,16 @@ __device__ __forceinline__ double lik_factor(const GridDev &g, double val) {
     return val == 0.5 ? g.inv_max : g.z_hit * val + g.c_rand;
 }
 
+// Where probabilityOf's look-up of cell (gx, gy) goes in the factor table, for ANY int gx, gy: the table has H + 1 rows
+// of g.fpitch = W + 16 entries, column W of every row and the whole of row H hold the neutral factor 1.0, and a
+// coordinate outside [0, W) x [0, H) (GridMap.java:276; negative values wrap to huge unsigned ones) is clamped onto that
+// border.  Two v_min_u32 and one full-rate v_mad_u32_u24 replace two compares, a select and a quarter-rate 32-bit
+// multiply: the scoring loop is as much bound by its ~40 vector instructions per look-up as by the look-up itself
+// (DESIGN.md section 4, round 2).  likelihoodData itself (d_lik) stays W x H.
+__device__ __forceinline__ uint32_t fac_index(const GridDev &g, int32_t gx, int32_t gy) {
+    return __umul24(min((uint32_t)gy, (uint32_t)g.H), (uint32_t)g.fpitch) + min((uint32_t)gx, (uint32_t)g.W);
+}
+
 // SensorModel.inverseSensorModel (J/slam/SensorModel.java:31-41) -> class 0 free, 1 prior, 2 occupied
 __device__ __forceinline__ int32_t sensor_class(float cur, float measured, int32_t hit, float half_tol) {
     if (!hit) return cur < measured ? 0 : 1;

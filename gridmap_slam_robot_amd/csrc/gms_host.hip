@@ -250,6 +250,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     int32_t W, H;
     gms_grid_size(p, &W, &H);
     REQUIRE(W > 0 && H > 0 && (int64_t)W * H < (1ll << 31), "gms_map_create: grid size out of range");
+    REQUIRE(W + 16 < (1 << 24) && H < (1 << 24) && (int64_t)(H + 1) * (W + 16) < (1ll << 32), "gms_map_create: grid size out of range");   // fac_index: 24-bit factors, 32-bit index
     int ndev = gms_device_count();
     if (ndev <= 0) return fail(GMS_ERR_NO_DEVICE, "no HIP device visible: libgridmapslam has no CPU path");
     if (p->device < 0 || p->device >= ndev) return fail(GMS_ERR_NO_DEVICE, "device %d of %d not available", p->device, ndev);
@@ -282,7 +283,9 @@ int gms_map_create(const gms_params *p, gms_map **out) {
 
     ok = ok && hipMalloc(&m->d_log, cells * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_lik, cells * sizeof(double)) == hipSuccess;
-    m->fac_stride = g.cells + 16;
+    g.fpitch = W + 16;                                               // factor table with a neutral border (fac_index)
+    g.fneutral = (uint32_t)H * (uint32_t)g.fpitch + (uint32_t)W;
+    m->fac_stride = (int64_t)(H + 1) * g.fpitch;
     ok = ok && hipMalloc(&m->d_fac, (size_t)m->fac_stride * m->n_maps * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_cnt, cells * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_bbox, (size_t)m->n_maps * 8 * sizeof(int32_t)) == hipSuccess;
@@ -730,6 +733,7 @@ int gms_pf_destroy(gms_pf *pf) {
     hipFree(pf->d_pose); hipFree(pf->d_pose2); hipFree(pf->d_part); hipFree(pf->d_cs2);
     hipFree(pf->d_w); hipFree(pf->d_w2); hipFree(pf->d_logw); hipFree(pf->d_cs); hipFree(pf->d_hitbeams);
     hipFree(pf->d_nhit); hipFree(pf->d_stats); hipFree(pf->d_r01); hipFree(pf->d_idx);
+    hipFree(pf->d_ord); hipFree(pf->d_perm);
     pf_free_global(pf);
     if (pf->h_stats) hipHostFree(pf->h_stats);
     if (pf->h_stage) hipHostFree(pf->h_stage);
@@ -761,6 +765,9 @@ int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // Partic
     ok = ok && hipMalloc(&pf->d_r01, (size_t)m->n_maps * 8 + 16) == hipSuccess;          // (+16: copied in 16-byte units)
     ok = ok && ring_alloc(pf->r01_ring, (size_t)m->n_maps * 8 + 16) == GMS_OK;
     ok = ok && hipMalloc(&pf->d_idx, T * 4) == hipSuccess;
+    ok = ok && hipMalloc(&pf->d_ord, T * sizeof(float4)) == hipSuccess && hipMalloc(&pf->d_perm, T * 4) == hipSuccess;
+    pf->order_mode = -1;
+    if (const char *v = getenv("GMS_SCORE_ORDER")) pf->order_mode = atoi(v);
     ok = ok && hipHostMalloc(&pf->h_stats, (size_t)m->n_maps * sizeof(PfStatsDev) + (size_t)m->n_maps * 8) == hipSuccess;
     ok = ok && hipHostMalloc(&pf->h_stage, T * 3 * sizeof(float)) == hipSuccess;
     ok = ok && ring_alloc(pf->pose_ring, T * 3 * sizeof(float)) == GMS_OK;

@@ -24,6 +24,8 @@ struct GridDev {
     double c_rand;        // zRandom * 1.0 / SENSOR_MAX_RANGE
     double inv_max;       // 1.0 / SENSOR_MAX_RANGE
     int32_t ktaps, khalf;
+    int32_t fpitch;       // factor table: row pitch W + 16; column W of every row and all of row H hold the neutral 1.0 (fac_index)
+    uint32_t fneutral;    // factor table: index of one neutral entry (row H, column W)
 };
 
 // one ray of a scan in grid coordinates (GridMap.integrateObservation's locals)
@@ -88,9 +90,9 @@ struct gms_map {
     hipStream_t stream;
     double *d_log;        // [n_maps][H][W]
     double *d_lik;        // [n_maps][H][W]
-    double *d_fac;        // [n_maps][fac_stride]: per-cell scoring factor f(likelihood) (GridMap.java:285-288),
+    double *d_fac;        // [n_maps][fac_stride]: per-cell scoring factor f(likelihood) (GridMap.java:285-288), rows of g.fpitch entries with a neutral border (fac_index),
                           // kept in step with d_lik; entry [cells] of each map is the neutral factor 1.0
-    int64_t fac_stride;   // cells + 16
+    int64_t fac_stride;   // (H + 1) * fpitch
     uint32_t *d_cnt;      // [n_maps][H][W] per-scan packed counts, zero between calls
     int32_t *d_bbox;      // [2][n_maps][4] encoded box of the cells changed since the last likelihood build;
                           // double-buffered: k_apply clears the idle half, so no memset is ever queued
@@ -161,6 +163,9 @@ struct gms_pf {
     int32_t chunks_ready;           // d_cum / d_chunk_tot hold level 0 of the scan of d_global
     int32_t refine;                 // scan steps run findBestPose on every particle before weighting (gms_pf_set_refine)
     int32_t pending_nseg;           // > 0: d_w is stale, the weights are still d_part's segment products
+    float4 *d_ord;                  // [n_maps][n] {x, y, cos, sin} of the particles in locality order (k_order)
+    int32_t *d_perm;                // [n_maps][n] the particle at each position of that order
+    int32_t order_mode;             // -1 the launcher decides (large launches only), 0 never, 1 always (GMS_SCORE_ORDER; results do not depend on it)
 };
 
 // one rank's side of the RCCL exchanges of a sharded filter (gms_host.hip)

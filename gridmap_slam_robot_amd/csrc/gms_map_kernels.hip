@@ -663,7 +663,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 const int32_t r = idx / LK_TW, c = idx - r * LK_TW;
                 const size_t o = (size_t)(ty0 + r) * g.W + tx0 + c;               // tile is inside the map (bit 3 clear)
                 mlik[o] = vc;
-                mfac[o] = fc;
+                mfac[(size_t)(ty0 + r) * g.fpitch + tx0 + c] = fc;
             }
             if (tstate && threadIdx.x == 0) *tstate = want;
             continue;
@@ -702,7 +702,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                     const int32_t gy = ty0 + r0 + o;
                     if (gx < g.W && gy < g.H) {
                         mlik[(size_t)gy * g.W + gx] = total;
-                        mfac[(size_t)gy * g.W + gx] = lik_factor(g, total);
+                        mfac[(size_t)gy * g.fpitch + gx] = lik_factor(g, total);
                     }
                 }
             }
@@ -722,7 +722,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                     double total = 0.0;
                     for (int32_t i = 0; i < ntaps; i++) total += taps_s[i] * hs[(r + i) * PHS + c];
                     mlik[(size_t)gy * g.W + gx] = total;
-                    mfac[(size_t)gy * g.W + gx] = lik_factor(g, total);
+                    mfac[(size_t)gy * g.fpitch + gx] = lik_factor(g, total);
                 }
             }
         }
@@ -739,11 +739,14 @@ k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ li
                         gridDim.x, smem, nullptr, tile_state);
 }
 
-// scoring factors from an existing likelihood field (upload / copy); entry [cells] = neutral 1.0
+// scoring factors from an existing likelihood field (upload / copy), and the table's neutral border (fac_index)
 __global__ void k_factors(GridDev g, const double *__restrict__ lik, double *__restrict__ fac, int64_t fac_stride) {
     const int32_t mi = blockIdx.y;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= g.cells; i += (int64_t)gridDim.x * blockDim.x)
-        fac[(size_t)mi * fac_stride + i] = i < g.cells ? lik_factor(g, lik[(size_t)mi * g.cells + i]) : 1.0;
+    double *mfac = fac + (size_t)mi * fac_stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < fac_stride; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t gy = (int32_t)(i / g.fpitch), gx = (int32_t)(i - (int64_t)gy * g.fpitch);
+        mfac[i] = gx < g.W && gy < g.H ? lik_factor(g, lik[(size_t)mi * g.cells + (size_t)gy * g.W + gx]) : 1.0;
+    }
 }
 
 // GridMapApp.calculateCombined (J/app/GridMapApp.java:439-458): one combined map out of the n_maps of a batch,

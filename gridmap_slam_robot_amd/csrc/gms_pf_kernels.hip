@@ -113,12 +113,10 @@ k_compact_beams(const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stri
 // probabilityOf: one beam end point (GridMap.java:273-288).  The factor f(likelihoodData[cell]) is
 // read from the map's factor table, which the likelihood kernel keeps in step with likelihoodData
 // (same multiply-then-add, same `== 0.5` test: GridMap.java:285-288); a beam whose end point falls
-// outside the map (:276) reads the neutral entry [cells] = 1.0, so the loop has no branch.
+// outside the map (:276) reads the neutral entry [g.fneutral] = 1.0, so the loop has no branch.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t cell_or_neutral(const GridDev &g, int32_t gx, int32_t gy) {
-    const bool in = (uint32_t)gx < (uint32_t)g.W && (uint32_t)gy < (uint32_t)g.H;    // :276
-    const uint32_t m = in ? 0xffffffffu : 0u;                                       // arithmetic select: no branch
-    return (((uint32_t)gy * (uint32_t)g.W + (uint32_t)gx) & m) | ((uint32_t)g.cells & ~m);
+    return fac_index(g, gx, gy);                                                     // :276 -> the table's neutral border
 }
 // fast form (no division, no branch); `guard` accumulates "an exact quotient is needed"
 __device__ __forceinline__ uint32_t beam_cell_fast(const GridDev &g, const XformDev &t, double lx, double ly, bool &guard) {
@@ -174,7 +172,7 @@ k_score(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const
                 const int32_t j = base + u * 64 + lane;
                 bm[u] = sb[j < nb ? j : 0];
                 const uint32_t c = beam_cell_fast(g, t, bm[u].x, bm[u].y, guard);
-                cell[u] = j < nb ? c : (uint32_t)g.cells;
+                cell[u] = j < nb ? c : g.fneutral;
             }
             if (__builtin_expect(guard, 0)) {                          // ~4e-6 of the end points
                 asm volatile("; exact quotients for this batch" ::: "memory");
@@ -182,7 +180,7 @@ k_score(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const
                 for (int u = 0; u < SCORE_U; u++) {
                     const int32_t j = base + u * 64 + lane;
                     const uint32_t c = beam_cell(g, t, bm[u].x, bm[u].y);
-                    cell[u] = j < nb ? c : (uint32_t)g.cells;
+                    cell[u] = j < nb ? c : g.fneutral;
                 }
             }
             double f[SCORE_U];
@@ -248,7 +246,7 @@ k_score_b(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
             const int32_t j = base + u;
             bm[u] = hb[j < j1 ? j : j0];                              // wave-uniform
             const uint32_t c = beam_cell_fast(g, t, bm[u].x, bm[u].y, guard);
-            cell[u] = j < j1 ? c : (uint32_t)g.cells;
+            cell[u] = j < j1 ? c : g.fneutral;
         }
         if (__builtin_expect(guard, 0)) {                              // ~4e-6 of the end points
             asm volatile("; exact quotients for this batch" ::: "memory");
@@ -256,7 +254,7 @@ k_score_b(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
             for (int u = 0; u < SCORE_U; u++) {
                 const int32_t j = base + u;
                 const uint32_t c = beam_cell(g, t, bm[u].x, bm[u].y);
-                cell[u] = j < j1 ? c : (uint32_t)g.cells;
+                cell[u] = j < j1 ? c : g.fneutral;
             }
         }
         double f[SCORE_U];
@@ -277,6 +275,98 @@ k_score_b(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// Locality order of the particles for a large scoring launch.  The texture-address pipe serves an 8-byte gather of 64
+// lanes in ~48 clocks when every lane has a line of its own and in ~25 when NEIGHBOURING lanes share lines (it merges
+// adjacent lanes only: tools/microbench/gather_coalesce.hip), and the caller's particles come in no particular order.
+// One workgroup per map buckets its particles by (theta, y, x) -- 64 x 8 x 8 bins, theta-major, at least 0.5 degrees
+// and 2 cells wide, wider when the cloud is -- with a counting sort in LDS, and stores {x, y, cos, sin} and the particle
+// index in bucket order: neighbouring lanes of k_score_c then hold neighbouring poses, whose beam end points fall into
+// the same cells' lines (C5: the scoring kernel 328 -> 247 us).  Which lane forms which particle's product does not
+// enter the arithmetic: weights are bit-identical with or without the order (and whatever the arrival order of the
+// atomics inside a bucket).  pose_src != nullptr: the poses enter the filter here (as in k_score_c / k_pose_trig).
+// ---------------------------------------------------------------------------------------------
+#define ORD_TBITS 6
+#define ORD_XBITS 3
+#define ORD_BINS (1 << (ORD_TBITS + 2 * ORD_XBITS))
+#define ORD_THREADS 1024
+__global__ void __launch_bounds__(ORD_THREADS)
+k_order(GridDev g, const float *__restrict__ pose_src, const float *__restrict__ pose, const float *__restrict__ cs, int32_t n,
+        float4 *__restrict__ ord, int32_t *__restrict__ perm, float *__restrict__ pose_dst, float *__restrict__ cs_dst) {
+    __shared__ uint32_t s_hist[ORD_BINS];
+    __shared__ float s_lo[3][ORD_THREADS / 64], s_hi[3][ORD_THREADS / 64];
+    __shared__ uint32_t s_wsum[ORD_THREADS / 64];
+    const int32_t mi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *src = (pose_src ? pose_src : pose) + (size_t)mi * n * 3;
+    // bounds of the cloud (NaN coordinates are ignored by fminf / fmaxf and land in bin 0 below)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int32_t i = tid; i < n; i += ORD_THREADS)
+#pragma unroll
+        for (int d = 0; d < 3; d++) { const float v = src[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, GMS_WAVE));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, GMS_WAVE));
+        }
+        if (lane == 0) { s_lo[d][wave] = lo[d]; s_hi[d][wave] = hi[d]; }
+    }
+    for (int32_t b = tid; b < ORD_BINS; b += ORD_THREADS) s_hist[b] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        lo[d] = s_lo[d][0]; hi[d] = s_hi[d][0];
+        for (int w = 1; w < ORD_THREADS / 64; w++) { lo[d] = fminf(lo[d], s_lo[d][w]); hi[d] = fmaxf(hi[d], s_hi[d][w]); }
+    }
+    const float nxy = (float)(1 << ORD_XBITS), nth = (float)(1 << ORD_TBITS);
+    const float inv_x = nxy / fmaxf(hi[0] - lo[0], nxy * 2.0f * g.resf), inv_y = nxy / fmaxf(hi[1] - lo[1], nxy * 2.0f * g.resf);
+    const float inv_t = nth / fmaxf(hi[2] - lo[2], nth * 0.0087266463f);
+    auto key_of = [&](float x, float y, float th) -> uint32_t {
+        const uint32_t ix = (uint32_t)fminf(fmaxf((x - lo[0]) * inv_x, 0.0f), nxy - 1.0f);
+        const uint32_t iy = (uint32_t)fminf(fmaxf((y - lo[1]) * inv_y, 0.0f), nxy - 1.0f);
+        const uint32_t it = (uint32_t)fminf(fmaxf((th - lo[2]) * inv_t, 0.0f), nth - 1.0f);
+        return (it << (2 * ORD_XBITS)) | (iy << ORD_XBITS) | ix;
+    };
+    for (int32_t i = tid; i < n; i += ORD_THREADS)
+        atomicAdd(&s_hist[key_of(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2])], 1u);
+    __syncthreads();
+    {   // exclusive prefix over the bins: thread t owns bins 4t .. 4t+3
+        constexpr int PER = ORD_BINS / ORD_THREADS;
+        uint32_t c[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { c[k] = s_hist[tid * PER + k]; sum += c[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, GMS_WAVE);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - sum;
+        for (int w = 0; w < wave; w++) base += s_wsum[w];
+#pragma unroll
+        for (int k = 0; k < PER; k++) { s_hist[tid * PER + k] = base; base += c[k]; }
+    }
+    __syncthreads();
+    for (int32_t i = tid; i < n; i += ORD_THREADS) {
+        const size_t gi = (size_t)mi * n + i;
+        const float x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1], th = src[3 * (size_t)i + 2];
+        float c, sn;
+        if (pose_src) {
+            pose_trig(th, c, sn);                                      // Transform.java:15-16
+            pose_dst[3 * gi] = x; pose_dst[3 * gi + 1] = y; pose_dst[3 * gi + 2] = th;
+            cs_dst[2 * gi] = c; cs_dst[2 * gi + 1] = sn;
+        } else {
+            c = cs[2 * gi]; sn = cs[2 * gi + 1];
+        }
+        const uint32_t pos = atomicAdd(&s_hist[key_of(x, y, th)], 1u);
+        ord[(size_t)mi * n + pos] = make_float4(x, y, c, sn);
+        perm[(size_t)mi * n + pos] = i;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // probabilityOf, cache-blocked form (the default).  PMC counters on MI355X show the two kernels above
 // bound by L2->L1 line fills (TCP_PENDING_STALL, TA_ADDR_STALLED_BY_TC: every 8-byte look-up drags a
 // 128-byte line into a 32 KiB L1 that 16 wavefronts with 16 different access patches keep evicting).
@@ -292,7 +382,8 @@ __global__ void __launch_bounds__(1024)
 k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const gms_beam *__restrict__ beams,
           int32_t B, int32_t beam_stride, const float *__restrict__ pose, const float *__restrict__ cs, int32_t n,
           int32_t nseg, double *__restrict__ part, double *__restrict__ w, double *__restrict__ logw,
-          const float *__restrict__ pose_src, float *__restrict__ pose_dst, float *__restrict__ cs_dst) {
+          const float *__restrict__ pose_src, float *__restrict__ pose_dst, float *__restrict__ cs_dst,
+          const float4 *__restrict__ ord, const int32_t *__restrict__ perm) {
     __shared__ double2 s_beam[128 + SCORE_U];        // this segment's beams with wasHit, in order
     __shared__ int32_t s_nb;
     // Workgroup -> (beam segment, particle group), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs
@@ -335,10 +426,16 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     // pose_src: the poses enter the filter through this launch (SLAM.java:90): every segment's workgroup takes its
     // particles' trig itself -- the arithmetic hides under the first wavefront's beam compaction -- and segment 0
     // stores pose and trig where the other kernels expect them (what k_pose_trig does in a launch of its own)
+    // ord: the lanes take the particles in k_order's locality order; op is the particle whose product this lane forms
     const int32_t p = grp * blockDim.x + threadIdx.x;
-    const size_t gi = (size_t)mi * n + (p < n ? p : 0);
+    const size_t li = (size_t)mi * n + (p < n ? p : 0);
+    const int32_t op = ord ? perm[li] : (p < n ? p : 0);
+    const size_t gi = (size_t)mi * n + op;
     XformDev t;
-    if (pose_src) {
+    if (ord) {
+        const float4 o = ord[li];
+        t.c = (double)o.z; t.s = (double)o.w; t.px = (double)o.x; t.py = (double)o.y;
+    } else if (pose_src) {
         const float x = pose_src[3 * gi], y = pose_src[3 * gi + 1], th = pose_src[3 * gi + 2];
         float c, sn;
         pose_trig(th, c, sn);                                          // Transform.java:15-16
@@ -365,14 +462,14 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
         for (int u = 0; u < SCORE_U; u++) {
             bm[u] = s_beam[base + u];                                  // same address in every lane: LDS broadcast
             const uint32_t c = beam_cell_fast(g, t, bm[u].x, bm[u].y, guard);
-            cell[u] = base + u < nb ? c : (uint32_t)g.cells;
+            cell[u] = base + u < nb ? c : g.fneutral;
         }
         if (__builtin_expect(guard, 0)) {                              // ~4e-6 of the end points
             asm volatile("; exact quotients for this batch" ::: "memory");
 #pragma unroll
             for (int u = 0; u < SCORE_U; u++) {
                 const uint32_t c = beam_cell(g, t, bm[u].x, bm[u].y);
-                cell[u] = base + u < nb ? c : (uint32_t)g.cells;
+                cell[u] = base + u < nb ? c : g.fneutral;
             }
         }
     };
@@ -392,7 +489,7 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
         w[gi] = prod;
         logw[gi] = log(mnt) + (double)e * 0.6931471805599453;
     } else {
-        part[((size_t)mi * nseg + seg) * n + p] = prod;               // <= 128 factors >= 0.01: no underflow
+        part[((size_t)mi * nseg + seg) * n + op] = prod;              // <= 128 factors >= 0.01: no underflow
     }
 }
 
@@ -1150,10 +1247,36 @@ static void launch_compact(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32
                        pf->d_hitbeams, pf->d_nhit);
 }
 
+// beam segments of the default scoring kernel (see gms_launch_pf_score)
+static int64_t score_segments(const gms_map *m, int32_t B) {
+    const int32_t seglen = B <= GMS_SCORE_SHORT_SCAN ? GMS_SCORE_SEGLEN_SHORT : GMS_SCORE_SEGLEN;
+    int64_t nseg = ((int64_t)B + seglen - 1) / seglen;
+    if (m->score_segments > 0) nseg = m->score_segments;          // GMS_SCORE_SEGMENTS: experiments (every handle alike)
+    const int64_t min_seg = ((int64_t)B + 127) / 128;
+    if (nseg < min_seg) nseg = min_seg;
+    if (nseg < 1) nseg = 1;
+    if (nseg > GMS_SCORE_MAXSEG) nseg = GMS_SCORE_MAXSEG;         // B <= GMS_MAX_BEAMS = 128 * GMS_SCORE_MAXSEG
+    return nseg;
+}
+
 void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_pose_src) {
     gms_map *m = pf->map;
     if (d_pose_src && m->score_variant != 2) { gms_launch_pf_pose_trig(pf, d_pose_src); d_pose_src = nullptr; }
     if (m->score_variant != 2) launch_compact(pf, d_beams, B, beam_stride);
+    bool ordered = false;
+    if (m->score_variant == 2) {
+        // The locality order (k_order) costs a launch of its own, ~6 us for 4096 particles per map, and takes a fifth to a
+        // quarter off the scoring kernel: it pays once the scoring launch is several rounds of workgroups deep (C5: 6144
+        // workgroups, 328 -> 247 us), not at 256 workgroups (C3: -3 us for +5.5).  Results are the same either way.
+        const int64_t wgs = score_segments(m, B) * (((int64_t)pf->n + 1023) / 1024) * pf->n_maps;
+        ordered = pf->order_mode > 0 || (pf->order_mode < 0 && wgs >= 2048 && pf->n <= 32768);
+        if (ordered) {
+            ProfScope po(m, GMS_K_ORDER);
+            hipLaunchKernelGGL(k_order, dim3(pf->n_maps), dim3(ORD_THREADS), 0, m->stream, m->gd, d_pose_src, pf->d_pose, pf->d_cs,
+                               pf->n, pf->d_ord, pf->d_perm, pf->d_pose, pf->d_cs);
+            d_pose_src = nullptr;                                     // stored by k_order
+        }
+    }
     ProfScope ps(m, GMS_K_SCORE);
     pf->pending_nseg = 0;
     if (m->score_variant == 2) {
@@ -1169,16 +1292,11 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
         // come with small filters, where the launch is a handful of workgroups and the time is one workgroup's walk
         // through its segment: 12 beams per segment (C2: 18.4 -> 8.4 us).  Either way a function of B only.
         // <= 128 beams per segment (the LDS beam table; also keeps a segment product >= 0.01^128, a normal double).
-        const int32_t seglen = B <= GMS_SCORE_SHORT_SCAN ? GMS_SCORE_SEGLEN_SHORT : GMS_SCORE_SEGLEN;
-        int64_t nseg = ((int64_t)B + seglen - 1) / seglen;
-        if (m->score_segments > 0) nseg = m->score_segments;          // GMS_SCORE_SEGMENTS: experiments (every handle alike)
-        const int64_t min_seg = ((int64_t)B + 127) / 128;
-        if (nseg < min_seg) nseg = min_seg;
-        if (nseg < 1) nseg = 1;
-        if (nseg > GMS_SCORE_MAXSEG) nseg = GMS_SCORE_MAXSEG;         // B <= GMS_MAX_BEAMS = 128 * GMS_SCORE_MAXSEG
+        const int64_t nseg = score_segments(m, B);
         hipLaunchKernelGGL(k_score_c, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
                            m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
-                           pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pf->d_pose, pf->d_cs);
+                           pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pf->d_pose, pf->d_cs,
+                           ordered ? pf->d_ord : nullptr, ordered ? pf->d_perm : nullptr);
         if (nseg > 1) pf->pending_nseg = (int32_t)nseg;               // combined by the next consumer of the weights
         return;
     }

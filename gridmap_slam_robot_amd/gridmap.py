@@ -309,7 +309,7 @@ class GridMap:
     # -- measurement ------------------------------------------------------------------------------
     def profile(self, on=True):
         """on: True/False, or a bitmask of kernel classes (bit k = _lib.K_*)."""
-        mask = (0xFF if on else 0) if isinstance(on, bool) else int(on)
+        mask = ((1 << len(_lib.KERNEL_NAMES)) - 1 if on else 0) if isinstance(on, bool) else int(on)
         check(load().gms_profile_enable(self._h, mask))
 
     # -- device-resident inputs (raw device pointers, e.g. torch tensor .data_ptr()) -------------------

@@ -327,7 +327,8 @@ int gms_slam_update_sharded_end_dev(gms_pf *pf, const gms_beam *dev_beams, int32
 /* ---- measurement ------------------------------------------------------------------------------- */
 enum {
     GMS_K_RAYCAST = 0, GMS_K_APPLY = 1, GMS_K_LIKELIHOOD = 2, GMS_K_SCORE = 3, GMS_K_REDUCE = 4,
-    GMS_K_RESAMPLE = 5, GMS_K_REFINE = 6, GMS_K_EXCHANGE = 7 /* the grouped RCCL launch of a sharded scan step */, GMS_K_COUNT = 8
+    GMS_K_RESAMPLE = 5, GMS_K_REFINE = 6, GMS_K_EXCHANGE = 7 /* the grouped RCCL launch of a sharded scan step */,
+    GMS_K_ORDER = 8 /* the locality order of the particles ahead of a large scoring launch */, GMS_K_COUNT = 9
 };
 /* Bracket kernel launches of this map handle (and its filters) with HIP events on its stream:
  * bit k of `mask` enables kernel class k (GMS_K_*); 0 turns profiling off. */

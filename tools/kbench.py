@@ -40,6 +40,23 @@ def main():
         ky = np.floor(Ph[:, 1] / float(met)).astype(np.int64)
         kx = np.floor(Ph[:, 0] / float(met)).astype(np.int64)
         Ph = Ph[np.lexsort((Ph[:, 0], kx, ky, kt))]
+    elif args.sort.startswith("morton") or args.sort.startswith("chunkmorton"):
+        # Morton order of (x, y, theta) bins of <cells> cells and <deg> degrees; "chunkmorton" sorts inside each
+        # 1024-particle group only (what one scoring workgroup could do for itself)
+        _, qc, qd = args.sort.split(":")
+        def spread(v):
+            v = v.astype(np.uint64) & np.uint64(0x3ff)
+            for sh, mk in ((16, 0x30000ff), (8, 0x300f00f), (4, 0x30c30c3), (2, 0x9249249)):
+                v = (v | (v << np.uint64(sh))) & np.uint64(mk)
+            return v
+        ix = np.floor((Ph[:, 0] - Ph[:, 0].min()) / (float(qc) * res)).astype(np.int64)
+        iy = np.floor((Ph[:, 1] - Ph[:, 1].min()) / (float(qc) * res)).astype(np.int64)
+        it = np.floor((Ph[:, 2] - Ph[:, 2].min()) / np.radians(float(qd))).astype(np.int64)
+        key = spread(ix) | (spread(iy) << np.uint64(1)) | (spread(it) << np.uint64(2))
+        if args.sort.startswith("chunk"):
+            Ph = Ph[np.concatenate([g0 + np.argsort(key[g0:g0 + 1024], kind="stable") for g0 in range(0, N, 1024)])]
+        else:
+            Ph = Ph[np.argsort(key, kind="stable")]
     elif args.sort.startswith("kd"):
         # recursive median split on the widest of (x, y, theta * lever) in cells: compact clusters at every scale
         lever = float(args.sort.split(":")[1]) if ":" in args.sort else 150.0
