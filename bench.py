@@ -44,6 +44,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 GATHER_CEILING_LANES_PER_S = 818e9   # tools/microbench/gather8.hip on MI355X: independent 8-byte look-ups whose patch stays in L1
+GATHER_CEILING_MERGED_PER_S = 1590e9  # tools/microbench/gather_coalesce.hip: the same when 4 neighbouring lanes share a line (particles in locality order)
 MIN_BRACKETED_LAUNCHES = 16
 
 
@@ -142,8 +143,6 @@ class Workload:
             for s in range(self.n_sets):
                 t = T // 2 + s
                 P = np.stack([synth.make_particles(trs[i % nt].poses[t], self.n_local, seed=7 + i + 64 * s) for i in range(M)])
-                if os.environ.get("GMS_EXP_SORT_CLOUD"):     # experiment: what a locality order of the particles would buy
-                    P = np.stack([q[np.lexsort((q[:, 0] // (2 * res), q[:, 1] // (2 * res), q[:, 2] // np.radians(0.5)))] for q in P])
                 self.pose_sets.append(torch.from_numpy(P).to(dev))
             self.n_hit = int(trs[0].scans[T // 2]["hit"].sum())
             self.scan0 = trs[0].scans[T // 2]
@@ -464,12 +463,17 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
         "avg_launch_us_minus_bracket": net_s * 1e6, "frac_minus_bracket": alg / net_s / 1e9 / HBM_PEAK_GBS,
     }
     if dom == "score":
-        # what the counters say bounds this kernel (profiles/: the factor table is L2/Infinity-Cache resident, traffic is
-        # a fraction of the algorithmic bytes; TA_BUSY per look-up instruction = distinct 128-byte lines per wavefront)
-        roof["bound_measured"] = "l1-gather (texture-address pipe: one 128-byte line per clock)"
+        # what bounds this kernel (profiles/: the factor table is L2/Infinity-Cache resident, traffic is a fraction of the
+        # algorithmic bytes; tools/microbench/gather_coalesce.hip: the address pipe takes ~48 clocks per 64-lane 8-byte
+        # gather unless NEIGHBOURING lanes share a line)
+        roof["bound_measured"] = "l1-gather (texture-address pipe: ~48 clocks per 64-lane look-up, ~25 when neighbouring lanes share lines)"
         lookups = wl.n_local * wl.n_hit * wl.M
         roof["lookups_per_s"] = lookups / dom_avg_s
         roof["gather_ceiling_frac"] = lookups / dom_avg_s / GATHER_CEILING_LANES_PER_S
+        if prof.get("order", (0, 0))[1]:
+            # k_order ran: neighbouring lanes share lines, which the pipe merges; the independent-lane ceiling no longer binds
+            roof["particles_in_locality_order"] = True
+            roof["gather_ceiling_merged_frac"] = lookups / dom_avg_s / GATHER_CEILING_MERGED_PER_S
     st = wl.pf.stats()
     st0 = st[0] if isinstance(st, list) else st
     # Neff recomputed on the host from the LOG-weights of the same scored population (no underflow there): if the raw
