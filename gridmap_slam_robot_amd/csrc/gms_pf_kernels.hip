@@ -278,12 +278,18 @@ k_score_b(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
 // Locality order of the particles for a large scoring launch.  The texture-address pipe serves an 8-byte gather of 64
 // lanes in ~48 clocks when every lane has a line of its own and in ~25 when NEIGHBOURING lanes share lines (it merges
 // adjacent lanes only: tools/microbench/gather_coalesce.hip), and the caller's particles come in no particular order.
-// One workgroup per map buckets its particles by (theta, y, x) -- 64 x 8 x 8 bins, theta-major, at least 0.5 degrees
-// and 2 cells wide, wider when the cloud is -- with a counting sort in LDS, and stores {x, y, cos, sin} and the particle
-// index in bucket order: neighbouring lanes of k_score_c then hold neighbouring poses, whose beam end points fall into
-// the same cells' lines (C5: the scoring kernel 328 -> 247 us).  Which lane forms which particle's product does not
-// enter the arithmetic: weights are bit-identical with or without the order (and whatever the arrival order of the
-// atomics inside a bucket).  pose_src != nullptr: the poses enter the filter here (as in k_score_c / k_pose_trig).
+// The particles of a map are bucketed by (theta, y, x) -- 64 x 8 x 8 bins, theta-major, at least 0.5 degrees and 2 cells
+// wide, wider when the cloud is -- by a counting sort in LDS, and {x, y, cos, sin} and the particle index are stored in
+// bucket order: neighbouring lanes of k_score_c then hold neighbouring poses, whose beam end points fall into the same
+// cells' lines (C5: the scoring kernel 328 -> 250 us).  Which lane forms which particle's product does not enter the
+// arithmetic: weights are bit-identical with or without the order (and whatever the arrival order of the atomics
+// inside a bucket).
+// grid = (map, slice of 1024 particles).  Every workgroup histograms ALL particles of its map (12 bytes each, from L2)
+// -- so it knows every bucket's start and how many particles of EARLIER slices precede its own in each bucket -- and
+// then places only its own slice: position = bucket start + earlier slices' count + arrival rank inside the slice.
+// No workgroup waits for another, the double-precision sincos of the poses that enter through this launch (pose_src;
+// what k_score_c / k_pose_trig do otherwise) is one per thread instead of n / 1024, and the work spreads over
+// n_maps x n / 1024 CUs (one workgroup per map: 15.6 us at C5, 5.3 of them trig on 64 CUs).
 // ---------------------------------------------------------------------------------------------
 #define ORD_TBITS 6
 #define ORD_XBITS 3
@@ -292,13 +298,17 @@ k_score_b(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
 __global__ void __launch_bounds__(ORD_THREADS)
 k_order(GridDev g, const float *__restrict__ pose_src, const float *__restrict__ pose, const float *__restrict__ cs, int32_t n,
         float4 *__restrict__ ord, int32_t *__restrict__ perm, float *__restrict__ pose_dst, float *__restrict__ cs_dst) {
-    __shared__ uint32_t s_hist[ORD_BINS];
+    __shared__ uint32_t s_all[ORD_BINS];       // particles per bucket, then the buckets' starts
+    __shared__ uint32_t s_before[ORD_BINS];    // ... of the slices before this workgroup's
+    __shared__ uint32_t s_own[ORD_BINS];       // arrival counter of this workgroup's slice
     __shared__ float s_lo[3][ORD_THREADS / 64], s_hi[3][ORD_THREADS / 64];
     __shared__ uint32_t s_wsum[ORD_THREADS / 64];
-    const int32_t mi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t mi = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *src = (pose_src ? pose_src : pose) + (size_t)mi * n * 3;
+    const int32_t own = slice * ORD_THREADS + tid;                    // this thread's particle
     // bounds of the cloud (NaN coordinates are ignored by fminf / fmaxf and land in bin 0 below)
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 4
     for (int32_t i = tid; i < n; i += ORD_THREADS)
 #pragma unroll
         for (int d = 0; d < 3; d++) { const float v = src[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
@@ -311,7 +321,7 @@ k_order(GridDev g, const float *__restrict__ pose_src, const float *__restrict__
         }
         if (lane == 0) { s_lo[d][wave] = lo[d]; s_hi[d][wave] = hi[d]; }
     }
-    for (int32_t b = tid; b < ORD_BINS; b += ORD_THREADS) s_hist[b] = 0u;
+    for (int32_t b = tid; b < ORD_BINS; b += ORD_THREADS) { s_all[b] = 0u; s_before[b] = 0u; s_own[b] = 0u; }
     __syncthreads();
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -327,14 +337,18 @@ k_order(GridDev g, const float *__restrict__ pose_src, const float *__restrict__
         const uint32_t it = (uint32_t)fminf(fmaxf((th - lo[2]) * inv_t, 0.0f), nth - 1.0f);
         return (it << (2 * ORD_XBITS)) | (iy << ORD_XBITS) | ix;
     };
-    for (int32_t i = tid; i < n; i += ORD_THREADS)
-        atomicAdd(&s_hist[key_of(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2])], 1u);
+#pragma unroll 4
+    for (int32_t i = tid; i < n; i += ORD_THREADS) {
+        const uint32_t key = key_of(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2]);
+        atomicAdd(&s_all[key], 1u);
+        if (i < slice * ORD_THREADS) atomicAdd(&s_before[key], 1u);   // (uniform per iteration: i / 1024 < slice)
+    }
     __syncthreads();
-    {   // exclusive prefix over the bins: thread t owns bins 4t .. 4t+3
+    {   // exclusive prefix over the buckets: thread t owns buckets 4t .. 4t+3
         constexpr int PER = ORD_BINS / ORD_THREADS;
         uint32_t c[PER], sum = 0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) { c[k] = s_hist[tid * PER + k]; sum += c[k]; }
+        for (int k = 0; k < PER; k++) { c[k] = s_all[tid * PER + k]; sum += c[k]; }
         uint32_t incl = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -346,12 +360,12 @@ k_order(GridDev g, const float *__restrict__ pose_src, const float *__restrict__
         uint32_t base = incl - sum;
         for (int w = 0; w < wave; w++) base += s_wsum[w];
 #pragma unroll
-        for (int k = 0; k < PER; k++) { s_hist[tid * PER + k] = base; base += c[k]; }
+        for (int k = 0; k < PER; k++) { s_all[tid * PER + k] = base; base += c[k]; }
     }
     __syncthreads();
-    for (int32_t i = tid; i < n; i += ORD_THREADS) {
-        const size_t gi = (size_t)mi * n + i;
-        const float x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1], th = src[3 * (size_t)i + 2];
+    if (own < n) {
+        const size_t gi = (size_t)mi * n + own;
+        const float x = src[3 * (size_t)own], y = src[3 * (size_t)own + 1], th = src[3 * (size_t)own + 2];
         float c, sn;
         if (pose_src) {
             pose_trig(th, c, sn);                                      // Transform.java:15-16
@@ -360,9 +374,10 @@ k_order(GridDev g, const float *__restrict__ pose_src, const float *__restrict__
         } else {
             c = cs[2 * gi]; sn = cs[2 * gi + 1];
         }
-        const uint32_t pos = atomicAdd(&s_hist[key_of(x, y, th)], 1u);
+        const uint32_t key = key_of(x, y, th);
+        const uint32_t pos = s_all[key] + s_before[key] + atomicAdd(&s_own[key], 1u);
         ord[(size_t)mi * n + pos] = make_float4(x, y, c, sn);
-        perm[(size_t)mi * n + pos] = i;
+        perm[(size_t)mi * n + pos] = own;
     }
 }
 
@@ -1265,15 +1280,15 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
     if (m->score_variant != 2) launch_compact(pf, d_beams, B, beam_stride);
     bool ordered = false;
     if (m->score_variant == 2) {
-        // The locality order (k_order) costs a launch of its own, ~6 us for 4096 particles per map, and takes a fifth to a
+        // The locality order (k_order) costs a launch of its own, ~8 us for 4096 particles per map, and takes a fifth to a
         // quarter off the scoring kernel: it pays once the scoring launch is several rounds of workgroups deep (C5: 6144
         // workgroups, 328 -> 247 us), not at 256 workgroups (C3: -3 us for +5.5).  Results are the same either way.
         const int64_t wgs = score_segments(m, B) * (((int64_t)pf->n + 1023) / 1024) * pf->n_maps;
         ordered = pf->order_mode > 0 || (pf->order_mode < 0 && wgs >= 2048 && pf->n <= 32768);
         if (ordered) {
             ProfScope po(m, GMS_K_ORDER);
-            hipLaunchKernelGGL(k_order, dim3(pf->n_maps), dim3(ORD_THREADS), 0, m->stream, m->gd, d_pose_src, pf->d_pose, pf->d_cs,
-                               pf->n, pf->d_ord, pf->d_perm, pf->d_pose, pf->d_cs);
+            hipLaunchKernelGGL(k_order, dim3(pf->n_maps, (unsigned)((pf->n + ORD_THREADS - 1) / ORD_THREADS)), dim3(ORD_THREADS), 0,
+                               m->stream, m->gd, d_pose_src, pf->d_pose, pf->d_cs, pf->n, pf->d_ord, pf->d_perm, pf->d_pose, pf->d_cs);
             d_pose_src = nullptr;                                     // stored by k_order
         }
     }
