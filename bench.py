@@ -462,6 +462,11 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
         "event_bracket_empty_kernel_us": meas["bracket_us"],
         "avg_launch_us_minus_bracket": net_s * 1e6, "frac_minus_bracket": alg / net_s / 1e9 / HBM_PEAK_GBS,
     }
+    if roof["traffic"] and roof["traffic"] < 0.5 * alg:
+        # the HBM peak is the yardstick the contract asks for, not what binds: most of the algorithmic bytes never leave the
+        # caches, so `frac` can pass 1 (C5 with the particles in locality order)
+        roof["note"] = ("%.0f %% of the algorithmic bytes reach the fabric (PMC): the working set is served by L2 / Infinity Cache, "
+                        "frac is algorithmic bytes over the HBM peak and may exceed 1" % (100.0 * roof["traffic"] / alg))
     if dom == "score":
         # what bounds this kernel (profiles/: the factor table is L2/Infinity-Cache resident, traffic is a fraction of the
         # algorithmic bytes; tools/microbench/gather_coalesce.hip: the address pipe takes ~48 clocks per 64-lane 8-byte
