@@ -278,7 +278,7 @@ k_score_b(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
 // Locality order of the particles for a large scoring launch.  The texture-address pipe serves an 8-byte gather of 64
 // lanes in ~48 clocks when every lane has a line of its own and in ~25 when NEIGHBOURING lanes share lines (it merges
 // adjacent lanes only: tools/microbench/gather_coalesce.hip), and the caller's particles come in no particular order.
-// The particles of a map are bucketed by (theta, y, x) -- 64 x 8 x 8 bins, theta-major, at least 0.5 degrees and 2 cells
+// The particles of a map are bucketed by (theta, y, x) -- 64 x 16 x 4 bins, theta-major, at least 0.5 degrees and one cell
 // wide, wider when the cloud is -- by a counting sort in LDS, and {x, y, cos, sin} and the particle index are stored in
 // bucket order: neighbouring lanes of k_score_c then hold neighbouring poses, whose beam end points fall into the same
 // cells' lines (C5: the scoring kernel 328 -> 250 us).  Which lane forms which particle's product does not enter the
@@ -291,9 +291,16 @@ k_score_b(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
 // what k_score_c / k_pose_trig do otherwise) is one per thread instead of n / 1024, and the work spreads over
 // n_maps x n / 1024 CUs (one workgroup per map: 15.6 us at C5, 5.3 of them trig on 64 CUs).
 // ---------------------------------------------------------------------------------------------
+// theta x y x x buckets and their smallest widths.  Measured at C5 (scoring kernel, us): 64 x 8 x 8 at >= 2 cells 250;
+// 64 x 16 x 4 at >= 2 cells 245; 64 x 16 x 4 at >= 1 cell 234 (kept); 64 x 64 x 1 236; 64 x 32 x 2 238; 128 x 16 x 2 239; 32 x 32 x 4 240;
+// 64 x 8 x 8 at >= 1 cell 249; >= 0.25 / 1 degree instead of 0.5: 239 / 241.  The table's rows run along x, and the pipe merges
+// neighbouring lanes on neighbouring ADDRESSES: fine buckets in y (same row), coarse in x (a run inside the row).
 #define ORD_TBITS 6
-#define ORD_XBITS 3
-#define ORD_BINS (1 << (ORD_TBITS + 2 * ORD_XBITS))
+#define ORD_YBITS 4
+#define ORD_XBITS 2
+#define ORD_MIN_CELLS 1.0f
+#define ORD_MIN_RAD 0.0087266463f
+#define ORD_BINS (1 << (ORD_TBITS + ORD_XBITS + ORD_YBITS))
 #define ORD_THREADS 1024
 __global__ void __launch_bounds__(ORD_THREADS)
 k_order(GridDev g, const float *__restrict__ pose_src, const float *__restrict__ pose, const float *__restrict__ cs, int32_t n,
@@ -328,14 +335,14 @@ k_order(GridDev g, const float *__restrict__ pose_src, const float *__restrict__
         lo[d] = s_lo[d][0]; hi[d] = s_hi[d][0];
         for (int w = 1; w < ORD_THREADS / 64; w++) { lo[d] = fminf(lo[d], s_lo[d][w]); hi[d] = fmaxf(hi[d], s_hi[d][w]); }
     }
-    const float nxy = (float)(1 << ORD_XBITS), nth = (float)(1 << ORD_TBITS);
-    const float inv_x = nxy / fmaxf(hi[0] - lo[0], nxy * 2.0f * g.resf), inv_y = nxy / fmaxf(hi[1] - lo[1], nxy * 2.0f * g.resf);
-    const float inv_t = nth / fmaxf(hi[2] - lo[2], nth * 0.0087266463f);
+    const float nx = (float)(1 << ORD_XBITS), ny = (float)(1 << ORD_YBITS), nth = (float)(1 << ORD_TBITS);
+    const float inv_x = nx / fmaxf(hi[0] - lo[0], nx * ORD_MIN_CELLS * g.resf), inv_y = ny / fmaxf(hi[1] - lo[1], ny * ORD_MIN_CELLS * g.resf);
+    const float inv_t = nth / fmaxf(hi[2] - lo[2], nth * ORD_MIN_RAD);
     auto key_of = [&](float x, float y, float th) -> uint32_t {
-        const uint32_t ix = (uint32_t)fminf(fmaxf((x - lo[0]) * inv_x, 0.0f), nxy - 1.0f);
-        const uint32_t iy = (uint32_t)fminf(fmaxf((y - lo[1]) * inv_y, 0.0f), nxy - 1.0f);
+        const uint32_t ix = (uint32_t)fminf(fmaxf((x - lo[0]) * inv_x, 0.0f), nx - 1.0f);
+        const uint32_t iy = (uint32_t)fminf(fmaxf((y - lo[1]) * inv_y, 0.0f), ny - 1.0f);
         const uint32_t it = (uint32_t)fminf(fmaxf((th - lo[2]) * inv_t, 0.0f), nth - 1.0f);
-        return (it << (2 * ORD_XBITS)) | (iy << ORD_XBITS) | ix;
+        return (it << (ORD_XBITS + ORD_YBITS)) | (iy << ORD_XBITS) | ix;
     };
 #pragma unroll 4
     for (int32_t i = tid; i < n; i += ORD_THREADS) {
