@@ -60,8 +60,7 @@ k_partials_apply(double *__restrict__ w, double *__restrict__ logw, const float 
     if (blockIdx.x < (uint32_t)nblk_global)
         partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y);
     else
-        apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - (uint32_t)nblk_global, blockIdx.y, gridDim.x - (uint32_t)nblk_global,
-                   gridDim.y > 1, threadIdx.x);
+        apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - (uint32_t)nblk_global, blockIdx.y, gridDim.x - (uint32_t)nblk_global);
 }
 
 // ---- sharded filters, one all-gather per scan (gms_slam_update_sharded_*) ---------------------------------------
@@ -76,7 +75,7 @@ k_partials_pack_apply(double *__restrict__ w, double *__restrict__ logw, const f
         partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, (uint32_t)(offset / GMS_BLOCK) + blockIdx.x, 0);
         pack_raw_block(w, pose, n, blockIdx.x, packed_local);         // each thread re-reads the weight it stored itself
     } else {
-        apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - n_local_blocks, 0, gridDim.x - n_local_blocks, false, threadIdx.x);
+        apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - n_local_blocks, 0, gridDim.x - n_local_blocks);
     }
 }
 

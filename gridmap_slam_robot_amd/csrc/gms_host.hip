@@ -870,8 +870,7 @@ int gms_pf_score(gms_pf *pf, const gms_beam *beams, int32_t B) {       // GridMa
 
 // poses := dev_xytheta (may be NULL: keep the current ones), then weights: one launch with the default scoring kernel.
 // refine: the poses are replaced by findBestPose's argmax first (SLAM.java:96-97), which takes launches of its own.
-static int set_poses_and_score_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, bool refine = false,
-                                   bool with_pending_apply = false) {
+static int set_poses_and_score_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, bool refine = false) {
     REQUIRE(pf && dev_beams, "null argument");
     gms_map *m = pf->map;
     REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
@@ -881,7 +880,7 @@ static int set_poses_and_score_dev(gms_pf *pf, const float *dev_xytheta, const g
         gms_launch_pf_refine(pf, dev_beams, B, B);                                // :96-97
         dev_xytheta = nullptr;
     }
-    gms_launch_pf_score(pf, dev_beams, B, B, dev_xytheta, with_pending_apply);
+    gms_launch_pf_score(pf, dev_beams, B, B, dev_xytheta);
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
@@ -1125,9 +1124,7 @@ int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *de
     if (pf->offset != 0 || pf->n_global != pf->n)
         return fail(GMS_ERR_STATE, "sharded filter: the collectives belong to the caller (see distributed.py)");
     int rc = GMS_OK;
-    // (a step that will pair its launches also hands the previous step's pending apply pass to the scoring launch)
-    const bool paired = integrate && (gms_can_pair_launches(pf, B) || (pf->n_maps > 1 && B > 0 && !m->need_full_build && m->pair_launches));
-    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B, pf->refine != 0, paired);   // SLAM.java:90, :96-97, :99
+    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B, pf->refine != 0);   // SLAM.java:90, :96-97, :99
     if (!rc && integrate && gms_can_pair_launches(pf, B)) {
         // The weight branch and the map branch are independent once the partials exist: they share launches
         // (gms_fused_kernels.hip).  (Two streams were measured: the event fork/join costs more than it hides.)
@@ -1429,7 +1426,7 @@ int gms_slam_update_sharded_begin_dev(gms_pf *pf, const float *dev_xytheta, cons
     REQUIRE(pf && dev_beams, "null argument");
     int rc = sharded_shape_ok(pf);
     if (rc) return rc;
-    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B, pf->refine != 0, true);   // SLAM.java:90, :96-97, :99 (+ the pending apply pass)
+    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B, pf->refine != 0);   // SLAM.java:90, :96-97, :99
     if (rc) return rc;
     gms_launch_partials_pack_apply(pf);                                          // :100-115 | previous scan's GridMap.java:223
     HIPCHK(hipGetLastError());

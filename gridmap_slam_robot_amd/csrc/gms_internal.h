@@ -220,7 +220,7 @@ void gms_launch_partials_pack_apply(gms_pf *pf);
 void gms_launch_raycast_norm_chunks(gms_pf *pf, const gms_beam *d_beams, int32_t B, bool raycast);
 void gms_launch_pf_fold_neff(gms_pf *pf);
 void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride,
-                         const float *d_pose_src = nullptr, bool with_pending_apply = false);   // d_pose_src: set the poses in the same launch
+                         const float *d_pose_src = nullptr);   // d_pose_src: set the poses in the same launch
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials);
 void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed);
 void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local, bool own);

@@ -425,21 +425,20 @@ __global__ void k_trace_ray(int32_t W, int32_t H, float x0, float y0, float x1, 
 #define APPLY_TH 4
 __device__ __forceinline__ void
 apply_body(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
-           int32_t *__restrict__ bbox_idle, uint32_t bx, uint32_t by, uint32_t gdx, bool lazy_log, uint32_t tid) {
-    // bx / gdx / tid: a 256-thread slice of the launch (the workgroup itself in k_apply and the 256-thread pairs; a quarter
-    // of a 1024-thread workgroup when the pass rides beside the scoring kernel).  No barriers in here.
+           int32_t *__restrict__ bbox_idle, uint32_t bx, uint32_t by, uint32_t gdx) {
     const int32_t mi = (int32_t)by;
-    if (bx == 0 && tid < 4) bbox_idle[4 * mi + tid] = 0;
+    if (bx == 0 && threadIdx.x < 4) bbox_idle[4 * mi + threadIdx.x] = 0;
     int32_t x0, y0, x1, y1;
     bbox_decode(bbox + 4 * mi, g.W, g.H, x0, y0, x1, y1);
     if (x1 <= 0) return;
     const int32_t qx0 = x0 / APPLY_TW, qy0 = y0 / APPLY_TH;
     const int32_t qnx = (x1 - 1) / APPLY_TW - qx0 + 1, qny = (y1 - 1) / APPLY_TH - qy0 + 1;
     const bool vec = (g.W & 3) == 0;
+    const bool lazy_log = gridDim.y > 1;                 // batched maps (uniform)
     for (int32_t t = (int32_t)bx; t < qnx * qny; t += (int32_t)gdx) {
         const int32_t tx0 = (qx0 + t % qnx) * APPLY_TW, ty0 = (qy0 + t / qnx) * APPLY_TH;
-        const int32_t y = ty0 + (int32_t)(tid >> 6);
-        const int32_t xb = tx0 + (int32_t)(tid & 63) * 4;
+        const int32_t y = ty0 + (threadIdx.x >> 6);
+        const int32_t xb = tx0 + (threadIdx.x & 63) * 4;
         if (y >= g.H || xb >= g.W) continue;
         const size_t o = (size_t)mi * g.cells + (size_t)y * g.W + xb;
         if (vec) {                                       // rows are 16-byte aligned: one 16-byte count load
@@ -473,7 +472,7 @@ apply_body(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ c
 __global__ void __launch_bounds__(256)
 k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
         int32_t *__restrict__ bbox_idle) {
-    apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y > 1 /* batched maps */, threadIdx.x);
+    apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------

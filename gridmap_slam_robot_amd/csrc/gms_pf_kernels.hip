@@ -405,19 +405,7 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
           int32_t B, int32_t beam_stride, const float *__restrict__ pose, const float *__restrict__ cs, int32_t n,
           int32_t nseg, double *__restrict__ part, double *__restrict__ w, double *__restrict__ logw,
           const float *__restrict__ pose_src, float *__restrict__ pose_dst, float *__restrict__ cs_dst,
-          const float4 *__restrict__ ord, const int32_t *__restrict__ perm,
-          uint32_t n_score_blocks, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
-          int32_t *__restrict__ bbox_idle) {
-    if (blockIdx.x >= n_score_blocks) {
-        // The PREVIOUS scan's `logData[c] += ...` (GridMap.java:223), left pending by a paired scan step, rides here (single
-        // maps): it touches logData and the counts, this kernel reads the factor table only.  Beside the block partials, the
-        // next launch, it costs that launch 2.1 us; here it costs 0.8 (C3, A/B on one box: 55.5 -> 54.9 us per step).
-        // Batched maps keep it beside the partials: 200 MB of boxes at C5 take 37 us out of this kernel's look-ups.
-        const uint32_t q = blockDim.x >> 8;                            // 256-thread slices per workgroup
-        apply_body(g, logd, cnt, bbox, bbox_idle, (blockIdx.x - n_score_blocks) * q + (threadIdx.x >> 8), blockIdx.z,
-                   (gridDim.x - n_score_blocks) * q, gridDim.z > 1, threadIdx.x & 255u);
-        return;
-    }
+          const float4 *__restrict__ ord, const int32_t *__restrict__ perm) {
     __shared__ double2 s_beam[128 + SCORE_U];        // this segment's beams with wasHit, in order
     __shared__ int32_t s_nb;
     // Workgroup -> (beam segment, particle group), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs
@@ -427,7 +415,7 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     const int32_t mi = blockIdx.z;
     int32_t seg, grp;
     {
-        const int32_t i = blockIdx.x, ngrp = (int32_t)n_score_blocks / nseg;
+        const int32_t i = blockIdx.x, ngrp = gridDim.x / nseg;
 #ifndef GMS_EXP_NO_XCD_ADJ
         if ((nseg & 7) == 0) {
             const int32_t spx = nseg >> 3, j = i >> 3;
@@ -1293,8 +1281,7 @@ static int64_t score_segments(const gms_map *m, int32_t B) {
     return nseg;
 }
 
-void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_pose_src,
-                         bool with_pending_apply) {
+void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_pose_src) {
     gms_map *m = pf->map;
     if (d_pose_src && m->score_variant != 2) { gms_launch_pf_pose_trig(pf, d_pose_src); d_pose_src = nullptr; }
     if (m->score_variant != 2) launch_compact(pf, d_beams, B, beam_stride);
@@ -1328,20 +1315,10 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
         // through its segment: 12 beams per segment (C2: 18.4 -> 8.4 us).  Either way a function of B only.
         // <= 128 beams per segment (the LDS beam table; also keeps a segment product >= 0.01^128, a normal double).
         const int64_t nseg = score_segments(m, B);
-        // a paired scan step hands its pending apply pass to this launch (see k_score_c); 256-thread slices of 1024-thread
-        // workgroups, as many slices as the pass runs workgroups elsewhere
-        uint32_t n_apply = 0;
-        if (with_pending_apply && m->apply_pending && threads == 1024 && pf->n_maps == 1) {
-            const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
-            n_apply = (uint32_t)((all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS) + 3) / 4;
-        }
-        int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4;
-        hipLaunchKernelGGL(k_score_c, dim3((unsigned)(nseg * groups) + n_apply, 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
+        hipLaunchKernelGGL(k_score_c, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
                            m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
                            pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pf->d_pose, pf->d_cs,
-                           ordered ? pf->d_ord : nullptr, ordered ? pf->d_perm : nullptr,
-                           (uint32_t)(nseg * groups), m->d_log, m->d_cnt, cur, idle);
-        if (n_apply) gms_apply_done(m);
+                           ordered ? pf->d_ord : nullptr, ordered ? pf->d_perm : nullptr);
         if (nseg > 1) pf->pending_nseg = (int32_t)nseg;               // combined by the next consumer of the weights
         return;
     }

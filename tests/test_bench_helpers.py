@@ -22,10 +22,7 @@ def test_algorithmic_bytes_follow_the_survey():
     assert b.algorithmic_bytes("likelihood", cells=2048 * 2048, full_rebuild=True, paired=False) == 16 * 2048 * 2048      # 64 MiB
     assert b.algorithmic_bytes("raycast", visits=1000, n_particles=256, paired=False) == 16 * 1000
     assert b.algorithmic_bytes("raycast", visits=1000, n_particles=256, paired=True) == 16 * 1000 + 16 * 256             # + normalise
-    # the previous scan's apply pass rides beside the scoring launch (single maps) or the block partials (batched maps)
-    assert b.algorithmic_bytes("reduce", visits=1000, n_particles=256, paired=True) == 16 * 256
-    assert b.algorithmic_bytes("score", visits=1000, n_particles=256, n_hit=10, n_beams=10, paired=True) == 8 * 256 * 10 + 20 * 256 + 17 * 10 + 16 * 1000
-    assert b.algorithmic_bytes("reduce", visits=1000, n_particles=256, paired=True, n_maps=2) == 2 * (16 * 256 + 16 * 1000)
+    assert b.algorithmic_bytes("reduce", visits=1000, n_particles=256, paired=True) == 16 * 256 + 16 * 1000              # + previous apply
     assert b.algorithmic_bytes("likelihood", dirty_cells=4096, n_particles=256, paired=True) == 16 * 4096 + 32 * 256     # + resample
     assert b.algorithmic_bytes("score", n_particles=4096, n_hit=1000, n_beams=1080, n_maps=64) == 64 * (8 * 4096 * 1000 + 20 * 4096 + 17 * 1080)
 
