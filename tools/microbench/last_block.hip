@@ -8,8 +8,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
-#define NSEG 16
+#ifndef NSEG
+#define NSEG 16      // -DNSEG=32 -DNGRP=1: the shape of a small filter (C2: 30 segment workgroups, one particle group)
+#endif
+#ifndef NGRP
 #define NGRP 16
+#endif
 #define N (NGRP * 1024)
 
 __device__ __forceinline__ double busy(double v, int iters) {
