@@ -13,7 +13,7 @@ from collections import defaultdict
 CLASS_OF = [("k_raycast_tile", "raycast"), ("k_raycast<false, 16>", "raycast"), ("k_score_c", "score"), ("k_score_b", "score"), ("k_score(", "score"), ("k_norm_raycast", "raycast"),
             ("k_raycast<false", "raycast"), ("k_lik_resample", "likelihood"), ("k_likelihood", "likelihood"),
             ("k_partials_apply", "reduce"), ("k_partials", "reduce"), ("k_normalize_pack", "reduce"), ("k_apply", "apply"),
-            ("k_chunk_sums", "resample"), ("k_resample", "resample"), ("k_pose_trig", "pose_trig")]
+            ("k_chunk_sums", "resample"), ("k_resample", "resample"), ("k_pose_trig", "pose_trig"), ("k_order", "order")]
 
 
 def per_kernel(d):
