@@ -121,8 +121,12 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
                const double *__restrict__ chunk_off, const double *__restrict__ r01_maps, double r01, double fraction,
                int32_t n, int64_t offset,
                float *__restrict__ pose2, float *__restrict__ cs2, double *__restrict__ w2, int32_t *__restrict__ idx_out,
-               const double *__restrict__ p2, int64_t nblk_global, PfStatsDev *__restrict__ stats, int32_t raw_weights) {
+               const double *__restrict__ p2, int64_t nblk_global, PfStatsDev *__restrict__ stats, int32_t raw_weights,
+               int32_t *__restrict__ bbox_clear) {
     extern __shared__ __align__(16) unsigned char smem[];
+    // the box half the next ray cast will raise: cleared here because that ray cast may share its launch with this scan's
+    // deferred apply pass (k_raycast_apply), which otherwise does the clearing
+    if (blockIdx.x == 0 && threadIdx.x < 4) bbox_clear[4 * blockIdx.y + threadIdx.x] = 0;
     if (blockIdx.x < n_res_blocks)                      // a multiple of 8 keeps the likelihood tiles' XCD round-robin aligned
         resample_body(glob, n_global, nchunks, cum, chunk_off, r01_maps, r01, fraction, n, offset, pose2, cs2, w2, idx_out, p2,
                       nblk_global, stats, blockIdx.x, blockIdx.y, smem, raw_weights != 0);
@@ -170,7 +174,7 @@ void gms_launch_partials_apply(gms_pf *pf, double *d_partials) {
     hipLaunchKernelGGL(k_partials_apply, dim3((uint32_t)nblk + n_apply, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw,
                        pf->d_pose, pf->n, pf->offset, nblk, d_partials,
                        pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg, m->gd, m->d_log,
-                       m->d_cnt, cur, idle);
+                       m->d_cnt_pend, cur, idle);
     pf->pending_nseg = 0;
     gms_apply_done(m);
 }
@@ -203,7 +207,7 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
                            m->d_lik, m->d_fac, m->fac_stride, m->d_taps, bb, tiles_x, tiles_y, m->d_cnt, m->d_tile_state, n_res, pf->d_global, \
                            pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, r01_maps, pf->r01_scalar, fraction, pf->n, pf->offset, \
                            pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats,       \
-                           pf->global_raw);                                                                              \
+                           pf->global_raw, m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4);                       \
     } while (0)
     if (k == 3) LR_LAUNCH(3);
     else if (k == 5) LR_LAUNCH(5);
@@ -228,7 +232,7 @@ void gms_launch_partials_pack_apply(gms_pf *pf) {
     hipLaunchKernelGGL(k_partials_pack_apply, dim3(n_local + n_apply), dim3(256), 0, m->stream, pf->d_w, pf->d_logw, pf->d_pose,
                        pf->n, pf->offset, nblk_global_of(pf), pf->d_partials,
                        pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg,
-                       pf->d_global_own + pf->offset, n_local, m->gd, m->d_log, m->d_cnt, cur, idle);
+                       pf->d_global_own + pf->offset, n_local, m->gd, m->d_log, m->d_cnt_pend, cur, idle);
     pf->pending_nseg = 0;
     if (n_apply) gms_apply_done(m);
 }

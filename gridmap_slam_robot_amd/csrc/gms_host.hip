@@ -223,7 +223,7 @@ static int map_free(gms_map *m) {
     if (!m) return GMS_OK;
     prof_drain(m);
     for (ProfSlot &s : m->prof_free) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
-    hipFree(m->d_log); hipFree(m->d_lik); hipFree(m->d_fac); hipFree(m->d_cnt); hipFree(m->d_bbox); hipFree(m->d_taps); hipFree(m->d_tile_state);
+    hipFree(m->d_log); hipFree(m->d_lik); hipFree(m->d_fac); hipFree(m->d_cnt); hipFree(m->d_cnt_pend); hipFree(m->d_bbox); hipFree(m->d_taps); hipFree(m->d_tile_state);
     hipFree(m->d_beams); hipFree(m->d_poses); hipFree(m->d_scratch);
     hipFree(m->d_trace_cells); hipFree(m->d_trace_cls); hipFree(m->d_trace_cnt);
     if (m->h_beams) hipHostFree(m->h_beams);
@@ -287,7 +287,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     g.fneutral = (uint32_t)H * (uint32_t)g.fpitch + (uint32_t)W;
     m->fac_stride = (int64_t)(H + 1) * g.fpitch;
     ok = ok && hipMalloc(&m->d_fac, (size_t)m->fac_stride * m->n_maps * sizeof(double)) == hipSuccess;
-    ok = ok && hipMalloc(&m->d_cnt, cells * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_cnt, cells * sizeof(uint32_t)) == hipSuccess && hipMalloc(&m->d_cnt_pend, cells * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_bbox, (size_t)m->n_maps * 8 * sizeof(int32_t)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_taps, GMS_MAX_TAPS * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_tile_state, (size_t)((g.W + 63) / 64) * ((g.H + 31) / 32) * m->n_maps) == hipSuccess;
@@ -302,6 +302,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     hipMemsetAsync(m->d_log, 0, cells * sizeof(double), m->stream);   // logOdds(0.5) == 0.0 (createMapData(null))
     hipMemsetAsync(m->d_lik, 0, cells * sizeof(double), m->stream);
     hipMemsetAsync(m->d_cnt, 0, cells * sizeof(uint32_t), m->stream);
+    hipMemsetAsync(m->d_cnt_pend, 0, cells * sizeof(uint32_t), m->stream);
     hipMemsetAsync(m->d_bbox, 0, (size_t)m->n_maps * 8 * sizeof(int32_t), m->stream);
     gms_launch_factors(m);        // likelihoodData == 0 everywhere (createMapData(null))
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -665,7 +666,28 @@ int gms_map_build_likelihood(gms_map *m) {                              // GridM
     return finish_likelihood(m, 0);
 }
 
+// integrateObservation + computeLikelihoodMap with the scan's apply pass deferred: [ray cast | the previous scan's apply pass]
+// -> dirty-tile likelihood rebuild with the new counts added on the fly.  Two launches per scan instead of three; the map
+// comes out bit-identical (tests/test_gpu_parity.py, test_gpu_closed_loop.py); anything else that touches the map first
+// runs the pending pass (gms_flush_apply).  Single maps in the steady state (a field to rebuild incrementally exists).
+static bool can_defer_update(const gms_map *m, int32_t B) {
+    return m->pair_launches && m->n_maps == 1 && B > 0 && B <= 4096 && !m->need_full_build;
+}
+static int deferred_update(gms_map *m, const gms_beam *dev_beams, int32_t B, int32_t beam_stride, const float *dev_poses, int32_t pose_stride) {
+    if (m->apply_pending) gms_launch_raycast_apply(m, dev_beams, B, beam_stride, dev_poses, pose_stride);
+    else gms_launch_raycast(m, dev_beams, B, beam_stride, dev_poses, pose_stride);
+    gms_launch_likelihood(m, 1, true);
+    gms_defer_apply(m);
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
 int gms_map_update(gms_map *m, const gms_beam *beams, int32_t B, const float *poses) {
+    if (m && can_defer_update(m, B)) {
+        int rc = stage_beams(m, beams, B);
+        if (!rc) rc = stage_poses(m, poses);
+        return rc ? rc : deferred_update(m, m->d_beams, B, m->max_beams, m->d_poses, 3);
+    }
     int rc = gms_map_integrate(m, beams, B, poses);
     if (rc) return rc;
     return finish_likelihood(m, m->need_full_build ? 0 : 1);
@@ -678,12 +700,25 @@ int gms_map_update_at(gms_map *m, const gms_beam *beams, int32_t B, gms_pf *pf, 
 }
 
 int gms_map_update_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, const float *dev_poses) {
+    REQUIRE(m && dev_beams && dev_poses, "null argument");
+    REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
+    if (can_defer_update(m, B)) {
+        HIPCHK(hipSetDevice(m->device));
+        return deferred_update(m, dev_beams, B, B, dev_poses, 3);
+    }
     int rc = gms_map_integrate_dev(m, dev_beams, B, dev_poses);
     if (rc) return rc;
     return finish_likelihood(m, m->need_full_build ? 0 : 1);
 }
 
 int gms_map_update_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, gms_pf *pf, int32_t which) {
+    REQUIRE(m && dev_beams && pf && pf->map == m, "gms_map_update_at_dev: bad arguments");
+    REQUIRE(which == 0 || which == 1, "which must be 0 (weighted pose) or 1 (strongest particle)");
+    REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
+    if (can_defer_update(m, B)) {
+        HIPCHK(hipSetDevice(m->device));
+        return deferred_update(m, dev_beams, B, B, stats_pose_ptr(pf, which), (int32_t)(sizeof(PfStatsDev) / sizeof(float)));
+    }
     int rc = gms_map_integrate_at_dev(m, dev_beams, B, pf, which);
     if (rc) return rc;
     return finish_likelihood(m, m->need_full_build ? 0 : 1);
@@ -1104,8 +1139,7 @@ static int paired_likelihood_resample(gms_pf *pf, const double *r01, double frac
         std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);
         pf->have_global = 0;
         pf->stats_current = 0;
-        m->apply_pending = 1;
-        m->bbox_dirty = 0;
+        gms_defer_apply(m);
     } else {                                // no resample to pair with: the immediate protocol
         gms_launch_apply_counts(m);
         return finish_likelihood(m, 1);

@@ -93,7 +93,9 @@ struct gms_map {
     double *d_fac;        // [n_maps][fac_stride]: per-cell scoring factor f(likelihood) (GridMap.java:285-288), rows of g.fpitch entries with a neutral border (fac_index),
                           // kept in step with d_lik; entry [cells] of each map is the neutral factor 1.0
     int64_t fac_stride;   // (H + 1) * fpitch
-    uint32_t *d_cnt;      // [n_maps][H][W] per-scan packed counts, zero between calls
+    uint32_t *d_cnt;      // [n_maps][H][W] per-scan packed counts (n_free | n_occ << 16): the grid the NEXT ray cast accumulates into, all zero between scans
+    uint32_t *d_cnt_pend; // the second grid: while apply_pending, the counts of the scan whose apply pass is deferred (the two swap roles
+                          // when a scan's apply is deferred, so that the next ray cast can share a launch with that apply pass)
     int32_t *d_bbox;      // [2][n_maps][4] encoded box of the cells changed since the last likelihood build;
                           // double-buffered: k_apply clears the idle half, so no memset is ever queued
     int32_t bbox_cur;     // half in use
@@ -190,7 +192,9 @@ void gms_launch_trace_ray(gms_map *m, float x0, float y0, float x1, float y1, in
                           int32_t *d_cells, int32_t cap, int32_t *d_count);
 void gms_launch_apply_ray(gms_map *m, RayIn ray);
 void gms_launch_apply_counts(gms_map *m);
-void gms_launch_likelihood(gms_map *m, int32_t dirty_only);
+void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending = false);
+void gms_launch_raycast_apply(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses, int32_t pose_stride);
+void gms_defer_apply(gms_map *m);       // host bookkeeping: the scan just cast keeps its counts until a later launch applies them
 void gms_launch_fill(gms_map *m, double *d, double v, int64_t n);
 void gms_launch_combine(gms_map *src, gms_map *dst);
 void gms_launch_deskew(gms_map *m, const double *d_angle, const double *d_distance, const uint8_t *d_hit, int32_t length,

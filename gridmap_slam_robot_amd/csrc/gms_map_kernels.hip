@@ -427,7 +427,7 @@ __device__ __forceinline__ void
 apply_body(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
            int32_t *__restrict__ bbox_idle, uint32_t bx, uint32_t by, uint32_t gdx) {
     const int32_t mi = (int32_t)by;
-    if (bx == 0 && threadIdx.x < 4) bbox_idle[4 * mi + threadIdx.x] = 0;
+    if (bbox_idle && bx == 0 && threadIdx.x < 4) bbox_idle[4 * mi + threadIdx.x] = 0;     // (nullptr: the other half is in use, see k_raycast_apply)
     int32_t x0, y0, x1, y1;
     bbox_decode(bbox + 4 * mi, g.W, g.H, x0, y0, x1, y1);
     if (x1 <= 0) return;
@@ -733,10 +733,30 @@ template <int KH>
 __global__ void __launch_bounds__(256)
 k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
              int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
-             int32_t tiles_x, int32_t tiles_y, uint8_t *__restrict__ tile_state) {
+             int32_t tiles_x, int32_t tiles_y, uint8_t *__restrict__ tile_state, const uint32_t *__restrict__ cnt_pending,
+             int32_t *__restrict__ bbox_clear) {
     extern __shared__ __align__(16) unsigned char smem[];
+    // bbox_clear: the box half the NEXT ray cast will raise (it shares its launch with this scan's deferred apply pass,
+    // which therefore cannot clear it: k_raycast_apply); nobody reads it during this launch
+    if (bbox_clear && blockIdx.x == 0 && threadIdx.x < 4) bbox_clear[4 * blockIdx.y + threadIdx.x] = 0;
     likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, dirty_only, tiles_x, tiles_y, blockIdx.x, blockIdx.y,
-                        gridDim.x, smem, nullptr, tile_state);
+                        gridDim.x, smem, cnt_pending, tile_state);
+}
+
+// The stand-alone map update (GridMap.integrateObservation + computeLikelihoodMap as an entry point of its own) in two
+// launches instead of three: this scan's ray cast (into the idle count grid and the idle box half) beside the PREVIOUS
+// scan's `logData[c] += ...` (GridMap.java:223, from the other count grid); the likelihood pass that follows adds this
+// scan's counts on the fly, as it does in the paired scan step.  grid.x = ray blocks + apply blocks, one map.
+__global__ void __launch_bounds__(256)
+k_raycast_apply(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride, const float *__restrict__ poses,
+                int32_t pose_stride, uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox_next, int32_t nw_max, uint32_t n_ray_blocks,
+                double *__restrict__ logd, uint32_t *__restrict__ cnt_pend, const int32_t *__restrict__ bbox_pend) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x < n_ray_blocks)
+        raycast_body<false, 4>(g, beams, B, beam_stride, poses, pose_stride, nullptr, cnt, bbox_next, nullptr, nullptr, 0, nullptr, nw_max,
+                               blockIdx.x, 0, smem, nullptr);
+    else
+        apply_body(g, logd, cnt_pend, bbox_pend, nullptr, blockIdx.x - n_ray_blocks, 0, gridDim.x - n_ray_blocks);
 }
 
 // scoring factors from an existing likelihood field (upload / copy), and the table's neutral border (fac_index)
@@ -873,12 +893,34 @@ static void apply_launch(gms_map *m) {
     const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
     dim3 grid(all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS, m->n_maps);
     int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4;
-    hipLaunchKernelGGL(k_apply, grid, dim3(256), 0, m->stream, m->gd, m->d_log, m->d_cnt, cur, idle);
+    // a deferred pass applies the grid that was set aside (gms_defer_apply); the immediate one the grid just cast into
+    hipLaunchKernelGGL(k_apply, grid, dim3(256), 0, m->stream, m->gd, m->d_log, m->apply_pending ? m->d_cnt_pend : m->d_cnt, cur, idle);
 }
 void gms_apply_done(gms_map *m) {          // host bookkeeping after a deferred apply pass has been enqueued
     m->bbox_cur = 1 - m->bbox_cur;
     m->bbox_dirty = 0;
     m->apply_pending = 0;
+}
+void gms_defer_apply(gms_map *m) {         // the scan just cast (and already in the likelihood field) keeps its counts for a later launch
+    uint32_t *t = m->d_cnt; m->d_cnt = m->d_cnt_pend; m->d_cnt_pend = t;       // the other grid is all zero: the next ray cast's
+    m->apply_pending = 1;
+    m->bbox_dirty = 0;
+}
+
+// this scan's ray cast beside the previous scan's deferred apply pass (k_raycast_apply); single maps, scans of <= 4096 beams
+void gms_launch_raycast_apply(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
+                              int32_t pose_stride) {
+    ProfScope ps(m, GMS_K_RAYCAST);
+    const uint32_t n_ray = (uint32_t)((B + 3) / 4);
+    const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
+    const uint32_t n_apply = (uint32_t)(all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS);
+    int32_t *pend = m->d_bbox + (size_t)m->bbox_cur * 4, *next = m->d_bbox + (size_t)(1 - m->bbox_cur) * 4;
+    const size_t smem = rc_smem(m, 4);
+    if (smem > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k_raycast_apply, dim3(n_ray + n_apply), dim3(256), smem, m->stream, m->gd, d_beams, B, beam_stride, d_poses,
+                       pose_stride, m->d_cnt, next, rc_nw_max(m), n_ray, m->d_log, m->d_cnt_pend, pend);
+    gms_apply_done(m);                      // the box of the scan just cast is the current half now
 }
 void gms_flush_apply(gms_map *m) {
     if (!m->apply_pending) return;
@@ -893,8 +935,10 @@ void gms_launch_apply_counts(gms_map *m) {
     m->bbox_dirty = 1;
 }
 
-void gms_launch_likelihood(gms_map *m, int32_t dirty_only) {
-    gms_flush_apply(m);
+void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending) {
+    // counts_pending: the scan just cast is not in logData yet; its counts (m->d_cnt) are added on the fly and its apply pass
+    // is deferred by the caller (gms_defer_apply); the other box half is cleared for the next ray cast
+    if (!counts_pending) gms_flush_apply(m);
     ProfScope ps(m, GMS_K_LIKELIHOOD);
     const int32_t k = m->gd.khalf;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
@@ -908,13 +952,15 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only) {
     blocks = (blocks + 7) & ~7;                      // keep the XCD round-robin aligned
     dim3 grid(blocks, m->n_maps);
     const int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;
+    const uint32_t *pend = counts_pending ? m->d_cnt : (const uint32_t *)nullptr;
+    int32_t *bb_clear = counts_pending ? m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4 : (int32_t *)nullptr;
 #define LK_LAUNCH(KH)                                                                                         \
     do {                                                                                                      \
         if (smem > 48 * 1024)                                                                                 \
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_likelihood<KH>),                           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                       \
         hipLaunchKernelGGL(k_likelihood<KH>, grid, dim3(256), smem, m->stream, m->gd, m->d_log, m->d_lik,     \
-                           m->d_fac, m->fac_stride, m->d_taps, bb, dirty_only, tiles_x, tiles_y, m->d_tile_state);                                      \
+                           m->d_fac, m->fac_stride, m->d_taps, bb, dirty_only, tiles_x, tiles_y, m->d_tile_state, pend, bb_clear);                      \
     } while (0)
     if (k == 3) LK_LAUNCH(3);
     else if (k == 5) LK_LAUNCH(5);

@@ -1,0 +1,100 @@
+"""The stand-alone map update defers a scan's apply pass to the next scan's ray-cast launch (two launches per scan instead
+of three: gms_map_update*, k_raycast_apply).  Whatever is called in between has to find the map as the immediate protocol
+(GMS_PAIR_LAUNCHES=0: ray cast, apply, likelihood, one launch each) would have left it: random interleavings of every
+map entry point on twin maps, compared bit for bit, and against the oracle at the end."""
+import os
+
+import numpy as np
+import pytest
+
+from gridmap_slam_robot_amd import GridMap, Observation, ParticleFilter, synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def twin_maps(monkeypatch, ext, res):
+    monkeypatch.delenv("GMS_PAIR_LAUNCHES", raising=False)
+    a = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    monkeypatch.setenv("GMS_PAIR_LAUNCHES", "0")              # read when a map is created
+    b = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    monkeypatch.delenv("GMS_PAIR_LAUNCHES", raising=False)
+    return a, b
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GMS_FUZZ_SEEDS", "6"))))
+def test_random_interleavings_equal_the_immediate_protocol(monkeypatch, seed):
+    import torch
+    rng = np.random.default_rng(400 + seed)
+    ext, res, B = 12.8, 0.05, int(rng.integers(20, 300))
+    tr = synth.make_trace(ext, res, B, T=40, seed=seed, n_scans=40)
+    a, b = twin_maps(monkeypatch, ext, res)
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    log = g.new_log()
+    pa, pb = ParticleFilter(a, 700), ParticleFilter(b, 700)
+    dev = torch.device("cuda", 0)
+    deferred_calls = 0
+    for t in range(36):
+        scan, pose = tr.scans[t], tr.poses[t]
+        op = rng.choice(["update", "update", "update", "update_dev", "integrate", "ray", "likelihood", "download", "slam", "update_at", "copy"])
+        if op == "update":
+            a.update(scan, pose); b.update(scan, pose); g.integrate(log, scan, pose); deferred_calls += 1
+        elif op == "update_dev":
+            bd = torch.from_numpy(scan.view(np.uint8).copy()).to(dev)
+            pd = torch.from_numpy(np.asarray(pose, dtype=np.float32).copy()).to(dev)
+            a.update_dev(bd.data_ptr(), len(scan), pd.data_ptr()); b.update_dev(bd.data_ptr(), len(scan), pd.data_ptr())
+            torch.cuda.synchronize()
+            g.integrate(log, scan, pose); deferred_calls += 1
+        elif op == "integrate":                                # integrateObservation alone: the field is rebuilt by a later call
+            a.integrate_observation(scan, pose); b.integrate_observation(scan, pose); g.integrate(log, scan, pose)
+        elif op == "ray":                                      # applyMeasurement on a single ray (GridMap.java:193-231)
+            args = (10.5, 20.25, float(rng.uniform(5, 200)), float(rng.uniform(5, 200)), float(rng.uniform(0.5, 6.0)), bool(rng.integers(2)))
+            a.apply_measurement(*args); b.apply_measurement(*args); g.apply_measurement(log, *args)
+        elif op == "likelihood":
+            a.compute_likelihood_map(); b.compute_likelihood_map()
+        elif op == "download":
+            assert np.array_equal(a.download_log(), b.download_log())
+        elif op == "slam":                                     # a fused scan step: its own deferred apply pass meets the map's
+            P = synth.make_particles(pose, 700, seed=t, sigma_xy=0.03, sigma_theta_deg=1.0)
+            r01 = float(rng.random())
+            pa.slam_update(P, scan, r01, 0.5); pb.slam_update(P, scan, r01, 0.5)
+            wp = pa.last_step()["weighted_pose"]
+            assert np.array_equal(wp, pb.last_step()["weighted_pose"], equal_nan=True)      # (NaN when every weight underflowed: an empty map)
+            g.integrate(log, scan, wp)
+        elif op == "update_at":
+            P = synth.make_particles(pose, 700, seed=t, sigma_xy=0.03, sigma_theta_deg=1.0)
+            for m_, p_ in ((a, pa), (b, pb)):
+                p_.set_poses(P); p_.score(scan); p_.normalize(); m_.update_at(scan, p_)
+            g.integrate(log, scan, pa.weighted_pose())
+        elif op == "copy":
+            c = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+            c.copy_from(a)                                      # createMapData(other)
+            assert np.array_equal(c.download_log(), b.download_log())
+            c.close()
+        if t % 5 == 4:
+            assert np.array_equal(a.download_likelihood(), b.download_likelihood())      # (stale alike after integrate-only calls)
+    assert deferred_calls >= 5
+    a.compute_likelihood_map(); b.compute_likelihood_map()
+    got = a.download_log().reshape(-1)
+    assert np.array_equal(got, b.download_log().reshape(-1))
+    assert np.array_equal(a.download_likelihood(), b.download_likelihood())
+    assert np.array_equal(got != 0, log != 0)
+    nz = log != 0
+    assert np.max(np.abs(got[nz] - log[nz]) / np.abs(log[nz])) <= 1e-12
+    assert np.array_equal(a.download_likelihood().reshape(-1), g.build_likelihood(got))
+    for x in (pa, pb, a, b):
+        x.close()
+
+
+def test_update_costs_two_launches_in_the_steady_state(monkeypatch):
+    tr = synth.make_trace(12.8, 0.05, 180, T=12, seed=1, n_scans=12)
+    a, b = twin_maps(monkeypatch, 12.8, 0.05)
+    for m, want_apply in ((a, 0), (b, 6)):
+        m.update(tr.scans[0], tr.poses[0]); m.update(tr.scans[1], tr.poses[1])      # the first call builds the whole field
+        m.profile_reset(); m.profile(True)
+        for t in range(2, 8):
+            m.update(tr.scans[t], tr.poses[t])
+        prof = m.profile_get(); m.profile(False)
+        assert prof["raycast"][1] == 6 and prof["likelihood"][1] == 6 and prof["apply"][1] == want_apply
+    assert np.array_equal(a.download_log(), b.download_log()) and np.array_equal(a.download_likelihood(), b.download_likelihood())
+    a.close(); b.close()
