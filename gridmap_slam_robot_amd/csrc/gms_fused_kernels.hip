@@ -27,8 +27,17 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
                int32_t nw_max, uint32_t n_ray_blocks,
                const double *__restrict__ partials, int64_t nblk_global, double *__restrict__ w, const float *__restrict__ pose,
                int32_t n, int64_t offset, PackedParticle *__restrict__ packed, double *__restrict__ cum,
-               double *__restrict__ chunk_tot, int64_t nchunks, double *__restrict__ p2, PfStatsDev *__restrict__ stats) {
+               double *__restrict__ chunk_tot, int64_t nchunks, double *__restrict__ p2, PfStatsDev *__restrict__ stats,
+               uint32_t n_norm_blocks, double *__restrict__ logd, uint32_t *__restrict__ cnt_pend, const int32_t *__restrict__ bbox_pend) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x >= n_ray_blocks + n_norm_blocks) {
+        // The PREVIOUS scan's `logData[c] += ...` (GridMap.java:223) from the other count grid: it needs nothing of this launch
+        // and only has to be done before this scan's likelihood pass.  Its ~5 us hide under the ray cast's 17 us latency chain
+        // on CUs that launch leaves idle (beside the block partials, round 1's place, it cost that launch 2.3 us).
+        apply_body(g, logd, cnt_pend, bbox_pend, nullptr, blockIdx.x - n_ray_blocks - n_norm_blocks, 0,
+                   gridDim.x - n_ray_blocks - n_norm_blocks);
+        return;
+    }
     if (blockIdx.x < n_ray_blocks) {
         __shared__ RedLds L;
         __shared__ float s_pose[3];
@@ -151,21 +160,34 @@ void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticl
     if (own) { pf->d_global = pf->d_global_own; pf->global_raw = 0; }     // normalised weights are packed (as apply_partials does)
     const uint32_t n_ray = (uint32_t)((B + RCF_RAYS - 1) / RCF_RAYS), n_norm = (uint32_t)((pf->n + 255) / 256);
     const size_t smem = rc_smem(m, RCF_RAYS);
-    int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * 4;
+    // a deferred apply pass rides along: the ray cast then raises the OTHER box half (cleared by the previous likelihood launch)
+    // while the pass reads the pending scan's half; afterwards that other half is the current one (gms_apply_done)
+    uint32_t n_apply = 0;
+    if (m->apply_pending) {
+        const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
+#ifndef GMS_APPLY_BLOCKS_RIDING
+#define GMS_APPLY_BLOCKS_RIDING 512
+#endif
+        n_apply = (uint32_t)(all < GMS_APPLY_BLOCKS_RIDING ? all : GMS_APPLY_BLOCKS_RIDING);
+    }
+    int32_t *pend = m->d_bbox + (size_t)m->bbox_cur * 4;
+    int32_t *bb = n_apply ? m->d_bbox + (size_t)(1 - m->bbox_cur) * 4 : pend;
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_norm_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k_norm_raycast, dim3(n_ray + n_norm), dim3(256), smem, m->stream, m->gd, d_beams, B, m->d_cnt, bb,
+    hipLaunchKernelGGL(k_norm_raycast, dim3(n_ray + n_norm + n_apply), dim3(256), smem, m->stream, m->gd, d_beams, B, m->d_cnt, bb,
                        rc_nw_max(m), n_ray, d_partials, nblk_global_of(pf), pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local,
                        own ? pf->d_cum : (double *)nullptr, own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf),
-                       own ? pf->d_p2 : (double *)nullptr, pf->d_stats);
+                       own ? pf->d_p2 : (double *)nullptr, pf->d_stats, n_norm, m->d_log, m->d_cnt_pend, pend);
+    if (n_apply) gms_apply_done(m);
     pf->chunks_ready = own ? 1 : 0;
     pf->neff_folded = 0;
 }
 
 // block partials (SLAM.java:100-115) beside the apply pass the previous paired step left pending
-void gms_launch_partials_apply(gms_pf *pf, double *d_partials) {
+void gms_launch_partials_apply(gms_pf *pf, double *d_partials, bool apply_rides_later) {
     gms_map *m = pf->map;
-    if (!m->apply_pending) { gms_launch_pf_partials(pf, d_partials); return; }
+    // apply_rides_later: the caller's next launch is gms_launch_norm_raycast, which takes the pending pass along (single maps)
+    if (!m->apply_pending || apply_rides_later) { gms_launch_pf_partials(pf, d_partials); return; }
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
     const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);

@@ -1163,8 +1163,8 @@ int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *de
         // The weight branch and the map branch are independent once the partials exist: they share launches
         // (gms_fused_kernels.hip).  (Two streams were measured: the event fork/join costs more than it hides.)
         pf->d_global = pf->d_global_own;
-        gms_launch_partials_apply(pf, pf->d_partials);                                    // :100-115 | previous scan's :223
-        gms_launch_norm_raycast(pf, pf->d_partials, pf->d_global, true, dev_beams, B);    // :120-124 | :93
+        gms_launch_partials_apply(pf, pf->d_partials, true);                              // :100-115
+        gms_launch_norm_raycast(pf, pf->d_partials, pf->d_global, true, dev_beams, B);    // :120-124 | :93 | previous scan's :223
         pf->have_global = 1;
         pf->stats_current = 1;
         return paired_likelihood_resample(pf, r01, resample_fraction);           // :105 | GridMapApp.java:185-186

@@ -215,7 +215,7 @@ void gms_launch_pf_chunk_sums(gms_pf *pf);
 // paired launches (gms_fused_kernels.hip)
 void gms_flush_apply(gms_map *m);
 void gms_apply_done(gms_map *m);
-void gms_launch_partials_apply(gms_pf *pf, double *d_partials);
+void gms_launch_partials_apply(gms_pf *pf, double *d_partials, bool apply_rides_later = false);
 bool gms_can_pair_launches(const gms_pf *pf, int32_t B);
 void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local, bool own,
                              const gms_beam *d_beams, int32_t B);
