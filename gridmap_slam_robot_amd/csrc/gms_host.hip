@@ -1173,11 +1173,12 @@ int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *de
         // batched maps: the ray cast runs 16 rays per workgroup (1024 threads), so only the other two pairs apply:
         // [partials | previous apply] -> normalise -> ray cast -> [likelihood | resample]
         pf->d_global = pf->d_global_own;
-        gms_launch_partials_apply(pf, pf->d_partials);
+        const bool ride = (int64_t)B * m->n_maps > 4096 && m->raycast_tile;     // the tiled ray cast takes the pending apply pass along
+        gms_launch_partials_apply(pf, pf->d_partials, ride);
         gms_launch_pf_apply_partials(pf, pf->d_partials, pf->d_global, true);
         pf->have_global = 1;
         pf->stats_current = 1;
-        gms_launch_raycast(m, dev_beams, B, B, stats_pose_ptr(pf, 0), (int32_t)(sizeof(PfStatsDev) / sizeof(float)));
+        gms_launch_raycast(m, dev_beams, B, B, stats_pose_ptr(pf, 0), (int32_t)(sizeof(PfStatsDev) / sizeof(float)), ride);
         return paired_likelihood_resample(pf, r01, resample_fraction);
     }
     if (!rc) rc = gms_pf_normalize(pf, nullptr);                                 // :100-124

@@ -185,7 +185,7 @@ struct gms_comm {
 // ---- kernel launchers (gms_map_kernels.hip / gms_pf_kernels.hip) -----------------------------
 
 void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
-                        int32_t pose_stride);
+                        int32_t pose_stride, bool take_pending_apply = false);
 void gms_launch_trace_scan(gms_map *m, const gms_beam *d_beams, int32_t B, const float *d_pose,
                            int32_t *d_cells, uint8_t *d_cls, int32_t cap, int32_t *d_counts);
 void gms_launch_trace_ray(gms_map *m, float x0, float y0, float x1, float y1, int32_t extra,

@@ -305,10 +305,20 @@ k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam
 #define RCT_TILE_CELLS 32768            // 64 KiB of 16-bit cells
 #define RCT_LDS_BYTES (RCT_WORDS * RCT_RAYS * 8 + RCT_TILE_CELLS * 2)
 
+__device__ void apply_slices(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
+                             uint32_t first_block);
+
 __global__ void __launch_bounds__(RCT_THREADS)
 k_raycast_tile(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride, const float *__restrict__ poses,
-               int32_t pose_stride, uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox) {
+               int32_t pose_stride, uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox, uint32_t n_ray_blocks,
+               double *__restrict__ logd, uint32_t *__restrict__ cnt_pend, const int32_t *__restrict__ bbox_pend) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x >= n_ray_blocks) {
+        // the PREVIOUS scan's deferred `logData[c] += ...` (GridMap.java:223), from the other count grid, as four 256-thread
+        // slices per workgroup: bandwidth-bound work beside this kernel's LDS-bound work (defined below this kernel)
+        apply_slices(g, logd, cnt_pend, bbox_pend, n_ray_blocks);
+        return;
+    }
     uint64_t *s_slots = reinterpret_cast<uint64_t *>(smem);            // [RCT_WORDS][RCT_RAYS]
     uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_slots + RCT_WORDS * RCT_RAYS);         // [RCT_TILE_CELLS / 2]
     __shared__ RayMeta s_meta[RCT_RAYS];
@@ -425,9 +435,10 @@ __global__ void k_trace_ray(int32_t W, int32_t H, float x0, float y0, float x1, 
 #define APPLY_TH 4
 __device__ __forceinline__ void
 apply_body(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
-           int32_t *__restrict__ bbox_idle, uint32_t bx, uint32_t by, uint32_t gdx) {
+           int32_t *__restrict__ bbox_idle, uint32_t bx, uint32_t by, uint32_t gdx, uint32_t tid = threadIdx.x) {
+    // (bx, gdx, tid) name a 256-thread slice: the workgroup itself, or a quarter of a 1024-thread one (k_raycast_tile).  No barriers here.
     const int32_t mi = (int32_t)by;
-    if (bbox_idle && bx == 0 && threadIdx.x < 4) bbox_idle[4 * mi + threadIdx.x] = 0;     // (nullptr: the other half is in use, see k_raycast_apply)
+    if (bbox_idle && bx == 0 && tid < 4) bbox_idle[4 * mi + tid] = 0;     // (nullptr: the other half is in use, see k_raycast_apply)
     int32_t x0, y0, x1, y1;
     bbox_decode(bbox + 4 * mi, g.W, g.H, x0, y0, x1, y1);
     if (x1 <= 0) return;
@@ -437,8 +448,8 @@ apply_body(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ c
     const bool lazy_log = gridDim.y > 1;                 // batched maps (uniform)
     for (int32_t t = (int32_t)bx; t < qnx * qny; t += (int32_t)gdx) {
         const int32_t tx0 = (qx0 + t % qnx) * APPLY_TW, ty0 = (qy0 + t / qnx) * APPLY_TH;
-        const int32_t y = ty0 + (threadIdx.x >> 6);
-        const int32_t xb = tx0 + (threadIdx.x & 63) * 4;
+        const int32_t y = ty0 + (int32_t)(tid >> 6);
+        const int32_t xb = tx0 + (int32_t)(tid & 63u) * 4;
         if (y >= g.H || xb >= g.W) continue;
         const size_t o = (size_t)mi * g.cells + (size_t)y * g.W + xb;
         if (vec) {                                       // rows are 16-byte aligned: one 16-byte count load
@@ -467,6 +478,13 @@ apply_body(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ c
             }
         }
     }
+}
+
+__device__ void apply_slices(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
+                             uint32_t first_block) {
+    const uint32_t q = blockDim.x >> 8;
+    apply_body(g, logd, cnt, bbox, nullptr, (blockIdx.x - first_block) * q + (threadIdx.x >> 8), blockIdx.y, (gridDim.x - first_block) * q,
+               threadIdx.x & 255u);
 }
 
 __global__ void __launch_bounds__(256)
@@ -842,16 +860,34 @@ static void rc_launch(gms_map *m, dim3 grid, const gms_beam *d_beams, int32_t B,
 }
 
 void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
-                        int32_t pose_stride) {
-    gms_flush_apply(m);
+                        int32_t pose_stride, bool take_pending_apply) {
+    const bool tile = (int64_t)B * m->n_maps > 4096 && m->raycast_tile;
+    // take_pending_apply: a deferred apply pass rides in this launch (tiled form only) instead of a launch of its own: the ray
+    // cast then raises the other box half (cleared by the previous likelihood launch) and fills the other count grid
+    const bool riding = take_pending_apply && tile && m->apply_pending;
+    if (!riding) gms_flush_apply(m);
     ProfScope ps(m, GMS_K_RAYCAST);
     int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;
-    if ((int64_t)B * m->n_maps > 4096 && m->raycast_tile) {
+    if (tile) {
         // batched maps: throughput-bound; 64 consecutive beams per workgroup, counts accumulated in an LDS tile
         const size_t smem = RCT_LDS_BYTES;
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast_tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(k_raycast_tile, dim3((B + RCT_RAYS - 1) / RCT_RAYS, m->n_maps), dim3(RCT_THREADS), smem, m->stream, m->gd,
-                           d_beams, B, beam_stride, d_poses, pose_stride, m->d_cnt, bb);
+        const uint32_t n_ray = (uint32_t)((B + RCT_RAYS - 1) / RCT_RAYS);
+        uint32_t n_apply = 0;
+        int32_t *next = bb;
+        if (riding) {
+            const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
+#ifndef GMS_APPLY_RIDING_TILE
+#define GMS_APPLY_RIDING_TILE 4        // workgroups of four 256-thread slices per map (C5 step, us: 1 / 2 / 3 / 4 / 6 / 8 / 16 / 32: 462 / 427 / 421 / 419 / 422 / 422 / 427 / 427; the pass beside the partials: 431)
+#endif
+            n_apply = (uint32_t)((all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS) + 3) / 4;
+            if (n_apply > GMS_APPLY_RIDING_TILE) n_apply = GMS_APPLY_RIDING_TILE;
+            if (n_apply < 1) n_apply = 1;
+            next = m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4;
+        }
+        hipLaunchKernelGGL(k_raycast_tile, dim3(n_ray + n_apply, m->n_maps), dim3(RCT_THREADS), smem, m->stream, m->gd,
+                           d_beams, B, beam_stride, d_poses, pose_stride, m->d_cnt, next, n_ray, m->d_log, m->d_cnt_pend, bb);
+        if (riding) gms_apply_done(m);
     } else if ((int64_t)B * m->n_maps > 4096)       // (GMS_RAYCAST_TILE=0, or not enough LDS: 16 rays per workgroup, direct atomics)
         rc_launch<false, 16>(m, dim3((B + 15) / 16, m->n_maps), d_beams, B, beam_stride, d_poses, pose_stride, nullptr, m->d_cnt, bb,
                              nullptr, nullptr, 0, nullptr);
