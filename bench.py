@@ -54,7 +54,7 @@ MIN_BRACKETED_LAUNCHES = 16
 def algorithmic_bytes(kind: str, *, n_particles=0, n_hit=0, n_beams=0, cells=0, visits=0, dirty_cells=0, n_maps=1,
                       paired=True, full_rebuild=False) -> float:
     """Per launch.  A paired launch (gms_fused_kernels.hip) does the work of both members; `paired` adds the partner's
-    bytes to the class the launch is booked under (reduce: + previous scan's apply; raycast: + normalise;
+    bytes to the class the launch is booked under (raycast: + normalise + the previous scan's apply;
     likelihood: + resample)."""
     score = 8.0 * n_particles * n_hit + 20.0 * n_particles + 17.0 * n_beams   # 8 B/beam-eval + pose+weight/particle + beam table
     reduce_ = 16.0 * n_particles                                              # 16 B per particle
@@ -63,8 +63,9 @@ def algorithmic_bytes(kind: str, *, n_particles=0, n_hit=0, n_beams=0, cells=0, 
     resample = 32.0 * n_particles                                             # 8 B weight + 12 B pose read + 12 B pose write
     lik = 16.0 * (cells if full_rebuild else dirty_cells)                     # 16 B per cell rebuilt
     order = 52.0 * n_particles                                                # 12 B pose read, 20 B pose+trig and 20 B ordered copy + index written
-    per_map = {"score": score, "reduce": reduce_ + (apply_ if paired else 0.0), "apply": apply_,
-               "raycast": raycast + (reduce_ if paired else 0.0), "likelihood": lik + (resample if paired else 0.0),
+    # (the previous scan's apply pass rides in the ray-cast launch of a paired step: beside the partials until round 2's second count grid)
+    per_map = {"score": score, "reduce": reduce_, "apply": apply_,
+               "raycast": raycast + ((reduce_ + apply_) if paired else 0.0), "likelihood": lik + (resample if paired else 0.0),
                "resample": resample, "order": order}.get(kind, 0.0)
     return per_map * n_maps
 
