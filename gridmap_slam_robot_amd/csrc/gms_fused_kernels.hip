@@ -208,10 +208,9 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
     ProfScope ps(m, GMS_K_LIKELIHOOD);
     const int32_t k = m->gd.khalf;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
-    const size_t RH = LK_TH + 2 * k, RW = LK_TW + 2 * k;
-    const size_t smem_l = (RH * (RW + 1) + RH * (LK_TW + 1) + (2 * k + 1)) * sizeof(double);
+    const size_t smem_l = gms_likelihood_lds_bytes(k);
     int32_t blocks = tiles_x * tiles_y;
-    const int32_t cap = (smem_l <= 40 * 1024 ? 1024 : (smem_l <= 53 * 1024 ? 768 : 512)) / (m->n_maps > 4 ? 4 : m->n_maps);
+    const int32_t cap = gms_likelihood_blocks_cap(smem_l, m->n_maps);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~7;
     const int64_t nch = nchunks_of(pf);

@@ -521,9 +521,15 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     const int32_t k = KH > 0 ? KH : g.khalf;
     const int32_t ntaps = 2 * k + 1;
     const int32_t RW = LK_TW + 2 * k, RH = LK_TH + 2 * k;     // staged columns / rows
+    // LDS: the thresholded cells, then the horizontal sums.  KH > 0 stages the cells as their CODES, one byte each (0, 1, 2
+    // for 0, 0.5, 1; outside the map 0: Util.java:396 skips those taps, `total + tap * 0.0` leaves a non-negative total unchanged)
+    // and widens them when the horizontal pass reads them: 25 KiB per workgroup instead of 47 (KH = 5), i.e. twice the
+    // workgroups per CU, and this kernel lives on resident workgroups (likelihood_lds_bytes).  The generic path keeps doubles.
     const int32_t PIN = RW + 1, PHS = LK_TW + 1;              // LDS pitches (doubles)
-    double *in_s = reinterpret_cast<double *>(smem);          // [RH][PIN]
-    double *hs = in_s + (size_t)RH * PIN;                     // [RH][PHS]
+    constexpr int32_t PINB = (LK_TW + 2 * (KH > 0 ? KH : 1) + 7) & ~7;      // byte pitch of the code rows: a multiple of 8
+    double *in_s = reinterpret_cast<double *>(smem);          // [RH][PIN] (generic path)
+    uint8_t *in_b = reinterpret_cast<uint8_t *>(smem);        // [RH][PINB] (KH > 0)
+    double *hs = KH > 0 ? reinterpret_cast<double *>(smem + (((size_t)RH * PINB + 15) & ~(size_t)15)) : in_s + (size_t)RH * PIN;   // [RH][PHS]
     double *taps_s = hs + (size_t)RH * PHS;                   // [ntaps] (generic path)
     __shared__ int32_t s_mask[3];
     int32_t tile_iter = 0;
@@ -660,7 +666,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                     const int32_t idx = (int32_t)threadIdx.x + q * 256;
                     const int32_t r = idx / CRW, c = idx - r * CRW;
                     const uint32_t code = (codes >> (2 * q)) & 3u;
-                    if (idx < CRW * CRH) in_s[r * PIN + c] = code == 3u ? 0.0 : 0.5 * (double)code;
+                    if (idx < CRW * CRH) in_b[r * PINB + c] = (uint8_t)(code == 3u ? 0u : code);
                 }
             }
             if (t + (int32_t)gdx < ntiles) issue_loads(t + (int32_t)gdx);      // in flight during the rest of this tile
@@ -693,9 +699,14 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             for (int32_t sidx = threadIdx.x; sidx < RH * (LK_TW / LK_STRIP); sidx += blockDim.x) {
                 const int32_t r = sidx / (LK_TW / LK_STRIP), c0 = (sidx - r * (LK_TW / LK_STRIP)) * LK_STRIP;
                 double v[LK_STRIP + 2 * (KH > 0 ? KH : 1)];
-                const double *row = in_s + r * PIN + c0;
+                // c0 and PINB are multiples of 8: the strip's LK_STRIP + 2 KH codes come as 8-byte words
+                const uint64_t *row = reinterpret_cast<const uint64_t *>(in_b + r * PINB + c0);
+                constexpr int NQ = (LK_STRIP + 2 * KH + 7) / 8;
+                uint64_t q[NQ];
 #pragma unroll
-                for (int j = 0; j < LK_STRIP + 2 * KH; j++) v[j] = row[j];
+                for (int j = 0; j < NQ; j++) q[j] = row[j];
+#pragma unroll
+                for (int j = 0; j < LK_STRIP + 2 * KH; j++) v[j] = 0.5 * (double)(uint32_t)((q[j >> 3] >> (8 * (j & 7))) & 0xffu);   // exact: {0, 0.5, 1}
 #pragma unroll
                 for (int o = 0; o < LK_STRIP; o++) {
                     double total = 0.0;
@@ -971,6 +982,23 @@ void gms_launch_apply_counts(gms_map *m) {
     m->bbox_dirty = 1;
 }
 
+// dynamic LDS of a likelihood workgroup (likelihood_body's layout) and how many of them to launch per map
+size_t gms_likelihood_lds_bytes(int32_t k) {
+    const size_t RH = LK_TH + 2 * k, RW = LK_TW + 2 * k;
+    if (k == 3 || k == 5) return ((RH * ((RW + 7) & ~(size_t)7) + 15) & ~(size_t)15) + RH * (LK_TW + 1) * sizeof(double);
+    return (RH * (RW + 1) + RH * (LK_TW + 1) + (2 * (size_t)k + 1)) * sizeof(double);
+}
+int32_t gms_likelihood_blocks_cap(size_t smem, int32_t n_maps) {
+    // persistent workgroups: as many as stay resident (160 KiB of LDS per CU, 256 CUs; registers allow five)
+#ifndef GMS_LIK_WG_PER_CU
+#define GMS_LIK_WG_PER_CU 5
+#endif
+    int32_t per_cu = (int32_t)((160 * 1024) / (smem + 256));
+    if (per_cu > GMS_LIK_WG_PER_CU) per_cu = GMS_LIK_WG_PER_CU;
+    if (per_cu < 1) per_cu = 1;
+    return per_cu * 256 / (n_maps > 4 ? 4 : n_maps);
+}
+
 void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending) {
     // counts_pending: the scan just cast is not in logData yet; its counts (m->d_cnt) are added on the fly and its apply pass
     // is deferred by the caller (gms_defer_apply); the other box half is cleared for the next ray cast
@@ -978,12 +1006,10 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending) 
     ProfScope ps(m, GMS_K_LIKELIHOOD);
     const int32_t k = m->gd.khalf;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
-    const size_t RH = LK_TH + 2 * k, RW = LK_TW + 2 * k;
-    const size_t smem = (RH * (RW + 1) + RH * (LK_TW + 1) + (2 * k + 1)) * sizeof(double);
-    // persistent workgroups: 4 per CU when LDS allows, each walks tiles blockIdx.x, += gridDim.x
+    const size_t smem = gms_likelihood_lds_bytes(k);
+    // persistent workgroups, each walks tiles blockIdx.x, += gridDim.x
     int32_t blocks = tiles_x * tiles_y;
-    // persistent workgroups per CU by LDS: 4 up to 40 KiB each, 3 up to 53 KiB (KH = 5: 47 KiB), else 2
-    const int32_t cap = (smem <= 40 * 1024 ? 1024 : (smem <= 53 * 1024 ? 768 : 512)) / (m->n_maps > 4 ? 4 : m->n_maps);
+    const int32_t cap = gms_likelihood_blocks_cap(smem, m->n_maps);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~7;                      // keep the XCD round-robin aligned
     dim3 grid(blocks, m->n_maps);
