@@ -14,6 +14,11 @@
 #include "gms_map_kernels.hip"
 #include "gms_pf_kernels.hip"
 
+// 256-thread workgroups of a deferred apply pass that rides beside a ray cast (128 to 2048 measure alike at C3)
+#ifndef GMS_APPLY_BLOCKS_RIDING
+#define GMS_APPLY_BLOCKS_RIDING 512
+#endif
+
 // rays per 256-thread workgroup of the paired launches (one producer wavefront, three consumers)
 #ifndef RCF_RAYS
 #define RCF_RAYS 4
@@ -96,8 +101,14 @@ k_raycast_norm_chunks(GridDev g, const gms_beam *__restrict__ beams, int32_t B, 
                       const double *__restrict__ partials, int64_t nblk_global, double *__restrict__ w, const float *__restrict__ pose,
                       int32_t n, int64_t offset, const PackedParticle *__restrict__ glob_raw, int64_t n_global, int64_t nchunks,
                       double *__restrict__ cum, double *__restrict__ chunk_tot, double *__restrict__ p2,
-                      PfStatsDev *__restrict__ stats) {
+                      PfStatsDev *__restrict__ stats, uint32_t n_chunk_blocks, double *__restrict__ logd,
+                      uint32_t *__restrict__ cnt_pend, const int32_t *__restrict__ bbox_pend) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x >= n_ray_blocks + n_norm_blocks + n_chunk_blocks) {           // the previous scan's deferred apply pass (see k_norm_raycast)
+        const uint32_t first = n_ray_blocks + n_norm_blocks + n_chunk_blocks;
+        apply_body(g, logd, cnt_pend, bbox_pend, nullptr, blockIdx.x - first, 0, gridDim.x - first);
+        return;
+    }
     if (blockIdx.x < n_ray_blocks) {
         __shared__ RedLds L;
         __shared__ float s_pose[3];
@@ -165,9 +176,6 @@ void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticl
     uint32_t n_apply = 0;
     if (m->apply_pending) {
         const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
-#ifndef GMS_APPLY_BLOCKS_RIDING
-#define GMS_APPLY_BLOCKS_RIDING 512
-#endif
         n_apply = (uint32_t)(all < GMS_APPLY_BLOCKS_RIDING ? all : GMS_APPLY_BLOCKS_RIDING);
     }
     int32_t *pend = m->d_bbox + (size_t)m->bbox_cur * 4;
@@ -240,12 +248,12 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
 // ---- sharded filters, one all-gather per scan ----------------------------------------------------------------------
 // this shard's partials at their global slots of d_partials and its raw pack at its slot of d_global_own (the payloads
 // of the two all-gathers, both in place), beside the apply pass a previous paired step left pending
-void gms_launch_partials_pack_apply(gms_pf *pf) {
+void gms_launch_partials_pack_apply(gms_pf *pf, bool apply_rides_later) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_REDUCE);
     const uint32_t n_local = (uint32_t)((pf->n + GMS_BLOCK - 1) / GMS_BLOCK);
     uint32_t n_apply = 0;
-    if (m->apply_pending) {
+    if (m->apply_pending && !apply_rides_later) {      // (rides later: beside this scan's ray cast, gms_launch_raycast_norm_chunks)
         const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
         n_apply = (uint32_t)(all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS);
     }
@@ -267,13 +275,22 @@ void gms_launch_raycast_norm_chunks(gms_pf *pf, const gms_beam *d_beams, int32_t
     const uint32_t n_ray = raycast ? (uint32_t)((B + RCF_RAYS - 1) / RCF_RAYS) : 0u, n_norm = (uint32_t)((pf->n + 255) / 256);
     const uint32_t n_chunk = (uint32_t)nblk_global_of(pf);
     const size_t smem = rc_smem(m, RCF_RAYS);
-    int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * 4;
+    // a deferred apply pass rides beside the ray cast, as in gms_launch_norm_raycast
+    uint32_t n_apply = 0;
+    if (raycast && m->apply_pending) {
+        const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
+        n_apply = (uint32_t)(all < GMS_APPLY_BLOCKS_RIDING ? all : GMS_APPLY_BLOCKS_RIDING);
+    }
+    int32_t *pend = m->d_bbox + (size_t)m->bbox_cur * 4;
+    int32_t *bb = n_apply ? m->d_bbox + (size_t)(1 - m->bbox_cur) * 4 : pend;
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast_norm_chunks), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
-    hipLaunchKernelGGL(k_raycast_norm_chunks, dim3(n_ray + n_norm + n_chunk), dim3(256), smem, m->stream, m->gd, d_beams, B, m->d_cnt,
-                       bb, rc_nw_max(m), n_ray, n_norm, pf->d_partials, nblk_global_of(pf), pf->d_w, pf->d_pose, pf->n, pf->offset,
-                       pf->d_global_own, pf->n_global, nchunks_of(pf), pf->d_cum, pf->d_chunk_tot, pf->d_p2, pf->d_stats);
+    hipLaunchKernelGGL(k_raycast_norm_chunks, dim3(n_ray + n_norm + n_chunk + n_apply), dim3(256), smem, m->stream, m->gd, d_beams, B,
+                       m->d_cnt, bb, rc_nw_max(m), n_ray, n_norm, pf->d_partials, nblk_global_of(pf), pf->d_w, pf->d_pose, pf->n,
+                       pf->offset, pf->d_global_own, pf->n_global, nchunks_of(pf), pf->d_cum, pf->d_chunk_tot, pf->d_p2, pf->d_stats,
+                       n_chunk, m->d_log, m->d_cnt_pend, pend);
+    if (n_apply) gms_apply_done(m);
     pf->chunks_ready = 1;
     pf->neff_folded = 0;
 }

@@ -1457,15 +1457,19 @@ static int sharded_shape_ok(const gms_pf *pf) {
 
 // poses := dev_xytheta (may be NULL), weights, this shard's block partials and raw pack in their slots of the
 // gather buffers (gms_pf_gather_buffers)
-int gms_slam_update_sharded_begin_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B) {
+static int sharded_begin(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, bool apply_rides_later) {
     REQUIRE(pf && dev_beams, "null argument");
     int rc = sharded_shape_ok(pf);
     if (rc) return rc;
     rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B, pf->refine != 0);   // SLAM.java:90, :96-97, :99
     if (rc) return rc;
-    gms_launch_partials_pack_apply(pf);                                          // :100-115 | previous scan's GridMap.java:223
+    gms_launch_partials_pack_apply(pf, apply_rides_later);                       // :100-115 | previous scan's GridMap.java:223 (unless it rides beside the ray cast)
     HIPCHK(hipGetLastError());
     return GMS_OK;
+}
+
+int gms_slam_update_sharded_begin_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B) {
+    return sharded_begin(pf, dev_xytheta, dev_beams, B, false);      // (the end half's `integrate` is not known yet)
 }
 
 int gms_pf_gather_buffers(gms_pf *pf, void **dev_packed_global, int64_t *packed_bytes_per_rank, double **dev_partials_global,
@@ -1506,7 +1510,7 @@ int gms_slam_update_sharded_dev(gms_pf *pf, gms_comm *c, const float *dev_xythet
     if (rc) return rc;
     if (c->broken) return fail(GMS_ERR_STATE, "communicator is broken (an earlier exchange failed): destroy it");
     if (c->pending) return fail(GMS_ERR_STATE, "gms_pf_normalize_sharded_end has not been called for the previous exchange");
-    rc = gms_slam_update_sharded_begin_dev(pf, dev_xytheta, dev_beams, B);
+    rc = sharded_begin(pf, dev_xytheta, dev_beams, B, integrate && gms_can_pair_launches(pf, B));
     if (rc) return rc;
     const size_t np = (size_t)nblk_of(pf->n) * GMS_PARTIAL_STRIDE;               // doubles per rank
     double *own_partials = pf->d_partials + (size_t)c->rank * np;
