@@ -400,13 +400,17 @@ k_order(GridDev g, const float *__restrict__ pose_src, const float *__restrict__
 // GridMap.java:267-288); with more than one segment the per-segment products are stored and
 // multiplied in segment order by k_score_combine.  One segment => the reference's product exactly.
 // ---------------------------------------------------------------------------------------------
+// U: look-ups in flight per lane beside the software pipeline.  1 for particles in the caller's order (C3: 1 / 2 / 3 / 4 -> 20.6 / 21.2 /
+// 24.9 / 21.0 us: more gathers in flight from 64 unrelated lanes thrash the L1 patch); 3 for particles in k_order's locality order, whose
+// neighbouring lanes share lines (C5: 1 / 2 / 3 / 4 -> 240 / 233 / 223 / 237 us; 3 divides the 45-beam segment: no padded batch).
+template <int U>
 __global__ void __launch_bounds__(1024)
 k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const gms_beam *__restrict__ beams,
           int32_t B, int32_t beam_stride, const float *__restrict__ pose, const float *__restrict__ cs, int32_t n,
           int32_t nseg, double *__restrict__ part, double *__restrict__ w, double *__restrict__ logw,
           const float *__restrict__ pose_src, float *__restrict__ pose_dst, float *__restrict__ cs_dst,
           const float4 *__restrict__ ord, const int32_t *__restrict__ perm) {
-    __shared__ double2 s_beam[128 + SCORE_U];        // this segment's beams with wasHit, in order
+    __shared__ double2 s_beam[128 + U];        // this segment's beams with wasHit, in order
     __shared__ int32_t s_nb;
     // Workgroup -> (beam segment, particle group), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs
     // (each with an L2 of its own), so id & 7 picks the XCD and every XCD gets nseg / 8 ADJACENT segments for all particle
@@ -442,7 +446,7 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
             if (hit) s_beam[base + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = make_double2(mb[b].local_x, mb[b].local_y);
             base += __popcll(mask);
         }
-        if (threadIdx.x < SCORE_U) s_beam[base + threadIdx.x] = make_double2(0.0, 0.0);   // padding of the last batch
+        if (threadIdx.x < U) s_beam[base + threadIdx.x] = make_double2(0.0, 0.0);   // padding of the last batch
         if (threadIdx.x == 0) s_nb = base;
     }
     // pose_src: the poses enter the filter through this launch (SLAM.java:90): every segment's workgroup takes its
@@ -477,11 +481,11 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     // Software pipeline: the cell indices of batch b+1 are computed while the look-ups of batch b are in
     // flight, so the vector ALU work hides under the gather latency inside each wavefront (the gathers,
     // not the arithmetic, are the scarcer resource: tools/microbench/gather8.hip).
-    auto cells_of = [&](int32_t base, uint32_t cell[SCORE_U]) {
-        double2 bm[SCORE_U];
+    auto cells_of = [&](int32_t base, uint32_t cell[U]) {
+        double2 bm[U];
         bool guard = false;
 #pragma unroll
-        for (int u = 0; u < SCORE_U; u++) {
+        for (int u = 0; u < U; u++) {
             bm[u] = s_beam[base + u];                                  // same address in every lane: LDS broadcast
             const uint32_t c = beam_cell_fast(g, t, bm[u].x, bm[u].y, guard);
             cell[u] = base + u < nb ? c : g.fneutral;
@@ -489,21 +493,21 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
         if (__builtin_expect(guard, 0)) {                              // ~4e-6 of the end points
             asm volatile("; exact quotients for this batch" ::: "memory");
 #pragma unroll
-            for (int u = 0; u < SCORE_U; u++) {
+            for (int u = 0; u < U; u++) {
                 const uint32_t c = beam_cell(g, t, bm[u].x, bm[u].y);
                 cell[u] = base + u < nb ? c : g.fneutral;
             }
         }
     };
-    uint32_t cell[SCORE_U];
+    uint32_t cell[U];
     if (nb > 0) cells_of(0, cell);
-    for (int32_t base = 0; base < nb; base += SCORE_U) {
-        double f[SCORE_U];
+    for (int32_t base = 0; base < nb; base += U) {
+        double f[U];
 #pragma unroll
-        for (int u = 0; u < SCORE_U; u++) f[u] = fac[cell[u]];         // issue the look-ups of this batch
-        if (base + SCORE_U < nb) cells_of(base + SCORE_U, cell);       // ... and compute the next batch's cells meanwhile
+        for (int u = 0; u < U; u++) f[u] = fac[cell[u]];         // issue the look-ups of this batch
+        if (base + U < nb) cells_of(base + U, cell);       // ... and compute the next batch's cells meanwhile
 #pragma unroll
-        for (int u = 0; u < SCORE_U; u++) prod *= f[u];                // beam order: batch by batch, u ascending
+        for (int u = 0; u < U; u++) prod *= f[u];                // beam order: batch by batch, u ascending
     }
     if (nseg == 1) {
         int e;
@@ -1315,10 +1319,15 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
         // through its segment: 12 beams per segment (C2: 18.4 -> 8.4 us).  Either way a function of B only.
         // <= 128 beams per segment (the LDS beam table; also keeps a segment product >= 0.01^128, a normal double).
         const int64_t nseg = score_segments(m, B);
-        hipLaunchKernelGGL(k_score_c, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
-                           m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
-                           pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pf->d_pose, pf->d_cs,
-                           ordered ? pf->d_ord : nullptr, ordered ? pf->d_perm : nullptr);
+        if (ordered)
+            hipLaunchKernelGGL(k_score_c<3>, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
+                               m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
+                               pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pf->d_pose, pf->d_cs, pf->d_ord, pf->d_perm);
+        else
+            hipLaunchKernelGGL(k_score_c<1>, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
+                               m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
+                               pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pf->d_pose, pf->d_cs, (const float4 *)nullptr,
+                               (const int32_t *)nullptr);
         if (nseg > 1) pf->pending_nseg = (int32_t)nseg;               // combined by the next consumer of the weights
         return;
     }
