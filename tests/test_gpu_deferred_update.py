@@ -98,3 +98,45 @@ def test_update_costs_two_launches_in_the_steady_state(monkeypatch):
         assert prof["raycast"][1] == 6 and prof["likelihood"][1] == 6 and prof["apply"][1] == want_apply
     assert np.array_equal(a.download_log(), b.download_log()) and np.array_equal(a.download_likelihood(), b.download_likelihood())
     a.close(); b.close()
+
+
+def test_batched_steps_with_the_tiled_ray_cast_carry_the_apply_pass(monkeypatch):
+    """n_maps x beams > 4096: the batched fused step ray-casts with the LDS-tile kernel, and from the second step on the
+    previous scan's apply pass rides inside that launch (four 256-thread slices per workgroup, the other count grid, the
+    other box half).  Six steps back to back == the separate entry points on a twin handle, map by map, bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    M, N, B = 16, 900, 300
+    ext, res = 12.8, 0.05
+    traces = [synth.make_trace(ext, res, B, T=12, seed=60 + i) for i in range(4)]
+    monkeypatch.delenv("GMS_PAIR_LAUNCHES", raising=False)
+    a = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M)
+    monkeypatch.setenv("GMS_PAIR_LAUNCHES", "0")
+    b = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M)
+    monkeypatch.delenv("GMS_PAIR_LAUNCHES", raising=False)
+    for m in (a, b):
+        for t in range(3):
+            m.update(np.stack([traces[i % 4].scans[t] for i in range(M)]), np.stack([traces[i % 4].poses[t] for i in range(M)]))
+    pa, pb = ParticleFilter(a, N), ParticleFilter(b, N)
+    rng = np.random.default_rng(3)
+    a.profile_reset(); a.profile(True)
+    for t in range(3, 9):
+        P = np.stack([synth.make_particles(traces[i % 4].poses[t], N, seed=10 * t + i, sigma_xy=0.04, sigma_theta_deg=2.0) for i in range(M)])
+        Pd = torch.from_numpy(P).to(dev)
+        scans = np.stack([traces[i % 4].scans[t] for i in range(M)])
+        sd = torch.from_numpy(scans.view(np.uint8).copy()).to(dev)
+        r01 = rng.random(M)
+        frac = -1.0 if t == 6 else 0.9
+        pa.slam_update_dev(Pd.data_ptr(), sd.data_ptr(), B, r01, frac, True)
+        pb.slam_update_dev(Pd.data_ptr(), sd.data_ptr(), B, r01, frac, True)
+        torch.cuda.synchronize()
+        if t in (4, 6, 8):
+            assert pa.stats() == pb.stats()
+            assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights())
+            assert np.array_equal(a.download_likelihood(), b.download_likelihood())
+        if t in (6, 8):
+            assert np.array_equal(a.download_log(), b.download_log())      # (reading the log-odds runs the pending pass: both ways are covered)
+    prof = a.profile_get(); a.profile(False)
+    assert prof["apply"][1] <= 2           # the pass had a launch of its own only where a download forced it
+    for x in (pa, pb, a, b):
+        x.close()
