@@ -996,7 +996,15 @@ int32_t gms_likelihood_blocks_cap(size_t smem, int32_t n_maps) {
     int32_t per_cu = (int32_t)((160 * 1024) / (smem + 256));
     if (per_cu > GMS_LIK_WG_PER_CU) per_cu = GMS_LIK_WG_PER_CU;
     if (per_cu < 1) per_cu = 1;
-    return per_cu * 256 / (n_maps > 4 ? 4 : n_maps);
+    const int32_t resident = per_cu * 256;
+    if (n_maps <= 4) return resident / n_maps;
+    // many maps: two residencies' worth of workgroups over all maps, a quarter of one at most per map.  A map's dirty box is a few
+    // dozen tiles; workgroups beyond that only cost their dispatch (C5, 64 maps: 320 / 160 / 80 / 40 / 20 / 10 per map ->
+    // 50.3 / 48.0 / 48.2 / 43.9 / 47.8 / 65.8 us for the likelihood | resample launch)
+    int32_t per_map = 2 * resident / n_maps;
+    if (per_map > resident / 4) per_map = resident / 4;
+    if (per_map < 8) per_map = 8;
+    return per_map;
 }
 
 void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending) {
