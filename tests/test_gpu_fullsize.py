@@ -304,3 +304,41 @@ def test_likelihood_full_rebuild_on_a_dense_map_equals_the_oracle():
     assert np.max(np.abs(got - log2) / np.maximum(np.abs(log2), 1.0)) <= 1e-12
     assert np.array_equal(np.sign(got), np.sign(log2))
     assert np.array_equal(m.download_likelihood().reshape(-1), g.build_likelihood(got))
+
+
+@pytest.mark.parametrize("order_mode", [0, 1])
+def test_a_million_particles(monkeypatch, order_mode):
+    """2^20 particles on one handle (1024 scoring groups, 4096 reduction blocks, three scan levels): weights of a sample against
+    the oracle, the normalised population sums to 1, the strongest particle is the oracle's among the sample's candidates,
+    systematic resampling returns non-decreasing sources with copy counts within 1 of N w; with and without the locality order."""
+    N, B = int(os.environ.get("GMS_TEST_BIG_N", 1 << 20)), 96          # (run once with 1 << 24, the library's limit)
+    ext, res = 12.8, 0.05
+    tr = synth.make_trace(ext, res, B, T=10, seed=8, n_scans=6)
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    m = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    for t in range(4):
+        m.update(tr.scans[t], tr.poses[t])
+    lik = g.build_likelihood(m.download_log().reshape(-1))
+    P = synth.make_particles(tr.poses[4], N, seed=3, sigma_xy=0.05, sigma_theta_deg=2.0)
+    monkeypatch.setenv("GMS_SCORE_ORDER", str(order_mode))
+    pf = ParticleFilter(m, N)
+    pf.set_poses(P)
+    pf.score(tr.scans[4])
+    w = pf.get_weights()
+    sample = np.random.default_rng(0).choice(N, 4000, replace=False)
+    sample = np.concatenate([sample, [0, 1023, 1024, N - 1025, N - 1]])
+    want = g.score(lik, tr.scans[4], P[sample])
+    ok = want > 1e-290
+    assert ok.sum() > 1000 and rel_err(w[sample][ok], want[ok]) <= 1e-11
+    st = pf.normalize()
+    assert st["weight_sum"] > 0 and abs(st["weight_sum"] - w.sum()) <= 1e-9 * w.sum()
+    assert w[st["strongest"]] == w.max() and st["strongest"] == int(np.argmax(w))          # first maximum (SLAM.java:110-115)
+    wn = pf.get_weights()
+    assert abs(wn.sum() - 1.0) <= 1e-9
+    assert abs(st["neff"] - 1.0 / np.sum(wn * wn)) <= 1e-6 * st["neff"]
+    idx, amb = pf.resample(0.4142, want_indices=True)
+    assert idx.shape == (N,) and (np.diff(idx) >= 0).all() and idx.min() >= 0 and idx.max() < N
+    copies = np.bincount(idx, minlength=N)
+    assert np.max(np.abs(copies - N * wn)) <= 1.0 + 1e-6
+    assert np.array_equal(pf.get_poses(), P[idx])
+    pf.close(); m.close()
