@@ -781,7 +781,7 @@ int gms_pf_destroy(gms_pf *pf) {
 int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // ParticleFilter.java:43, SLAM.java:65-77
     REQUIRE(m && out, "gms_pf_create: null argument");
     *out = nullptr;
-    REQUIRE(n >= 1 && n <= (1 << 24), "gms_pf_create: particle count out of range");
+    REQUIRE(n >= 1 && n <= GMS_MAX_PARTICLES, "gms_pf_create: particle count out of range (1 .. GMS_MAX_PARTICLES)");
     HIPCHK(hipSetDevice(m->device));
     gms_pf *pf = new (std::nothrow) gms_pf();
     if (!pf) return fail(GMS_ERR_NOMEM, "out of host memory");
@@ -817,7 +817,7 @@ int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // Partic
 int gms_pf_set_shard(gms_pf *pf, int64_t offset, int64_t n_global) {
     REQUIRE(pf, "null filter");
     REQUIRE(offset >= 0 && offset % GMS_BLOCK == 0, "shard offset must be a multiple of GMS_BLOCK");
-    REQUIRE(n_global >= offset + pf->n && n_global <= (1 << 26), "shard does not fit n_global");
+    REQUIRE(n_global >= offset + pf->n && n_global <= GMS_MAX_PARTICLES, "shard does not fit n_global (at most GMS_MAX_PARTICLES in all)");
     HIPCHK(hipSetDevice(pf->map->device));
     HIPCHK(hipStreamSynchronize(pf->map->stream));
     pf->offset = offset;

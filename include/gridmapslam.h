@@ -42,6 +42,8 @@ extern "C" {
 #define GMS_MAX_TAPS 129        /* likelihood kernel taps (odd) */
 #define GMS_BLOCK 256           /* particles per reduction block; shard offsets are multiples of it */
 #define GMS_MAX_BEAMS 4096      /* beams per scan (per map): gms_params.max_beams may not exceed it */
+#define GMS_MAX_PARTICLES (1 << 20)   /* particles per map of a filter, and the global population of a sharded one: the resampling
+                                         kernels keep two levels of the cumulative-weight scan in LDS (133 KiB at this size) */
 
 enum {
     GMS_OK = 0,

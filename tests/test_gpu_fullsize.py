@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from gridmap_slam_robot_amd import GridMap, Observation, ParticleFilter, synth
+from gridmap_slam_robot_amd import GridMap, Observation, ParticleFilter, _lib, synth
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -311,7 +311,7 @@ def test_a_million_particles(monkeypatch, order_mode):
     """2^20 particles on one handle (1024 scoring groups, 4096 reduction blocks, three scan levels): weights of a sample against
     the oracle, the normalised population sums to 1, the strongest particle is the oracle's among the sample's candidates,
     systematic resampling returns non-decreasing sources with copy counts within 1 of N w; with and without the locality order."""
-    N, B = int(os.environ.get("GMS_TEST_BIG_N", 1 << 20)), 96          # (run once with 1 << 24, the library's limit)
+    N, B = 1 << 20, 96                                             # GMS_MAX_PARTICLES
     ext, res = 12.8, 0.05
     tr = synth.make_trace(ext, res, B, T=10, seed=8, n_scans=6)
     g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
@@ -341,4 +341,8 @@ def test_a_million_particles(monkeypatch, order_mode):
     copies = np.bincount(idx, minlength=N)
     assert np.max(np.abs(copies - N * wn)) <= 1.0 + 1e-6
     assert np.array_equal(pf.get_poses(), P[idx])
-    pf.close(); m.close()
+    pf.close()
+    with pytest.raises(_lib.GmsError) as e:                       # one more does not fit the resampling kernels' LDS: refused at creation
+        ParticleFilter(m, N + 1)
+    assert e.value.code == _lib.GMS_ERR_INVALID
+    m.close()
