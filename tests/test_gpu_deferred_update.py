@@ -140,3 +140,37 @@ def test_batched_steps_with_the_tiled_ray_cast_carry_the_apply_pass(monkeypatch)
     assert prof["apply"][1] <= 2           # the pass had a launch of its own only where a download forced it
     for x in (pa, pb, a, b):
         x.close()
+
+
+def test_the_largest_batch_1024_maps(monkeypatch):
+    """gms_params.n_maps at its limit (1024 small maps): three fused steps == the separate entry points on a twin handle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    M, N, B = 1024, 96, 40
+    ext, res = 6.4, 0.05
+    traces = [synth.make_trace(ext, res, B, T=8, seed=80 + i) for i in range(4)]
+    monkeypatch.delenv("GMS_PAIR_LAUNCHES", raising=False)
+    a = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M)
+    monkeypatch.setenv("GMS_PAIR_LAUNCHES", "0")
+    b = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M)
+    monkeypatch.delenv("GMS_PAIR_LAUNCHES", raising=False)
+    for m in (a, b):
+        for t in range(2):
+            m.update(np.stack([traces[i % 4].scans[t] for i in range(M)]), np.stack([traces[i % 4].poses[t] for i in range(M)]))
+    pa, pb = ParticleFilter(a, N), ParticleFilter(b, N)
+    rng = np.random.default_rng(4)
+    for t in range(2, 5):
+        P = np.stack([synth.make_particles(traces[i % 4].poses[t], N, seed=7 * t + i, sigma_xy=0.04, sigma_theta_deg=2.0) for i in range(M)])
+        Pd = torch.from_numpy(P).to(dev)
+        scans = np.stack([traces[i % 4].scans[t] for i in range(M)])
+        sd = torch.from_numpy(scans.view(np.uint8).copy()).to(dev)
+        r01 = rng.random(M)
+        pa.slam_update_dev(Pd.data_ptr(), sd.data_ptr(), B, r01, 0.9, True)
+        pb.slam_update_dev(Pd.data_ptr(), sd.data_ptr(), B, r01, 0.9, True)
+        torch.cuda.synchronize()
+    assert pa.stats() == pb.stats()
+    assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights())
+    assert np.array_equal(a.download_likelihood(), b.download_likelihood())
+    assert np.array_equal(a.download_log(), b.download_log())
+    for x in (pa, pb, a, b):
+        x.close()
