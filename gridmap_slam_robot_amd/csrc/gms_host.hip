@@ -255,6 +255,13 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     if (ndev <= 0) return fail(GMS_ERR_NO_DEVICE, "no HIP device visible: libgridmapslam has no CPU path");
     if (p->device < 0 || p->device >= ndev) return fail(GMS_ERR_NO_DEVICE, "device %d of %d not available", p->device, ndev);
     HIPCHK(hipSetDevice(p->device));
+    {   // the likelihood pass stages a tile with a halo of (ktaps - 1) / 2 cells in LDS: 11 taps 25 KiB, 65 taps 149 KiB
+        int lds_max = 0;
+        if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, p->device) != hipSuccess) lds_max = 64 * 1024;
+        if (gms_likelihood_lds_bytes((p->ktaps - 1) / 2) + 4096 > (size_t)lds_max)
+            return fail(GMS_ERR_INVALID, "gms_map_create: a blur kernel of %d taps needs %zu bytes of LDS per workgroup, this device offers %d",
+                        p->ktaps, gms_likelihood_lds_bytes((p->ktaps - 1) / 2) + 4096, lds_max);
+    }
 
     gms_map *m = new (std::nothrow) gms_map();
     if (!m) return fail(GMS_ERR_NOMEM, "out of host memory");

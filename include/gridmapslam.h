@@ -39,7 +39,8 @@ extern "C" {
 #define GMS_VERSION_MAJOR 0
 #define GMS_VERSION_MINOR 1
 
-#define GMS_MAX_TAPS 129        /* likelihood kernel taps (odd) */
+#define GMS_MAX_TAPS 129        /* size of gms_params.kernel; gms_map_create refuses a kernel whose halo does not fit the likelihood
+                                   pass's LDS tile (MI355X: up to 65 taps) */
 #define GMS_BLOCK 256           /* particles per reduction block; shard offsets are multiples of it */
 #define GMS_MAX_BEAMS 4096      /* beams per scan (per map): gms_params.max_beams may not exceed it */
 #define GMS_MAX_PARTICLES (1 << 20)   /* particles per map of a filter, and the global population of a sharded one: the resampling
