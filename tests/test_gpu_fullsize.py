@@ -346,3 +346,34 @@ def test_a_million_particles(monkeypatch, order_mode):
         ParticleFilter(m, N + 1)
     assert e.value.code == _lib.GMS_ERR_INVALID
     m.close()
+
+
+def test_a_large_map_far_from_the_origin():
+    """8192 x 8192 cells (16 384 x 16 384 was run once by hand), the robot near the far corner, so that every cell index is
+    large: the ray-cast map, the likelihood field and the weights against the oracle."""
+    W, res = 8192, 0.05
+    ext = W * res
+    tr = synth.make_trace(40.0, res, 360, T=8, seed=3, n_scans=6)
+    m = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    assert (m.W, m.H) == (W, W)
+    log = g.new_log()
+    off = np.array([ext / 2 - 25.0, -(ext / 2 - 25.0), 0.0], dtype=np.float32)
+    for t in range(4):
+        pose = (tr.poses[t] + off).astype(np.float32)
+        m.update(tr.scans[t], pose)
+        g.integrate(log, tr.scans[t], pose)
+    got = m.download_log().reshape(-1)
+    assert np.array_equal(got != 0, log != 0)
+    nz = log != 0
+    assert rel_err(got[nz], log[nz]) <= 1e-13
+    lik = g.build_likelihood(got)
+    assert np.array_equal(m.download_likelihood().reshape(-1), lik)
+    N = 2048
+    P = synth.make_particles((tr.poses[4] + off).astype(np.float32), N, seed=1, sigma_xy=0.05, sigma_theta_deg=2.0)
+    pf = ParticleFilter(m, N)
+    pf.set_poses(P); pf.score(tr.scans[4])
+    want = g.score(lik, tr.scans[4], P)
+    ok = want > 1e-290
+    assert ok.sum() > N // 4 and rel_err(pf.get_weights()[ok], want[ok]) <= 1e-11
+    pf.close(); m.close()
