@@ -20,8 +20,9 @@ GMS_PARTIAL_STRIDE = 9
 PACKED_BYTES = 24
 
 GMS_OK, GMS_ERR_INVALID, GMS_ERR_NO_DEVICE, GMS_ERR_HIP, GMS_ERR_NOMEM, GMS_ERR_STATE = 0, -1, -2, -3, -4, -5
-K_RAYCAST, K_APPLY, K_LIKELIHOOD, K_SCORE, K_REDUCE, K_RESAMPLE, K_REFINE, K_EXCHANGE, K_COUNT = range(9)
+K_RAYCAST, K_APPLY, K_LIKELIHOOD, K_SCORE, K_REDUCE, K_RESAMPLE, K_REFINE, K_EXCHANGE, K_ORDER, K_COUNT = range(10)   # enum of gridmapslam.h (GMS_K_*)
 KERNEL_NAMES = ["raycast", "apply", "likelihood", "score", "reduce", "resample", "refine", "exchange", "order"]
+assert len(KERNEL_NAMES) == K_COUNT
 
 BEAM_DTYPE = np.dtype(
     [("local_x", "<f8"), ("local_y", "<f8"), ("distance", "<f8"), ("hit", "u1"), ("pad_", "u1", (7,))]
@@ -152,6 +153,8 @@ def load() -> C.CDLL:
     sig("gms_pf_weighted_pose", C.c_int, vp, vp)
     sig("gms_pf_resample", C.c_int, vp, vp, vp, vp)
     sig("gms_pf_resample_if", C.c_int, vp, vp, f64)
+    sig("gms_pf_last_resample_indices", C.c_int, vp, vp)
+    sig("gms_pf_count", C.c_int, vp, vp, vp, vp)
     sig("gms_pf_did_resample", C.c_int, vp, vp)
     sig("gms_pf_refine_poses", C.c_int, vp, vp, i32)
     sig("gms_pf_last_step", C.c_int, vp, vp, vp, vp, vp)

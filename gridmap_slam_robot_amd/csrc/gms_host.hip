@@ -314,8 +314,6 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     gms_launch_factors(m);        // likelihoodData == 0 everywhere (createMapData(null))
     HIPCHK(hipStreamSynchronize(m->stream));
     m->need_full_build = 1;
-    m->score_variant = 2;
-    if (const char *v = getenv("GMS_SCORE_VARIANT")) m->score_variant = atoi(v);
     m->pair_launches = 1;
     {   // the tiled batched ray cast: 8 KiB of slots + a 64 KiB tile + static LDS
         int lds_max = 0;
@@ -325,7 +323,6 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     }
     m->prof_stride = 1;
     if (const char *v = getenv("GMS_PAIR_LAUNCHES")) m->pair_launches = atoi(v) != 0;
-    if (const char *v = getenv("GMS_SCORE_SEGMENTS")) m->score_segments = atoi(v);
     *out = m;
     return GMS_OK;
 }
@@ -422,7 +419,20 @@ int gms_map_combine(gms_map *dst, gms_map *src) {                        // Grid
     REQUIRE(dst && src, "null argument");
     REQUIRE(dst->n_maps == 1 && dst->gd.W == src->gd.W && dst->gd.H == src->gd.H, "gms_map_combine: dst must be one map of the same size");
     HIPCHK(hipSetDevice(dst->device));
-    HIPCHK(hipStreamSynchronize(src->stream));
+    // src's deferred apply pass (a fused scan step or gms_map_update leaves the last scan's counts un-applied) is enqueued on
+    // src's stream; the combine reads src's log-odds on dst's stream, so dst's stream must wait for it -- an event after the
+    // flush, not a host synchronise before it (round 2 synchronised first and flushed afterwards: the combine could read
+    // pre-apply log-odds).
+    gms_flush_apply(src);
+    gms_flush_apply(dst);
+    if (src->stream != dst->stream) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, src->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(dst->stream, ev, 0);
+        hipEventDestroy(ev);                                         // released once the recorded work has completed
+        if (e != hipSuccess) return fail(GMS_ERR_HIP, "gms_map_combine: stream hand-over: %s", hipGetErrorString(e));
+    }
     gms_launch_combine(src, dst);
     dst->need_full_build = 1;
     HIPCHK(hipGetLastError());
@@ -1233,6 +1243,23 @@ int gms_pf_sample_motion(gms_pf *pf, double d_center, double d_theta, uint64_t s
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_pf_last_resample_indices(gms_pf *pf, int32_t *indices) {
+    REQUIRE(pf && indices, "null argument");
+    gms_map *m = pf->map;
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipMemcpyAsync(indices, pf->d_idx, (size_t)pf->n * pf->n_maps * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return GMS_OK;
+}
+
+int gms_pf_count(const gms_pf *pf, int32_t *n, int32_t *n_maps, int64_t *n_global) {
+    REQUIRE(pf, "null filter");
+    if (n) *n = pf->n;
+    if (n_maps) *n_maps = pf->n_maps;
+    if (n_global) *n_global = pf->n_global;
     return GMS_OK;
 }
 

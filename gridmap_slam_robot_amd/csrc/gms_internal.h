@@ -105,8 +105,6 @@ struct gms_map {
     gms_beam *d_beams;    // [n_maps][max_beams] staging
     float *d_poses;       // [n_maps][3] staging
     double *d_scratch;    // small device scratch
-    int32_t score_variant;    // 0: wavefront per particle; 1: lane per particle (k_score_b); 2: cache-blocked (k_score_c, default)
-    int32_t score_segments;   // k_score_b beam segments per workgroup (0 = auto)
     int32_t need_full_build;  // likelihood field must be rebuilt everywhere (upload/reset/copy)
     int32_t apply_pending;    // the last scan's counts are not in logData yet (deferred apply pass, gms_flush_apply)
     int32_t raycast_tile;     // batched ray casts accumulate in LDS tiles (k_raycast_tile; GMS_RAYCAST_TILE=0 turns it off)

@@ -1072,9 +1072,7 @@ void gms_launch_factors(gms_map *m) {
     hipLaunchKernelGGL(k_factors, dim3(1024, m->n_maps), dim3(256), 0, m->stream, m->gd, m->d_lik, m->d_fac, m->fac_stride);
 }
 
-void gms_launch_combine(gms_map *src, gms_map *dst) {
-    gms_flush_apply(src);
-    gms_flush_apply(dst);
+void gms_launch_combine(gms_map *src, gms_map *dst) {   // the caller has flushed both maps and ordered dst's stream behind src's
     hipLaunchKernelGGL(k_combine, dim3(2048), dim3(256), 0, dst->stream, src->d_log, src->n_maps, src->gd.cells, dst->d_log);
 }
 

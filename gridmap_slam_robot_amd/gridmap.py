@@ -493,6 +493,12 @@ class ParticleFilter:
         r = np.ascontiguousarray(np.broadcast_to(np.asarray(r01, dtype=np.float64), (self.n_maps,)))
         check(load().gms_pf_resample_if(self._h, ptr(r), fraction))
 
+    def last_resample_indices(self) -> np.ndarray:
+        """source slot of every particle after the last resampling step (also the one inside a scan step)."""
+        idx = np.empty(self._pshape(), dtype=np.int32)
+        check(load().gms_pf_last_resample_indices(self._h, ptr(idx)))
+        return idx
+
     def did_resample(self):
         f = np.empty(self.n_maps, dtype=np.int32)
         check(load().gms_pf_did_resample(self._h, ptr(f)))

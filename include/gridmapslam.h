@@ -214,6 +214,13 @@ int gms_pf_weighted_pose(gms_pf *pf, float *out);
 int gms_pf_resample(gms_pf *pf, const double *r01, int32_t *indices, int32_t *n_ambiguous);
 /* if (neff < fraction * n) resample()   (J/app/GridMapApp.java:185-186), decided on the device. */
 int gms_pf_resample_if(gms_pf *pf, const double *r01, double fraction);
+/* indices [n_maps][n]: the source slot of every particle after the last resampling step on this handle -- gms_pf_resample,
+ * gms_pf_resample_if or the resample inside a scan step (SLAM.java:140-149; slot m itself where the conditional resample
+ * did not run).  Synchronises the stream. */
+int gms_pf_last_resample_indices(gms_pf *pf, int32_t *indices);
+/* Particles held by this handle per map (ParticleFilter.java:43: `new Particle[n]`), maps, and the global population
+ * of a sharded filter; any pointer may be NULL. */
+int gms_pf_count(const gms_pf *pf, int32_t *n, int32_t *n_maps, int64_t *n_global);
 /* flags[n_maps]: whether the last gms_pf_resample / gms_pf_resample_if replaced the particles. */
 int gms_pf_did_resample(gms_pf *pf, int32_t *flags);
 /* What the last normalise / scan step left on the device, per map (any pointer may be NULL): the weighted pose

@@ -10,6 +10,8 @@ import pytest
 from gridmap_slam_robot_amd import GridMap, ParticleFilter, synth
 from oracle import oracle as orc
 
+from _checks import assert_resample_indices, near_boundary_slots
+
 pytestmark = pytest.mark.gpu
 
 
@@ -63,12 +65,12 @@ def test_thirty_scan_steps_against_the_oracle(monkeypatch, order_mode):
         if last["did_resample"]:
             resampled += 1
             idx, _ = orc.resample_indices(np.ascontiguousarray(wn), r01)              # SLAM.java:133-153
-            if last["n_ambiguous"] == 0:
-                # the device's normalised weights equal the oracle's to 1e-11: a threshold between two cumulative sums that
-                # close would be reported as ambiguous
-                same = np.all(got == P[idx], axis=1)
-                assert same.mean() > 0.999
-                assert np.allclose(pf.get_weights()[same], wn[idx][same], rtol=1e-10, atol=0)     # a child keeps its parent's weight (:141-148)
+            # The oracle scans ITS normalised weights, equal to the device's to 1e-11: besides the slots the device flags
+            # (blocked scan vs running sum), only a threshold within that distance of a boundary may pick a neighbour.
+            got_idx = pf.last_resample_indices()
+            assert_resample_indices(got_idx, idx, last["n_ambiguous"] + near_boundary_slots(wn, r01))
+            assert np.array_equal(got, P[got_idx])                                    # copies of the chosen particles, bit for bit
+            assert np.allclose(pf.get_weights(), wn[got_idx], rtol=1e-10, atol=0)     # a child keeps its parent's weight (:141-148)
         else:
             assert np.array_equal(got, P)
         particles = got

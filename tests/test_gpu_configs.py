@@ -16,6 +16,8 @@ import pytest
 from gridmap_slam_robot_amd import GridMap, ParticleFilter, synth
 from oracle import oracle as orc
 
+from _checks import assert_resample_indices
+
 pytestmark = pytest.mark.gpu
 
 
@@ -129,9 +131,7 @@ def test_c4_65536_particles_as_8_shards_against_the_oracle_and_the_standalone_fi
                 src_w = raw / st["weight_sum"]
                 want_idx, _ = orc.resample_indices(np.ascontiguousarray(src_w), r01)      # SLAM.java:133-153
                 got_src = _source_indices(poses, Ph)
-                if last["n_ambiguous"] == 0:
-                    assert np.array_equal(got_src, want_idx)
-                assert (np.diff(got_src) >= 0).all()
+                assert_resample_indices(got_src, want_idx, last["n_ambiguous"])
                 assert np.array_equal(weights, src_w[got_src])    # copies keep their weight (SLAM.java:42)
             else:
                 assert np.array_equal(poses, Ph)
@@ -223,8 +223,7 @@ def test_c5_full_size_64_maps_against_the_oracle():
             src_w = w_raw[i] / sts[i]["weight_sum"]
             want_idx, _ = orc.resample_indices(np.ascontiguousarray(src_w), float(r01[i]))
             got_src = _source_indices(poses[i], Ph[i])
-            if amb[i] == 0:
-                assert np.array_equal(got_src, want_idx)
+            assert_resample_indices(got_src, want_idx, amb[i])
             assert np.array_equal(weights[i], src_w[got_src])
         else:
             assert np.array_equal(poses[i], Ph[i])
@@ -280,5 +279,5 @@ def test_c3_at_the_bench_cloud_against_the_oracle():
         gw = pf.get_weights()
         idx, amb = pf.resample(0.37, want_indices=True)
         want_idx, _ = orc.resample_indices(np.ascontiguousarray(gw), 0.37)
-        assert amb > 0 or np.array_equal(idx, want_idx)
+        assert_resample_indices(idx, want_idx, amb)
     pf.close()

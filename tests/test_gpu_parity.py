@@ -13,6 +13,8 @@ from gridmap_slam_robot_amd import GridMap, Observation, ParticleFilter, _lib, s
 from gridmap_slam_robot_amd._lib import GmsError
 from oracle import oracle as orc
 
+from _checks import assert_resample_indices
+
 pytestmark = pytest.mark.gpu
 
 REL = 1e-5          # north_star tolerance on log-odds values and particle weights
@@ -282,10 +284,7 @@ def test_resample_indices_equal_the_sequential_reference(N, seed):
         orc.normalize(wn)
         idx, amb = pf.resample(r, want_indices=True)
         want, clamped = orc.resample_indices(wn, r)
-        if amb == 0:
-            assert np.array_equal(idx, want)
-        else:   # a boundary within rounding distance of U: neighbours allowed there, nowhere else
-            assert (np.abs(idx - want) <= 1).all() and (idx != want).sum() <= amb
+        assert_resample_indices(idx, want, amb)    # a boundary within rounding distance of U: neighbours allowed there, nowhere else
         # particles are copies: pose and (normalised) weight of the source
         assert np.array_equal(pf.get_poses(), P[idx])
         assert rel_err(pf.get_weights(), np.maximum(wn[idx], 0)) <= TIGHT or np.allclose(pf.get_weights(), wn[idx], rtol=1e-11, atol=0)
@@ -495,6 +494,38 @@ def test_combined_map_matches_calculate_combined():
     one.compute_likelihood_map()                                                            # GridMapApp.java:457
     g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
     assert np.array_equal(one.download_likelihood().reshape(-1), g.build_likelihood(got))
+
+
+@pytest.mark.parametrize("M", [1, 4])
+def test_combined_map_straight_after_a_scan_step(M):
+    """calculateCombined (GridMapApp.java:439-458) right behind SLAM.update on the batch, nothing read back in between: the
+    scan step leaves its `logData += ...` pass deferred on the batch's stream, and the combine runs on the destination's."""
+    ext, res, B, N = 3.2, 0.05, 72, 300
+    traces = [synth.make_trace(ext, res, B, T=8, seed=60 + i, n_scans=6) for i in range(M)]
+    mb = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M, max_beams=B)
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    st = lambda a: a[0] if M == 1 else np.stack(a)
+    for t in range(3):
+        mb.update(st([tr.scans[t] for tr in traces]), st([tr.poses[t] for tr in traces]))
+    logs = mb.download_log().reshape(M, -1).copy()
+    pf = ParticleFilter(mb, N)
+    one = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    for t in range(3, 6):                                      # several steps: deferred passes taken over by later launches too
+        P = st([synth.make_particles(tr.poses[t], N, seed=3 + i, sigma_xy=0.02, sigma_theta_deg=0.5) for i, tr in enumerate(traces)])
+        pf.slam_update(P, st([tr.scans[t] for tr in traces]), np.full(M, 0.3), 0.5, True)
+        one.combine_from(mb)                                   # <- no download, no synchronise since the step
+        wp = pf.last_step()["weighted_pose"].reshape(M, 3)
+        for i, tr in enumerate(traces):
+            g.integrate(logs[i], tr.scans[t], wp[i])           # the step integrated at its own weighted pose (SLAM.java:93)
+        want = orc.combine_maps(logs)
+        got = one.download_log().reshape(-1)
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin)
+        assert np.max(np.abs(got[fin] - want[fin]) / (np.abs(want[fin]) + 1e-9)) <= 1e-6
+    got_logs = mb.download_log().reshape(M, -1)
+    nz = logs != 0
+    assert np.array_equal(got_logs != 0, nz) and rel_err(got_logs[nz], logs[nz]) <= 1e-13
+    pf.close(); one.close(); mb.close()
 
 
 def test_deskew_and_recorded_trace_round_trip(tmp_path):
