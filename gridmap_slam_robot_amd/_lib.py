@@ -13,6 +13,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgridmapslam.so")
+if os.environ.get("GMS_LIBRARY"):          # experiments only (tools/ab_compare.sh alternates two builds on one box)
+    LIB_PATH = os.environ["GMS_LIBRARY"]
 
 GMS_MAX_TAPS = 129
 GMS_BLOCK = 256
@@ -101,6 +103,7 @@ def load() -> C.CDLL:
         fn.argtypes = list(argtypes)
 
     sig("gms_version", C.c_int)
+    sig("gms_build_info", C.c_char_p)
     sig("gms_last_error", C.c_char_p)
     sig("gms_device_count", C.c_int)
     sig("gms_params_default", C.c_int, pp, f32, f32, f32, f32, f32)

@@ -12,9 +12,6 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgridmapslam.so")
 # gms_fused_kernels.hip is the device translation unit: it includes gms_map_kernels.hip and gms_pf_kernels.hip
 SOURCES = ["gms_host.hip", "gms_fused_kernels.hip"]
-HEADERS = [os.path.join(CSRC, "gms_internal.h"), os.path.join(CSRC, "gms_device.h"),
-           os.path.join(CSRC, "gms_map_kernels.hip"), os.path.join(CSRC, "gms_pf_kernels.hip"),
-           os.path.join(ROOT, "include", "gridmapslam.h")]
 # -ffp-contract=off: the reference (JVM) never fuses a multiply with an add; parity depends on it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
          "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
@@ -27,24 +24,46 @@ def hipcc() -> str:
     return "hipcc"
 
 
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the library's sources: csrc/* and the public header, in name order."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.join(ROOT, "include", "gridmapslam.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def built_hash(lib: str = LIB) -> str | None:
+    """the source hash a built library carries (the string gms_build_info() returns), read from the file itself"""
+    try:
+        blob = open(lib, "rb").read()
+    except OSError:
+        return None
+    i = blob.find(b"GMS_SOURCE_HASH=")
+    return blob[i + 16:i + 32].decode("ascii", "replace") if i >= 0 else None
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps)
+    return built_hash() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+    """Compiles the library unless the in-tree one was built from exactly these sources; says which on stderr, with the hash
+    (the same string gms_build_info() returns at run time, so a log shows which binary ran)."""
+    want = source_hash()
+    if not force and built_hash() == want:
+        print(f"libgridmapslam: reused {want} (in-tree build of these sources)", file=sys.stderr)
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     extra = os.environ.get("GMS_EXTRA_FLAGS", "").split()      # experiments only (e.g. -DRC_RAYS=4)
-    cmd = [hipcc()] + FLAGS + extra + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    cmd = [hipcc()] + FLAGS + extra + [f'-DGMS_SOURCE_HASH="{want}"', "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    print(f"libgridmapslam: built {want}" + (f" (extra flags: {' '.join(extra)})" if extra else ""), file=sys.stderr)
     return LIB
 
 

@@ -218,7 +218,7 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
     const size_t smem_l = gms_likelihood_lds_bytes(k);
     int32_t blocks = tiles_x * tiles_y;
-    const int32_t cap = gms_likelihood_blocks_cap(smem_l, m->n_maps);
+    const int32_t cap = gms_likelihood_blocks_cap(m, smem_l);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~7;
     const int64_t nch = nchunks_of(pf);

@@ -46,6 +46,12 @@ static int32_t j_d2i_host(double d) {
 extern "C" {
 
 int gms_version(void) { return GMS_VERSION_MAJOR * 1000 + GMS_VERSION_MINOR; }
+#ifndef GMS_SOURCE_HASH
+#define GMS_SOURCE_HASH "unknown"
+#endif
+// sha256 prefix of the sources this binary was built from (gridmap_slam_robot_amd/build.py prints the same string)
+static const char g_build_info[] = "GMS_SOURCE_HASH=" GMS_SOURCE_HASH;
+const char *gms_build_info(void) { return g_build_info + 16; }
 const char *gms_last_error(void) { return g_err; }
 
 int gms_device_count(void) {
@@ -269,6 +275,14 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     m->n_maps = p->n_maps;
     m->device = p->device;
     m->max_beams = p->max_beams > 0 ? p->max_beams : 2048;
+    {   // residency arithmetic of the persistent-workgroup launches (gms_likelihood_blocks_cap)
+        int v = 0;
+        m->n_cus = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && v > 0 ? v : 256;
+        v = 0;
+        m->lds_per_cu = hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, p->device) == hipSuccess && v > 0 ? v : 64 * 1024;
+        v = 0;      // (a CU holds at least what one workgroup may ask for: some runtimes report the per-CU figure low)
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, p->device) == hipSuccess && v > m->lds_per_cu) m->lds_per_cu = v;
+    }
     GridDev &g = m->gd;
     g.W = W; g.H = H; g.cells = (int64_t)W * H;
     g.posx = (double)p->pos_x; g.posy = (double)p->pos_y;

@@ -84,6 +84,8 @@ struct gms_map {
     GridDev gd;
     int32_t n_maps;
     int32_t device;
+    int32_t n_cus;            // compute units of the device (hipDeviceAttributeMultiprocessorCount; 256 on MI355X)
+    int32_t lds_per_cu;       // bytes of LDS per compute unit (160 KiB on MI355X)
     int32_t max_beams;
     int32_t n_filters;        // live gms_pf handles bound to this map (gms_map_destroy refuses while > 0)
     hipStream_t own_stream;
@@ -192,7 +194,7 @@ void gms_launch_apply_ray(gms_map *m, RayIn ray);
 void gms_launch_apply_counts(gms_map *m);
 void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending = false);
 size_t gms_likelihood_lds_bytes(int32_t khalf);
-int32_t gms_likelihood_blocks_cap(size_t smem, int32_t n_maps);
+int32_t gms_likelihood_blocks_cap(const gms_map *m, size_t smem);
 void gms_launch_raycast_apply(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses, int32_t pose_stride);
 void gms_defer_apply(gms_map *m);       // host bookkeeping: the scan just cast keeps its counts until a later launch applies them
 void gms_launch_fill(gms_map *m, double *d, double v, int64_t n);

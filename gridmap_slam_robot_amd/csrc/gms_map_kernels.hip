@@ -988,15 +988,17 @@ size_t gms_likelihood_lds_bytes(int32_t k) {
     if (k == 3 || k == 5) return ((RH * ((RW + 7) & ~(size_t)7) + 15) & ~(size_t)15) + RH * (LK_TW + 1) * sizeof(double);
     return (RH * (RW + 1) + RH * (LK_TW + 1) + (2 * (size_t)k + 1)) * sizeof(double);
 }
-int32_t gms_likelihood_blocks_cap(size_t smem, int32_t n_maps) {
-    // persistent workgroups: as many as stay resident (160 KiB of LDS per CU, 256 CUs; registers allow five)
+int32_t gms_likelihood_blocks_cap(const gms_map *m, size_t smem) {
+    // persistent workgroups: as many as stay resident (LDS per CU and CU count of the map's device, read once at gms_map_create:
+    // 160 KiB and 256 on MI355X; registers allow five)
 #ifndef GMS_LIK_WG_PER_CU
 #define GMS_LIK_WG_PER_CU 5
 #endif
-    int32_t per_cu = (int32_t)((160 * 1024) / (smem + 256));
+    const int32_t n_maps = m->n_maps;
+    int32_t per_cu = (int32_t)((size_t)m->lds_per_cu / (smem + 256));
     if (per_cu > GMS_LIK_WG_PER_CU) per_cu = GMS_LIK_WG_PER_CU;
     if (per_cu < 1) per_cu = 1;
-    const int32_t resident = per_cu * 256;
+    const int32_t resident = per_cu * m->n_cus;
     if (n_maps <= 4) return resident / n_maps;
     // many maps: two residencies' worth of workgroups over all maps, a quarter of one at most per map.  A map's dirty box is a few
     // dozen tiles; workgroups beyond that only cost their dispatch (C5, 64 maps: 320 / 160 / 80 / 40 / 20 / 10 per map ->
@@ -1017,7 +1019,7 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending) 
     const size_t smem = gms_likelihood_lds_bytes(k);
     // persistent workgroups, each walks tiles blockIdx.x, += gridDim.x
     int32_t blocks = tiles_x * tiles_y;
-    const int32_t cap = gms_likelihood_blocks_cap(smem, m->n_maps);
+    const int32_t cap = gms_likelihood_blocks_cap(m, smem);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~7;                      // keep the XCD round-robin aligned
     dim3 grid(blocks, m->n_maps);

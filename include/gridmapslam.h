@@ -100,6 +100,9 @@ typedef struct gms_pf_stats {
 
 /* ---- library ---------------------------------------------------------------------------------- */
 int gms_version(void);                         /* major*1000 + minor */
+/* 16 hex digits: sha256 prefix of the sources (the csrc directory, this header) the loaded binary was built from; build() prints the
+ * same string ("built <hash>" / "reused <hash>"), so a log shows which binary ran. */
+const char *gms_build_info(void);
 const char *gms_last_error(void);              /* thread-local message of the last failing call */
 int gms_device_count(void);                    /* HIP devices visible; 0 when none (never throws) */
 

@@ -53,6 +53,19 @@ static gms_beam *beams_from(JNIEnv *env, jdoubleArray flat, jint B) {
     (*env)->ReleasePrimitiveArrayCritical(env, flat, p, JNI_ABORT);
     return out;
 }
+/* The C-ABI reads and writes pf->n * n_maps elements whatever the caller's `n` says: a mismatch is refused here
+ * (IllegalArgumentException) instead of overrunning the heap buffers sized from `n`.  want_single: the handle must
+ * hold exactly one particle on one map (the one-pose entry points). */
+static int particle_count_ok(JNIEnv *env, jlong pf, jint n, int want_single) {
+    int32_t have = 0, maps = 0;
+    if (gms_pf_count(PF(pf), &have, &maps, NULL) != GMS_OK) { throw_gms(env, GMS_ERR_INVALID); return 0; }
+    if (want_single ? (have != 1 || maps != 1) : ((int64_t)n != (int64_t)have * maps)) {
+        throw_named(env, "java/lang/IllegalArgumentException",
+                    want_single ? "this entry point needs a one-particle filter on a single map" : "particle count differs from the native filter's");
+        return 0;
+    }
+    return 1;
+}
 /* float[] -> heap copy (NULL array -> NULL, *ok stays 1) */
 static float *floats_from(JNIEnv *env, jfloatArray a, size_t n, int *ok) {
     *ok = 1;
@@ -176,6 +189,7 @@ JNIEXPORT void JNICALL CLS(pfSetShard)(JNIEnv *env, jclass c, jlong pf, jlong of
 JNIEXPORT void JNICALL CLS(pfSetRefine)(JNIEnv *env, jclass c, jlong pf, jboolean on) { throw_gms(env, gms_pf_set_refine(PF(pf), on ? 1 : 0)); }
 JNIEXPORT void JNICALL CLS(pfSetPoses)(JNIEnv *env, jclass c, jlong pf, jfloatArray xyt, jint n) {
     int ok;
+    if (!particle_count_ok(env, pf, n, 0)) return;
     float *p = floats_from(env, xyt, (size_t)n * 3, &ok);
     if (!p) return;
     const int rc = gms_pf_set_poses(PF(pf), p);                     /* copies into a pinned ring before returning */
@@ -183,6 +197,7 @@ JNIEXPORT void JNICALL CLS(pfSetPoses)(JNIEnv *env, jclass c, jlong pf, jfloatAr
     throw_gms(env, rc);
 }
 JNIEXPORT void JNICALL CLS(pfGetParticles)(JNIEnv *env, jclass c, jlong pf, jfloatArray xyt, jdoubleArray w, jint n) {
+    if (!particle_count_ok(env, pf, n, 0)) return;
     float *p = (float *)malloc((size_t)n * 3 * sizeof(float));
     double *q = (double *)malloc((size_t)n * sizeof(double));
     int rc = (p && q) ? gms_pf_get_poses(PF(pf), p) : GMS_ERR_NOMEM;
@@ -204,6 +219,7 @@ JNIEXPORT void JNICALL CLS(pfScore)(JNIEnv *env, jclass c, jlong pf, jdoubleArra
 }
 /* probabilityOf(map, obs, pose) for ONE pose (GridMap.java:261): pf is a one-particle filter on the map */
 JNIEXPORT jdouble JNICALL CLS(pfProbabilityOf)(JNIEnv *env, jclass c, jlong pf, jdoubleArray beams, jint B, jfloat x, jfloat y, jfloat theta) {
+    if (!particle_count_ok(env, pf, 1, 1)) return 0.0;           /* gms_pf_get_weights writes one double per particle */
     gms_beam *buf = beams_from(env, beams, B);
     if (!buf) return 0.0;
     const float pose[3] = { x, y, theta };
@@ -218,6 +234,7 @@ JNIEXPORT jdouble JNICALL CLS(pfProbabilityOf)(JNIEnv *env, jclass c, jlong pf, 
 /* findBestPose(map, obs, startPose) (GridMap.java:319): pf is a one-particle filter on the map; out3 = best pose */
 JNIEXPORT void JNICALL CLS(pfFindBestPose)(JNIEnv *env, jclass c, jlong pf, jdoubleArray beams, jint B, jfloat x, jfloat y, jfloat theta,
                                            jfloatArray out3) {
+    if (!particle_count_ok(env, pf, 1, 1)) return;
     gms_beam *buf = beams_from(env, beams, B);
     if (!buf) return;
     float pose[3] = { x, y, theta };
@@ -254,6 +271,7 @@ JNIEXPORT void JNICALL CLS(pfWeightedPose)(JNIEnv *env, jclass c, jlong pf, jflo
  * which must not happen inside a JNI critical region. */
 JNIEXPORT void JNICALL CLS(slamUpdate)(JNIEnv *env, jclass c, jlong pf, jfloatArray xyt, jint n, jdoubleArray beams, jint B, jdouble r01,
                                        jdouble resampleFraction, jboolean integrate, jdoubleArray out3) {
+    if (xyt && !particle_count_ok(env, pf, n, 0)) return;
     gms_beam *buf = beams_from(env, beams, B);
     if (!buf) return;
     int ok;
@@ -286,6 +304,7 @@ JNIEXPORT void JNICALL CLS(commDestroy)(JNIEnv *env, jclass c, jlong cm) { throw
 /* slamUpdate for this rank's shard of a sharded filter: every rank passes the same scan and r01 */
 JNIEXPORT void JNICALL CLS(slamUpdateSharded)(JNIEnv *env, jclass c, jlong pf, jlong cm, jfloatArray xyt, jint n, jdoubleArray beams, jint B,
                                               jdouble r01, jdouble resampleFraction, jboolean integrate, jdoubleArray out3) {
+    if (xyt && !particle_count_ok(env, pf, n, 0)) return;
     gms_beam *buf = beams_from(env, beams, B);
     if (!buf) return;
     int ok;

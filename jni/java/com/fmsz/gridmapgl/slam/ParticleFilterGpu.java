@@ -57,11 +57,12 @@ public class ParticleFilterGpu extends ParticleFilter {
             for (int i = 0; i < numberOfParticles; i++) { poses[3 * i] = sampled[i].x; poses[3 * i + 1] = sampled[i].y; poses[3 * i + 2] = sampled[i].theta; }
             xyt = poses;
         }
-        double[] beams = NativeSlam.flatten(z);
+        // A sharded filter resamples the all-gathered population on EVERY rank: the draw must be the same number in every
+        // JVM, and Math.random() is not.  updateSharded takes it as an argument.
         if (comm != 0)
-            NativeSlam.slamUpdateSharded(handle, comm, xyt, numberOfParticles, beams, z.getNumberOfMeasurements(), Math.random(), resampleFraction, !skipUpdate, stats);
-        else
-            NativeSlam.slamUpdate(handle, xyt, numberOfParticles, beams, z.getNumberOfMeasurements(), Math.random(), resampleFraction, !skipUpdate, stats);
+            throw new IllegalStateException("sharded filter: call updateSharded(z, sampled, skipUpdate, resampleFraction, r01) with the same r01 on every rank");
+        double[] beams = NativeSlam.flatten(z);
+        NativeSlam.slamUpdate(handle, xyt, numberOfParticles, beams, z.getNumberOfMeasurements(), Math.random(), resampleFraction, !skipUpdate, stats);
         if (!skipUpdate) map.deviceChanged(mapData);
         return stats[1];
     }
@@ -76,8 +77,8 @@ public class ParticleFilterGpu extends ParticleFilter {
     /**
      * Multi-GPU, one JVM per GPU: this filter holds particles [rank * n, (rank + 1) * n) of world * n.  id128 comes
      * from NativeSlam.commUniqueId on one rank and reaches the others by whatever channel the host has.  Every rank
-     * then calls update() with its shard of the samples, the same scan, and -- for the resampling draw -- must be given
-     * the same random number: use updateSharded below.
+     * then calls updateSharded() with its shard of the samples, the same scan and the same resampling draw r01; update()
+     * throws on a sharded filter (its Math.random() would differ from JVM to JVM).
      */
     public void joinShardedFilter(byte[] id128, int rank, int world, int device) {
         NativeSlam.pfSetShard(handle, (long) rank * numberOfParticles, (long) world * numberOfParticles);

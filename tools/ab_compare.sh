@@ -3,19 +3,17 @@
 #   1. build the baseline, cp gridmap_slam_robot_amd/lib/libgridmapslam.so gridmap_slam_robot_amd/lib/A.so
 #   2. build the candidate, cp ... gridmap_slam_robot_amd/lib/B.so
 #   3. gpurun -- 'bash tools/ab_compare.sh [rounds] [bench args...]'
-# Alternates A, B, A, B ... and prints ms_per_step and the per-class kernel times of every run.
+# Alternates A, B, A, B ... and prints ms_per_step and the per-class kernel times of every run.  The library under test is
+# chosen through GMS_LIBRARY (gridmap_slam_robot_amd/_lib.py): the product library is never overwritten.
 cd "$(dirname "$0")/.."
-L=gridmap_slam_robot_amd/lib
-ROUNDS=${1:-3}; shift
+L=$PWD/gridmap_slam_robot_amd/lib
+ROUNDS=${1:-3}; [ $# -gt 0 ] && shift
 ARGS=${@:---steps 200 --warmup 20 --no-cpu-baseline --no-secondary}
-cp $L/libgridmapslam.so $L/keep.so
 for r in $(seq 1 $ROUNDS); do
   for v in A B; do
-    cp $L/$v.so $L/libgridmapslam.so
-    python bench.py $ARGS 2>/dev/null | tail -1 | python -c "
+    GMS_LIBRARY=$L/$v.so python bench.py $ARGS 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$v', round(d['ms_per_step']*1e3,2), 'us/step', {k:v.get('avg_launch_us') for k,v in d['kernels'].items()}, flush=True)"
   done
 done
-cp $L/keep.so $L/libgridmapslam.so; rm -f $L/keep.so
