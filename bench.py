@@ -18,8 +18,10 @@ The default 1-GPU run also reports C5 and C2 in a "secondary" block (shorter run
          bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  value = total particles x steps / max-over-ranks wall time of the K steps.
-roofline = the dominant kernel's algorithmic bytes per launch / its average launch duration (HIP events on the
-library's stream, recorded inside the timed region; the stride is chosen so that at least 16 launches are bracketed).
+roofline = the dominant kernel's algorithmic bytes per launch / its average launch duration: HIP events on the library's
+stream around every launch of a REPLAY of the timed steps (the timed region itself carries no event brackets: they cost
+stream time), minus what the two event markers add (calibrated on an empty kernel); roofline.step is the whole step's
+algorithmic bytes over the wall time of a step.
 cpu_baseline = the C oracle (a port of the reference's Java loops; the reference itself cannot run here) on a bounded
 sample of the same workload, one host thread.  At N > 1 the run first VERIFIES itself: one untimed step on the sharded
 filter and, on rank 0, on a stand-alone filter of the whole population; "sharded_equals_standalone" reports whether
@@ -45,7 +47,6 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 GATHER_CEILING_LANES_PER_S = 818e9   # tools/microbench/gather8.hip on MI355X: independent 8-byte look-ups whose patch stays in L1
 GATHER_CEILING_MERGED_PER_S = 1590e9  # tools/microbench/gather_coalesce.hip: the same when 4 neighbouring lanes share a line (particles in locality order)
-MIN_BRACKETED_LAUNCHES = 16
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -365,31 +366,14 @@ class Workload:
 
 # ---------------------------------------------------------------------------------------------------------------------
 def measure(wl: Workload, steps: int, warmup: int):
-    """warm-up (every kernel class bracketed: find the dominant one), the timed region (exactly `steps` steps, only the
-    dominant class bracketed, every stride-th launch), a second informational pass with every class bracketed."""
-    from gridmap_slam_robot_amd import _lib
+    """warm-up (untimed), the timed region (exactly `steps` steps, NO event brackets: nothing but the steps themselves
+    between the two barriers), then a bracketed replay of the same steps: every launch of every kernel class between
+    HIP events on the library's stream, for the roofline and the per-kernel table."""
     m, torch, dist = wl.m, wl.torch, wl.dist
-    bracket_us = m.profile_calibrate(200) * 1e3
-    m.profile(True)
-    m.profile_reset()
+    bracket_ms, noop_ms = m.profile_calibrate2(200)
+    m.profile(False)
     for i in range(warmup):
         wl.step(i)
-    wl.barrier()
-    warm = m.profile_get()
-    m.profile(False)
-    compute = [k for k in warm if warm[k][1] > 0 and k != "exchange"]
-    dominant = max(compute, key=lambda k: warm[k][0], default="score") if warmup > 0 else "score"
-    dom_bit = 1 << _lib.KERNEL_NAMES.index(dominant)
-    per_step = max(1.0, warm[dominant][1] / warmup) if warmup > 0 and warm[dominant][1] else 1.0
-    # A bracket costs microseconds of stream time (two marker commands, 3-7 us per bracketed launch at C3): as few as
-    # give >= 16 bracketed launches -- but never every launch: at the driver's --steps 20 that alone would cost 12 % of
-    # `value`; every second launch is the floor (10 launches at 20 steps; the all-classes pass after the timed region
-    # brackets every launch of min(steps, 50) further steps: kernels.<class>.avg_launch_us).
-    stride = wl.args.event_stride or max(2, int(steps * per_step) // MIN_BRACKETED_LAUNCHES)
-
-    m.profile_reset()
-    m.profile_sample(stride)
-    m.profile(dom_bit)
     wl.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -397,9 +381,6 @@ def measure(wl: Workload, steps: int, warmup: int):
     issue = time.perf_counter() - t0          # host time to enqueue K steps (the GPU must not be waiting on it)
     wl.barrier()
     elapsed_rank = elapsed = time.perf_counter() - t0
-    dom_ms, dom_n = m.profile_get()[dominant]
-    m.profile(False)
-    m.profile_sample(1)
     per_rank = [elapsed_rank]
     if wl.world > 1 and dist.is_initialized():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=wl.dev)
@@ -408,16 +389,19 @@ def measure(wl: Workload, steps: int, warmup: int):
         per_rank = [float(x.item()) for x in allt]
         elapsed = max(per_rank)
 
+    # bracketed replay: the same steps again (the same pose sets, scans and draws), every launch timed
     m.profile(True)
     m.profile_reset()
-    nb = max(1, min(steps, 50))
+    nb = max(1, min(steps, 200))
     for i in range(nb):
-        wl.step(warmup + steps + i)
+        wl.step(warmup + i)
     wl.barrier()
     prof = m.profile_get()
     m.profile(False)
-    return dict(elapsed=elapsed, issue=issue, per_rank=per_rank, dominant=dominant, dom_ms=dom_ms, dom_n=dom_n, stride=stride,
-                prof=prof, nb=nb, bracket_us=bracket_us)
+    compute = [k for k in prof if prof[k][1] > 0 and k != "exchange"]
+    dominant = max(compute, key=lambda k: prof[k][0], default="score")
+    return dict(elapsed=elapsed, issue=issue, per_rank=per_rank, dominant=dominant, prof=prof, nb=nb,
+                bracket_us=bracket_ms * 1e3, noop_us=noop_ms * 1e3)
 
 
 def report(wl: Workload, meas: dict, steps: int, warmup: int):
@@ -432,15 +416,22 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
     kw = dict(n_particles=wl.n_local, n_hit=wl.n_hit, n_beams=wl.B, cells=m.W * m.H, visits=visits, dirty_cells=dirty, n_maps=wl.M,
               paired=bool(paired), full_rebuild=a.full_rebuild)
     nb, prof = meas["nb"], meas["prof"]
+    # The two event markers of a bracket are stream commands of their own: a bracketed launch reads longer than the kernel's
+    # duration in a kernel trace by (bracket around an empty kernel) - (an empty kernel back to back), both measured at start-up
+    # (gms_profile_calibrate2).  avg_launch_us has that subtracted -- it is what `rocprofv3 --kernel-trace --stats` shows
+    # for the kernel (profiles/) -- and avg_bracketed_us is the raw reading.
+    marker_us = max(0.0, meas["bracket_us"] - meas["noop_us"])
     kernels = {}
     for k, (ms, n) in prof.items():
         if not n:
             continue
         lps = n / nb
         ab = algorithmic_bytes(k, **kw) / max(1.0, lps) if k != "exchange" else None
-        us = ms / n * 1e3
+        raw_us = ms / n * 1e3
+        us = max(raw_us - marker_us, 0.05)
         tr = pmc_traffic(wl.name, k) if not (a.full_rebuild or a.particles or a.host_inputs) else None
-        e = {"launches_per_step": round(lps, 2), "avg_launch_us": round(us, 2), "ms_per_step": round(ms / nb, 5)}
+        e = {"launches_per_step": round(lps, 2), "avg_launch_us": round(us, 2), "avg_bracketed_us": round(raw_us, 2),
+             "us_per_step": round(us * lps, 2)}
         if ab:
             e.update({"algorithmic_bytes_per_launch": int(ab), "algorithmic_gb_per_s": round(ab / (us * 1e-6) / 1e9, 1),
                       "hbm_frac": round(ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
@@ -450,18 +441,26 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
     dom = meas["dominant"]
     lps_dom = max(1.0, prof[dom][1] / nb) if prof[dom][1] else 1.0
     alg = algorithmic_bytes(dom, **kw) / lps_dom
-    dom_avg_s = (meas["dom_ms"] / max(meas["dom_n"], 1)) * 1e-3
+    dom_raw_s = (prof[dom][0] / max(prof[dom][1], 1)) * 1e-3
+    dom_avg_s = max(dom_raw_s - marker_us * 1e-6, 5e-8)
     achieved = alg / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
-    net_s = max(dom_avg_s - meas["bracket_us"] * 1e-6, 1e-9)
+    # the whole step against the same peak: SURVEY 8(d)'s per-unit figures over everything one scan does (8 B per beam
+    # evaluation + pose, weight and beam table; 16 B per visited cell of the map update; 16 B per cell of the likelihood
+    # rebuild; 16 B per particle for the normaliser, 32 B per particle for the resampling) over the wall time of a step
+    step_bytes = (algorithmic_bytes("score", **kw) + algorithmic_bytes("apply", **kw) + algorithmic_bytes("reduce", **kw)
+                  + algorithmic_bytes("resample", **kw) + algorithmic_bytes("likelihood", **dict(kw, paired=False)))
+    step_s = elapsed / steps
     roof = {
         "kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": pmc_traffic(wl.name, dom) if not (a.full_rebuild or a.particles or a.host_inputs) else None,
-        "algorithmic_bytes_per_launch": alg, "avg_launch_us": dom_avg_s * 1e6, "launches_timed": meas["dom_n"],
-        "event_stride": meas["stride"],
-        # the same bracket around an empty kernel (dispatch latency + ~1 us): a kernel-trace profiler's duration for the
-        # dominant kernel is about avg_launch_us minus this (profiles/ holds that trace)
-        "event_bracket_empty_kernel_us": meas["bracket_us"],
-        "avg_launch_us_minus_bracket": net_s * 1e6, "frac_minus_bracket": alg / net_s / 1e9 / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_launch": alg, "avg_launch_us": dom_avg_s * 1e6, "avg_bracketed_us": dom_raw_s * 1e6,
+        "launches_timed": prof[dom][1],
+        "measured": f"HIP events on the library's stream around every launch of a replay of the timed steps ({nb} steps), "
+                    "minus what the two event markers add (event_markers_us)",
+        "event_bracket_empty_kernel_us": meas["bracket_us"], "empty_kernel_back_to_back_us": meas["noop_us"], "event_markers_us": marker_us,
+        "step": {"algorithmic_bytes_per_step": step_bytes, "achieved": step_bytes / step_s / 1e9, "unit": "GB/s",
+                 "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS, "launches_per_step": round(sum(v[1] for v in prof.values()) / nb, 2),
+                 "kernel_us_per_step": round(sum(e["us_per_step"] for e in kernels.values()), 2)},
     }
     if roof["traffic"] and roof["traffic"] < 0.5 * alg:
         # the HBM peak is the yardstick the contract asks for, not what binds: most of the algorithmic bytes never leave the
@@ -642,7 +641,6 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline's scan-step loop")
     ap.add_argument("--full-rebuild", action="store_true", help="rebuild the whole likelihood field every scan")
     ap.add_argument("--host-inputs", action="store_true", help="hand poses and scans over as HOST buffers every step (PCIe-inclusive rate; never the headline value)")
-    ap.add_argument("--event-stride", type=int, default=0, help="timed region: HIP events around every n-th launch of the dominant kernel (0 = as few as give >= 16 bracketed launches)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "in-library", "torch-single", "torch-two"],
                     help="sharded runs: first exchange route to try (auto = in-library RCCL; later routes are fall-backs)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (all-gather) code path even with one rank")

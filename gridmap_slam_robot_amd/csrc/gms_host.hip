@@ -193,6 +193,30 @@ int gms_profile_calibrate(gms_map *m, int32_t reps, double *bracket_ms) {
     return GMS_OK;
 }
 
+// The same, split into its two parts.  bracket_ms: as gms_profile_calibrate.  kernel_ms: what ONE empty kernel takes when the
+// launches are already queued and run back to back with no events between them (a spinning kernel holds the stream while the
+// host enqueues them, so the host's launch rate does not enter): the floor a kernel-trace profiler shows for any launch.
+// bracket_ms - kernel_ms is what the two event markers add to a bracketed launch.
+int gms_profile_calibrate2(gms_map *m, int32_t reps, double *bracket_ms, double *kernel_ms) {
+    REQUIRE(m && bracket_ms && kernel_ms && reps > 0 && reps <= 1024, "gms_profile_calibrate2: bad arguments");
+    int rc = gms_profile_calibrate(m, reps, bracket_ms);
+    if (rc) return rc;
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    gms_launch_spin(m, 30.0 + 6.0 * reps);             // microseconds: ample for the host to enqueue what follows
+    gms_launch_noop(m);
+    HIPCHK(hipEventRecord(a, m->stream));
+    for (int32_t i = 0; i < reps; i++) gms_launch_noop(m);
+    HIPCHK(hipEventRecord(b, m->stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a); hipEventDestroy(b);
+    *kernel_ms = (double)ms / reps;
+    return GMS_OK;
+}
+
 // ---- pinned staging rings -----------------------------------------------------------------------------
 static int ring_alloc(StageRing &r, size_t bytes) {
     for (int i = 0; i < GMS_STAGE_SLOTS; i++) {

@@ -1060,6 +1060,13 @@ void gms_launch_copy(gms_map *m, void *dst, const void *src, size_t nbytes) {
 }
 
 __global__ void k_noop() {}
+// holds the stream for `us` microseconds (wall_clock64: the 100 MHz constant clock); calibration only
+__global__ void k_spin(double us) {
+    const uint64_t t0 = wall_clock64();
+    const uint64_t ticks = (uint64_t)(us * 100.0);
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+void gms_launch_spin(gms_map *m, double us) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, m->stream, us); }
 void gms_launch_noop(gms_map *m) { hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, m->stream); }
 
 // likelihoodData / the factor table were written by something other than the likelihood kernel: nothing is known

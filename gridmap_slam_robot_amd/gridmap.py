@@ -335,6 +335,13 @@ class GridMap:
         check(load().gms_profile_calibrate(self._h, reps, C.byref(v)))
         return v.value
 
+    def profile_calibrate2(self, reps: int = 200):
+        """(event bracket around an empty kernel, one empty kernel in a back-to-back queue), both in milliseconds; their
+        difference is what the two event markers add to a bracketed launch."""
+        a, b = C.c_double(), C.c_double()
+        check(load().gms_profile_calibrate2(self._h, reps, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def profile_reset(self):
         check(load().gms_profile_reset(self._h))
 

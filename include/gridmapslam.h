@@ -356,6 +356,10 @@ int gms_profile_get(gms_map *m, int32_t k, double *total_ms, int64_t *launches);
  * ~1 us an empty kernel runs), over `reps` launches on the handle's stream.  A kernel-trace profiler reports the
  * kernel's own duration, i.e. roughly the bracketed time minus this. */
 int gms_profile_calibrate(gms_map *m, int32_t reps, double *bracket_ms);
+/* The same in its two parts: bracket_ms as above; kernel_ms = what one empty kernel takes when `reps` of them run back to back
+ * with nothing between them (the floor of any launch in a kernel trace).  bracket_ms - kernel_ms is what the two event markers
+ * add to a bracketed launch: subtract it from a bracketed duration to get what a kernel-trace profiler reports. */
+int gms_profile_calibrate2(gms_map *m, int32_t reps, double *bracket_ms, double *kernel_ms);
 
 /* ---- diagnostics ------------------------------------------------------------------------------- */
 /* The float-rounded device primitives the parity contract leans on, for tests: op 0 = (float)sqrt(a)
