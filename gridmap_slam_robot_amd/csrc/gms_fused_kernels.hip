@@ -33,8 +33,10 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
                const double *__restrict__ partials, int64_t nblk_global, double *__restrict__ w, const float *__restrict__ pose,
                int32_t n, int64_t offset, PackedParticle *__restrict__ packed, double *__restrict__ cum,
                double *__restrict__ chunk_tot, int64_t nchunks, double *__restrict__ p2, PfStatsDev *__restrict__ stats,
-               uint32_t n_norm_blocks, double *__restrict__ logd, uint32_t *__restrict__ cnt_pend, const int32_t *__restrict__ bbox_pend) {
+               uint32_t n_norm_blocks, double *__restrict__ logd, uint32_t *__restrict__ cnt_pend, const int32_t *__restrict__ bbox_pend,
+               uint32_t n_near_blocks) {
     extern __shared__ __align__(16) unsigned char smem[];
+    // workgroups: [far-field ray blocks | near-field ray blocks) = n_ray_blocks, then normalise, then the riding apply pass
     if (blockIdx.x >= n_ray_blocks + n_norm_blocks) {
         // The PREVIOUS scan's `logData[c] += ...` (GridMap.java:223) from the other count grid: it needs nothing of this launch
         // and only has to be done before this scan's likelihood pass.  Its ~5 us hide under the ray cast's 17 us latency chain
@@ -55,8 +57,11 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
             s_pose[2] = (float)(f[3] / f[0]);
         }
         __syncthreads();
-        raycast_body<false, RCF_RAYS, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,
-                               smem, s_pose);
+        if (blockIdx.x >= n_ray_blocks - n_near_blocks)
+            raycast_near_body(g, beams, B, B, nullptr, 0, cnt, bbox, blockIdx.x - (n_ray_blocks - n_near_blocks), 0, smem, s_pose);
+        else
+            raycast_body<false, RCF_RAYS, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,
+                                             smem, s_pose, n_near_blocks ? 1 : 0);
     } else {
         normalize_pack_body(partials, nblk_global, w, pose, n, offset, packed, cum, chunk_tot, nchunks, p2, stats,
                             blockIdx.x - n_ray_blocks, 0);
@@ -102,7 +107,7 @@ k_raycast_norm_chunks(GridDev g, const gms_beam *__restrict__ beams, int32_t B, 
                       int32_t n, int64_t offset, const PackedParticle *__restrict__ glob_raw, int64_t n_global, int64_t nchunks,
                       double *__restrict__ cum, double *__restrict__ chunk_tot, double *__restrict__ p2,
                       PfStatsDev *__restrict__ stats, uint32_t n_chunk_blocks, double *__restrict__ logd,
-                      uint32_t *__restrict__ cnt_pend, const int32_t *__restrict__ bbox_pend) {
+                      uint32_t *__restrict__ cnt_pend, const int32_t *__restrict__ bbox_pend, uint32_t n_near_blocks) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (blockIdx.x >= n_ray_blocks + n_norm_blocks + n_chunk_blocks) {           // the previous scan's deferred apply pass (see k_norm_raycast)
         const uint32_t first = n_ray_blocks + n_norm_blocks + n_chunk_blocks;
@@ -121,8 +126,11 @@ k_raycast_norm_chunks(GridDev g, const gms_beam *__restrict__ beams, int32_t B, 
             s_pose[2] = (float)(f[3] / f[0]);
         }
         __syncthreads();
-        raycast_body<false, RCF_RAYS, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,
-                               smem, s_pose);
+        if (blockIdx.x >= n_ray_blocks - n_near_blocks)
+            raycast_near_body(g, beams, B, B, nullptr, 0, cnt, bbox, blockIdx.x - (n_ray_blocks - n_near_blocks), 0, smem, s_pose);
+        else
+            raycast_body<false, RCF_RAYS, 4>(g, beams, B, B, nullptr, 0, nullptr, cnt, bbox, nullptr, nullptr, 0, nullptr, nw_max, blockIdx.x, 0,
+                                             smem, s_pose, n_near_blocks ? 1 : 0);
     } else if (blockIdx.x < n_ray_blocks + n_norm_blocks) {
         normalize_own_body(partials, nblk_global, w, pose, n, offset, glob_raw, stats, blockIdx.x - n_ray_blocks);
     } else {
@@ -169,8 +177,9 @@ void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticl
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_RAYCAST);
     if (own) { pf->d_global = pf->d_global_own; pf->global_raw = 0; }     // normalised weights are packed (as apply_partials does)
-    const uint32_t n_ray = (uint32_t)((B + RCF_RAYS - 1) / RCF_RAYS), n_norm = (uint32_t)((pf->n + 255) / 256);
-    const size_t smem = rc_smem(m, RCF_RAYS);
+    const uint32_t n_near = m->raycast_near ? rc_near_blocks(B) : 0u;
+    const uint32_t n_ray = (uint32_t)((B + RCF_RAYS - 1) / RCF_RAYS) + n_near, n_norm = (uint32_t)((pf->n + 255) / 256);
+    const size_t smem = rc_smem(m, RCF_RAYS, n_near);
     // a deferred apply pass rides along: the ray cast then raises the OTHER box half (cleared by the previous likelihood launch)
     // while the pass reads the pending scan's half; afterwards that other half is the current one (gms_apply_done)
     uint32_t n_apply = 0;
@@ -185,7 +194,7 @@ void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticl
     hipLaunchKernelGGL(k_norm_raycast, dim3(n_ray + n_norm + n_apply), dim3(256), smem, m->stream, m->gd, d_beams, B, m->d_cnt, bb,
                        rc_nw_max(m), n_ray, d_partials, nblk_global_of(pf), pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local,
                        own ? pf->d_cum : (double *)nullptr, own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf),
-                       own ? pf->d_p2 : (double *)nullptr, pf->d_stats, n_norm, m->d_log, m->d_cnt_pend, pend);
+                       own ? pf->d_p2 : (double *)nullptr, pf->d_stats, n_norm, m->d_log, m->d_cnt_pend, pend, n_near);
     if (n_apply) gms_apply_done(m);
     pf->chunks_ready = own ? 1 : 0;
     pf->neff_folded = 0;
@@ -272,9 +281,10 @@ void gms_launch_raycast_norm_chunks(gms_pf *pf, const gms_beam *d_beams, int32_t
     ProfScope ps(m, GMS_K_RAYCAST);
     pf->d_global = pf->d_global_own;
     pf->global_raw = 1;
-    const uint32_t n_ray = raycast ? (uint32_t)((B + RCF_RAYS - 1) / RCF_RAYS) : 0u, n_norm = (uint32_t)((pf->n + 255) / 256);
+    const uint32_t n_near = raycast && m->raycast_near ? rc_near_blocks(B) : 0u;
+    const uint32_t n_ray = raycast ? (uint32_t)((B + RCF_RAYS - 1) / RCF_RAYS) + n_near : 0u, n_norm = (uint32_t)((pf->n + 255) / 256);
     const uint32_t n_chunk = (uint32_t)nblk_global_of(pf);
-    const size_t smem = rc_smem(m, RCF_RAYS);
+    const size_t smem = rc_smem(m, RCF_RAYS, n_near);
     // a deferred apply pass rides beside the ray cast, as in gms_launch_norm_raycast
     uint32_t n_apply = 0;
     if (raycast && m->apply_pending) {
@@ -289,7 +299,7 @@ void gms_launch_raycast_norm_chunks(gms_pf *pf, const gms_beam *d_beams, int32_t
     hipLaunchKernelGGL(k_raycast_norm_chunks, dim3(n_ray + n_norm + n_chunk + n_apply), dim3(256), smem, m->stream, m->gd, d_beams, B,
                        m->d_cnt, bb, rc_nw_max(m), n_ray, n_norm, pf->d_partials, nblk_global_of(pf), pf->d_w, pf->d_pose, pf->n,
                        pf->offset, pf->d_global_own, pf->n_global, nchunks_of(pf), pf->d_cum, pf->d_chunk_tot, pf->d_p2, pf->d_stats,
-                       n_chunk, m->d_log, m->d_cnt_pend, pend);
+                       n_chunk, m->d_log, m->d_cnt_pend, pend, n_near);
     if (n_apply) gms_apply_done(m);
     pf->chunks_ready = 1;
     pf->neff_folded = 0;

@@ -358,6 +358,8 @@ int gms_map_create(const gms_params *p, gms_map **out) {
         if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, m->device) != hipSuccess) lds_max = 64 * 1024;
         m->raycast_tile = lds_max >= 80 * 1024;
         if (const char *v = getenv("GMS_RAYCAST_TILE")) m->raycast_tile = m->raycast_tile && atoi(v) != 0;
+        m->raycast_near = lds_max >= 40 * 1024;                       // 25 KiB tile + slots + static LDS
+        if (const char *v = getenv("GMS_RAYCAST_NEAR")) m->raycast_near = m->raycast_near && atoi(v) != 0;
     }
     m->prof_stride = 1;
     if (const char *v = getenv("GMS_PAIR_LAUNCHES")) m->pair_launches = atoi(v) != 0;

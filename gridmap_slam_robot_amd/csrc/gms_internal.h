@@ -110,6 +110,7 @@ struct gms_map {
     int32_t need_full_build;  // likelihood field must be rebuilt everywhere (upload/reset/copy)
     int32_t apply_pending;    // the last scan's counts are not in logData yet (deferred apply pass, gms_flush_apply)
     int32_t raycast_tile;     // batched ray casts accumulate in LDS tiles (k_raycast_tile; GMS_RAYCAST_TILE=0 turns it off)
+    int32_t raycast_near;     // single-map ray casts: the first 64 steps of every ray go through near-field workgroups with an LDS tile (GMS_RAYCAST_NEAR=0 turns it off)
     int32_t pair_launches;    // scan steps pair independent kernels in one launch (GMS_PAIR_LAUNCHES=0 turns it off)
     gms_beam *h_beams;    // pinned staging (de-skew inputs, single-ray entry)
     StageRing beam_ring;  // pinned staging of scans handed over as host buffers

@@ -116,6 +116,26 @@ __device__ __forceinline__ void ray_phase_a(RayWalk &k, int32_t w0, int32_t w1, 
             //   t    = vcc ? -dx : dy
             //   err  = err + t                       error -= dx  /  error += dy                 (:119 / :122; a - b == a + (-b))
             //   word = word + word + vcc             shift the decision in (bit 31 - j after 32 steps)
+#if defined(GMS_EXP_DDA_SPEC)
+            // experiment: both successors beside the compare, one select picks (chain: max(cmp, add) -> select; five instructions)
+            float t2;
+            asm volatile("v_cmp_lt_f32_e32 vcc, 0, %0\n\t"
+                         "v_add_f32_e32 %2, %0, %5\n\t"
+                         "v_add_f32_e32 %3, %0, %4\n\t"
+                         "v_cndmask_b32_e32 %0, %3, %2, vcc\n\t"
+                         "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+                         : "+v"(err), "+v"(word), "=&v"(t), "=&v"(t2)
+                         : "v"(dy), "v"(ndx)
+                         : "vcc");
+#elif defined(GMS_EXP_DDA_3INSTR)
+            // experiment, WRONG results (no decision word): what a three-instruction step would cost
+            asm volatile("v_cmp_lt_f32_e32 vcc, 0, %0\n\t"
+                         "v_cndmask_b32_e32 %2, %3, %4, vcc\n\t"
+                         "v_add_f32_e32 %0, %0, %2"
+                         : "+v"(err), "+v"(word), "=&v"(t)
+                         : "v"(dy), "v"(ndx)
+                         : "vcc");
+#else
             asm volatile("v_cmp_lt_f32_e32 vcc, 0, %0\n\t"
                          "v_cndmask_b32_e32 %2, %3, %4, vcc\n\t"
                          "v_add_f32_e32 %0, %0, %2\n\t"
@@ -123,6 +143,7 @@ __device__ __forceinline__ void ray_phase_a(RayWalk &k, int32_t w0, int32_t w1, 
                          : "+v"(err), "+v"(word), "=&v"(t)
                          : "v"(dy), "v"(ndx)
                          : "vcc");
+#endif
         }
         word = __brev(word);                           // decision j at bit j
         lds_publish_u64(&slots[(w - w0) * stride + slot], ((uint64_t)(RC_VALID | ycount) << 32) | (uint64_t)word);
@@ -171,6 +192,9 @@ __device__ __forceinline__ int32_t ray_phase_b(const GridDev &g, const RayMeta &
                     if (t_cells) { t_cells[2 * o] = cx; t_cells[2 * o + 1] = cy; }
                     if (t_cls) t_cls[o] = (uint8_t)cls;
                 }
+#ifdef GMS_EXP_SKIP_NEAR
+            } else if (k < GMS_EXP_SKIP_NEAR) {        // experiment, WRONG results: no count atomics for the first cells of every ray
+#endif
             } else if (cls != 1) {
                 const uint32_t inc = cls == 0 ? 1u : 0x10000u;
                 const uint32_t ux = (uint32_t)(cx - tile.x0), uy = (uint32_t)(cy - tile.y0);
@@ -221,7 +245,8 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
              const float *__restrict__ poses, int32_t pose_stride, const RayIn *__restrict__ single,
              uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox, int32_t *__restrict__ t_cells,
              uint8_t *__restrict__ t_cls, int32_t cap, int32_t *__restrict__ t_counts, int32_t nw_max,
-             uint32_t bx, uint32_t by, unsigned char *smem, const float *pose_lds) {
+             uint32_t bx, uint32_t by, unsigned char *smem, const float *pose_lds, int32_t first_blk = 0) {
+    // first_blk = 1: the rays' first 64 steps (block 0) are counted by the near-field workgroups (raycast_near_body)
     uint64_t *s_slots = reinterpret_cast<uint64_t *>(smem);            // [nw_max][RC_RAYS]
     __shared__ RayMeta s_meta[RC_RAYS];
     __shared__ int32_t s_bb[4];
@@ -251,6 +276,9 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
     __syncthreads();
     int32_t bb[4] = { 0, 0, 0, 0 };
     if (wave == 0) {
+#ifdef GMS_EXP_SETPRIO
+        __builtin_amdgcn_s_setprio(3);                 // experiment: the producer's recurrence ahead of the consumers on its SIMD
+#endif
         if (lane < RC_RAYS) {
             RayWalk wk = ray_walk_begin(r);
             ray_phase_a(wk, 0, (my_n_eff + 31) >> 5, s_slots, RC_RAYS, lane);
@@ -260,7 +288,7 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
 #pragma unroll
         for (int q = 0; q < RC_RAYS; q++) nblk_max = max(nblk_max, (s_meta[q].n_eff + 63) >> 6);
         constexpr int32_t NC = NWAVES - 1;
-        for (int32_t q = wave - 1; q < nblk_max * RC_RAYS; q += NC) {
+        for (int32_t q = wave - 1 + first_blk * RC_RAYS; q < nblk_max * RC_RAYS; q += NC) {
             const int32_t blk = q / RC_RAYS, ray = q - blk * RC_RAYS;
             const RayMeta mt = s_meta[ray];
             if (blk * 64 >= mt.n_eff) continue;
@@ -278,15 +306,130 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The near field of a scan.  Every ray of a scan leaves the same cell, and the cells around it are crossed by dozens to
+// hundreds of rays: the start cell alone takes one count atomic per ray, all on one address, and same-address atomics
+// serialise at ~10 ns each -- with the direct atomics of raycast_body the 720 rays of a C3 scan kept the memory-side atomic
+// unit busy for 3.7-4.4 us after the last ray had been walked (measured by leaving the first 16 / 64 cells of every ray
+// uncounted: k_raycast 17.1 -> 13.1 / 12.6 us, the scan step 54.0 -> 52.5 / 52.1 us).
+// So the first 64 steps of every ray (block 0 of phase B) belong to NEAR-FIELD workgroups: one takes RCN_RAYS = 16
+// CONSECUTIVE beams (a wedge), walks their first 64 steps itself (two decision words per ray: 64 steps of the recurrence, a
+// fraction of a microsecond), counts them in an LDS tile of the wedge's near box (16-bit cells, ds_add) and flushes the tile
+// row by row: one global atomic per touched cell and workgroup, consecutive lanes on consecutive cells -- 45 atomics on the
+// start cell instead of 720.  The far-field workgroups skip block 0 (raycast_body, first_blk = 1).  The counts in d_cnt are the
+// same (integer adds commute); a cell outside the tile, or a wedge whose box does not fit, takes the direct atomics.
+// ---------------------------------------------------------------------------------------------
+#ifndef RCN_RAYS
+#define RCN_RAYS 16                     // beams per near-field workgroup (C3 scan step, us: 8 / 16 / 32 / 64 -> 53.1 / 52.1 / 52.0 / 55.0; without the near field 53.4)
+#endif
+#define RCN_TILE_CELLS 12288            // 24 KiB of 16-bit cells: the 64-step walks of a wedge that spans a half plane are at most 128 x 66 cells
+#define RCN_LDS_BYTES (2 * RCN_RAYS * 8 + RCN_TILE_CELLS * 2)
+static_assert(RCN_RAYS >= 1 && RCN_RAYS <= 64, "the near-field producer is one wavefront, a lane per ray");
+
+__device__ __forceinline__ void
+raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride,
+                  const float *__restrict__ poses, int32_t pose_stride, uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox,
+                  uint32_t bx, uint32_t by, unsigned char *smem, const float *pose_lds) {
+    uint64_t *s_slots = reinterpret_cast<uint64_t *>(smem);                                   // [2][RCN_RAYS]
+    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_slots + 2 * RCN_RAYS);                  // [RCN_TILE_CELLS / 2]
+    __shared__ RayMeta s_nmeta[RCN_RAYS];
+    __shared__ int32_t s_nbb[4];
+    __shared__ int32_t s_nbox[4];                                                             // wedge box x0, y0, x1, y1 (inclusive)
+    const int32_t mi = (int32_t)by;
+    const int32_t lane = threadIdx.x & 63;
+    const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t nwaves = __builtin_amdgcn_readfirstlane((int32_t)(blockDim.x >> 6));
+    for (int32_t i = threadIdx.x; i < 2 * RCN_RAYS; i += blockDim.x) s_slots[i] = 0ull;
+    RayDev r;
+    r.dx = r.dy = r.error = 0.0f; r.x = r.y = r.x_inc = r.y_inc = r.n = 0;
+    int32_t my_nwords = 0;
+    if (wave == 0) {
+        const int32_t b = (int32_t)bx * RCN_RAYS + lane;
+        RayMeta mt;
+        mt.n_eff = 0; mt.x0 = mt.y0 = mt.x_inc = mt.y_inc = mt.hit = 0; mt.sx = mt.sy = mt.measured = 0.0f;
+        int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
+        if (lane < RCN_RAYS && b < B) {
+            const RayIn ray = make_ray(g, beams[(size_t)mi * beam_stride + b], pose_lds ? pose_lds : poses + (size_t)pose_stride * mi);
+            mt = ray_meta(g, ray, r);
+            if (mt.n_eff > 0) {
+                // the first 64 steps: at most 63 moves from the start cell, split between x and y roughly as dx : dy (+2 for
+                // the rounding of the recurrence); a cell outside the box takes the direct-atomic path: the box is a hint
+                const int32_t steps = min(mt.n_eff, 64) - 1;
+                const float tot = r.dx + r.dy;
+                const int32_t mx = tot > 0.0f ? min(steps, (int32_t)((float)steps * (r.dx / tot)) + 2) : 0;
+                const int32_t my = tot > 0.0f ? min(steps, (int32_t)((float)steps * (r.dy / tot)) + 2) : 0;
+                const int32_t ex = mt.x0 + mt.x_inc * mx, ey = mt.y0 + mt.y_inc * my;
+                bx0 = max(min(mt.x0, ex), 0); bx1 = min(max(mt.x0, ex), g.W - 1);
+                by0 = max(min(mt.y0, ey), 0); by1 = min(max(mt.y0, ey), g.H - 1);
+            }
+        }
+        my_nwords = min((mt.n_eff + 31) >> 5, 2);
+        if (lane < RCN_RAYS) s_nmeta[lane] = mt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            bx0 = min(bx0, __shfl_xor(bx0, o, GMS_WAVE)); by0 = min(by0, __shfl_xor(by0, o, GMS_WAVE));
+            bx1 = max(bx1, __shfl_xor(bx1, o, GMS_WAVE)); by1 = max(by1, __shfl_xor(by1, o, GMS_WAVE));
+        }
+        if (lane == 0) { s_nbox[0] = bx0; s_nbox[1] = by0; s_nbox[2] = bx1; s_nbox[3] = by1; }
+    }
+    __syncthreads();
+    CountTile tile;
+    tile.cells = s_tile; tile.x0 = s_nbox[0]; tile.y0 = s_nbox[1];
+    tile.w = s_nbox[2] >= s_nbox[0] ? s_nbox[2] - s_nbox[0] + 1 : 0;
+    tile.h = s_nbox[3] >= s_nbox[1] ? s_nbox[3] - s_nbox[1] + 1 : 0;
+    // 8 bits per count: RCN_RAYS * (1 + extra) visits of one cell at most
+    if ((int64_t)tile.w * tile.h > RCN_TILE_CELLS || RCN_RAYS * (1 + g.extra) > 255) tile.w = tile.h = 0;       // direct atomics
+    const int32_t tcells = tile.w * tile.h;
+    for (int32_t i = threadIdx.x; i < (tcells + 1) / 2; i += blockDim.x) s_tile[i] = 0u;
+    __syncthreads();
+    int32_t bb[4] = { 0, 0, 0, 0 };
+    if (wave == 0) {
+        RayWalk wk = ray_walk_begin(r);
+        if (lane < RCN_RAYS && my_nwords > 0) ray_phase_a(wk, 0, my_nwords, s_slots, RCN_RAYS, lane);
+    } else {
+        for (int32_t ray = wave - 1; ray < RCN_RAYS; ray += nwaves - 1) {
+            RayMeta mt = s_nmeta[ray];
+            if (mt.n_eff <= 0) continue;
+            mt.n_eff = min(mt.n_eff, 64);                      // block 0 only: the far-field workgroups count the rest
+            ray_phase_b<false>(g, mt, s_slots, RCN_RAYS, ray, 0, lane, cnt + (size_t)mi * g.cells, bb, 0, nullptr, nullptr, 0, tile, 0);
+        }
+    }
+    __syncthreads();
+    // flush: one atomic per touched cell, lanes on consecutive cells of a row
+    uint32_t *mcnt = cnt + (size_t)mi * g.cells;
+    for (int32_t ry = wave; ry < tile.h; ry += nwaves) {
+        const int32_t cy = tile.y0 + ry, rbase = ry * tile.w;
+        for (int32_t rx = lane; rx < tile.w; rx += 64) {
+            const int32_t i = rbase + rx;
+            const uint32_t v = (s_tile[i >> 1] >> ((i & 1) << 4)) & 0xffffu;
+            if (v) {
+                const int32_t cx = tile.x0 + rx;
+                atomicAdd(&mcnt[(size_t)cy * g.W + cx], (v & 0xffu) | ((v >> 8) << 16));
+                bb[0] = max(bb[0], g.W - 1 - cx); bb[1] = max(bb[1], g.H - 1 - cy);
+                bb[2] = max(bb[2], cx + 1);       bb[3] = max(bb[3], cy + 1);
+            }
+        }
+    }
+    bbox_commit(bb, lane, bbox + 4 * mi, s_nbb);
+}
+// whether a scan of B beams gets near-field workgroups, and how many
+static inline uint32_t rc_near_blocks(int32_t B) { return B >= 32 ? (uint32_t)((B + RCN_RAYS - 1) / RCN_RAYS) : 0u; }
+
 template <bool TRACE, int RC_RAYS>
 __global__ void __launch_bounds__(RC_RAYS * 64)
 k_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride,
           const float *__restrict__ poses, int32_t pose_stride, const RayIn *__restrict__ single,
           uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox, int32_t *__restrict__ t_cells,
-          uint8_t *__restrict__ t_cls, int32_t cap, int32_t *__restrict__ t_counts, int32_t nw_max) {
+          uint8_t *__restrict__ t_cls, int32_t cap, int32_t *__restrict__ t_counts, int32_t nw_max, uint32_t n_near_blocks) {
     extern __shared__ __align__(16) unsigned char smem[];
+    // grid.x = ray blocks + near-field blocks (the latter only for the count form with four rays per workgroup)
+    if (!TRACE && RC_RAYS == 4 && n_near_blocks && blockIdx.x >= gridDim.x - n_near_blocks) {
+        raycast_near_body(g, beams, B, beam_stride, poses, pose_stride, cnt, bbox, blockIdx.x - (gridDim.x - n_near_blocks), blockIdx.y, smem,
+                          nullptr);
+        return;
+    }
     raycast_body<TRACE, RC_RAYS>(g, beams, B, beam_stride, poses, pose_stride, single, cnt, bbox, t_cells, t_cls, cap, t_counts,
-                                 nw_max, blockIdx.x, blockIdx.y, smem, nullptr);
+                                 nw_max, blockIdx.x, blockIdx.y, smem, nullptr, n_near_blocks ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -779,13 +922,15 @@ k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ li
 __global__ void __launch_bounds__(256)
 k_raycast_apply(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t beam_stride, const float *__restrict__ poses,
                 int32_t pose_stride, uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox_next, int32_t nw_max, uint32_t n_ray_blocks,
-                double *__restrict__ logd, uint32_t *__restrict__ cnt_pend, const int32_t *__restrict__ bbox_pend) {
+                uint32_t n_near_blocks, double *__restrict__ logd, uint32_t *__restrict__ cnt_pend, const int32_t *__restrict__ bbox_pend) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (blockIdx.x < n_ray_blocks)
         raycast_body<false, 4>(g, beams, B, beam_stride, poses, pose_stride, nullptr, cnt, bbox_next, nullptr, nullptr, 0, nullptr, nw_max,
-                               blockIdx.x, 0, smem, nullptr);
+                               blockIdx.x, 0, smem, nullptr, n_near_blocks ? 1 : 0);
+    else if (blockIdx.x < n_ray_blocks + n_near_blocks)
+        raycast_near_body(g, beams, B, beam_stride, poses, pose_stride, cnt, bbox_next, blockIdx.x - n_ray_blocks, 0, smem, nullptr);
     else
-        apply_body(g, logd, cnt_pend, bbox_pend, nullptr, blockIdx.x - n_ray_blocks, 0, gridDim.x - n_ray_blocks);
+        apply_body(g, logd, cnt_pend, bbox_pend, nullptr, blockIdx.x - n_ray_blocks - n_near_blocks, 0, gridDim.x - n_ray_blocks - n_near_blocks);
 }
 
 // scoring factors from an existing likelihood field (upload / copy), and the table's neutral border (fac_index)
@@ -856,18 +1001,22 @@ __global__ void k_debug_f32(int32_t op, const float *__restrict__ a, float *__re
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline int32_t rc_nw_max(const gms_map *m) { return (m->gd.W + m->gd.H + 1 + 31) / 32; }
-static inline size_t rc_smem(const gms_map *m, int rays) { return (size_t)rc_nw_max(m) * rays * sizeof(uint64_t); }
+static inline size_t rc_smem(const gms_map *m, int rays, uint32_t n_near = 0) {
+    const size_t a = (size_t)rc_nw_max(m) * rays * sizeof(uint64_t);
+    return n_near && a < RCN_LDS_BYTES ? (size_t)RCN_LDS_BYTES : a;              // near-field blocks carry their count tile
+}
 
 template <bool TRACE, int RAYS>
 static void rc_launch(gms_map *m, dim3 grid, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
                       int32_t pose_stride, const RayIn *single, uint32_t *cnt, int32_t *bbox, int32_t *t_cells, uint8_t *t_cls,
-                      int32_t cap, int32_t *t_counts) {
-    const size_t smem = rc_smem(m, RAYS);
+                      int32_t cap, int32_t *t_counts, uint32_t n_near = 0) {
+    const size_t smem = rc_smem(m, RAYS, n_near);
+    grid.x += n_near;                                       // near-field workgroups behind the ray blocks (raycast_near_body)
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast<TRACE, RAYS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
     hipLaunchKernelGGL((k_raycast<TRACE, RAYS>), grid, dim3(RAYS * 64), smem, m->stream, m->gd, d_beams, B, beam_stride, d_poses,
-                       pose_stride, single, cnt, bbox, t_cells, t_cls, cap, t_counts, rc_nw_max(m));
+                       pose_stride, single, cnt, bbox, t_cells, t_cls, cap, t_counts, rc_nw_max(m), n_near);
 }
 
 void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
@@ -904,7 +1053,7 @@ void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t 
                              nullptr, nullptr, 0, nullptr);
     else
         rc_launch<false, 4>(m, dim3((B + 3) / 4, m->n_maps), d_beams, B, beam_stride, d_poses, pose_stride, nullptr, m->d_cnt, bb,
-                            nullptr, nullptr, 0, nullptr);
+                            nullptr, nullptr, 0, nullptr, m->raycast_near ? rc_near_blocks(B) : 0u);
 }
 
 void gms_launch_trace_scan(gms_map *m, const gms_beam *d_beams, int32_t B, const float *d_pose, int32_t *d_cells,
@@ -962,11 +1111,12 @@ void gms_launch_raycast_apply(gms_map *m, const gms_beam *d_beams, int32_t B, in
     const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
     const uint32_t n_apply = (uint32_t)(all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS);
     int32_t *pend = m->d_bbox + (size_t)m->bbox_cur * 4, *next = m->d_bbox + (size_t)(1 - m->bbox_cur) * 4;
-    const size_t smem = rc_smem(m, 4);
+    const uint32_t n_near = m->raycast_near ? rc_near_blocks(B) : 0u;
+    const size_t smem = rc_smem(m, 4, n_near);
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k_raycast_apply, dim3(n_ray + n_apply), dim3(256), smem, m->stream, m->gd, d_beams, B, beam_stride, d_poses,
-                       pose_stride, m->d_cnt, next, rc_nw_max(m), n_ray, m->d_log, m->d_cnt_pend, pend);
+    hipLaunchKernelGGL(k_raycast_apply, dim3(n_ray + n_near + n_apply), dim3(256), smem, m->stream, m->gd, d_beams, B, beam_stride, d_poses,
+                       pose_stride, m->d_cnt, next, rc_nw_max(m), n_ray, n_near, m->d_log, m->d_cnt_pend, pend);
     gms_apply_done(m);                      // the box of the scan just cast is the current half now
 }
 void gms_flush_apply(gms_map *m) {
