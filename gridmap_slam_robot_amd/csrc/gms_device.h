@@ -10,6 +10,18 @@
 
 #define GMS_WAVE 64
 
+// Development builds only (-DGMS_STAMPS, tools/stamps.py): wall-clock stamps (100 MHz) of a kernel's stages, one row of
+// GMS_STAMP_SLOTS per workgroup, written by thread 0.  Compiled out of the product library.
+#define GMS_STAMP_SLOTS 16
+#ifdef GMS_STAMPS
+__device__ unsigned long long *g_gms_stamps;
+#define GMS_STAMP_T(tid, row, slot) do { if (g_gms_stamps && threadIdx.x == (tid)) g_gms_stamps[(size_t)(row) * GMS_STAMP_SLOTS + (slot)] = wall_clock64(); } while (0)
+#else
+#define GMS_STAMP_T(tid, row, slot) do { } while (0)
+#endif
+#define GMS_STAMP(row, slot) GMS_STAMP_T(0, row, slot)
+#define GMS_STAMP_ROW(kernel_id, wg) ((kernel_id) * 1024u + ((wg) < 1023u ? (wg) : 1023u))      // rows of the stamp buffer: [4 kernels][1024 workgroups]
+
 // (int) of a double, JLS 5.1.3: truncate toward zero, saturate, NaN -> 0.
 __device__ __forceinline__ int32_t j_d2i(double d) {
     if (d != d) return 0;

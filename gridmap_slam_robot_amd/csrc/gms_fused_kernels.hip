@@ -37,12 +37,14 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
                uint32_t n_near_blocks) {
     extern __shared__ __align__(16) unsigned char smem[];
     // workgroups: [far-field ray blocks | near-field ray blocks) = n_ray_blocks, then normalise, then the riding apply pass
+    GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 0);
     if (blockIdx.x >= n_ray_blocks + n_norm_blocks) {
         // The PREVIOUS scan's `logData[c] += ...` (GridMap.java:223) from the other count grid: it needs nothing of this launch
         // and only has to be done before this scan's likelihood pass.  Its ~5 us hide under the ray cast's 17 us latency chain
         // on CUs that launch leaves idle (beside the block partials, round 1's place, it cost that launch 2.3 us).
         apply_body(g, logd, cnt_pend, bbox_pend, nullptr, blockIdx.x - n_ray_blocks - n_norm_blocks, 0,
                    gridDim.x - n_ray_blocks - n_norm_blocks);
+        GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 15);
         return;
     }
     if (blockIdx.x < n_ray_blocks) {
@@ -57,6 +59,7 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
             s_pose[2] = (float)(f[3] / f[0]);
         }
         __syncthreads();
+        GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 1);
         if (blockIdx.x >= n_ray_blocks - n_near_blocks)
             raycast_near_body(g, beams, B, B, nullptr, 0, cnt, bbox, blockIdx.x - (n_ray_blocks - n_near_blocks), 0, smem, s_pose);
         else
@@ -65,6 +68,7 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
     } else {
         normalize_pack_body(partials, nblk_global, w, pose, n, offset, packed, cum, chunk_tot, nchunks, p2, stats,
                             blockIdx.x - n_ray_blocks, 0);
+        GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 14);
     }
 }
 
@@ -154,6 +158,7 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
     extern __shared__ __align__(16) unsigned char smem[];
     // the box half the next ray cast will raise: cleared here because that ray cast may share its launch with this scan's
     // deferred apply pass (k_raycast_apply), which otherwise does the clearing
+    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 0);
     if (blockIdx.x == 0 && threadIdx.x < 4) bbox_clear[4 * blockIdx.y + threadIdx.x] = 0;
     if (blockIdx.x < n_res_blocks)                      // a multiple of 8 keeps the likelihood tiles' XCD round-robin aligned
         resample_body(glob, n_global, nchunks, cum, chunk_off, r01_maps, r01, fraction, n, offset, pose2, cs2, w2, idx_out, p2,
@@ -161,6 +166,7 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
     else
         likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, 1, tiles_x, tiles_y, blockIdx.x - n_res_blocks,
                             blockIdx.y, gridDim.x - n_res_blocks, smem, cnt_pending, tile_state);
+    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), blockIdx.x < n_res_blocks ? 1 : 2);
 }
 
 // ---------------------------------------------------------------------------------------------

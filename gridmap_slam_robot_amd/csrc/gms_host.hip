@@ -781,6 +781,13 @@ int gms_map_update_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, gms_
     return finish_likelihood(m, m->need_full_build ? 0 : 1);
 }
 
+// development: where instrumented builds (-DGMS_STAMPS) write their stage time stamps; GMS_ERR_STATE in a product build
+int gms_debug_set_stamps(gms_map *m, void *dev_buffer) {
+    REQUIRE(m, "null map");
+    HIPCHK(hipSetDevice(m->device));
+    return gms_set_stamp_buffer(m, dev_buffer) ? GMS_OK : fail(GMS_ERR_STATE, "this build carries no stage stamps (compile with -DGMS_STAMPS)");
+}
+
 int gms_debug_f32(gms_map *m, int32_t op, const float *in, float *out, int64_t n) {
     REQUIRE(m && in && out && n > 0 && op >= 0 && op <= 2, "gms_debug_f32: bad arguments");
     HIPCHK(hipSetDevice(m->device));

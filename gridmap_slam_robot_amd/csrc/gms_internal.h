@@ -204,6 +204,7 @@ void gms_launch_deskew(gms_map *m, const double *d_angle, const double *d_distan
                        double d_center, double d_theta, gms_beam *d_out);
 void gms_launch_factors(gms_map *m);   // d_fac from d_lik (after an upload / copy)
 void gms_launch_noop(gms_map *m);
+bool gms_set_stamp_buffer(gms_map *m, void *dev_buffer);
 void gms_launch_spin(gms_map *m, double us);
 void gms_launch_copy(gms_map *m, void *dst, const void *src, size_t nbytes);   // src may be pinned host memory
 void gms_invalidate_tile_state(gms_map *m);

@@ -108,43 +108,22 @@ __device__ __forceinline__ void ray_phase_a(RayWalk &k, int32_t w0, int32_t w1, 
     for (int32_t w = w0; w < w1; ++w) {
         uint32_t word = 0;
         float t;
-#pragma unroll
-        for (int32_t j = 0; j < 32; ++j) {
-            // one step of RayIterator.next (RayIterator.java:117-123) in four VALU instructions, the wavefront's issue
-            // rate being the limit (one lane per ray, one phase-A wavefront per SIMD):
-            //   vcc  = 0 < err                       c = error > 0                               (:117)
-            //   t    = vcc ? -dx : dy
-            //   err  = err + t                       error -= dx  /  error += dy                 (:119 / :122; a - b == a + (-b))
-            //   word = word + word + vcc             shift the decision in (bit 31 - j after 32 steps)
-#if defined(GMS_EXP_DDA_SPEC)
-            // experiment: both successors beside the compare, one select picks (chain: max(cmp, add) -> select; five instructions)
-            float t2;
-            asm volatile("v_cmp_lt_f32_e32 vcc, 0, %0\n\t"
-                         "v_add_f32_e32 %2, %0, %5\n\t"
-                         "v_add_f32_e32 %3, %0, %4\n\t"
-                         "v_cndmask_b32_e32 %0, %3, %2, vcc\n\t"
-                         "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
-                         : "+v"(err), "+v"(word), "=&v"(t), "=&v"(t2)
-                         : "v"(dy), "v"(ndx)
-                         : "vcc");
-#elif defined(GMS_EXP_DDA_3INSTR)
-            // experiment, WRONG results (no decision word): what a three-instruction step would cost
-            asm volatile("v_cmp_lt_f32_e32 vcc, 0, %0\n\t"
-                         "v_cndmask_b32_e32 %2, %3, %4, vcc\n\t"
-                         "v_add_f32_e32 %0, %0, %2"
-                         : "+v"(err), "+v"(word), "=&v"(t)
-                         : "v"(dy), "v"(ndx)
-                         : "vcc");
-#else
-            asm volatile("v_cmp_lt_f32_e32 vcc, 0, %0\n\t"
-                         "v_cndmask_b32_e32 %2, %3, %4, vcc\n\t"
-                         "v_add_f32_e32 %0, %0, %2\n\t"
-                         "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
-                         : "+v"(err), "+v"(word), "=&v"(t)
-                         : "v"(dy), "v"(ndx)
-                         : "vcc");
-#endif
-        }
+        // one step of RayIterator.next (RayIterator.java:117-123) in four VALU instructions, the wavefront's issue rate being
+        // the limit (one lane per ray, one phase-A wavefront per SIMD: 4.6 clocks per instruction):
+        //   vcc  = 0 < err                       c = error > 0                               (:117)
+        //   t    = vcc ? -dx : dy
+        //   err  = err + t                       error -= dx  /  error += dy                 (:119 / :122; a - b == a + (-b))
+        //   word = word + word + vcc             shift the decision in (bit 31 - j after 32 steps)
+        // All 32 steps of a word are ONE asm statement: between two statements the compiler pads a hazard it cannot rule out
+        // with an s_nop, a fifth issue slot per step (tools/microbench/dda_chain.hip: 24.2 -> 18.5 clocks per step).
+#define GMS_DDA_STEP "v_cmp_lt_f32_e32 vcc, 0, %0\n\tv_cndmask_b32_e32 %2, %3, %4, vcc\n\tv_add_f32_e32 %0, %0, %2\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
+#define GMS_DDA_STEP4 GMS_DDA_STEP GMS_DDA_STEP GMS_DDA_STEP GMS_DDA_STEP
+        asm volatile(GMS_DDA_STEP4 GMS_DDA_STEP4 GMS_DDA_STEP4 GMS_DDA_STEP4 GMS_DDA_STEP4 GMS_DDA_STEP4 GMS_DDA_STEP4 GMS_DDA_STEP4
+                     : "+v"(err), "+v"(word), "=&v"(t)
+                     : "v"(dy), "v"(ndx)
+                     : "vcc");
+#undef GMS_DDA_STEP4
+#undef GMS_DDA_STEP
         word = __brev(word);                           // decision j at bit j
         lds_publish_u64(&slots[(w - w0) * stride + slot], ((uint64_t)(RC_VALID | ycount) << 32) | (uint64_t)word);
         ycount += __popc(word);
@@ -192,9 +171,6 @@ __device__ __forceinline__ int32_t ray_phase_b(const GridDev &g, const RayMeta &
                     if (t_cells) { t_cells[2 * o] = cx; t_cells[2 * o + 1] = cy; }
                     if (t_cls) t_cls[o] = (uint8_t)cls;
                 }
-#ifdef GMS_EXP_SKIP_NEAR
-            } else if (k < GMS_EXP_SKIP_NEAR) {        // experiment, WRONG results: no count atomics for the first cells of every ray
-#endif
             } else if (cls != 1) {
                 const uint32_t inc = cls == 0 ? 1u : 0x10000u;
                 const uint32_t ux = (uint32_t)(cx - tile.x0), uy = (uint32_t)(cy - tile.y0);
@@ -274,15 +250,14 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
         s_count[lane] = 0;
     }
     __syncthreads();
+    GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 2);
     int32_t bb[4] = { 0, 0, 0, 0 };
     if (wave == 0) {
-#ifdef GMS_EXP_SETPRIO
-        __builtin_amdgcn_s_setprio(3);                 // experiment: the producer's recurrence ahead of the consumers on its SIMD
-#endif
         if (lane < RC_RAYS) {
             RayWalk wk = ray_walk_begin(r);
             ray_phase_a(wk, 0, (my_n_eff + 31) >> 5, s_slots, RC_RAYS, lane);
         }
+        GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 3);
     } else {
         int32_t nblk_max = 0;
 #pragma unroll
@@ -296,6 +271,7 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
                                                  (int32_t)bx * RC_RAYS + ray, t_cells, t_cls, cap);
             if (TRACE && lane == 0) atomicAdd(&s_count[ray], n);
         }
+        GMS_STAMP_T(64, GMS_STAMP_ROW(2, blockIdx.x), 4);
     }
     if (TRACE) {
         __syncthreads();
@@ -303,6 +279,7 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
         if (threadIdx.x < RC_RAYS && b < B && t_counts) t_counts[b] = s_count[threadIdx.x];
     } else {
         bbox_commit(bb, lane, bbox + 4 * mi, s_bb);
+        GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 5);
     }
 }
 
@@ -382,6 +359,7 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
     const int32_t tcells = tile.w * tile.h;
     for (int32_t i = threadIdx.x; i < (tcells + 1) / 2; i += blockDim.x) s_tile[i] = 0u;
     __syncthreads();
+    GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 9);
     int32_t bb[4] = { 0, 0, 0, 0 };
     if (wave == 0) {
         RayWalk wk = ray_walk_begin(r);
@@ -395,6 +373,7 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
         }
     }
     __syncthreads();
+    GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 10);
     // flush: one atomic per touched cell, lanes on consecutive cells of a row
     uint32_t *mcnt = cnt + (size_t)mi * g.cells;
     for (int32_t ry = wave; ry < tile.h; ry += nwaves) {
@@ -410,7 +389,9 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
             }
         }
     }
+    GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 11);
     bbox_commit(bb, lane, bbox + 4 * mi, s_nbb);
+    GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 12);
 }
 // whether a scan of B beams gets near-field workgroups, and how many
 static inline uint32_t rc_near_blocks(int32_t B) { return B >= 32 ? (uint32_t)((B + RCN_RAYS - 1) / RCN_RAYS) : 0u; }
@@ -1207,6 +1188,16 @@ void gms_launch_copy(gms_map *m, void *dst, const void *src, size_t nbytes) {
     const int64_t blocks = (n16 + 255) / 256;
     hipLaunchKernelGGL(k_copy16, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, m->stream,
                        reinterpret_cast<uint4 *>(dst), reinterpret_cast<const uint4 *>(src), n16);
+}
+
+bool gms_set_stamp_buffer(gms_map *m, void *dev_buffer) {
+#ifdef GMS_STAMPS
+    hipStreamSynchronize(m->stream);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gms_stamps), &dev_buffer, sizeof(dev_buffer)) == hipSuccess;
+#else
+    (void)m; (void)dev_buffer;
+    return false;
+#endif
 }
 
 __global__ void k_noop() {}

@@ -280,6 +280,7 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     // (each with an L2 of its own), so id & 7 picks the XCD and every XCD gets nseg / 8 ADJACENT segments for all particle
     // groups: its L2 then holds the windows of a few neighbouring beams instead of the whole scan's (C3: 23.8 -> 22.3 us
     // for segment-major order, -> see DESIGN.md for the adjacent-segment form; C5: 335 -> 326 us).
+    GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 0);
     const int32_t mi = blockIdx.z;
     int32_t seg, grp;
     {
@@ -339,6 +340,7 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
         t.px = (double)pose[3 * gi]; t.py = (double)pose[3 * gi + 1];
     }
     __syncthreads();
+    GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 1);
     const int32_t nb = s_nb;
     if (p >= n) return;
     double prod = 1.0;                                                 // GridMap.java:262
@@ -381,6 +383,7 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     } else {
         part[((size_t)mi * nseg + seg) * n + op] = prod;              // <= 128 factors >= 0.01: no underflow
     }
+    GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 2);
 }
 
 // product of the per-segment products, in segment order, with an exact exponent (no underflow on the
@@ -707,7 +710,9 @@ __global__ void __launch_bounds__(256)
 k_partials(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n,
            int64_t offset, int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part,
            int32_t part_nseg) {
+    GMS_STAMP(GMS_STAMP_ROW(1, blockIdx.x), 0);
     partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y);
+    GMS_STAMP(GMS_STAMP_ROW(1, blockIdx.x), 1);
 }
 
 // Level 0 of the cumulative weights: one wavefront = one 64-particle chunk, lane = particle, inclusive scan by

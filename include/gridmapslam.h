@@ -365,6 +365,9 @@ int gms_profile_calibrate2(gms_map *m, int32_t reps, double *bracket_ms, double 
 /* The float-rounded device primitives the parity contract leans on, for tests: op 0 = (float)sqrt(a)
  * (GridMap.java:217), 1 = (float)cos((double)a), 2 = (float)sin((double)a) (J/math/MathUtil.java:30-40). */
 int gms_debug_f32(gms_map *m, int32_t op, const float *in, float *out, int64_t n);
+/* Development: instrumented builds (-DGMS_STAMPS) write wall-clock stamps of their kernels' stages to dev_buffer
+ * ([workgroup][16] uint64, 10 ns units; NULL turns it off); a product build returns GMS_ERR_STATE.  tools/stamps.py. */
+int gms_debug_set_stamps(gms_map *m, void *dev_buffer);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

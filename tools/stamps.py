@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Stage timeline of one C3 scan step from an instrumented build (development tool).
+
+  GMS_EXTRA_FLAGS=-DGMS_STAMPS python -m gridmap_slam_robot_amd.build --force; cp .../libgridmapslam.so .../exp_stamps.so; rebuild the product
+  GMS_LIBRARY=$PWD/gridmap_slam_robot_amd/lib/exp_stamps.so python tools/stamps.py [--config C3] [--steps 40]
+
+Every instrumented kernel writes wall-clock stamps (100 MHz) of its stages per workgroup; the stamps of the LAST step are
+printed relative to the first workgroup entering the scoring kernel: first / median / last workgroup per stage."""
+import argparse, ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+STAGES = {
+    0: ("k_score_c", {0: "entered", 1: "beams compacted, trig done", 2: "products stored"}),
+    1: ("k_partials", {0: "entered", 1: "left"}),
+    2: ("k_norm_raycast", {0: "entered", 1: "ray: pose folded", 2: "far: rays set up", 3: "far: recurrence done (producer)", 4: "far: first consumer done",
+                           5: "far: box committed", 9: "near: tile cleared", 10: "near: 64 steps counted", 11: "near: tile flushed", 12: "near: box committed",
+                           14: "normalise: left", 15: "apply: left"}),
+    3: ("k_lik_resample", {0: "entered", 1: "resample: left", 2: "likelihood: left"}),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--steps", type=int, default=40)
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    import bench
+    from gridmap_slam_robot_amd import _lib
+    args = argparse.Namespace(particles=0, exchange="auto", host_inputs=False, full_rebuild=False)
+    wl = bench.Workload(a.config, args, torch, dist, 0, 1, 0, False)
+    buf = torch.zeros(4 * 1024 * 16, dtype=torch.int64, device=wl.dev)
+    _lib.check(_lib.load().gms_debug_set_stamps(wl.m._h, C.c_void_p(buf.data_ptr())))
+    for i in range(a.steps):
+        wl.step(i)
+    torch.cuda.synchronize()
+    s = buf.cpu().numpy().reshape(4, 1024, 16).astype(np.float64)
+    _lib.check(_lib.load().gms_debug_set_stamps(wl.m._h, None))
+    s[s == 0] = np.nan
+    t0 = np.nanmin(s[0, :, 0])
+    print(f"{a.config}: stage stamps of the last of {a.steps} steps, microseconds after the first scoring workgroup entered")
+    for kid, (name, slots) in STAGES.items():
+        for slot, what in slots.items():
+            v = (s[kid, :, slot] - t0) * 0.01
+            v = v[~np.isnan(v)]
+            if v.size:
+                print(f"  {name:16s} {what:34s} n={v.size:4d}  first {v.min():7.2f}  median {np.median(v):7.2f}  last {v.max():7.2f}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
