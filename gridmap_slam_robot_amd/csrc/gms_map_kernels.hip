@@ -52,12 +52,14 @@ __device__ __forceinline__ void bbox_decode(const int32_t *bb, int32_t W, int32_
 struct RayMeta {
     int32_t x0, y0, x_inc, y_inc, n_eff, hit;
     float sx, sy, measured;
+    int32_t hx, hy;            // far corner of a box that contains every cell of the walk (ray_meta), inside the map
 };
 
 // Decision words travel from the phase-A wavefront to the phase-B wavefronts through LDS slots of 8 bytes,
 // (RC_VALID | number of y steps before the word) << 32 | decision word: one ds_write_b64, so a reader sees a slot either
 // empty (cleared at kernel start) or complete.  Slot of word w of ray `slot`: slots[w * stride + slot].
 #define RC_VALID 0x80000000u
+#define RC_BOX_MARGIN 5           // cells beyond the end point's cell that a walk's box allows for (ray_meta)
 
 // The slots are written and polled with explicit DS instructions: through a generic pointer the compiler emits flat
 // accesses, and marking them volatile adds a full wait after every one (the producer would stall on each publish).
@@ -84,7 +86,33 @@ __device__ __forceinline__ RayMeta ray_meta(const GridDev &g, const RayIn &ray, 
     mt.sx = ray.sx; mt.sy = ray.sy; mt.measured = ray.measured; mt.hit = ray.hit;
     const bool inb0 = !(r.x < 0 || r.x >= g.W || r.y < 0 || r.y >= g.H);
     mt.n_eff = (inb0 && r.n > 0) ? min(r.n, g.W + g.H + 1) : 0;
+    // Where the walk can go.  It is monotonic in x and in y and makes n - 1 moves; the recurrence keeps `error` inside (-dx, dy], so
+    // after k moves the number of x moves is within (max(dx, dy) + drift) / (dx + dy) < 1.3 of k dx / (dx + dy) (the float drift of
+    // `error` over a walk is below a quarter of a cell), and n - 1 = extra + |floor x1 - x| + |floor y1 - y| (RayIterator.java:75-100):
+    // at most |floor x1 - x| + extra + 4.3 moves along x, likewise along y.  RC_BOX_MARGIN = 5 makes the box [x0, hx] x [y0, hy] a
+    // superset of the visited cells; the scan's dirty box is raised from these boxes BEFORE the walk (no reduction and no barrier
+    // at the kernel's end), and a counted cell that were ever outside its ray's box would still raise the dirty box by itself
+    // (ray_phase_b).
+    const int64_t ax = llabs((int64_t)j_d2i(floor((double)(ray.ex + 0.5f))) - (int64_t)r.x) + g.extra + RC_BOX_MARGIN;
+    const int64_t ay = llabs((int64_t)j_d2i(floor((double)(ray.ey + 0.5f))) - (int64_t)r.y) + g.extra + RC_BOX_MARGIN;
+    const int32_t moves = mt.n_eff > 0 ? mt.n_eff - 1 : 0;
+    mt.hx = min(max(r.x + r.x_inc * (int32_t)min((int64_t)moves, ax), 0), g.W - 1);
+    mt.hy = min(max(r.y + r.y_inc * (int32_t)min((int64_t)moves, ay), 0), g.H - 1);
     return mt;
+}
+// encoded box of one ray's walk (all zero: the ray visits nothing)
+__device__ __forceinline__ void ray_box(const GridDev &g, const RayMeta &mt, int32_t bb[4]) {
+    if (mt.n_eff <= 0) { bb[0] = bb[1] = bb[2] = bb[3] = 0; return; }
+    bb[0] = g.W - 1 - min(mt.x0, mt.hx); bb[1] = g.H - 1 - min(mt.y0, mt.hy);
+    bb[2] = max(mt.x0, mt.hx) + 1;       bb[3] = max(mt.y0, mt.hy) + 1;
+}
+// raise the scan's dirty box by the union of the lanes' boxes: wave butterfly, then four atomics by lane 0, not waited for
+__device__ __forceinline__ void bbox_raise_wave(int32_t bb[4], int32_t lane, int32_t *__restrict__ bbox_map) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        for (int q = 0; q < 4; q++) bb[q] = max(bb[q], __shfl_xor(bb[q], o, GMS_WAVE));
+    if (lane == 0 && bb[2] > 0)
+        for (int q = 0; q < 4; q++) atomicMax(&bbox_map[q], bb[q]);
 }
 
 // phase A for one ray: the float `error` recurrence, 32 decisions per published slot.  Resumable: words [w0, w1) are
@@ -142,7 +170,7 @@ struct CountTile {         // per-workgroup accumulation tile in LDS (batched ma
 
 template <bool TRACE>
 __device__ __forceinline__ int32_t ray_phase_b(const GridDev &g, const RayMeta &mt, const uint64_t *__restrict__ slots, int32_t stride,
-                                               int32_t slot, int32_t blk, int32_t lane, uint32_t *__restrict__ mcnt, int32_t bb[4],
+                                               int32_t slot, int32_t blk, int32_t lane, uint32_t *__restrict__ mcnt, int32_t *__restrict__ bbox_map,
                                                int32_t b, int32_t *__restrict__ t_cells, uint8_t *__restrict__ t_cls, int32_t cap,
                                                const CountTile tile = CountTile{nullptr, 0, 0, 0, 0}, int32_t w_base = 0) {
     const int32_t nwords = (mt.n_eff + 31) >> 5;
@@ -180,31 +208,17 @@ __device__ __forceinline__ int32_t ray_phase_b(const GridDev &g, const RayMeta &
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
                     atomicAdd(&mcnt[(size_t)cy * g.W + cx], inc);
-                    bb[0] = max(bb[0], g.W - 1 - cx); bb[1] = max(bb[1], g.H - 1 - cy);
-                    bb[2] = max(bb[2], cx + 1);       bb[3] = max(bb[3], cy + 1);
+                    // the dirty box was raised from the rays' boxes before the walk (ray_meta); a cell outside its ray's box --
+                    // there should be none -- raises it here
+                    if (__builtin_expect(cx < min(mt.x0, mt.hx) || cx > max(mt.x0, mt.hx) || cy < min(mt.y0, mt.hy) || cy > max(mt.y0, mt.hy), 0)) {
+                        atomicMax(&bbox_map[0], g.W - 1 - cx); atomicMax(&bbox_map[1], g.H - 1 - cy);
+                        atomicMax(&bbox_map[2], cx + 1);       atomicMax(&bbox_map[3], cy + 1);
+                    }
                 }
             }
         }
     }
     return __popcll(__ballot(valid));
-}
-
-// workgroup-level max of the encoded box in LDS, then at most four global atomics per workgroup, and only
-// where they would raise the box (same-address global atomics serialise in L2: ~10 ns each)
-__device__ __forceinline__ void bbox_commit(int32_t bb[4], int32_t lane, int32_t *__restrict__ bbox_map, int32_t *s_bb) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        for (int q = 0; q < 4; q++) bb[q] = max(bb[q], __shfl_xor(bb[q], o, GMS_WAVE));
-    if (threadIdx.x < 4) s_bb[threadIdx.x] = 0;
-    __syncthreads();
-    if (lane == 0 && bb[2] > 0)
-        for (int q = 0; q < 4; q++) atomicMax(&s_bb[q], bb[q]);
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const int32_t v = s_bb[threadIdx.x];
-        if (v > 0 && v > __hip_atomic_load(&bbox_map[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(&bbox_map[threadIdx.x], v);
-    }
 }
 
 // One workgroup = RC_RAYS rays, NWAVES wavefronts.  Wavefront 0 is the producer: lane r runs phase A of ray r and
@@ -225,7 +239,6 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
     // first_blk = 1: the rays' first 64 steps (block 0) are counted by the near-field workgroups (raycast_near_body)
     uint64_t *s_slots = reinterpret_cast<uint64_t *>(smem);            // [nw_max][RC_RAYS]
     __shared__ RayMeta s_meta[RC_RAYS];
-    __shared__ int32_t s_bb[4];
     __shared__ int32_t s_count[RC_RAYS];
 
     const int32_t mi = (int32_t)by;
@@ -249,9 +262,14 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
         s_meta[lane] = mt;
         s_count[lane] = 0;
     }
+    if (!TRACE && first_blk == 0 && wave == 0) {
+        // the scan's dirty box from the rays' boxes, up front (with near-field workgroups in the launch, they raise it for their wedges)
+        int32_t hb[4] = { 0, 0, 0, 0 };
+        if (lane < RC_RAYS) ray_box(g, s_meta[lane], hb);
+        bbox_raise_wave(hb, lane, bbox + 4 * mi);
+    }
     __syncthreads();
     GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 2);
-    int32_t bb[4] = { 0, 0, 0, 0 };
     if (wave == 0) {
         if (lane < RC_RAYS) {
             RayWalk wk = ray_walk_begin(r);
@@ -267,7 +285,7 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
             const int32_t blk = q / RC_RAYS, ray = q - blk * RC_RAYS;
             const RayMeta mt = s_meta[ray];
             if (blk * 64 >= mt.n_eff) continue;
-            const int32_t n = ray_phase_b<TRACE>(g, mt, s_slots, RC_RAYS, ray, blk, lane, TRACE ? nullptr : cnt + (size_t)mi * g.cells, bb,
+            const int32_t n = ray_phase_b<TRACE>(g, mt, s_slots, RC_RAYS, ray, blk, lane, TRACE ? nullptr : cnt + (size_t)mi * g.cells, TRACE ? nullptr : bbox + 4 * mi,
                                                  (int32_t)bx * RC_RAYS + ray, t_cells, t_cls, cap);
             if (TRACE && lane == 0) atomicAdd(&s_count[ray], n);
         }
@@ -278,7 +296,6 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
         const int32_t b = (int32_t)bx * RC_RAYS + (int32_t)threadIdx.x;
         if (threadIdx.x < RC_RAYS && b < B && t_counts) t_counts[b] = s_count[threadIdx.x];
     } else {
-        bbox_commit(bb, lane, bbox + 4 * mi, s_bb);
         GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 5);
     }
 }
@@ -310,7 +327,6 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
     uint64_t *s_slots = reinterpret_cast<uint64_t *>(smem);                                   // [2][RCN_RAYS]
     uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_slots + 2 * RCN_RAYS);                  // [RCN_TILE_CELLS / 2]
     __shared__ RayMeta s_nmeta[RCN_RAYS];
-    __shared__ int32_t s_nbb[4];
     __shared__ int32_t s_nbox[4];                                                             // wedge box x0, y0, x1, y1 (inclusive)
     const int32_t mi = (int32_t)by;
     const int32_t lane = threadIdx.x & 63;
@@ -342,6 +358,11 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
         }
         my_nwords = min((mt.n_eff + 31) >> 5, 2);
         if (lane < RCN_RAYS) s_nmeta[lane] = mt;
+        {   // the scan's dirty box from the WHOLE walks of this wedge's rays (the far-field workgroups of these rays leave it to this one)
+            int32_t hb[4];
+            ray_box(g, mt, hb);
+            bbox_raise_wave(hb, lane, bbox + 4 * mi);
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             bx0 = min(bx0, __shfl_xor(bx0, o, GMS_WAVE)); by0 = min(by0, __shfl_xor(by0, o, GMS_WAVE));
@@ -360,7 +381,6 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
     for (int32_t i = threadIdx.x; i < (tcells + 1) / 2; i += blockDim.x) s_tile[i] = 0u;
     __syncthreads();
     GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 9);
-    int32_t bb[4] = { 0, 0, 0, 0 };
     if (wave == 0) {
         RayWalk wk = ray_walk_begin(r);
         if (lane < RCN_RAYS && my_nwords > 0) ray_phase_a(wk, 0, my_nwords, s_slots, RCN_RAYS, lane);
@@ -369,7 +389,7 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
             RayMeta mt = s_nmeta[ray];
             if (mt.n_eff <= 0) continue;
             mt.n_eff = min(mt.n_eff, 64);                      // block 0 only: the far-field workgroups count the rest
-            ray_phase_b<false>(g, mt, s_slots, RCN_RAYS, ray, 0, lane, cnt + (size_t)mi * g.cells, bb, 0, nullptr, nullptr, 0, tile, 0);
+            ray_phase_b<false>(g, mt, s_slots, RCN_RAYS, ray, 0, lane, cnt + (size_t)mi * g.cells, bbox + 4 * mi, 0, nullptr, nullptr, 0, tile, 0);
         }
     }
     __syncthreads();
@@ -381,17 +401,10 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
         for (int32_t rx = lane; rx < tile.w; rx += 64) {
             const int32_t i = rbase + rx;
             const uint32_t v = (s_tile[i >> 1] >> ((i & 1) << 4)) & 0xffffu;
-            if (v) {
-                const int32_t cx = tile.x0 + rx;
-                atomicAdd(&mcnt[(size_t)cy * g.W + cx], (v & 0xffu) | ((v >> 8) << 16));
-                bb[0] = max(bb[0], g.W - 1 - cx); bb[1] = max(bb[1], g.H - 1 - cy);
-                bb[2] = max(bb[2], cx + 1);       bb[3] = max(bb[3], cy + 1);
-            }
+            if (v) atomicAdd(&mcnt[(size_t)cy * g.W + tile.x0 + rx], (v & 0xffu) | ((v >> 8) << 16));      // (inside the box raised above)
         }
     }
     GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 11);
-    bbox_commit(bb, lane, bbox + 4 * mi, s_nbb);
-    GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 12);
 }
 // whether a scan of B beams gets near-field workgroups, and how many
 static inline uint32_t rc_near_blocks(int32_t B) { return B >= 32 ? (uint32_t)((B + RCN_RAYS - 1) / RCN_RAYS) : 0u; }
@@ -446,7 +459,6 @@ k_raycast_tile(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t
     uint64_t *s_slots = reinterpret_cast<uint64_t *>(smem);            // [RCT_WORDS][RCT_RAYS]
     uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_slots + RCT_WORDS * RCT_RAYS);         // [RCT_TILE_CELLS / 2]
     __shared__ RayMeta s_meta[RCT_RAYS];
-    __shared__ int32_t s_bb[4];
     __shared__ int32_t s_box[5];                                        // wedge box x0, y0, x1, y1 (inclusive); longest walk in words
 
     const int32_t mi = blockIdx.y;
@@ -477,6 +489,11 @@ k_raycast_tile(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t
         }
         my_nwords = (mt.n_eff + 31) >> 5;
         s_meta[lane] = mt;
+        {   // the map's dirty box from the rays' boxes, up front
+            int32_t hb[4];
+            ray_box(g, mt, hb);
+            bbox_raise_wave(hb, lane, bbox + 4 * mi);
+        }
         int32_t nwm = my_nwords;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -496,7 +513,6 @@ k_raycast_tile(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t
     const int32_t tcells = tile.w * tile.h;
     const int32_t nwords_max = s_box[4];
     for (int32_t i = threadIdx.x; i < (tcells + 1) / 2; i += RCT_THREADS) s_tile[i] = 0u;
-    int32_t bb[4] = { 0, 0, 0, 0 };
     RayWalk wk = ray_walk_begin(r);
     for (int32_t wb = 0; wb < nwords_max; wb += RCT_WORDS) {           // one round = up to 512 steps of every ray
         for (int32_t i = threadIdx.x; i < RCT_WORDS * RCT_RAYS; i += RCT_THREADS) s_slots[i] = 0ull;
@@ -510,7 +526,7 @@ k_raycast_tile(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t
                 const int32_t blk = blk0 + q / RCT_RAYS, ray = q % RCT_RAYS;
                 const RayMeta mt = s_meta[ray];
                 if (blk * 64 >= mt.n_eff) continue;
-                ray_phase_b<false>(g, mt, s_slots, RCT_RAYS, ray, blk, lane, cnt + (size_t)mi * g.cells, bb, 0, nullptr, nullptr, 0,
+                ray_phase_b<false>(g, mt, s_slots, RCT_RAYS, ray, blk, lane, cnt + (size_t)mi * g.cells, bbox + 4 * mi, 0, nullptr, nullptr, 0,
                                    tile, wb);
             }
         }
@@ -524,15 +540,9 @@ k_raycast_tile(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t
         for (int32_t rx = lane; rx < tile.w; rx += 64) {
             const int32_t i = rbase + rx;
             const uint32_t v = (s_tile[i >> 1] >> ((i & 1) << 4)) & 0xffffu;
-            if (v) {
-                const int32_t cx = tile.x0 + rx;
-                atomicAdd(&mcnt[(size_t)cy * g.W + cx], (v & 0xffu) | ((v >> 8) << 16));
-                bb[0] = max(bb[0], g.W - 1 - cx); bb[1] = max(bb[1], g.H - 1 - cy);
-                bb[2] = max(bb[2], cx + 1);       bb[3] = max(bb[3], cy + 1);
-            }
+            if (v) atomicAdd(&mcnt[(size_t)cy * g.W + tile.x0 + rx], (v & 0xffu) | ((v >> 8) << 16));      // (inside the box raised above)
         }
     }
-    bbox_commit(bb, lane, bbox + 4 * mi, s_bb);
 }
 
 // plain RayIterator walk (gms_map_trace_ray)
