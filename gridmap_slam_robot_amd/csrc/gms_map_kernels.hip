@@ -784,6 +784,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
         for (int o = 32; o > 0; o >>= 1) seen |= __shfl_xor(seen, o, GMS_WAVE);
         if ((threadIdx.x & 63) == 0) atomicOr(smask, seen);
         __syncthreads();
+        if (tile_iter == 0) GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 3);      // first tile: loads arrived, codes known
         const int32_t mask = *smask;
         if (KH > 0) {
             // Re-arm the slot of the PREVIOUS tile (every thread read it before arriving at this barrier); it is used
@@ -850,6 +851,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 }
             }
             __syncthreads();
+            if (tile_iter == 1) GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 4);  // first tile (non-uniform): horizontal sums done
             // ---- phase 3: strips of LK_STRIP outputs along y
             {
                 const int32_t c = threadIdx.x & (LK_TW - 1), r0 = (threadIdx.x >> 6) * LK_STRIP;

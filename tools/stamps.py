@@ -17,7 +17,7 @@ STAGES = {
     2: ("k_norm_raycast", {0: "entered", 1: "ray: pose folded", 2: "far: rays set up", 3: "far: recurrence done (producer)", 4: "far: first consumer done",
                            5: "far: box committed", 9: "near: tile cleared", 10: "near: 64 steps counted", 11: "near: tile flushed", 12: "near: box committed",
                            14: "normalise: left", 15: "apply: left"}),
-    3: ("k_lik_resample", {0: "entered", 1: "resample: left", 2: "likelihood: left"}),
+    3: ("k_lik_resample", {0: "entered", 1: "resample: left", 3: "likelihood: first tile staged", 4: "likelihood: first tile H pass done (non-uniform)", 2: "likelihood: left"}),
 }
 
 
@@ -48,6 +48,21 @@ def main():
             v = v[~np.isnan(v)]
             if v.size:
                 print(f"  {name:16s} {what:34s} n={v.size:4d}  first {v.min():7.2f}  median {np.median(v):7.2f}  last {v.max():7.2f}")
+    # likelihood workgroups that blurred a tile: time from entering to leaving
+    L = s[3]
+    blur = ~np.isnan(L[:, 4])
+    if blur.any():
+        d = (L[blur, 2] - L[blur, 0]) * 0.01
+        e = (L[blur, 3] - L[blur, 0]) * 0.01
+        h = (L[blur, 4] - L[blur, 3]) * 0.01
+        v = (L[blur, 2] - L[blur, 4]) * 0.01
+        print(f"  likelihood workgroups with a non-uniform first tile: {int(blur.sum())}; enter->staged median {np.median(e):.2f} max {e.max():.2f}; "
+              f"staged->H done median {np.median(h):.2f} max {h.max():.2f}; H done->left median {np.median(v):.2f} max {v.max():.2f}; total median {np.median(d):.2f} max {d.max():.2f}")
+    sc = s[0]
+    dur = (sc[:256, 2] - sc[:256, 1]) * 0.01
+    print("  k_score_c lookup phase per workgroup (us), by blockIdx & 7 (XCD) rows and blockIdx >> 3 columns:")
+    for x in range(8):
+        print("   ", " ".join(f"{dur[x + 8 * j]:5.1f}" for j in range(32)))
     return 0
 
 
