@@ -237,7 +237,7 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~7;
     const int64_t nch = nchunks_of(pf);
-    const size_t smem_r = (size_t)(nch + 1 + (nch + 63) / 64 + 1) * sizeof(double);
+    const size_t smem_r = gms_resample_lds_bytes(nch);
     const size_t smem = smem_l > smem_r ? smem_l : smem_r;
     const uint32_t n_res = (uint32_t)((pf->n + 255) / 256);
     const int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;

@@ -819,7 +819,7 @@ static int pf_alloc_global(gms_pf *pf) {
     HIPCHK(hipMalloc(&pf->d_p2, M * nblk * 2 * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_global_own, M * pf->n_global * sizeof(PackedParticle)));
     pf->d_global = pf->d_global_own;
-    HIPCHK(hipMalloc(&pf->d_chunk_tot, M * (nch + 1) * sizeof(double)));
+    HIPCHK(hipMalloc(&pf->d_chunk_tot, M * (nch + 1 + nch * 8) * sizeof(double)));     // chunk totals of all maps, then every chunk's eight octet boundaries (chunk_sub_of)
     HIPCHK(hipMalloc(&pf->d_cum, M * pf->n_global * sizeof(double)));
     return GMS_OK;
 }

@@ -16,6 +16,7 @@
 #include "gms_device.h"
 
 #define SCAN_CHUNK 64
+#define RES_SUB_MAX_CHUNKS 1024     // resampling: populations of up to 65536 keep the octet boundaries of every chunk in LDS (64 KiB at the limit)
 
 // ---------------------------------------------------------------------------------------------
 __global__ void k_pf_init(float *pose, float *cs, double *w, double *logw, int64_t total, double w0) {
@@ -720,9 +721,15 @@ k_partials(double *__restrict__ w, double *__restrict__ logw, const float *__res
 // and the pass over a gathered population all produce the same bits); a 256-thread workgroup = one reduction
 // block = four chunks, whose {sum wn, sum wn^2} are combined in chunk order for calculateNeff (SLAM.java:180-190).
 // Every thread of the workgroup calls; v = normalised weight of particle i of this map (0 beyond the population).
+// The in-chunk cumulative weight at the end of every octet (lanes 7, 15, ... 63) also goes to sub[chunk][8], compactly, for the first
+// 8-way step of the resampling search (lanes beyond the population add 0.0: their value is the chunk's last one, which is what a
+// search clamped to the chunk's length reads).  sub follows the chunk totals of all maps in the same allocation (chunk_sub_of).
+__device__ __forceinline__ double *chunk_sub_of(double *chunk_tot_all, int64_t nchunks, int32_t n_maps, int32_t mi) {
+    return chunk_tot_all + (size_t)n_maps * (nchunks + 1) + (size_t)mi * nchunks * 8;
+}
 __device__ __forceinline__ void block_chunk_scan(double v, int64_t i, int64_t n_pop, int64_t blk, int64_t nchunks,
                                                  double *__restrict__ cum, double *__restrict__ chunk_tot,
-                                                 double *__restrict__ p2_blk) {
+                                                 double *__restrict__ p2_blk, double *__restrict__ sub) {
     __shared__ double s_ct[4][2];
     const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double inc = v;
@@ -734,6 +741,7 @@ __device__ __forceinline__ void block_chunk_scan(double v, int64_t i, int64_t n_
     const double sq = wave_sum_f64(v * v);
     const double tot = __shfl(inc, 63, GMS_WAVE);
     if (i < n_pop) cum[i] = inc;
+    if ((lane & 7) == 7 && blk * 4 + wave < nchunks) sub[(blk * 4 + wave) * 8 + (lane >> 3)] = inc;
     if (lane == 0) {
         const int64_t c = blk * 4 + wave;
         if (c < nchunks) chunk_tot[c] = tot;
@@ -771,7 +779,7 @@ normalize_pack_body(const double *__restrict__ partials_all, int64_t nblk_global
     }
     if (cum)                                          // uniform
         block_chunk_scan(wn, i, n, bx, nchunks, cum + (size_t)mi * n, chunk_tot + (size_t)mi * (nchunks + 1),
-                         p2_all + ((size_t)mi * nblk_global + bx) * 2);
+                         p2_all + ((size_t)mi * nblk_global + bx) * 2, chunk_sub_of(chunk_tot, nchunks, (int32_t)gridDim.y, mi));
 }
 
 __global__ void __launch_bounds__(256)
@@ -803,7 +811,7 @@ chunk_sums_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, i
     const int64_t i = (int64_t)bx * 256 + threadIdx.x;
     const double v = i < n_global ? g[i].w : 0.0;
     block_chunk_scan(v, i, n_global, bx, nchunks, cum_all + (size_t)mi * n_global, chunk_tot + (size_t)mi * (nchunks + 1),
-                     p2_all + ((size_t)mi * nblk_global + bx) * 2);
+                     p2_all + ((size_t)mi * nblk_global + bx) * 2, chunk_sub_of(chunk_tot, nchunks, (int32_t)gridDim.y, mi));
 }
 
 __global__ void __launch_bounds__(256)
@@ -835,7 +843,7 @@ chunk_sums_raw_body(const PackedParticle *__restrict__ glob_raw, int64_t n_globa
     const double sum = fold_sum(partials, nblk_global, COL_SUM, L.a);
     const int64_t i = (int64_t)bx * 256 + threadIdx.x;
     const double v = i < n_global ? glob_raw[i].w / sum : 0.0;
-    block_chunk_scan(v, i, n_global, bx, nchunks, cum, chunk_tot, p2 + (size_t)bx * 2);
+    block_chunk_scan(v, i, n_global, bx, nchunks, cum, chunk_tot, p2 + (size_t)bx * 2, chunk_sub_of(chunk_tot, nchunks, 1, 0));
 }
 
 // raw pack of one reduction block (the all-gather payload): weight as scored, pose
@@ -897,6 +905,22 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
     double tv[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) { const int64_t c = (int64_t)threadIdx.x + k * (int64_t)blockDim.x; tv[k] = c < nchunks ? tot[c] : 0.0; }
+    // Populations of at most RES_SUB_MAX_CHUNKS chunks: the in-chunk cumulative weight at the end of every octet, eight per chunk
+    // (a compact table the scan's level 0 leaves behind the chunk totals), goes to LDS as well (loaded here, beside the chunk totals: the
+    // loads fly during the Neff fold).  The search below then takes
+    // its first 8-way step from LDS instead of from memory: one dependent round trip fewer per output slot.
+    const bool use_sub = nchunks <= RES_SUB_MAX_CHUNKS;
+    double *sub = reinterpret_cast<double *>(smem) + (nchunks + 1) + ((nchunks + 63) / 64 + 1);        // [nchunks][8]
+    const double *sub_g = chunk_sub_of(const_cast<double *>(chunk_off), nchunks, (int32_t)gridDim.y, mi);       // written with the chunk totals (block_chunk_scan)
+    if (use_sub) {
+        for (int64_t e0 = (int64_t)threadIdx.x; e0 < nchunks * 8; e0 += 8 * (int64_t)blockDim.x) {      // eight coalesced loads in flight per thread
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int64_t e = e0 + k * (int64_t)blockDim.x; v[k] = e < nchunks * 8 ? sub_g[e] : 0.0; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int64_t e = e0 + k * (int64_t)blockDim.x; if (e < nchunks * 8) sub[e] = v[k]; }
+        }
+    }
     double norm_sum, sq_sum;
     fold_neff(p2_all + (size_t)mi * nblk_global * 2, nblk_global, norm_sum, sq_sum, L.a);   // calculateNeff (SLAM.java:180-190)
     if (bx == 0 && threadIdx.x == 0) { stats[mi].norm_sum = norm_sum; stats[mi].sq_sum = sq_sum; }
@@ -979,23 +1003,30 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
             const int64_t len = min((int64_t)SCAN_CHUNK, n_global - i0);
             double cv[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) cv[k] = cm[i0 + min((int64_t)(8 * k + 7), len - 1)];
+            for (int k = 0; k < 8; k++) cv[k] = use_sub ? sub[lo * 8 + k] : cm[i0 + min((int64_t)(8 * k + 7), len - 1)];
             int32_t oct = 0;
 #pragma unroll
             for (int k = 0; k < 8; k++) oct += (8 * k + 7 < len && U > base + cv[k]) ? 1 : 0;
             if (oct > 7) oct = 7;
+            const double before_oct = oct > 0 ? cv[oct - 1] : 0.0;      // in-chunk cumulative weight just before this octet (oct > 0)
 #pragma unroll
             for (int k = 0; k < 8; k++) cv[k] = cm[i0 + min((int64_t)(8 * oct + k), len - 1)];
             int64_t a = 8 * oct;
 #pragma unroll
             for (int k = 0; k < 8; k++) a += (8 * oct + k < len && U > base + cv[k]) ? 1 : 0;
             src = i0 + (a < len ? a : len - 1);
-            // boundary within rounding distance of U: a sequential scan may choose a neighbour
+            // boundary within rounding distance of U: a sequential scan may choose a neighbour.  cm[src] and cm[src - 1] are
+            // among the values already at hand (the octet's eight, the octet boundary before it, the previous chunk's end):
+            // the same operands as loading them again, without the round trip.
             const double tol = N * 4.5e-16 * fabs(off[nchunks]);
-            bool amb = fabs(U - (base + cm[src])) <= tol;
+            const int32_t ki = (int32_t)(src - i0) - 8 * oct;           // 0..7: where cm[src] sits in cv[]
+            double c_src = cv[0], c_prev = before_oct;
+#pragma unroll
+            for (int k = 1; k < 8; k++) if (ki == k) { c_src = cv[k]; c_prev = cv[k - 1]; }
+            bool amb = fabs(U - (base + c_src)) <= tol;
             if (src > 0) {
-                const int64_t pc = (src - 1) / SCAN_CHUNK;
-                amb = amb || fabs(U - (off[pc] + cm[src - 1])) <= tol;
+                if (ki > 0 || oct > 0) amb = amb || fabs(U - (base + c_prev)) <= tol;                  // src - 1 lies in this chunk
+                else amb = amb || fabs(U - (off[lo - 1] + (use_sub ? sub[(lo - 1) * 8 + 7] : cm[src - 1]))) <= tol;   // ... ends the chunk before
             }
             if (amb) atomicAdd(&stats[mi].n_ambiguous, 1);
         }
@@ -1116,6 +1147,10 @@ k_refine(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, cons
 // ---------------------------------------------------------------------------------------------
 static inline int64_t nblk_global_of(const gms_pf *pf) { return (pf->n_global + GMS_BLOCK - 1) / GMS_BLOCK; }
 static inline int64_t nchunks_of(const gms_pf *pf) { return (pf->n_global + SCAN_CHUNK - 1) / SCAN_CHUNK; }
+// dynamic LDS of a resampling workgroup: chunk offsets, super-chunk offsets, and (small populations) the octet boundaries
+static inline size_t gms_resample_lds_bytes(int64_t nch) {
+    return (size_t)(nch + 1 + (nch + 63) / 64 + 1 + (nch <= RES_SUB_MAX_CHUNKS ? nch * 8 : 0)) * sizeof(double);
+}
 
 void gms_launch_pf_init(gms_pf *pf) {
     const int64_t total = (int64_t)pf->n_maps * pf->n;
@@ -1271,7 +1306,7 @@ void gms_launch_pf_resample(gms_pf *pf, double fraction) {
     gms_launch_pf_chunk_sums(pf);
     ProfScope ps(m, GMS_K_RESAMPLE);
     const int64_t nch = nchunks_of(pf);
-    const size_t smem = (size_t)(nch + 1 + (nch + 63) / 64 + 1) * sizeof(double);
+    const size_t smem = gms_resample_lds_bytes(nch);
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resample), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
