@@ -629,6 +629,54 @@ def cpu_baseline(wl: Workload, budget_s: float, with_score_sweep: bool):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def trace_replay(path: str, steps: int, warmup: int, particles: int, extent: float, res: float, local_rank: int, torch):
+    """A recorded trace (DataRecorder format, gridmap_slam_robot_amd/trace.py) through the device path frame by frame, as
+    GridMapApp.onHandleData runs it (J/app/GridMapApp.java:133-192): read_trace -> gms_map_deskew (raw measurements handed over
+    as host arrays: 17 bytes per measurement over PCIe) -> gms_pf_sample_motion -> fused scan step.  The first frames only map
+    (dead-reckoned pose); `steps` frames are timed, the recording repeated as often as needed (its drive is a closed circle)."""
+    from gridmap_slam_robot_amd import GridMap, ParticleFilter, synth
+    from gridmap_slam_robot_amd.replay import TraceReplay
+    from gridmap_slam_robot_amd.trace import read_trace
+    frames = read_trace(path)
+    B = max(len(f.angle) for f in frames)
+    m = GridMap(extent, extent, res, (-extent / 2, -extent / 2), device=local_rank, max_beams=max(2048, B))
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    pf = ParticleFilter(m, particles)
+    # the pose the recording starts from: one odometry step before its first frame's end pose (the synthetic recording's drive)
+    start = synth.true_pose(synth.make_world(extent, 4321), -1, len(frames))
+    rp = TraceReplay(m, pf, start, seed=2024)
+    boot = min(6, len(frames) // 4)
+    for f in frames[:boot]:
+        rp.bootstrap(f)
+    r01 = np.random.default_rng(3).random(4096)
+    k = boot
+    def nxt():
+        nonlocal k
+        f = frames[k]
+        k = k + 1 if k + 1 < len(frames) else 0
+        return f
+    for i in range(warmup):
+        rp.step(nxt(), float(r01[i % 4096]))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        rp.step(nxt(), float(r01[(warmup + i) % 4096]))
+    issue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    st = pf.stats()
+    est = pf.weighted_pose()
+    out = {"recording": os.path.relpath(path, ROOT), "frames_in_recording": len(frames), "beams": B, "particles": particles,
+           "grid": [m.W, m.H], "resolution_m": res, "bootstrap_frames": boot, "frames_timed": steps,
+           "ms_per_frame": el / steps * 1e3, "host_issue_ms_per_frame": issue / steps * 1e3, "scans_per_s": steps / el,
+           "particle_scan_evals_per_s": particles * steps / el,
+           "inputs": "raw polar measurements from host memory every frame (PCIe-inclusive); motion model, weights, resampling and map on the device",
+           "calls_per_frame": ["gms_map_deskew", "gms_pf_sample_motion", "gms_slam_update_dev"],
+           "neff_last": st["neff"], "weighted_pose_last": [float(x) for x in est]}
+    pf.close(); m.close()
+    return out
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -645,6 +693,11 @@ def main() -> int:
                     help="sharded runs: first exchange route to try (auto = in-library RCCL; later routes are fall-backs)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (all-gather) code path even with one rank")
     ap.add_argument("--no-verify", action="store_true", help="sharded runs: skip the sharded == stand-alone check")
+    ap.add_argument("--trace", default="", help="replay a recorded trace (DataRecorder format) frame by frame instead of the synthetic C3 step; "
+                    "the JSON line then carries the replay under 'trace_replay' and value = particles x frames / s")
+    ap.add_argument("--trace-particles", type=int, default=1024)
+    ap.add_argument("--trace-extent", type=float, default=25.6, help="map extent (m) for --trace")
+    ap.add_argument("--trace-res", type=float, default=0.05, help="map resolution (m) for --trace")
     args = ap.parse_args()
     if args.config not in ("C2", "C3", "C4", "C5"):
         print("bench.py: --config must be C2, C3, C4 or C5", file=sys.stderr)
@@ -678,6 +731,17 @@ def main() -> int:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+
+    if args.trace:
+        tr = trace_replay(args.trace, args.steps, args.warmup, args.trace_particles, args.trace_extent, args.trace_res, local_rank, torch)
+        out = {"metric": "particle-scan evals/sec", "value": tr["particle_scan_evals_per_s"], "unit": "particle-scan evals/s", "n_gpus": 1,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": tr["ms_per_frame"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic recording (tools/make_recording.py)",
+               "config": {"workload": f"trace replay: {tr['particles']} particles x {tr['beams']} beams, {tr['grid'][0]}x{tr['grid'][1]} grid @ {tr['resolution_m']} m, "
+                                      "de-skew + motion model + full scan step per recorded frame"},
+               "trace_replay": tr, "roofline": None, "cpu_baseline": None}
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        return 0
 
     sharded = world > 1 or args.force_sharded
     want_cpu = world == 1 and not args.no_cpu_baseline
@@ -751,6 +815,12 @@ def main() -> int:
                 del w2
             except Exception as e:
                 sec[name] = {"error": repr(e)}
+        rec = os.path.join(ROOT, "tests", "golden", "recording_360.bin")
+        if os.path.exists(rec):
+            try:
+                sec["trace_replay"] = trace_replay(rec, 200, 20, 1024, 25.6, 0.05, local_rank, torch)
+            except Exception as e:
+                sec["trace_replay"] = {"error": repr(e)}
         out["secondary"] = sec
 
     os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -1187,8 +1187,11 @@ static void launch_compact(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32
 // where the launch is a handful of workgroups and the time is one workgroup's walk through its segment: 12 beams per
 // segment (C2: 18.4 -> 8.4 us).  <= 128 beams per segment (the LDS beam table; also keeps a segment product >= 0.01^128, a
 // normal double).
+// Long scans (> 768 beams: config 5's 1080) take 90 beams per segment: half the segment products per particle to store and to
+// combine (C5, 64 maps x 4096 x 1080: 45 / 68 / 90 / 120 beams per segment -> 402 / 398 / 392 / 386 us per batched step; 90 keeps
+// a single-map filter of 16384 particles at 192 workgroups, 120 would leave it 144 for 256 CUs).
 static int64_t score_segments(int32_t B) {
-    const int32_t seglen = B <= GMS_SCORE_SHORT_SCAN ? GMS_SCORE_SEGLEN_SHORT : GMS_SCORE_SEGLEN;
+    const int32_t seglen = B <= GMS_SCORE_SHORT_SCAN ? GMS_SCORE_SEGLEN_SHORT : (B > GMS_SCORE_LONG_SCAN ? GMS_SCORE_SEGLEN_LONG : GMS_SCORE_SEGLEN);
     int64_t nseg = ((int64_t)B + seglen - 1) / seglen;
     const int64_t min_seg = ((int64_t)B + 127) / 128;
     if (nseg < min_seg) nseg = min_seg;

@@ -312,6 +312,16 @@ class GridMap:
         mask = ((1 << len(_lib.KERNEL_NAMES)) - 1 if on else 0) if isinstance(on, bool) else int(on)
         check(load().gms_profile_enable(self._h, mask))
 
+    def deskew_dev(self, angles, distances, hits, d_center: float, d_theta: float):
+        """deskew() without the read-back: the beams stay in the map's device staging buffer; returns (device address, count).
+        Nothing is synchronised: the next launches on the handle's stream see them."""
+        a = np.ascontiguousarray(angles, dtype=np.float64)
+        d = np.ascontiguousarray(distances, dtype=np.float64)
+        h = np.ascontiguousarray(hits, dtype=np.uint8)
+        dev = C.c_void_p()
+        check(load().gms_map_deskew(self._h, ptr(a), ptr(d), ptr(h), len(a), d_center, d_theta, None, C.byref(dev)))
+        return dev.value, len(a)
+
     # -- device-resident inputs (raw device pointers, e.g. torch tensor .data_ptr()) -------------------
     def update_dev(self, dev_beams: int, B: int, dev_poses: int):
         check(load().gms_map_update_dev(self._h, C.c_void_p(dev_beams), B, C.c_void_p(dev_poses)))

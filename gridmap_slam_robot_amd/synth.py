@@ -140,3 +140,42 @@ CONFIGS = {
     "C4": dict(particles=65536, beams=720, extent=40.96, resolution=0.02, n_maps=1),
     "C5": dict(particles=4096, beams=1080, extent=51.2, resolution=0.05, n_maps=64),
 }
+
+
+def make_recording(extent_m: float, B: int, T: int = 64, seed: int = 1234, n_frames=None, noise: float = 0.01):
+    """A synthetic RECORDING of the same drive: what DataRecorder would have saved (J/app/DataRecorder.java:381-400) -- per
+    revolution the odometry u = (dCenter, dTheta) since the previous one and the RAW polar measurements {angle, distance,
+    wasHit}, each taken from where the robot was at that instant of the revolution, so that the de-skew loop of
+    GridMapApp.onHandleData (J/app/GridMapApp.java:143-175) has something to undo.  Measurement i of `length` is taken at the
+    fraction d_i = -(length - i) / length of the motion before the frame's end (:150).  Returns (frames, end poses [n][3])."""
+    from .trace import Frame
+    world = make_world(extent_m, seed)
+    rng = np.random.default_rng(seed + 2)
+    n = T if n_frames is None else n_frames
+    poses = np.stack([true_pose(world, t, T).astype(np.float64) for t in range(-1, n)])      # poses[k] = end pose of frame k - 1
+    frames = []
+    for k in range(n):
+        p0, p1 = poses[k], poses[k + 1]
+        d_center = float(math.hypot(p1[0] - p0[0], p1[1] - p0[1]))
+        d_theta = float(p1[2] - p0[2])
+        i = np.arange(B, dtype=np.float64)
+        frac = -(B - i) / B                                                  # -1 .. -1/B
+        # where the robot was when measurement i was taken: back along the motion of this frame
+        th = p1[2] + d_theta * frac
+        px = p1[0] + np.cos(th) * d_center * frac
+        py = p1[1] + np.sin(th) * d_center * frac
+        local = 2 * math.pi * i / B - math.pi / 2
+        dist = np.array([cast(world, (px[j], py[j]), np.array([local[j] + th[j]]))[0] for j in range(B)])
+        dist = dist + rng.normal(0.0, noise, size=B)
+        hit = dist < MAX_RANGE
+        dist = np.where(hit, np.maximum(dist, 0.02), MAX_RANGE)
+        frames.append(Frame(float(np.float32(0.1 * k)), d_center, d_theta, local.copy(), dist, hit.astype(np.uint8)))
+    return frames, poses[1:].astype(np.float32)
+
+
+def dead_reckon(pose, d_center: float, d_theta: float) -> np.ndarray:
+    """Odometry.apply without its noise (J/slam/Odometry.java:77-96): heading first, then the step along the new heading."""
+    th = np.float32(np.float64(pose[2]) + d_theta)
+    c, s = np.float32(math.cos(float(th))), np.float32(math.sin(float(th)))
+    return np.array([np.float32(np.float64(pose[0]) + np.float64(c) * d_center), np.float32(np.float64(pose[1]) + np.float64(s) * d_center), th],
+                    dtype=np.float32)
