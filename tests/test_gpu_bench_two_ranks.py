@@ -39,3 +39,24 @@ def test_bench_with_two_ranks_on_one_gpu_falls_back_verifies_and_reports():
     assert d["verify"]["population"] == 2048 and d["verify"]["mismatches"] is None
     assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
     assert d["value"] > 0 and d["roofline"]["launches_timed"] >= 1 and d["cpu_baseline"] is None
+
+
+def test_bench_config5_with_two_ranks_shards_by_map_without_a_collective():
+    """Config 5 (64 independent maps per handle) at N > 1: every rank runs its own 64 maps, nothing is exchanged on the data
+    path; the line must carry the aggregate over both ranks and each rank's own time."""
+    env = dict(os.environ, GMS_BENCH_DIST_BACKEND="gloo", GMS_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--config", "C5", "--particles", "256"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["maps"] == 64 and d["config"]["particles_total"] == 2 * 64 * 256
+    assert "no collective" in d["config"]["parallelism"] and d["config"]["exchange"] is None
+    assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
+    # value = all ranks' particles x steps / the slowest rank's time
+    assert abs(d["value"] - 2 * 64 * 256 * 3 / (max(d["per_rank_ms_per_step"]) * 1e-3 * 3)) <= 1e-4 * d["value"]      # (per-rank times are printed to five decimals)
+    assert d.get("sharded_equals_standalone") is None          # nothing is sharded: there is nothing to verify against
