@@ -10,10 +10,14 @@ FETCH_SIZE is doubled for gfx950 (128-byte requests are tallied at 64 B).  Kerne
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
-CLASS_OF = [("k_raycast_tile", "raycast"), ("k_raycast<false, 16>", "raycast"), ("k_score_c", "score"), ("k_score_b", "score"), ("k_score(", "score"), ("k_norm_raycast", "raycast"),
+CLASS_OF = [("k_raycast_tile", "raycast"), ("k_raycast<false, 16>", "raycast"), ("k_score_c", "score"), ("k_norm_raycast", "raycast"), ("k_raycast_norm_chunks", "raycast"), ("k_raycast_apply", "raycast"),
             ("k_raycast<false", "raycast"), ("k_lik_resample", "likelihood"), ("k_likelihood", "likelihood"),
             ("k_partials_apply", "reduce"), ("k_partials", "reduce"), ("k_normalize_pack", "reduce"), ("k_apply", "apply"),
             ("k_chunk_sums", "resample"), ("k_resample", "resample"), ("k_pose_trig", "pose_trig"), ("k_order", "order")]
+
+
+STEP_KERNELS = ("k_score_c", "k_order", "k_partials", "k_normalize_pack", "k_norm_raycast", "k_raycast_tile", "k_lik_resample",
+                "k_raycast_norm_chunks")
 
 
 def per_kernel(d):
@@ -35,6 +39,11 @@ def main():
             fh.write("kernel,dispatches,mean_counter_kb,min,max\n")
             for k, (n, mean, lo, hi) in d.items():
                 fh.write(f'"{k}",{n},{mean:.1f},{lo:.1f},{hi:.1f}\n')
+    # Traffic is kept PER KERNEL.  A class's per-launch figure is taken over the kernels that the scan step itself launches
+    # (STEP_KERNELS): kernels of the same class that belong to another loop of the run -- the stand-alone map update that bench.py
+    # times for BASELINE's second metric launches k_raycast_apply and k_likelihood<..., true> -- are listed but not added in.
+    # A class with two launches per step (batched maps: k_partials and k_normalize_pack are both "reduce") gets the mean of the
+    # two, as bench.py divides the class's algorithmic bytes by its launches per step.
     classes = {}
     for name in set(fetch) | set(write):
         cls = next((c for pat, c in CLASS_OF if name.startswith(pat.rstrip("("))), None)
@@ -42,27 +51,26 @@ def main():
             continue
         n = max(fetch.get(name, (0,))[0], write.get(name, (0,))[0])
         classes.setdefault(cls, []).append((n, name))
+    res = {}
     for cls, members in classes.items():
         top = max(n for n, _ in members)
-        e = {"kernels": {}, "fetch_size_kb_raw": 0.0, "write_size_kb": 0.0}
+        kern = {}
         for n, name in members:
-            if 2 * n < top:                  # a kernel of the class that ran only during set-up
-                continue
             fk, wk = fetch.get(name, (0, 0.0))[1], write.get(name, (0, 0.0))[1]
-            e["kernels"][name] = {"fetch_kb": round(fk, 1), "write_kb": round(wk, 1), "dispatches": n}
-            e["fetch_size_kb_raw"] += fk
-            e["write_size_kb"] += wk
-        classes[cls] = e
-    res = {}
-    for cls, e in classes.items():
-        res[cls] = {"kernels": e["kernels"], "fetch_size_kb_raw": round(e["fetch_size_kb_raw"], 1),
-                    "write_size_kb": round(e["write_size_kb"], 1),
-                    "hbm_bytes_per_launch": int((2.0 * e["fetch_size_kb_raw"] + e["write_size_kb"]) * 1024)}
+            kern[name] = {"fetch_kb": round(fk, 1), "write_kb": round(wk, 1), "dispatches": n,
+                          "hbm_bytes": int((2.0 * fk + wk) * 1024), "in_scan_step": any(name.startswith(pfx) for pfx in STEP_KERNELS)}
+        step = [k for k, e in kern.items() if e["in_scan_step"] and 2 * e["dispatches"] >= top]
+        if not step:                         # a run that is not the scan step (e.g. the dense likelihood rebuild): its busiest kernel
+            step = [max(kern, key=lambda k: kern[k]["dispatches"])]
+        per_step = sum(kern[k]["hbm_bytes"] for k in step)
+        res[cls] = {"kernels": kern, "step_kernels": sorted(step), "launches_per_step": len(step), "hbm_bytes_per_step": per_step,
+                    "hbm_bytes_per_launch": int(per_step / len(step))}
     res["_note"] = ("per scan step and kernel class, bench.py; separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes with "
                     "--kernel-trace only; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM (gfx950 tallies 128-B requests at "
                     "64 B for wide reads; for the 8-byte gathers of k_score_c the factor is uncalibrated, so its read side is an "
                     "upper bound); Infinity-Cache hits are counted, not excluded.  Paired launches are booked under the class "
-                    "bench.py books them under (k_norm_raycast: raycast, k_lik_resample: likelihood, k_partials_apply: reduce).")
+                    "bench.py books them under (k_norm_raycast: raycast, k_lik_resample: likelihood, k_partials_apply: reduce); "
+                    "hbm_bytes_per_launch is over the scan step's own kernels (step_kernels), per kernel figures under kernels.")
     path = os.path.join(out, "pmc_traffic.json")
     if config:
         allc = {}
