@@ -3,7 +3,7 @@
 # of bench.py (C3 default, C5) and of the dense-map likelihood rebuild; raw output under gpurun_out/prof/, the summaries
 # that are kept go to profiles/<round>/ afterwards (tools/kstats.py, tools/pmc_summary.py).
 # usage: collect_profiles.sh <round dir name, e.g. r02>
-R=${1:-r02}
+R=${1:-r03}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/prof_$R"
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -30,9 +30,10 @@ stats dense_likelihood $K
 pmc dense FETCH_SIZE $K
 pmc dense WRITE_SIZE $K
 stats c3_full_rebuild $B --full-rebuild --steps 100 --warmup 10
+stats trace_replay python3 $ROOT/bench.py --trace $ROOT/tests/golden/recording_360.bin --steps 300 --warmup 20
 cd "$ROOT"
 mkdir -p "$OUT/keep"
-for n in c3_bench c5_bench dense_likelihood c3_full_rebuild; do
+for n in c3_bench c5_bench dense_likelihood c3_full_rebuild trace_replay; do
   cp "$OUT/${n}_kernel_stats.csv" "$OUT/keep/" 2>/dev/null
   cp "$OUT/$n.stdout" "$OUT/keep/${n}_under_rocprof.json" 2>/dev/null
 done
@@ -46,5 +47,14 @@ python3 bench.py --host-inputs --no-cpu-baseline --no-secondary > "$OUT/keep/ben
 python3 bench.py --full-rebuild --no-cpu-baseline --no-secondary > "$OUT/keep/bench_full_rebuild.json" 2>> "$OUT/bench.stderr"
 python3 bench.py --config C5 --steps 50 --warmup 5 > "$OUT/keep/bench_c5.json" 2>> "$OUT/bench.stderr"
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$OUT/keep/bench_steps20.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --trace tests/golden/recording_360.bin --steps 300 --warmup 20 > "$OUT/keep/bench_trace_replay.json" 2>> "$OUT/bench.stderr"
+# the microbenchmarks behind the ceilings bench.py quotes and behind DESIGN.md's launch-structure decision
+python3 tools/microbench/run_all.py > "$OUT/microbench.stdout" 2> "$OUT/microbench.stderr"
+cp gpurun_out/microbench/microbench.json "$OUT/keep/" 2>/dev/null
+cp gpurun_out/microbench/persistent_step.txt "$OUT/keep/persistent_step_model_run.txt" 2>/dev/null
+# stage timeline of a C3 step from the instrumented build, when it was shipped along (lib/exp_stamps.so)
+if [ -f gridmap_slam_robot_amd/lib/exp_stamps.so ]; then
+  GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/stamps.py > "$OUT/keep/c3_step_timeline.txt" 2>> "$OUT/bench.stderr"
+fi
 ls -la "$OUT/keep"
 for f in "$OUT"/keep/*_kernel_stats.csv; do echo "== $f"; python3 tools/kstats.py "$f" | head -8; done
