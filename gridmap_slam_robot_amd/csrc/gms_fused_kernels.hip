@@ -154,7 +154,7 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
                int32_t n, int64_t offset,
                float *__restrict__ pose2, float *__restrict__ cs2, double *__restrict__ w2, int32_t *__restrict__ idx_out,
                const double *__restrict__ p2, int64_t nblk_global, PfStatsDev *__restrict__ stats, int32_t raw_weights,
-               int32_t *__restrict__ bbox_clear) {
+               int32_t *__restrict__ bbox_clear, int32_t lik_mode) {
     extern __shared__ __align__(16) unsigned char smem[];
     // the box half the next ray cast will raise: cleared here because that ray cast may share its launch with this scan's
     // deferred apply pass (k_raycast_apply), which otherwise does the clearing
@@ -165,7 +165,7 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
                       nblk_global, stats, blockIdx.x, blockIdx.y, smem, raw_weights != 0);
     else
         likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, 1, tiles_x, tiles_y, blockIdx.x - n_res_blocks,
-                            blockIdx.y, gridDim.x - n_res_blocks, smem, cnt_pending, tile_state);
+                            blockIdx.y, gridDim.x - n_res_blocks, smem, cnt_pending, tile_state, lik_mode);
     GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), blockIdx.x < n_res_blocks ? 1 : 2);
 }
 
@@ -242,6 +242,8 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
     const uint32_t n_res = (uint32_t)((pf->n + 255) / 256);
     const int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;
     const double *r01_maps = pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01_src;
+    const int32_t lik_mode = m->lik_lazy ? 2 : 3;             // the factor table only: likelihoodData follows on demand (gms_ensure_lik)
+    if (m->lik_lazy) m->lik_stale = 1;
 #define LR_LAUNCH(KH)                                                                                                     \
     do {                                                                                                                  \
         if (smem > 48 * 1024)                                                                                             \
@@ -251,7 +253,7 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
                            m->d_lik, m->d_fac, m->fac_stride, m->d_taps, bb, tiles_x, tiles_y, m->d_cnt, m->d_tile_state, n_res, pf->d_global, \
                            pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, r01_maps, pf->r01_scalar, fraction, pf->n, pf->offset, \
                            pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats,       \
-                           pf->global_raw, m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4);                       \
+                           pf->global_raw, m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4, lik_mode);             \
     } while (0)
     if (k == 3) LR_LAUNCH(3);
     else if (k == 5) LR_LAUNCH(5);

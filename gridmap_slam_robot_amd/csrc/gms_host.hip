@@ -362,6 +362,8 @@ int gms_map_create(const gms_params *p, gms_map **out) {
         if (const char *v = getenv("GMS_RAYCAST_NEAR")) m->raycast_near = m->raycast_near && atoi(v) != 0;
     }
     m->prof_stride = 1;
+    m->lik_lazy = 1;
+    if (const char *v = getenv("GMS_LIK_LAZY")) m->lik_lazy = atoi(v) != 0;
     if (const char *v = getenv("GMS_PAIR_LAUNCHES")) m->pair_launches = atoi(v) != 0;
     *out = m;
     return GMS_OK;
@@ -401,6 +403,7 @@ int gms_map_synchronize(gms_map *m) {
 int gms_map_reset(gms_map *m) {                                        // GridMap.java:129-132
     REQUIRE(m, "null map");
     HIPCHK(hipSetDevice(m->device));
+    gms_ensure_lik(m);                 // likelihoodData keeps the last field (reset touches logData only)
     gms_flush_apply(m);
     HIPCHK(hipMemsetAsync(m->d_log, 0, (size_t)m->gd.cells * m->n_maps * sizeof(double), m->stream));
     m->need_full_build = 1;
@@ -418,6 +421,7 @@ static int map_xfer(gms_map *m, void *dev, void *host, bool to_device) {
 
 int gms_map_upload_log(gms_map *m, const double *log_data) {
     REQUIRE(m && log_data, "null argument");
+    gms_ensure_lik(m);
     gms_flush_apply(m);
     m->need_full_build = 1;
     return map_xfer(m, m->d_log, const_cast<double *>(log_data), true);
@@ -430,6 +434,7 @@ int gms_map_download_log(gms_map *m, double *log_data) {
 int gms_map_upload_likelihood(gms_map *m, const double *lik) {
     REQUIRE(m && lik, "null argument");
     m->need_full_build = 1;
+    m->lik_stale = 0;                  // replaced wholesale
     int rc = map_xfer(m, m->d_lik, const_cast<double *>(lik), true);
     if (rc) return rc;
     gms_launch_factors(m);
@@ -438,6 +443,7 @@ int gms_map_upload_likelihood(gms_map *m, const double *lik) {
 }
 int gms_map_download_likelihood(gms_map *m, double *lik) {
     REQUIRE(m && lik, "null argument");
+    gms_ensure_lik(m);
     return map_xfer(m, m->d_lik, lik, false);
 }
 
@@ -445,8 +451,10 @@ int gms_map_copy(gms_map *dst, const gms_map *src) {                  // GridMap
     REQUIRE(dst && src, "null argument");
     REQUIRE(dst->gd.W == src->gd.W && dst->gd.H == src->gd.H && dst->n_maps == src->n_maps, "gms_map_copy: shape mismatch");
     const size_t bytes = (size_t)src->gd.cells * src->n_maps * sizeof(double);
+    gms_ensure_lik(const_cast<gms_map *>(src));
     gms_flush_apply(const_cast<gms_map *>(src));
     gms_flush_apply(dst);
+    dst->lik_stale = 0;
     HIPCHK(hipStreamSynchronize(src->stream));
     HIPCHK(hipMemcpyAsync(dst->d_log, src->d_log, bytes, hipMemcpyDeviceToDevice, dst->stream));
     HIPCHK(hipMemcpyAsync(dst->d_lik, src->d_lik, bytes, hipMemcpyDeviceToDevice, dst->stream));
@@ -463,6 +471,7 @@ int gms_map_combine(gms_map *dst, gms_map *src) {                        // Grid
     // src's stream; the combine reads src's log-odds on dst's stream, so dst's stream must wait for it -- an event after the
     // flush, not a host synchronise before it (round 2 synchronised first and flushed afterwards: the combine could read
     // pre-apply log-odds).
+    gms_ensure_lik(dst);               // the destination's likelihoodData keeps its last field (its logData is about to be replaced)
     gms_flush_apply(src);
     gms_flush_apply(dst);
     if (src->stream != dst->stream) {
@@ -540,6 +549,7 @@ int gms_map_get_at_point(gms_map *m, int32_t mi, float point_x, float point_y, d
     if (idx < 0 || (int64_t)idx >= m->gd.cells)
         return fail(GMS_ERR_INVALID, "gms_map_get_at_point: index %d out of bounds (Java: ArrayIndexOutOfBoundsException)", idx);
     HIPCHK(hipSetDevice(m->device));
+    gms_ensure_lik(m);
     gms_flush_apply(m);
     double *h = reinterpret_cast<double *>(m->h_poses + (size_t)m->n_maps * 3);
     h = reinterpret_cast<double *>(((uintptr_t)h + 7) & ~(uintptr_t)7);
@@ -601,6 +611,7 @@ static int finish_likelihood(gms_map *m, int32_t dirty_only) {
 
 int gms_map_integrate(gms_map *m, const gms_beam *beams, int32_t B, const float *poses) {   // GridMap.java:173-191
     REQUIRE(m, "null map");
+    gms_ensure_lik(m);                 // integrateObservation leaves likelihoodData as the last rebuild made it: have it made first
     int rc = stage_beams(m, beams, B);
     if (rc) return rc;
     rc = stage_poses(m, poses);
@@ -617,6 +628,7 @@ int gms_map_integrate_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, cons
     REQUIRE(m && dev_beams && dev_poses, "null argument");
     REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
     HIPCHK(hipSetDevice(m->device));
+    gms_ensure_lik(m);
     if (B > 0) {
         gms_launch_raycast(m, dev_beams, B, B, dev_poses, 3);
         gms_launch_apply_counts(m);
@@ -630,6 +642,7 @@ int gms_map_integrate_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, g
     REQUIRE(which == 0 || which == 1, "which must be 0 (weighted pose) or 1 (strongest particle)");
     REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
     HIPCHK(hipSetDevice(m->device));
+    gms_ensure_lik(m);
     if (B > 0) {
         gms_launch_raycast(m, dev_beams, B, B, stats_pose_ptr(pf, which), (int32_t)(sizeof(PfStatsDev) / sizeof(float)));
         gms_launch_apply_counts(m);
@@ -641,6 +654,7 @@ int gms_map_integrate_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, g
 int gms_map_integrate_at(gms_map *m, const gms_beam *beams, int32_t B, gms_pf *pf, int32_t which) {
     REQUIRE(m && pf && pf->map == m, "gms_map_integrate_at: filter does not belong to this map");
     REQUIRE(which == 0 || which == 1, "which must be 0 (weighted pose) or 1 (strongest particle)");
+    gms_ensure_lik(m);
     int rc = stage_beams(m, beams, B);
     if (rc) return rc;
     if (B > 0) {
@@ -654,6 +668,7 @@ int gms_map_integrate_at(gms_map *m, const gms_beam *beams, int32_t B, gms_pf *p
 int gms_map_apply_ray(gms_map *m, float sx, float sy, float ex, float ey, float measured, int32_t hit) {
     REQUIRE(m, "null map");
     HIPCHK(hipSetDevice(m->device));
+    gms_ensure_lik(m);
     RayIn r;
     r.sx = sx; r.sy = sy; r.ex = ex; r.ey = ey; r.measured = measured; r.hit = hit != 0;
     gms_launch_apply_ray(m, r);
@@ -1272,6 +1287,7 @@ int gms_slam_update(gms_pf *pf, const float *xytheta, const gms_beam *beams, int
         rc = gms_pf_normalize(pf, nullptr);
         if (!rc && resample_fraction >= 0.0) rc = gms_pf_resample_if(pf, r01, resample_fraction);
         if (!rc && integrate) {
+            gms_ensure_lik(m);
             gms_launch_raycast(m, m->d_beams, B, m->max_beams, stats_pose_ptr(pf, 0), (int32_t)(sizeof(PfStatsDev) / sizeof(float)));
             gms_launch_apply_counts(m);
             rc = finish_likelihood(m, m->need_full_build ? 0 : 1);

@@ -112,6 +112,8 @@ struct gms_map {
     int32_t need_full_build;  // likelihood field must be rebuilt everywhere (upload/reset/copy)
     int32_t apply_pending;    // the last scan's counts are not in logData yet (deferred apply pass, gms_flush_apply)
     int32_t raycast_tile;     // batched ray casts accumulate in LDS tiles (k_raycast_tile; GMS_RAYCAST_TILE=0 turns it off)
+    int32_t lik_lazy;         // scan steps' dirty-tile rebuilds write the factor table only, likelihoodData on demand (GMS_LIK_LAZY=0 turns it off)
+    int32_t lik_stale;        // likelihoodData is behind the factor table somewhere (gms_ensure_lik brings it up to date)
     int32_t raycast_near;     // single-map ray casts: the first 64 steps of every ray go through near-field workgroups with an LDS tile (GMS_RAYCAST_NEAR=0 turns it off)
     int32_t pair_launches;    // scan steps pair independent kernels in one launch (GMS_PAIR_LAUNCHES=0 turns it off)
     gms_beam *h_beams;    // pinned staging (de-skew inputs, single-ray entry)
@@ -195,7 +197,8 @@ void gms_launch_trace_ray(gms_map *m, float x0, float y0, float x1, float y1, in
                           int32_t *d_cells, int32_t cap, int32_t *d_count);
 void gms_launch_apply_ray(gms_map *m, RayIn ray);
 void gms_launch_apply_counts(gms_map *m);
-void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending = false);
+void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending = false, bool materialize = false);
+void gms_ensure_lik(gms_map *m);        // likelihoodData up to date everywhere (the scan steps' rebuilds write the factor table only)
 size_t gms_likelihood_lds_bytes(int32_t khalf);
 int32_t gms_likelihood_blocks_cap(const gms_map *m, size_t smem);
 void gms_launch_raycast_apply(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses, int32_t pose_stride);

@@ -651,7 +651,12 @@ __device__ __forceinline__ void
 likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
                 int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
                 int32_t tiles_x, int32_t tiles_y, uint32_t bx, uint32_t by, uint32_t gdx, unsigned char *smem,
-                const uint32_t *__restrict__ cnt_pending = nullptr, uint8_t *__restrict__ tile_state = nullptr) {
+                const uint32_t *__restrict__ cnt_pending = nullptr, uint8_t *__restrict__ tile_state = nullptr, int32_t mode = 3) {
+    // mode: bit 0 = write likelihoodData, bit 1 = write the factor table (and keep tile_state, which describes the factor table).
+    // The scan steps' dirty-tile rebuilds write the factor table only (mode 2): nothing on the hot path reads likelihoodData
+    // (GridMap.java:150-156,371-388 are its only readers: getLikelihood and the renderer), so it is brought up to date on demand by a
+    // pass of mode 1 (gms_ensure_lik) -- half the stores of a rebuild, and half the dirty lines at the kernel's end.
+    const bool wr_lik = (mode & 1) != 0, wr_fac = (mode & 2) != 0;
     const int32_t k = KH > 0 ? KH : g.khalf;
     const int32_t ntaps = 2 * k + 1;
     const int32_t RW = LK_TW + 2 * k, RH = LK_TH + 2 * k;     // staged columns / rows
@@ -811,7 +816,8 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
         if (mask == 1 || mask == 2 || mask == 4) {
             // ---- uniform tile: every in-order sum sees the same inputs
             const uint8_t want = mask == 1 ? 1 : (mask == 2 ? 2 : 3);
-            if (tstate && tstate_old == want) continue;        // the tile already holds exactly these constants: no store
+            if (wr_fac && tstate && tstate_old == want) continue;    // the tile already holds exactly these constants: no store (mode 3: both
+                                                                    // arrays do -- a full rebuild invalidates the states first when likelihoodData is behind)
             const double cval = mask == 1 ? 0.0 : (mask == 2 ? 0.5 : 1.0);
             double hc = 0.0;
             for (int32_t i = 0; i < ntaps; i++) hc += taps_g[i] * cval;           // Util.java:393-401
@@ -821,13 +827,13 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             for (int32_t idx = threadIdx.x; idx < LK_TH * LK_TW; idx += blockDim.x) {
                 const int32_t r = idx / LK_TW, c = idx - r * LK_TW;
                 const size_t o = (size_t)(ty0 + r) * g.W + tx0 + c;               // tile is inside the map (bit 3 clear)
-                mlik[o] = vc;
-                mfac[(size_t)(ty0 + r) * g.fpitch + tx0 + c] = fc;
+                if (wr_lik) mlik[o] = vc;
+                if (wr_fac) mfac[(size_t)(ty0 + r) * g.fpitch + tx0 + c] = fc;
             }
-            if (tstate && threadIdx.x == 0) *tstate = want;
+            if (wr_fac && tstate && threadIdx.x == 0) *tstate = want;
             continue;
         }
-        if (tstate && threadIdx.x == 0) *tstate = 0;
+        if (wr_fac && tstate && threadIdx.x == 0) *tstate = 0;
 
         if (KH > 0) {
             // ---- phase 2: strips of LK_STRIP outputs along x
@@ -866,8 +872,8 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                     for (int i = 0; i < 2 * KH + 1; i++) total += taps_g[i] * v[o + i];
                     const int32_t gy = ty0 + r0 + o;
                     if (gx < g.W && gy < g.H) {
-                        mlik[(size_t)gy * g.W + gx] = total;
-                        mfac[(size_t)gy * g.fpitch + gx] = lik_factor(g, total);
+                        if (wr_lik) mlik[(size_t)gy * g.W + gx] = total;
+                        if (wr_fac) mfac[(size_t)gy * g.fpitch + gx] = lik_factor(g, total);
                     }
                 }
             }
@@ -886,8 +892,8 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 if (gx < g.W && gy < g.H) {
                     double total = 0.0;
                     for (int32_t i = 0; i < ntaps; i++) total += taps_s[i] * hs[(r + i) * PHS + c];
-                    mlik[(size_t)gy * g.W + gx] = total;
-                    mfac[(size_t)gy * g.fpitch + gx] = lik_factor(g, total);
+                    if (wr_lik) mlik[(size_t)gy * g.W + gx] = total;
+                    if (wr_fac) mfac[(size_t)gy * g.fpitch + gx] = lik_factor(g, total);
                 }
             }
         }
@@ -899,13 +905,13 @@ __global__ void __launch_bounds__(256)
 k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
              int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
              int32_t tiles_x, int32_t tiles_y, uint8_t *__restrict__ tile_state, const uint32_t *__restrict__ cnt_pending,
-             int32_t *__restrict__ bbox_clear) {
+             int32_t *__restrict__ bbox_clear, int32_t mode) {
     extern __shared__ __align__(16) unsigned char smem[];
     // bbox_clear: the box half the NEXT ray cast will raise (it shares its launch with this scan's deferred apply pass,
     // which therefore cannot clear it: k_raycast_apply); nobody reads it during this launch
     if (bbox_clear && blockIdx.x == 0 && threadIdx.x < 4) bbox_clear[4 * blockIdx.y + threadIdx.x] = 0;
     likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, dirty_only, tiles_x, tiles_y, blockIdx.x, blockIdx.y,
-                        gridDim.x, smem, PENDING ? cnt_pending : (const uint32_t *)nullptr, tile_state);
+                        gridDim.x, smem, PENDING ? cnt_pending : (const uint32_t *)nullptr, tile_state, mode);
 }
 
 // The stand-alone map update (GridMap.integrateObservation + computeLikelihoodMap as an entry point of its own) in two
@@ -1152,10 +1158,19 @@ int32_t gms_likelihood_blocks_cap(const gms_map *m, size_t smem) {
     return per_map;
 }
 
-void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending) {
+void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending, bool materialize) {
     // counts_pending: the scan just cast is not in logData yet; its counts (m->d_cnt) are added on the fly and its apply pass
     // is deferred by the caller (gms_defer_apply); the other box half is cleared for the next ray cast
-    if (!counts_pending) gms_flush_apply(m);
+    // materialize: bring likelihoodData up to date everywhere (mode 1) from logData and -- when an apply pass is still deferred --
+    // the counts that pass will add: exactly what the last rebuild of the factor table saw (gms_ensure_lik)
+    if (!counts_pending && !materialize) gms_flush_apply(m);
+    int32_t mode = 3;
+    if (materialize) mode = 1;
+    else if (dirty_only && m->lik_lazy && (counts_pending || m->lik_stale)) { mode = 2; m->lik_stale = 1; }   // the hot path: factor table only
+    else if (!dirty_only) {
+        if (m->lik_stale) gms_invalidate_tile_state(m);       // the tile states speak for the factor table only: trust none of them for likelihoodData
+        m->lik_stale = 0;
+    }
     ProfScope ps(m, GMS_K_LIKELIHOOD);
     const int32_t k = m->gd.khalf;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
@@ -1169,6 +1184,12 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending) 
     const int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;
     const uint32_t *pend = counts_pending ? m->d_cnt : (const uint32_t *)nullptr;
     int32_t *bb_clear = counts_pending ? m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4 : (int32_t *)nullptr;
+    uint8_t *tstate = m->d_tile_state;
+    if (materialize) {
+        dirty_only = 0; bb_clear = nullptr; tstate = nullptr;
+        counts_pending = m->apply_pending != 0;
+        pend = counts_pending ? m->d_cnt_pend : (const uint32_t *)nullptr;       // (gms_defer_apply has swapped the grids)
+    }
 #define LK_LAUNCH(KH)                                                                                         \
     do {                                                                                                      \
         if (counts_pending) LK_LAUNCH2(KH, true); else LK_LAUNCH2(KH, false);                                 \
@@ -1179,13 +1200,21 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending) 
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_likelihood<KH, PEND>),                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                       \
         hipLaunchKernelGGL((k_likelihood<KH, PEND>), grid, dim3(256), smem, m->stream, m->gd, m->d_log, m->d_lik,     \
-                           m->d_fac, m->fac_stride, m->d_taps, bb, dirty_only, tiles_x, tiles_y, m->d_tile_state, pend, bb_clear);                      \
+                           m->d_fac, m->fac_stride, m->d_taps, bb, dirty_only, tiles_x, tiles_y, tstate, pend, bb_clear, mode);                         \
     } while (0)
     if (k == 3) LK_LAUNCH(3);
     else if (k == 5) LK_LAUNCH(5);
     else LK_LAUNCH(0);
 #undef LK_LAUNCH
 #undef LK_LAUNCH2
+}
+
+// likelihoodData as the reference would have it: the field of the last computeLikelihoodMap / scan step, everywhere
+void gms_ensure_lik(gms_map *m) {
+    if (!m->lik_stale) return;
+    hipSetDevice(m->device);
+    gms_launch_likelihood(m, 0, false, true);
+    m->lik_stale = 0;
 }
 
 // pinned host memory -> device memory, 16 bytes per lane (nbytes rounded up by the caller's buffers).  A kernel rather
