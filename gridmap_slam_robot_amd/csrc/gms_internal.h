@@ -56,6 +56,7 @@ struct PfStatsDev {
 #define GMS_SCORE_SHORT_SCAN 384
 #define GMS_SCORE_SEGLEN_LONG 90   // ... and of scans of more than GMS_SCORE_LONG_SCAN beams
 #define GMS_SCORE_LONG_SCAN 768
+#define GMS_SCORE_SEGLEN_LONG_BATCHED 120   // ... on batched handles (which are never sharded)
 static_assert(128 * GMS_SCORE_MAXSEG >= GMS_MAX_BEAMS, "a scan must fit GMS_SCORE_MAXSEG segments of 128 beams");
 #define GMS_PARTIAL_STRIDE 9   // per block: sum w, max w, first argmax, n_zero, max logw, sum w^2, sum x*w, sum y*w, sum th*w
 

@@ -1190,8 +1190,11 @@ static void launch_compact(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32
 // Long scans (> 768 beams: config 5's 1080) take 90 beams per segment: half the segment products per particle to store and to
 // combine (C5, 64 maps x 4096 x 1080: 45 / 68 / 90 / 120 beams per segment -> 402 / 398 / 392 / 386 us per batched step; 90 keeps
 // a single-map filter of 16384 particles at 192 workgroups, 120 would leave it 144 for 256 CUs).
-static int64_t score_segments(int32_t B) {
-    const int32_t seglen = B <= GMS_SCORE_SHORT_SCAN ? GMS_SCORE_SEGLEN_SHORT : (B > GMS_SCORE_LONG_SCAN ? GMS_SCORE_SEGLEN_LONG : GMS_SCORE_SEGLEN);
+// Batched handles (n_maps > 1) are never sharded -- the "function of the beam count only" rule is what makes a shard round like
+// the stand-alone filter -- and bring their workgroups by the thousand: their long scans take 120 beams per segment.
+static int64_t score_segments(int32_t B, bool batched) {
+    const int32_t seglen = B <= GMS_SCORE_SHORT_SCAN ? GMS_SCORE_SEGLEN_SHORT
+                         : (B > GMS_SCORE_LONG_SCAN ? (batched ? GMS_SCORE_SEGLEN_LONG_BATCHED : GMS_SCORE_SEGLEN_LONG) : GMS_SCORE_SEGLEN);
     int64_t nseg = ((int64_t)B + seglen - 1) / seglen;
     const int64_t min_seg = ((int64_t)B + 127) / 128;
     if (nseg < min_seg) nseg = min_seg;
@@ -1202,7 +1205,7 @@ static int64_t score_segments(int32_t B) {
 
 void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_pose_src) {
     gms_map *m = pf->map;
-    const int64_t nseg = score_segments(B);
+    const int64_t nseg = score_segments(B, pf->n_maps > 1);
     // The locality order (k_order) costs a launch of its own, ~8 us for 4096 particles per map, and takes a fifth to a
     // quarter off the scoring kernel: it pays once the scoring launch is several rounds of workgroups deep (C5: 6144
     // workgroups, 328 -> 247 us), not at 256 workgroups (C3: -3 us for +5.5).  Results are the same either way.
