@@ -10,6 +10,11 @@
 
 #define GMS_WAVE 64
 
+// A store that is written through to memory at once (agent scope) instead of staying dirty in the XCD's L2 until the kernel's end
+// write-back: for data nobody in this launch reads again.
+__device__ __forceinline__ void store_through(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_through(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Development builds only (-DGMS_STAMPS, tools/stamps.py): wall-clock stamps (100 MHz) of a kernel's stages, one row of
 // GMS_STAMP_SLOTS per workgroup, written by thread 0.  Compiled out of the product library.
 #define GMS_STAMP_SLOTS 16

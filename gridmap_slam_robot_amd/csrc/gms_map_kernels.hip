@@ -600,8 +600,20 @@ apply_body(const GridDev &g, double *__restrict__ logd, uint32_t *__restrict__ c
             const double lv[4] = { la.x, la.y, lb.x, lb.y };
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (cc[i]) logd[o + i] = lv[i] + ((double)(cc[i] & 0xffffu) * g.l_free + (double)(cc[i] >> 16) * g.l_occ);
-            *reinterpret_cast<uint4 *>(cnt + o) = make_uint4(0u, 0u, 0u, 0u);
+                if (cc[i]) {
+                    const double nv = lv[i] + ((double)(cc[i] & 0xffffu) * g.l_free + (double)(cc[i] >> 16) * g.l_occ);
+                    // Single maps: written through to memory at once.  The pass hides under the ray cast it shares a launch with, and
+                    // ~7 MB of dirty lines left in the L2s would be written back at the kernel's END, in front of the next launch
+                    // (C3 step 49.5 -> 48.2 us).  Batched maps are bandwidth-bound here and keep the L2's write combining (C5: the
+                    // tiled ray cast 65 -> 73 us with write-through).
+                    if (lazy_log) logd[o + i] = nv; else store_through(&logd[o + i], nv);
+                }
+            if (lazy_log) {
+                *reinterpret_cast<uint4 *>(cnt + o) = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                store_through(reinterpret_cast<uint64_t *>(cnt + o), (uint64_t)0);
+                store_through(reinterpret_cast<uint64_t *>(cnt + o + 2), (uint64_t)0);
+            }
         } else {
             for (int i = 0; i < 4 && xb + i < g.W; i++) {
                 const uint32_t c = cnt[o + i];
@@ -646,6 +658,9 @@ k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const 
 #define LK_TH 32
 #define LK_STRIP 8
 
+// the factor table's stores go through to memory at once: nobody in the launch reads them again, and dirty lines would be written
+// back at the kernel's end, in front of the next scan's scoring launch (C3 step -0.4 us, C5 -5 us)
+#define FAC_STORE(p, v) store_through((p), (v))
 template <int KH>   // KH > 0: compile-time half width; KH == 0: runtime g.khalf (generic, slower)
 __device__ __forceinline__ void
 likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
@@ -828,7 +843,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 const int32_t r = idx / LK_TW, c = idx - r * LK_TW;
                 const size_t o = (size_t)(ty0 + r) * g.W + tx0 + c;               // tile is inside the map (bit 3 clear)
                 if (wr_lik) mlik[o] = vc;
-                if (wr_fac) mfac[(size_t)(ty0 + r) * g.fpitch + tx0 + c] = fc;
+                if (wr_fac) FAC_STORE(&mfac[(size_t)(ty0 + r) * g.fpitch + tx0 + c], fc);
             }
             if (wr_fac && tstate && threadIdx.x == 0) *tstate = want;
             continue;
@@ -873,7 +888,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                     const int32_t gy = ty0 + r0 + o;
                     if (gx < g.W && gy < g.H) {
                         if (wr_lik) mlik[(size_t)gy * g.W + gx] = total;
-                        if (wr_fac) mfac[(size_t)gy * g.fpitch + gx] = lik_factor(g, total);
+                        if (wr_fac) FAC_STORE(&mfac[(size_t)gy * g.fpitch + gx], lik_factor(g, total));
                     }
                 }
             }
@@ -893,7 +908,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                     double total = 0.0;
                     for (int32_t i = 0; i < ntaps; i++) total += taps_s[i] * hs[(r + i) * PHS + c];
                     if (wr_lik) mlik[(size_t)gy * g.W + gx] = total;
-                    if (wr_fac) mfac[(size_t)gy * g.fpitch + gx] = lik_factor(g, total);
+                    if (wr_fac) FAC_STORE(&mfac[(size_t)gy * g.fpitch + gx], lik_factor(g, total));
                 }
             }
         }
