@@ -191,8 +191,47 @@ __device__ __forceinline__ double angle_constrain(double a) {
 }
 
 // ---- wave64 helpers ------------------------------------------------------------------------------
+// The value lane (lane ^ O) holds, O one of 32, 16, 8, 4, 2, 1, without the LDS crossbar that __shfl_xor goes through
+// (ds_bpermute_b32: ~65 clocks per dependent use; the nine butterflies of the block partials took 1.5 us of k_partials' 4.5):
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves / rows of 16, DPP row rotations and quad permutations do
+// the rest.  FLIP: the other reading of the swap's result order / the rotation's direction (gms_debug_f32 op 3 checks both
+// against __shfl_xor on the device; the product uses the one that matches).
+template <int O, bool FLIP = false>
+__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v) {
+    static_assert(O == 32 || O == 16 || O == 8 || O == 4 || O == 2 || O == 1, "xor butterfly offsets of a 64-lane wavefront");
+    const uint32_t lane = __lane_id();
+    if constexpr (O == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // {lanes 32-63 of the first, lanes 0-31 of the second} exchanged
+        return (((lane & 32u) != 0u) != FLIP) ? r[0] : r[1];
+    } else if constexpr (O == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // odd rows of the first, even rows of the second
+        return (((lane & 16u) != 0u) != FLIP) ? r[0] : r[1];
+    } else if constexpr (O == 8) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);          // row_ror:8
+    } else if constexpr (O == 4) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);   // row_ror:4
+        const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12c, 0xf, 0xf, false);   // row_ror:12
+        return (((lane & 4u) != 0u) != FLIP) ? a : b;
+    } else if constexpr (O == 2) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);           // quad_perm:[2,3,0,1]
+    } else {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);           // quad_perm:[1,0,3,2]
+    }
+}
+template <int O> __device__ __forceinline__ int32_t wave_xor(int32_t v) { return (int32_t)wave_xor_u32<O>((uint32_t)v); }
+template <int O> __device__ __forceinline__ uint32_t wave_xor(uint32_t v) { return wave_xor_u32<O>(v); }
+template <int O> __device__ __forceinline__ float wave_xor(float v) { return __uint_as_float(wave_xor_u32<O>(__float_as_uint(v))); }
+template <int O> __device__ __forceinline__ double wave_xor(double v) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = wave_xor_u32<O>((uint32_t)u), hi = wave_xor_u32<O>((uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// the six steps of a descending butterfly: GMS_BUTTERFLY(STEP) expands STEP(32) ... STEP(1)
+#define GMS_BUTTERFLY(STEP) STEP(32) STEP(16) STEP(8) STEP(4) STEP(2) STEP(1)
+
 __device__ __forceinline__ double wave_sum_f64(double v) {   // fixed xor-butterfly shape
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GMS_WAVE);
+#define GMS_STEP_(O) v += wave_xor<O>(v);
+    GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
     return v;
 }

@@ -804,7 +804,7 @@ int gms_debug_set_stamps(gms_map *m, void *dev_buffer) {
 }
 
 int gms_debug_f32(gms_map *m, int32_t op, const float *in, float *out, int64_t n) {
-    REQUIRE(m && in && out && n > 0 && op >= 0 && op <= 2, "gms_debug_f32: bad arguments");
+    REQUIRE(m && in && out && n > 0 && op >= 0 && op <= 3 && (op != 3 || n % 64 == 0), "gms_debug_f32: bad arguments");
     HIPCHK(hipSetDevice(m->device));
     float *d_a = nullptr, *d_o = nullptr;
     HIPCHK(hipMalloc(&d_a, n * sizeof(float)));

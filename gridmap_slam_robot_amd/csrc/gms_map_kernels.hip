@@ -108,9 +108,9 @@ __device__ __forceinline__ void ray_box(const GridDev &g, const RayMeta &mt, int
 }
 // raise the scan's dirty box by the union of the lanes' boxes: wave butterfly, then four atomics by lane 0, not waited for
 __device__ __forceinline__ void bbox_raise_wave(int32_t bb[4], int32_t lane, int32_t *__restrict__ bbox_map) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        for (int q = 0; q < 4; q++) bb[q] = max(bb[q], __shfl_xor(bb[q], o, GMS_WAVE));
+#define GMS_STEP_(O) { _Pragma("unroll") for (int q = 0; q < 4; q++) bb[q] = max(bb[q], wave_xor<O>(bb[q])); }
+    GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
     if (lane == 0 && bb[2] > 0)
         for (int q = 0; q < 4; q++) atomicMax(&bbox_map[q], bb[q]);
 }
@@ -363,11 +363,9 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
             ray_box(g, mt, hb);
             bbox_raise_wave(hb, lane, bbox + 4 * mi);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            bx0 = min(bx0, __shfl_xor(bx0, o, GMS_WAVE)); by0 = min(by0, __shfl_xor(by0, o, GMS_WAVE));
-            bx1 = max(bx1, __shfl_xor(bx1, o, GMS_WAVE)); by1 = max(by1, __shfl_xor(by1, o, GMS_WAVE));
-        }
+#define GMS_STEP_(O) { bx0 = min(bx0, wave_xor<O>(bx0)); by0 = min(by0, wave_xor<O>(by0)); bx1 = max(bx1, wave_xor<O>(bx1)); by1 = max(by1, wave_xor<O>(by1)); }
+        GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
         if (lane == 0) { s_nbox[0] = bx0; s_nbox[1] = by0; s_nbox[2] = bx1; s_nbox[3] = by1; }
     }
     __syncthreads();
@@ -495,12 +493,10 @@ k_raycast_tile(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t
             bbox_raise_wave(hb, lane, bbox + 4 * mi);
         }
         int32_t nwm = my_nwords;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            bx0 = min(bx0, __shfl_xor(bx0, o, GMS_WAVE)); by0 = min(by0, __shfl_xor(by0, o, GMS_WAVE));
-            bx1 = max(bx1, __shfl_xor(bx1, o, GMS_WAVE)); by1 = max(by1, __shfl_xor(by1, o, GMS_WAVE));
-            nwm = max(nwm, __shfl_xor(nwm, o, GMS_WAVE));
-        }
+#define GMS_STEP_(O) { bx0 = min(bx0, wave_xor<O>(bx0)); by0 = min(by0, wave_xor<O>(by0)); bx1 = max(bx1, wave_xor<O>(bx1)); by1 = max(by1, wave_xor<O>(by1)); \
+                       nwm = max(nwm, wave_xor<O>(nwm)); }
+        GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
         if (lane == 0) { s_box[0] = bx0; s_box[1] = by0; s_box[2] = bx1; s_box[3] = by1; s_box[4] = nwm; }
     }
     __syncthreads();
@@ -800,8 +796,9 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 in_s[r * PIN + c] = val;
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) seen |= __shfl_xor(seen, o, GMS_WAVE);
+#define GMS_STEP_(O) seen |= wave_xor<O>(seen);
+        GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
         if ((threadIdx.x & 63) == 0) atomicOr(smask, seen);
         __syncthreads();
         if (tile_iter == 0) GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 3);      // first tile: loads arrived, codes known
@@ -1007,6 +1004,18 @@ __global__ void k_debug_f32(int32_t op, const float *__restrict__ a, float *__re
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float c, s;
         if (op == 0) out[i] = j_sqrtf(a[i]);
+        else if (op == 3) {
+            // wave_xor<O> against __shfl_xor, both readings of the swap order / rotation direction: bit k (k = 0..5 for O = 32..1) set
+            // when the product form differs from __shfl_xor in this lane, bit 6 + k when the FLIP form does.  (n is a multiple of 64.)
+            const uint32_t v = __float_as_uint(a[i]);
+            uint32_t code = 0;
+#define GMS_STEP_(O) { const uint32_t want = (uint32_t)__shfl_xor((int)v, O, GMS_WAVE);                              \
+                       code |= (wave_xor_u32<O, false>(v) != want ? 1u : 0u) << (5 - __builtin_ctz(O));            \
+                       code |= (wave_xor_u32<O, true>(v) != want ? 1u : 0u) << (11 - __builtin_ctz(O)); }
+            GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
+            out[i] = (float)code;
+        }
         else { pose_trig(a[i], c, s); out[i] = op == 1 ? c : s; }
     }
 }

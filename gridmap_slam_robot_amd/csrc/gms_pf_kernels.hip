@@ -129,16 +129,6 @@ __device__ __forceinline__ uint32_t beam_cell(const GridDev &g, const XformDev &
     return cell_or_neutral(g, gx, gy);
 }
 
-// multiply two (mantissa, exponent) products; scaling by powers of two is exact, so the mantissa
-// path rounds exactly like the plain product while it stays clear of the denormal range
-__device__ __forceinline__ void mx_mul(double &m, int32_t &e, double m2, int32_t e2) {
-    m *= m2;
-    e += e2;
-    int de;
-    m = frexp(m, &de);
-    e += de;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Locality order of the particles for a large scoring launch.  The texture-address pipe serves an 8-byte gather of 64
 // lanes in ~48 clocks when every lane has a line of its own and in ~25 when NEIGHBOURING lanes share lines (it merges
@@ -186,11 +176,9 @@ k_order(GridDev g, const float *__restrict__ pose_src, const float *__restrict__
         for (int d = 0; d < 3; d++) { const float v = src[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, GMS_WAVE));
-            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, GMS_WAVE));
-        }
+#define GMS_STEP_(O) { lo[d] = fminf(lo[d], wave_xor<O>(lo[d])); hi[d] = fmaxf(hi[d], wave_xor<O>(hi[d])); }
+        GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
         if (lane == 0) { s_lo[d][wave] = lo[d]; s_hi[d][wave] = hi[d]; }
     }
     for (int32_t b = tid; b < ORD_BINS; b += ORD_THREADS) { s_all[b] = 0u; s_before[b] = 0u; s_own[b] = 0u; }
@@ -388,24 +376,34 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
 }
 
 // product of the per-segment products, in segment order, with an exact exponent (no underflow on the
-// way); the loads of sixteen segments are issued together
+// way); the loads of sixteen segments are issued together.
+// Every segment product is split into mantissa and exponent first (independent of one another); the mantissas, all in
+// [0.5, 1), are multiplied in segment order WITHOUT renormalising in between -- thirty-two of them stay above 2^-32, far from
+// the denormal range, and scaling by a power of two does not change how a product rounds, so the bits are those of the
+// renormalised chain (a frexp after every factor: eight dependent double-precision operations per segment on a wavefront
+// that has its SIMD to itself; this form has one) -- and the exponents are added up as integers.
 __device__ __forceinline__ void combine_segments(const double *__restrict__ part, int32_t mi, int32_t n, int32_t nseg,
                                                  int64_t p, double &wv, double &lwv) {
     const double *q = part + ((size_t)mi * nseg) * n + p;
-    double mnt = 1.0;
+    double M = 1.0;
     int32_t e = 0;
     for (int32_t s0 = 0; s0 < nseg; s0 += 16) {                        // the default 16 segments: one round trip
         double v[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = s0 + k < nseg ? q[(size_t)(s0 + k) * n] : 1.0;
+        for (int k = 0; k < 16; k++) v[k] = q[(size_t)min(s0 + k, nseg - 1) * n];    // (clamped: no load behind a branch)
+        double m2[16];
+        int32_t e2[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            int e2;
-            const double m2 = frexp(v[k], &e2);
-            if (s0 + k == 0) { mnt = m2; e = e2; }
-            else if (s0 + k < nseg) mx_mul(mnt, e, m2, e2);
+            m2[k] = frexp(v[k], &e2[k]);
+            if (s0 + k >= nseg) { m2[k] = 1.0; e2[k] = 0; }            // (uniform) x * 1.0 == x: a missing segment changes nothing
         }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { M *= m2[k]; e += e2[k]; }       // 1.0 * m == m: the first factor enters as it is
     }
+    int de;
+    const double mnt = frexp(M, &de);
+    e += de;
     wv = ldexp(mnt, e);
     lwv = log(mnt) + (double)e * 0.6931471805599453;
 }
@@ -453,11 +451,9 @@ __device__ __forceinline__ void argmax_merge(double &v, double &i, double v2, do
 }
 
 __device__ __forceinline__ void group_argmax(double &v, double &i, double *ldsv, double *ldsi) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double v2 = __shfl_xor(v, o, GMS_WAVE), i2 = __shfl_xor(i, o, GMS_WAVE);
-        argmax_merge(v, i, v2, i2);
-    }
+#define GMS_STEP_(O) { const double v2 = wave_xor<O>(v), i2 = wave_xor<O>(i); argmax_merge(v, i, v2, i2); }
+    GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
     const int32_t wave = threadIdx.x >> 6, g4 = (wave >> 2) << 2;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { ldsv[wave] = v; ldsi[wave] = i; }
@@ -540,20 +536,19 @@ __device__ __forceinline__ void block_partials(double *__restrict__ w, double *_
             }
         }
     }
+    GMS_STAMP(GMS_STAMP_ROW(1, blockIdx.x), 2);
     // one barrier pair for all nine columns: wave butterflies first, then the four waves of the group
     // are combined in wave order by every thread (same shape as group_sum / group_argmax)
     double sums[6] = { s, nz, sq, xw, yw, tw };
 #pragma unroll
     for (int c = 0; c < 6; c++) sums[c] = wave_sum_f64(sums[c]);
     double mli = 0.0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double v2 = __shfl_xor(mv, o, GMS_WAVE), i2 = __shfl_xor(mx, o, GMS_WAVE);
-        argmax_merge(mv, mx, v2, i2);
-        const double l2 = __shfl_xor(ml, o, GMS_WAVE);
-        if (l2 > ml) ml = l2;
-    }
+#define GMS_STEP_(O) { const double v2 = wave_xor<O>(mv), i2 = wave_xor<O>(mx); argmax_merge(mv, mx, v2, i2); \
+                       const double l2 = wave_xor<O>(ml); if (l2 > ml) ml = l2; }
+    GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
     const int32_t wave = threadIdx.x >> 6, g4 = (wave >> 2) << 2;
+    GMS_STAMP(GMS_STAMP_ROW(1, blockIdx.x), 3);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
@@ -561,6 +556,7 @@ __device__ __forceinline__ void block_partials(double *__restrict__ w, double *_
         L.m[6][wave] = mv; L.m[7][wave] = mx; L.m[8][wave] = ml;
     }
     __syncthreads();
+    GMS_STAMP(GMS_STAMP_ROW(1, blockIdx.x), 4);
 #pragma unroll
     for (int c = 0; c < 6; c++) sums[c] = ((L.m[c][g4] + L.m[c][g4 + 1]) + L.m[c][g4 + 2]) + L.m[c][g4 + 3];
     mv = L.m[6][g4]; mx = L.m[7][g4]; ml = L.m[8][g4];
@@ -1118,12 +1114,10 @@ k_refine(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, cons
         if (prod > best) { best = prod; besti = q; }                   // :334 (q ascending per lane)
     }
     // first maximum over the lattice: larger probability wins, equal probabilities the smaller q
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double v2 = __shfl_xor(best, o, GMS_WAVE);
-        const int32_t i2 = __shfl_xor(besti, o, GMS_WAVE);
-        if (i2 >= 0 && (besti < 0 || v2 > best || (v2 == best && i2 < besti))) { best = v2; besti = i2; }
-    }
+#define GMS_STEP_(O) { const double v2 = wave_xor<O>(best); const int32_t i2 = wave_xor<O>(besti); \
+                       if (i2 >= 0 && (besti < 0 || v2 > best || (v2 == best && i2 < besti))) { best = v2; besti = i2; } }
+    GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
     if (lane == 0) { s_best[wave] = best; s_besti[wave] = besti; }
     __syncthreads();
     if (threadIdx.x == 0) {

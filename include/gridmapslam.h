@@ -363,7 +363,9 @@ int gms_profile_calibrate2(gms_map *m, int32_t reps, double *bracket_ms, double 
 
 /* ---- diagnostics ------------------------------------------------------------------------------- */
 /* The float-rounded device primitives the parity contract leans on, for tests: op 0 = (float)sqrt(a)
- * (GridMap.java:217), 1 = (float)cos((double)a), 2 = (float)sin((double)a) (J/math/MathUtil.java:30-40). */
+ * (GridMap.java:217), 1 = (float)cos((double)a), 2 = (float)sin((double)a) (J/math/MathUtil.java:30-40); 3 = self-check of the
+ * wavefront butterflies every reduction uses (n a multiple of 64): out[i] = a bit code, bits 0-5 set where the exchange with lane
+ * (i ^ 32, 16, 8, 4, 2, 1) does not deliver that lane's value (must be 0), bits 6-11 the same for the mirrored reading (must be 63 << 6 for the half-wave, row and quad-of-four steps that have one). */
 int gms_debug_f32(gms_map *m, int32_t op, const float *in, float *out, int64_t n);
 /* Development: instrumented builds (-DGMS_STAMPS) write wall-clock stamps of their kernels' stages to dev_buffer
  * ([workgroup][16] uint64, 10 ns units; NULL turns it off); a product build returns GMS_ERR_STATE.  tools/stamps.py. */
