@@ -40,6 +40,13 @@ done
 python3 tools/pmc_summary.py "$OUT/c3_FETCH_SIZE" "$OUT/c3_WRITE_SIZE" "$OUT/keep" c3_pmc C3
 python3 tools/pmc_summary.py "$OUT/c5_FETCH_SIZE" "$OUT/c5_WRITE_SIZE" "$OUT/keep" c5_pmc C5
 python3 tools/pmc_summary.py "$OUT/dense_FETCH_SIZE" "$OUT/dense_WRITE_SIZE" "$OUT/keep" dense_pmc dense_likelihood
+# the microbenchmarks behind the ceilings bench.py quotes and behind DESIGN.md's launch-structure decision
+python3 tools/microbench/run_all.py > "$OUT/microbench.stdout" 2> "$OUT/microbench.stderr"
+cp gpurun_out/microbench/microbench.json "$OUT/keep/" 2>/dev/null
+cp gpurun_out/microbench/persistent_step.txt "$OUT/keep/persistent_step_model_run.txt" 2>/dev/null
+# the bench lines below quote this collection's own PMC traffic and look-up ceilings: install them where bench.py reads them
+mkdir -p "profiles/$R"
+cp "$OUT/keep/pmc_traffic.json" "$OUT/keep/microbench.json" "profiles/$R/" 2>/dev/null
 # un-profiled bench lines
 python3 bench.py > "$OUT/keep/bench.json" 2> "$OUT/bench.stderr"
 python3 bench.py --force-sharded --no-cpu-baseline --no-secondary > "$OUT/keep/bench_sharded_one_rank.json" 2>> "$OUT/bench.stderr"
@@ -48,13 +55,10 @@ python3 bench.py --full-rebuild --no-cpu-baseline --no-secondary > "$OUT/keep/be
 python3 bench.py --config C5 --steps 50 --warmup 5 > "$OUT/keep/bench_c5.json" 2>> "$OUT/bench.stderr"
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$OUT/keep/bench_steps20.json" 2>> "$OUT/bench.stderr"
 python3 bench.py --trace tests/golden/recording_360.bin --steps 300 --warmup 20 > "$OUT/keep/bench_trace_replay.json" 2>> "$OUT/bench.stderr"
-# the microbenchmarks behind the ceilings bench.py quotes and behind DESIGN.md's launch-structure decision
-python3 tools/microbench/run_all.py > "$OUT/microbench.stdout" 2> "$OUT/microbench.stderr"
-cp gpurun_out/microbench/microbench.json "$OUT/keep/" 2>/dev/null
-cp gpurun_out/microbench/persistent_step.txt "$OUT/keep/persistent_step_model_run.txt" 2>/dev/null
 # stage timeline of a C3 step from the instrumented build, when it was shipped along (lib/exp_stamps.so)
 if [ -f gridmap_slam_robot_amd/lib/exp_stamps.so ]; then
   GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/stamps.py > "$OUT/keep/c3_step_timeline.txt" 2>> "$OUT/bench.stderr"
+  GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/stamps.py --config C2 2>> "$OUT/bench.stderr" | head -24 > "$OUT/keep/c2_step_timeline.txt"
 fi
 ls -la "$OUT/keep"
 for f in "$OUT"/keep/*_kernel_stats.csv; do echo "== $f"; python3 tools/kstats.py "$f" | head -8; done
