@@ -169,6 +169,20 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
     GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), blockIdx.x < n_res_blocks ? 1 : 2);
 }
 
+// ---- a recorded revolution's two preparations in one launch: de-skew of the raw scan  |  motion-model sample per particle ----
+// (GridMapApp.java:143-175 | SLAM.java:90, Odometry.java:77-96: independent of one another)
+__global__ void __launch_bounds__(256)
+k_deskew_motion(const double *__restrict__ angle, const double *__restrict__ distance, const uint8_t *__restrict__ hit, int32_t length,
+                double d_center, double d_theta, gms_beam *__restrict__ beams_out, uint32_t n_deskew_blocks,
+                float *__restrict__ pose, float *__restrict__ cs, int32_t n, int64_t offset, double d_center_sd, double d_theta_sd,
+                uint64_t seed, uint64_t sequence) {
+    if (blockIdx.x < n_deskew_blocks)
+        deskew_body(angle, distance, hit, length, d_center, d_theta, beams_out, (int32_t)(blockIdx.x * 256u + threadIdx.x));
+    else
+        motion_body(pose, cs, n, offset, d_center, d_theta, d_center_sd, d_theta_sd, seed, sequence, 0,
+                    (int32_t)((blockIdx.x - n_deskew_blocks) * 256u + threadIdx.x));
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers (single-map handles; the callers in gms_host.hip check the preconditions)
 // ---------------------------------------------------------------------------------------------
@@ -311,4 +325,15 @@ void gms_launch_raycast_norm_chunks(gms_pf *pf, const gms_beam *d_beams, int32_t
     if (n_apply) gms_apply_done(m);
     pf->chunks_ready = 1;
     pf->neff_folded = 0;
+}
+
+// de-skew of one raw scan beside the motion-model sample of a single-map filter's particles
+void gms_launch_deskew_motion(gms_pf *pf, const double *d_angle, const double *d_distance, const uint8_t *d_hit, int32_t length,
+                              double d_center, double d_theta, uint64_t seed, uint64_t sequence) {
+    gms_map *m = pf->map;
+    const double d_center_sd = (0.01 + fabs(d_center) * 0.05) / 2;               // Odometry.java:63
+    const double d_theta_sd = 5 * (3.141592653589793 / 180.0) + 0.1 * fabs(d_theta);   // :64
+    const uint32_t n_dk = (uint32_t)((length + 255) / 256), n_mo = (uint32_t)((pf->n + 255) / 256);
+    hipLaunchKernelGGL(k_deskew_motion, dim3(n_dk + n_mo), dim3(256), 0, m->stream, d_angle, d_distance, d_hit, length, d_center,
+                       d_theta, m->d_beams, n_dk, pf->d_pose, pf->d_cs, pf->n, pf->offset, d_center_sd, d_theta_sd, seed, sequence);
 }

@@ -1266,6 +1266,35 @@ int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *de
     return rc;
 }
 
+// One recorded revolution, as GridMapApp.onHandleData treats it (J/app/GridMapApp.java:133-192): de-skew the raw measurements with
+// the frame's odometry (:143-175), sample the motion model for every particle (SLAM.java:90), SLAM.update and the conditional
+// resample (:87-131, GridMapApp.java:185-186).  What gms_map_deskew + gms_pf_sample_motion + gms_slam_update_dev do in three
+// calls and six launches, as one call and five: the de-skew and the motion model are independent and share a launch.
+int gms_slam_frame(gms_pf *pf, const double *angle, const double *distance, const uint8_t *hit, int32_t length, double d_center,
+                   double d_theta, uint64_t seed, uint64_t sequence, const double *r01, double resample_fraction, int32_t integrate) {
+    REQUIRE(pf && angle && distance && hit && r01, "null argument");
+    gms_map *m = pf->map;
+    if (pf->n_maps != 1) return fail(GMS_ERR_STATE, "gms_slam_frame: one map per handle (a frame is one robot's revolution)");
+    if (pf->offset != 0 || pf->n_global != pf->n)
+        return fail(GMS_ERR_STATE, "sharded filter: the collectives belong to the caller (see distributed.py)");
+    REQUIRE(length > 0 && length <= m->max_beams, "measurement count exceeds gms_params.max_beams");
+    REQUIRE((size_t)length * 17 + 16 <= (size_t)m->n_maps * m->max_beams * sizeof(gms_beam), "scan too long for the staging buffer");
+    HIPCHK(hipSetDevice(m->device));
+    void *slot = nullptr;
+    int rc = ring_acquire(m->beam_ring, &slot);                        // the raw scan is read in place over PCIe (see gms_map_deskew)
+    if (rc) return rc;
+    double *h_a = static_cast<double *>(slot), *h_d = h_a + length;
+    uint8_t *h_h = reinterpret_cast<uint8_t *>(h_d + length);
+    memcpy(h_a, angle, (size_t)length * 8); memcpy(h_d, distance, (size_t)length * 8); memcpy(h_h, hit, (size_t)length);
+    gms_launch_deskew_motion(pf, h_a, h_d, h_h, length, d_center, d_theta, seed, sequence);
+    rc = ring_commit(m->beam_ring, m->stream);
+    if (rc) return rc;
+    pf->have_global = 0;
+    pf->stats_current = 0;
+    HIPCHK(hipGetLastError());
+    return gms_slam_update_dev(pf, nullptr, m->d_beams, length, r01, resample_fraction, integrate);
+}
+
 // The same with host-resident inputs (what a JNI caller has): one staging copy of the scan, one of the poses.
 int gms_slam_update(gms_pf *pf, const float *xytheta, const gms_beam *beams, int32_t B, const double *r01,
                     double resample_fraction, int32_t integrate, gms_pf_stats *stats) {

@@ -231,6 +231,8 @@ bool gms_can_pair_launches(const gms_pf *pf, int32_t B);
 void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local, bool own,
                              const gms_beam *d_beams, int32_t B);
 void gms_launch_lik_resample(gms_pf *pf, double fraction);
+void gms_launch_deskew_motion(gms_pf *pf, const double *d_angle, const double *d_distance, const uint8_t *d_hit, int32_t length,
+                              double d_center, double d_theta, uint64_t seed, uint64_t sequence);
 void gms_launch_partials_pack_apply(gms_pf *pf, bool apply_rides_later = false);
 void gms_launch_raycast_norm_chunks(gms_pf *pf, const gms_beam *d_beams, int32_t B, bool raycast);
 void gms_launch_pf_fold_neff(gms_pf *pf);

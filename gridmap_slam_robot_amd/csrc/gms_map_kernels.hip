@@ -970,10 +970,9 @@ __global__ void k_combine(const double *__restrict__ logs, int32_t n_maps, int64
 
 // The de-skew loop of GridMapApp.onHandleData (J/app/GridMapApp.java:143-175) + Measurement(x, y, wasHit, dummy)
 // (J/slam/Observation.java:69-76): raw polar measurements {angle, distance, hit} -> beams, on the device.
-__global__ void k_deskew(const double *__restrict__ angle, const double *__restrict__ distance,
-                         const uint8_t *__restrict__ hit, int32_t length, double d_center, double d_theta,
-                         gms_beam *__restrict__ out) {
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void deskew_body(const double *__restrict__ angle, const double *__restrict__ distance,
+                                            const uint8_t *__restrict__ hit, int32_t length, double d_center, double d_theta,
+                                            gms_beam *__restrict__ out, int32_t i) {
     if (i >= length) return;
     const double d_i = -(double)(length - i) / (double)length;                    // :150
     const double delta_theta = d_theta * d_i, delta_x = d_center * d_i;           // :157-158
@@ -986,6 +985,11 @@ __global__ void k_deskew(const double *__restrict__ angle, const double *__restr
     b.hit = hit[i] ? 1 : 0;
     for (int k = 0; k < 7; k++) b.pad_[k] = 0;
     out[i] = b;
+}
+__global__ void k_deskew(const double *__restrict__ angle, const double *__restrict__ distance,
+                         const uint8_t *__restrict__ hit, int32_t length, double d_center, double d_theta,
+                         gms_beam *__restrict__ out) {
+    deskew_body(angle, distance, hit, length, d_center, d_theta, out, (int32_t)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 __global__ void k_fill(double *__restrict__ d, double v, int64_t n) {

@@ -53,11 +53,9 @@ __device__ __forceinline__ void philox_round(uint32_t c[4], const uint32_t k[2])
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-__global__ void __launch_bounds__(256)
-k_motion(float *__restrict__ pose, float *__restrict__ cs, int32_t n, int64_t offset, double d_center, double d_theta,
-         double d_center_sd, double d_theta_sd, uint64_t seed, uint64_t sequence) {
-    const int32_t mi = blockIdx.y;
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void
+motion_body(float *__restrict__ pose, float *__restrict__ cs, int32_t n, int64_t offset, double d_center, double d_theta,
+            double d_center_sd, double d_theta_sd, uint64_t seed, uint64_t sequence, int32_t mi, int32_t i) {
     if (i >= n) return;
     const uint64_t index = (uint64_t)(offset + i) + ((uint64_t)mi << 40);      // maps draw from disjoint counters
     uint32_t c[4] = { (uint32_t)index, (uint32_t)(index >> 32), (uint32_t)sequence, (uint32_t)(sequence >> 32) };
@@ -81,6 +79,12 @@ k_motion(float *__restrict__ pose, float *__restrict__ cs, int32_t n, int64_t of
     pose[3 * gi] = (float)((double)pose[3 * gi] + (double)fc * d);               // :93  p.x += cos * d
     pose[3 * gi + 1] = (float)((double)pose[3 * gi + 1] + (double)fs * d);       // :94
     cs[2 * gi] = fc; cs[2 * gi + 1] = fs;
+}
+__global__ void __launch_bounds__(256)
+k_motion(float *__restrict__ pose, float *__restrict__ cs, int32_t n, int64_t offset, double d_center, double d_theta,
+         double d_center_sd, double d_theta_sd, uint64_t seed, uint64_t sequence) {
+    motion_body(pose, cs, n, offset, d_center, d_theta, d_center_sd, d_theta_sd, seed, sequence, (int32_t)blockIdx.y,
+                (int32_t)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 // One wavefront per map: order-preserving compaction of the beams with wasHit (GridMap.java:269); used

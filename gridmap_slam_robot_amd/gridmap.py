@@ -458,6 +458,16 @@ class ParticleFilter:
         check(load().gms_slam_update_dev(self._h, C.c_void_p(dev_xytheta or 0), C.c_void_p(dev_beams), B, ptr(r), fraction,
                                          1 if integrate else 0))
 
+    def slam_frame(self, angles, distances, hits, d_center: float, d_theta: float, seed: int, sequence: int, r01,
+                   fraction: float = 0.5, integrate: bool = True):
+        """One recorded revolution (GridMapApp.java:133-192) in one call: de-skew, motion-model sample, scan step."""
+        a = np.ascontiguousarray(angles, dtype=np.float64)
+        d = np.ascontiguousarray(distances, dtype=np.float64)
+        h = np.ascontiguousarray(hits, dtype=np.uint8)
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(r01, dtype=np.float64), (self.n_maps,)))
+        check(load().gms_slam_frame(self._h, ptr(a), ptr(d), ptr(h), a.size, d_center, d_theta, seed, sequence, ptr(r), fraction,
+                                    1 if integrate else 0))
+
     def slam_update(self, poses, obs, r01, fraction: float = 0.5, integrate: bool = True, fetch: bool = False):
         """SLAM.update + conditional resample with HOST inputs (poses may be None)."""
         b, B = self.map._beam_args(obs)

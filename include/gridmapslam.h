@@ -267,6 +267,13 @@ int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B);
  * (SLAM.java:82).  r01[n_maps] is read on the host.  Nothing is read back. */
 int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, const double *r01,
                         double resample_fraction, int32_t integrate);
+/* One recorded revolution as GridMapApp.onHandleData treats it (J/app/GridMapApp.java:133-192), in one call: the raw polar
+ * measurements are de-skewed with the frame's odometry (:143-175, as gms_map_deskew), every particle takes a motion-model sample
+ * (J/slam/SLAM.java:90, as gms_pf_sample_motion with the same seed and sequence), then the scan step of gms_slam_update_dev on
+ * the de-skewed scan.  Bit-identical to those three calls; the de-skew and the motion model share a launch (five launches per
+ * frame).  Single-map, stand-alone filters.  angle / distance / hit [length] are host arrays and may be reused on return. */
+int gms_slam_frame(gms_pf *pf, const double *angle, const double *distance, const uint8_t *hit, int32_t length, double d_center,
+                   double d_theta, uint64_t seed, uint64_t sequence, const double *r01, double resample_fraction, int32_t integrate);
 /* The same scan step with HOST inputs (what a JNI caller holds): poses (may be NULL) and the scan are copied into
  * pinned staging rings before the call returns (the caller may reuse its buffers at once) and pulled in by the
  * device without a stream synchronise; stats (may be NULL; when given the call synchronises) receives SLAM.update's

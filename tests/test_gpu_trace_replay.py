@@ -1,5 +1,5 @@
 """A recorded trace through the device path frame by frame -- read_trace -> gms_map_deskew -> gms_pf_sample_motion -> fused scan
-step (GridMapApp.onHandleData, J/app/GridMapApp.java:133-192; DataRecorder.load, J/app/DataRecorder.java:403-436) -- against
+step, and the same as one gms_slam_frame call per revolution (GridMapApp.onHandleData, J/app/GridMapApp.java:133-192; DataRecorder.load, J/app/DataRecorder.java:403-436) -- against
 the oracle step by step, the oracle being fed the device's state of the stage before.  The recording is the committed synthetic
 one (tests/golden/recording_360.bin, tools/make_recording.py; the reference ships none)."""
 import os
@@ -61,7 +61,7 @@ def test_recording_replays_against_the_oracle():
         # stage 3: SLAM.update + conditional resample (SLAM.java:87-131, GridMapApp.java:185-186)
         pa.slam_update_dev(0, dev, B, r01, 0.5, True)
         ra.frame_no += 1
-        rb.step(f, r01)                                                       # the same three calls, back to back
+        rb.step(f, r01)                                                       # gms_slam_frame: the same three stages as ONE call
         st, last = pa.stats(), pa.last_step()
         w = g.score(lik, obs.beams, P)
         wn = w.copy()
@@ -90,7 +90,7 @@ def test_recording_replays_against_the_oracle():
             nz = log != 0
             assert np.max(np.abs(gl[nz] - log[nz]) / np.abs(log[nz])) <= 1e-13
     assert resampled > 0
-    # the helper that reads nothing back arrives at the same filter and the same map, bit for bit
+    # the one-call frame (de-skew and motion model in one launch, nothing read back) arrives at the same filter and the same map, bit for bit
     assert np.array_equal(pa.get_poses(), pb.get_poses()) and np.array_equal(pa.get_weights(), pb.get_weights())
     assert np.array_equal(a.download_log(), b.download_log()) and np.array_equal(a.download_likelihood(), b.download_likelihood())
     # ... and the filter still knows where the robot is
@@ -99,3 +99,18 @@ def test_recording_replays_against_the_oracle():
     for h in (pa, pb):
         h.close()
     a.close(); b.close()
+
+
+def test_frame_call_refuses_what_it_cannot_do():
+    from gridmap_slam_robot_amd._lib import GmsError
+    m = GridMap(6.4, 6.4, 0.05, (-3.2, -3.2), n_maps=2, max_beams=512)
+    pf = ParticleFilter(m, 256)
+    ang = np.linspace(0, 2 * np.pi, 90, endpoint=False); dist = np.full(90, 2.0); hit = np.ones(90, dtype=np.uint8)
+    with pytest.raises(GmsError):
+        pf.slam_frame(ang, dist, hit, 0.01, 0.0, 1, 0, 0.5)                   # batched handle: a frame is one robot's revolution
+    pf.close(); m.close()
+    m = GridMap(6.4, 6.4, 0.05, (-3.2, -3.2), max_beams=64)
+    pf = ParticleFilter(m, 256)
+    with pytest.raises(GmsError):
+        pf.slam_frame(ang, dist, hit, 0.01, 0.0, 1, 0, 0.5)                   # more measurements than max_beams
+    pf.close(); m.close()
