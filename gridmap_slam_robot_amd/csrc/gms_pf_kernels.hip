@@ -380,7 +380,7 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
 }
 
 // product of the per-segment products, in segment order, with an exact exponent (no underflow on the
-// way); the loads of sixteen segments are issued together.
+// way); the loads of all segments are issued together.
 // Every segment product is split into mantissa and exponent first (independent of one another); the mantissas, all in
 // [0.5, 1), are multiplied in segment order WITHOUT renormalising in between -- thirty-two of them stay above 2^-32, far from
 // the denormal range, and scaling by a power of two does not change how a product rounds, so the bits are those of the
@@ -391,20 +391,27 @@ __device__ __forceinline__ void combine_segments(const double *__restrict__ part
     const double *q = part + ((size_t)mi * nseg) * n + p;
     double M = 1.0;
     int32_t e = 0;
-    for (int32_t s0 = 0; s0 < nseg; s0 += 16) {                        // the default 16 segments: one round trip
-        double v[16];
+    // every segment's load is issued before the first product is used: one round trip for up to GMS_SCORE_MAXSEG = 32 segments
+    // (a loop over chunks of sixteen was two dependent round trips for the thirty 12-beam segments of a short scan: C2's
+    // k_partials 7.1 -> 6.4 us)
+    double v[GMS_SCORE_MAXSEG];
+    const bool wide = nseg > 16;                                       // (uniform) the second sixteen only when there are any
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = q[(size_t)min(s0 + k, nseg - 1) * n];    // (clamped: no load behind a branch)
-        double m2[16];
-        int32_t e2[16];
+    for (int k = 0; k < 16; k++) v[k] = q[(size_t)min(k, nseg - 1) * n];            // (clamped: no load behind a branch)
+    if (wide) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            m2[k] = frexp(v[k], &e2[k]);
-            if (s0 + k >= nseg) { m2[k] = 1.0; e2[k] = 0; }            // (uniform) x * 1.0 == x: a missing segment changes nothing
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++) { M *= m2[k]; e += e2[k]; }       // 1.0 * m == m: the first factor enters as it is
+        for (int k = 16; k < GMS_SCORE_MAXSEG; k++) v[k] = q[(size_t)min(k, nseg - 1) * n];
     }
+#define GMS_FACTOR_(k) { int e2; double m2 = frexp(v[k], &e2);                                                     \
+                         if ((k) >= nseg) { m2 = 1.0; e2 = 0; }    /* (uniform) x * 1.0 == x: a missing segment changes nothing */ \
+                         M *= m2; e += e2; }                        /* 1.0 * m == m: the first factor enters as it is */
+#pragma unroll
+    for (int k = 0; k < 16; k++) GMS_FACTOR_(k)
+    if (wide) {
+#pragma unroll
+        for (int k = 16; k < GMS_SCORE_MAXSEG; k++) GMS_FACTOR_(k)
+    }
+#undef GMS_FACTOR_
     int de;
     const double mnt = frexp(M, &de);
     e += de;
