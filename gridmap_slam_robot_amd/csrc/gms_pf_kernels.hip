@@ -278,14 +278,11 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     int32_t seg, grp;
     {
         const int32_t i = blockIdx.x, ngrp = gridDim.x / nseg;
-#ifndef GMS_EXP_NO_XCD_ADJ
         if ((nseg & 7) == 0) {
             const int32_t spx = nseg >> 3, j = i >> 3;
             seg = (i & 7) * spx + j % spx;
             grp = j / spx;
-        } else
-#endif
-        {
+        } else {
             seg = i % nseg;
             grp = i / nseg;
         }
