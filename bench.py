@@ -225,8 +225,8 @@ class Workload:
         a, pf, m, B = self.args, self.pf, self.m, self.B
         if self.loop:
             t = (self.T // 2 + i) % self.T                      # the drive goes on round the circle, scan after scan
-            pf.sample_motion(self.odo[0], self.odo[1], 7, i)                                       # SLAM.java:90, 155-163
-            pf.slam_update_dev(0, self.beams_ptr(t), B, float(self.r01[i % 4096][0]), 0.5, True)   # :87-131, GridMapApp.java:185-186
+            # SLAM.java:87-131 with :90's motion-model sample inside the scoring launch, GridMapApp.java:185-186
+            pf.slam_update_u_dev(self.odo[0], self.odo[1], 7, i, self.beams_ptr(t), B, float(self.r01[i % 4096][0]), 0.5, True)
             return
         s = i % self.n_sets
         t = self.T // 2 + s

@@ -141,6 +141,7 @@ def load() -> C.CDLL:
     sig("gms_pf_set_poses_dev", C.c_int, vp, vp)
     sig("gms_pf_score_dev", C.c_int, vp, vp, i32)
     sig("gms_slam_update_dev", C.c_int, vp, vp, vp, i32, vp, f64, i32)
+    sig("gms_slam_update_u_dev", C.c_int, vp, f64, f64, C.c_uint64, C.c_uint64, vp, i32, vp, f64, i32)
     sig("gms_slam_frame", C.c_int, vp, vp, vp, vp, i32, f64, f64, C.c_uint64, C.c_uint64, vp, f64, i32)
     sig("gms_slam_update", C.c_int, vp, vp, vp, i32, vp, f64, i32, sp)
     sig("gms_pf_create", C.c_int, vp, i32, C.POINTER(vp))

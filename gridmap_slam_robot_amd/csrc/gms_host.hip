@@ -984,17 +984,20 @@ int gms_pf_score(gms_pf *pf, const gms_beam *beams, int32_t B) {       // GridMa
 
 // poses := dev_xytheta (may be NULL: keep the current ones), then weights: one launch with the default scoring kernel.
 // refine: the poses are replaced by findBestPose's argmax first (SLAM.java:96-97), which takes launches of its own.
-static int set_poses_and_score_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, bool refine = false) {
+static int set_poses_and_score_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, bool refine = false,
+                                   const MotionModel *motion = nullptr) {
     REQUIRE(pf && dev_beams, "null argument");
     gms_map *m = pf->map;
     REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
     HIPCHK(hipSetDevice(m->device));
     if (refine) {
         if (dev_xytheta) gms_launch_pf_pose_trig(pf, dev_xytheta);                // SLAM.java:90
+        if (motion) gms_launch_pf_motion(pf, motion->d_center, motion->d_theta, motion->seed, motion->sequence);
         gms_launch_pf_refine(pf, dev_beams, B, B);                                // :96-97
         dev_xytheta = nullptr;
+        motion = nullptr;
     }
-    gms_launch_pf_score(pf, dev_beams, B, B, dev_xytheta);
+    gms_launch_pf_score(pf, dev_beams, B, B, dev_xytheta, motion);                // (a motion-model sample rides in the scoring launch)
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
@@ -1230,14 +1233,32 @@ static int paired_likelihood_resample(gms_pf *pf, const double *r01, double frac
 // SLAM.update(z, u) (SLAM.java:80-131) + the resampling rule of its caller (GridMapApp.java:185-186) as one
 // call on device-resident inputs: poses := dev_xytheta (the motion-model samples), weights, bookkeeping,
 // conditional resample, map update at the weighted pose, likelihood rebuild.  Nothing is read back.
+static int slam_update_impl(gms_pf *pf, const float *dev_xytheta, const MotionModel *motion, const gms_beam *dev_beams, int32_t B,
+                            const double *r01, double resample_fraction, int32_t integrate);
+
 int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, const double *r01,
                         double resample_fraction, int32_t integrate) {
+    return slam_update_impl(pf, dev_xytheta, nullptr, dev_beams, B, r01, resample_fraction, integrate);
+}
+
+// SLAM.update(z, u) with its motion-model sample inside (SLAM.java:80-131, :90 included) + the caller's resampling rule: the
+// particles move by Odometry.apply (as gms_pf_sample_motion with the same seed and sequence: same Philox counters, same bits) on
+// their way into the scoring launch.  Four launches, as gms_slam_update_dev.
+int gms_slam_update_u_dev(gms_pf *pf, double d_center, double d_theta, uint64_t seed, uint64_t sequence, const gms_beam *dev_beams,
+                          int32_t B, const double *r01, double resample_fraction, int32_t integrate) {
+    MotionModel mo;
+    mo.d_center = d_center; mo.d_theta = d_theta; mo.seed = seed; mo.sequence = sequence;
+    return slam_update_impl(pf, nullptr, &mo, dev_beams, B, r01, resample_fraction, integrate);
+}
+
+static int slam_update_impl(gms_pf *pf, const float *dev_xytheta, const MotionModel *motion, const gms_beam *dev_beams, int32_t B,
+                            const double *r01, double resample_fraction, int32_t integrate) {
     REQUIRE(pf && dev_beams && r01, "null argument");
     gms_map *m = pf->map;
     if (pf->offset != 0 || pf->n_global != pf->n)
         return fail(GMS_ERR_STATE, "sharded filter: the collectives belong to the caller (see distributed.py)");
     int rc = GMS_OK;
-    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B, pf->refine != 0);   // SLAM.java:90, :96-97, :99
+    rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B, pf->refine != 0, motion);   // SLAM.java:90, :96-97, :99
     if (!rc && integrate && gms_can_pair_launches(pf, B)) {
         // The weight branch and the map branch are independent once the partials exist: they share launches
         // (gms_fused_kernels.hip).  (Two streams were measured: the event fork/join costs more than it hides.)

@@ -236,8 +236,12 @@ void gms_launch_deskew_motion(gms_pf *pf, const double *d_angle, const double *d
 void gms_launch_partials_pack_apply(gms_pf *pf, bool apply_rides_later = false);
 void gms_launch_raycast_norm_chunks(gms_pf *pf, const gms_beam *d_beams, int32_t B, bool raycast);
 void gms_launch_pf_fold_neff(gms_pf *pf);
-void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride,
-                         const float *d_pose_src = nullptr);   // d_pose_src: set the poses in the same launch
+struct MotionModel {            // one odometry step for gms_launch_pf_score's motion-model sample (Odometry.java:60-96)
+    double d_center, d_theta;
+    uint64_t seed, sequence;
+};
+void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_pose_src = nullptr,
+                         const MotionModel *motion = nullptr);   // d_pose_src: set the poses in the same launch
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials);
 void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed);
 void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local, bool own);

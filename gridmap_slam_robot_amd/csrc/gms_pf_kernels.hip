@@ -53,11 +53,15 @@ __device__ __forceinline__ void philox_round(uint32_t c[4], const uint32_t k[2])
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-__device__ __forceinline__ void
-motion_body(float *__restrict__ pose, float *__restrict__ cs, int32_t n, int64_t offset, double d_center, double d_theta,
-            double d_center_sd, double d_theta_sd, uint64_t seed, uint64_t sequence, int32_t mi, int32_t i) {
-    if (i >= n) return;
-    const uint64_t index = (uint64_t)(offset + i) + ((uint64_t)mi << 40);      // maps draw from disjoint counters
+// Odometry.apply for one particle, on values (J/slam/Odometry.java:77-96): (x, y, th) move on, (fc, fs) is the new heading's trig.
+// index: the particle's global index (+ the map's counter offset); the variates are Philox4x32-10 on (index, sequence) keyed by seed.
+struct MotionArgs {
+    int32_t on;
+    double d_center, d_theta, d_center_sd, d_theta_sd;
+    uint64_t seed, sequence;
+};
+__device__ __forceinline__ void motion_apply(float &x, float &y, float &th, float &fc, float &fs, uint64_t index, double d_center,
+                                             double d_theta, double d_center_sd, double d_theta_sd, uint64_t seed, uint64_t sequence) {
     uint32_t c[4] = { (uint32_t)index, (uint32_t)(index >> 32), (uint32_t)sequence, (uint32_t)(sequence >> 32) };
     uint32_t k[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
 #pragma unroll
@@ -71,13 +75,22 @@ motion_body(float *__restrict__ pose, float *__restrict__ cs, int32_t n, int64_t
     const double z0 = rad * cos(2.0 * 3.141592653589793 * u2), z1 = rad * sin(2.0 * 3.141592653589793 * u2);
     const double d = d_center + d_center_sd * z0;                                // ndCenter.sample()  :80
     const double theta = d_theta + d_theta_sd * z1;                              // ndTheta.sample()   :81
-    const size_t gi = (size_t)mi * n + i;
-    const float th = (float)angle_constrain((double)pose[3 * gi + 2] + theta);   // :92
-    float fc, fs;
+    th = (float)angle_constrain((double)th + theta);                             // :92
     pose_trig(th, fc, fs);                                                       // MathUtil.cos(float) :93
+    x = (float)((double)x + (double)fc * d);                                     // :93  p.x += cos * d
+    y = (float)((double)y + (double)fs * d);                                     // :94
+}
+__device__ __forceinline__ void
+motion_body(float *__restrict__ pose, float *__restrict__ cs, int32_t n, int64_t offset, double d_center, double d_theta,
+            double d_center_sd, double d_theta_sd, uint64_t seed, uint64_t sequence, int32_t mi, int32_t i) {
+    if (i >= n) return;
+    const uint64_t index = (uint64_t)(offset + i) + ((uint64_t)mi << 40);      // maps draw from disjoint counters
+    const size_t gi = (size_t)mi * n + i;
+    float x = pose[3 * gi], y = pose[3 * gi + 1], th = pose[3 * gi + 2], fc, fs;
+    motion_apply(x, y, th, fc, fs, index, d_center, d_theta, d_center_sd, d_theta_sd, seed, sequence);
     pose[3 * gi + 2] = th;
-    pose[3 * gi] = (float)((double)pose[3 * gi] + (double)fc * d);               // :93  p.x += cos * d
-    pose[3 * gi + 1] = (float)((double)pose[3 * gi + 1] + (double)fs * d);       // :94
+    pose[3 * gi] = x;
+    pose[3 * gi + 1] = y;
     cs[2 * gi] = fc; cs[2 * gi + 1] = fs;
 }
 __global__ void __launch_bounds__(256)
@@ -266,7 +279,7 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
           int32_t B, int32_t beam_stride, const float *__restrict__ pose, const float *__restrict__ cs, int32_t n,
           int32_t nseg, double *__restrict__ part, double *__restrict__ w, double *__restrict__ logw,
           const float *__restrict__ pose_src, float *__restrict__ pose_dst, float *__restrict__ cs_dst,
-          const float4 *__restrict__ ord, const int32_t *__restrict__ perm) {
+          const float4 *__restrict__ ord, const int32_t *__restrict__ perm, MotionArgs mo, int64_t offset) {
     __shared__ double2 s_beam[128 + U];        // this segment's beams with wasHit, in order
     __shared__ int32_t s_nb;
     // Workgroup -> (beam segment, particle group), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs
@@ -317,9 +330,13 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
         const float4 o = ord[li];
         t.c = (double)o.z; t.s = (double)o.w; t.px = (double)o.x; t.py = (double)o.y;
     } else if (pose_src) {
-        const float x = pose_src[3 * gi], y = pose_src[3 * gi + 1], th = pose_src[3 * gi + 2];
+        float x = pose_src[3 * gi], y = pose_src[3 * gi + 1], th = pose_src[3 * gi + 2];
         float c, sn;
-        pose_trig(th, c, sn);                                          // Transform.java:15-16
+        if (mo.on)                                                     // (uniform) the motion-model sample happens here: SLAM.java:90
+            motion_apply(x, y, th, c, sn, (uint64_t)(offset + op) + ((uint64_t)mi << 40), mo.d_center, mo.d_theta, mo.d_center_sd,
+                         mo.d_theta_sd, mo.seed, mo.sequence);
+        else
+            pose_trig(th, c, sn);                                      // Transform.java:15-16
         t.c = (double)c; t.s = (double)sn; t.px = (double)x; t.py = (double)y;
         if (seg == 0 && p < n) {
             pose_dst[3 * gi] = x; pose_dst[3 * gi + 1] = y; pose_dst[3 * gi + 2] = th;
@@ -1205,19 +1222,39 @@ static int64_t score_segments(int32_t B, bool batched) {
     return nseg;
 }
 
-void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_pose_src) {
+// motion (may be NULL): the particles take a motion-model sample on their way into the scoring kernel (SLAM.java:90 inside the launch
+// of :99): every segment's workgroup computes its particles' sample itself -- the same Philox counters, the same bits as k_motion --
+// reads the old poses from d_pose and segment 0 stores the new ones into d_pose2 / d_cs2, which then change places with d_pose / d_cs
+// (in place the other segments' workgroups would read poses that segment 0 had already moved).
+void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_pose_src,
+                         const MotionModel *motion) {
     gms_map *m = pf->map;
+    MotionArgs mo;
+    mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0;
     const int64_t nseg = score_segments(B, pf->n_maps > 1);
     // The locality order (k_order) costs a launch of its own, ~8 us for 4096 particles per map, and takes a fifth to a
     // quarter off the scoring kernel: it pays once the scoring launch is several rounds of workgroups deep (C5: 6144
     // workgroups, 328 -> 247 us), not at 256 workgroups (C3: -3 us for +5.5).  Results are the same either way.
     const int64_t wgs = nseg * (((int64_t)pf->n + 1023) / 1024) * pf->n_maps;
     const bool ordered = pf->order_mode > 0 || (pf->order_mode < 0 && wgs >= 2048 && pf->n <= 32768);
+    if (motion && ordered) {
+        // the locality order is built from the poses the particles score at: the sample gets a launch of its own in front of it
+        gms_launch_pf_motion(pf, motion->d_center, motion->d_theta, motion->seed, motion->sequence);
+        motion = nullptr;
+        d_pose_src = nullptr;
+    }
     if (ordered) {
         ProfScope po(m, GMS_K_ORDER);
         hipLaunchKernelGGL(k_order, dim3(pf->n_maps, (unsigned)((pf->n + ORD_THREADS - 1) / ORD_THREADS)), dim3(ORD_THREADS), 0,
                            m->stream, m->gd, d_pose_src, pf->d_pose, pf->d_cs, pf->n, pf->d_ord, pf->d_perm, pf->d_pose, pf->d_cs);
         d_pose_src = nullptr;                                     // stored by k_order
+    }
+    float *pose_dst = pf->d_pose, *cs_dst = pf->d_cs;
+    if (motion) {
+        mo.on = 1; mo.d_center = motion->d_center; mo.d_theta = motion->d_theta; mo.seed = motion->seed; mo.sequence = motion->sequence;
+        mo.d_center_sd = (0.01 + fabs(motion->d_center) * 0.05) / 2;             // Odometry.java:63
+        mo.d_theta_sd = 5 * (3.141592653589793 / 180.0) + 0.1 * fabs(motion->d_theta);   // :64
+        d_pose_src = pf->d_pose; pose_dst = pf->d_pose2; cs_dst = pf->d_cs2;
     }
     ProfScope ps(m, GMS_K_SCORE);
     pf->pending_nseg = 0;
@@ -1226,12 +1263,13 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
     if (ordered)
         hipLaunchKernelGGL(k_score_c<3>, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
                            m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
-                           pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pf->d_pose, pf->d_cs, pf->d_ord, pf->d_perm);
+                           pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pose_dst, cs_dst, pf->d_ord, pf->d_perm, mo, pf->offset);
     else
         hipLaunchKernelGGL(k_score_c<1>, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
                            m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
-                           pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pf->d_pose, pf->d_cs, (const float4 *)nullptr,
-                           (const int32_t *)nullptr);
+                           pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pose_dst, cs_dst, (const float4 *)nullptr,
+                           (const int32_t *)nullptr, mo, pf->offset);
+    if (motion) { std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); }
     if (nseg > 1) pf->pending_nseg = (int32_t)nseg;               // combined by the next consumer of the weights
 }
 

@@ -458,6 +458,13 @@ class ParticleFilter:
         check(load().gms_slam_update_dev(self._h, C.c_void_p(dev_xytheta or 0), C.c_void_p(dev_beams), B, ptr(r), fraction,
                                          1 if integrate else 0))
 
+    def slam_update_u_dev(self, d_center: float, d_theta: float, seed: int, sequence: int, dev_beams: int, B: int, r01,
+                          fraction: float = 0.5, integrate: bool = True):
+        """SLAM.update(z, u) with the motion-model sample inside the scoring launch (= sample_motion + slam_update_dev(0, ...))."""
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(r01, dtype=np.float64), (self.n_maps,)))
+        check(load().gms_slam_update_u_dev(self._h, d_center, d_theta, seed, sequence, C.c_void_p(dev_beams), B, ptr(r), fraction,
+                                           1 if integrate else 0))
+
     def slam_frame(self, angles, distances, hits, d_center: float, d_theta: float, seed: int, sequence: int, r01,
                    fraction: float = 0.5, integrate: bool = True):
         """One recorded revolution (GridMapApp.java:133-192) in one call: de-skew, motion-model sample, scan step."""

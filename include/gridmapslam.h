@@ -267,6 +267,12 @@ int gms_pf_score_dev(gms_pf *pf, const gms_beam *dev_beams, int32_t B);
  * (SLAM.java:82).  r01[n_maps] is read on the host.  Nothing is read back. */
 int gms_slam_update_dev(gms_pf *pf, const float *dev_xytheta, const gms_beam *dev_beams, int32_t B, const double *r01,
                         double resample_fraction, int32_t integrate);
+/* SLAM.update(z, u) with the motion-model sample inside (J/slam/SLAM.java:80-131, line 90 included) and the caller's resampling
+ * rule: every particle takes Odometry.apply (J/slam/Odometry.java:77-96; the variates of gms_pf_sample_motion for the same seed
+ * and sequence -- bit-identical to that call followed by gms_slam_update_dev with dev_xytheta = NULL) on its way into the scoring
+ * launch: four launches per scan, no launch for the motion model.  Stand-alone filters. */
+int gms_slam_update_u_dev(gms_pf *pf, double d_center, double d_theta, uint64_t seed, uint64_t sequence, const gms_beam *dev_beams,
+                          int32_t B, const double *r01, double resample_fraction, int32_t integrate);
 /* One recorded revolution as GridMapApp.onHandleData treats it (J/app/GridMapApp.java:133-192), in one call: the raw polar
  * measurements are de-skewed with the frame's odometry (:143-175, as gms_map_deskew), every particle takes a motion-model sample
  * (J/slam/SLAM.java:90, as gms_pf_sample_motion with the same seed and sequence), then the scan step of gms_slam_update_dev on
