@@ -197,7 +197,7 @@ void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticl
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_RAYCAST);
     if (own) { pf->d_global = pf->d_global_own; pf->global_raw = 0; }     // normalised weights are packed (as apply_partials does)
-    const uint32_t n_near = m->raycast_near ? rc_near_blocks(B) : 0u;
+    const uint32_t n_near = rc_near_blocks(m, B);
     const uint32_t n_ray = (uint32_t)((B + RCF_RAYS - 1) / RCF_RAYS) + n_near, n_norm = (uint32_t)((pf->n + 255) / 256);
     const size_t smem = rc_smem(m, RCF_RAYS, n_near);
     // a deferred apply pass rides along: the ray cast then raises the OTHER box half (cleared by the previous likelihood launch)
@@ -303,7 +303,7 @@ void gms_launch_raycast_norm_chunks(gms_pf *pf, const gms_beam *d_beams, int32_t
     ProfScope ps(m, GMS_K_RAYCAST);
     pf->d_global = pf->d_global_own;
     pf->global_raw = 1;
-    const uint32_t n_near = raycast && m->raycast_near ? rc_near_blocks(B) : 0u;
+    const uint32_t n_near = raycast ? rc_near_blocks(m, B) : 0u;
     const uint32_t n_ray = raycast ? (uint32_t)((B + RCF_RAYS - 1) / RCF_RAYS) + n_near : 0u, n_norm = (uint32_t)((pf->n + 255) / 256);
     const uint32_t n_chunk = (uint32_t)nblk_global_of(pf);
     const size_t smem = rc_smem(m, RCF_RAYS, n_near);

@@ -359,7 +359,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
         m->raycast_tile = lds_max >= 80 * 1024;
         if (const char *v = getenv("GMS_RAYCAST_TILE")) m->raycast_tile = m->raycast_tile && atoi(v) != 0;
         m->raycast_near = lds_max >= 40 * 1024;                       // 25 KiB tile + slots + static LDS
-        if (const char *v = getenv("GMS_RAYCAST_NEAR")) m->raycast_near = m->raycast_near && atoi(v) != 0;
+        if (const char *v = getenv("GMS_RAYCAST_NEAR")) m->raycast_near = !m->raycast_near ? 0 : (atoi(v) != 0 ? 2 : 0);   // 1: for every scan of 32 beams or more
     }
     m->prof_stride = 1;
     m->lik_lazy = 1;

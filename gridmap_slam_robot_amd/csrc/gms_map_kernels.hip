@@ -404,8 +404,15 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
     }
     GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 11);
 }
-// whether a scan of B beams gets near-field workgroups, and how many
-static inline uint32_t rc_near_blocks(int32_t B) { return B >= 32 ? (uint32_t)((B + RCN_RAYS - 1) / RCN_RAYS) : 0u; }
+// Whether a scan of B beams gets near-field workgroups, and how many.  They pay where many rays' atomics collide on the cells
+// around the robot: 720 beams at 2 cm (C3) -1.3 us per step; at 360 beams (C2, the recording) the tile's clear / walk / flush chain
+// ends 3 us after the far-field workgroups and costs the launch 0.8 us.  raycast_near: 0 never, 1 from GMS_RAYCAST_NEAR_MIN_BEAMS
+// beams on, 2 always (GMS_RAYCAST_NEAR=1: tests/test_gpu_near_field.py runs every beam count through them).
+#define GMS_RAYCAST_NEAR_MIN_BEAMS 512
+static inline uint32_t rc_near_blocks(const gms_map *m, int32_t B) {
+    if (!m->raycast_near || B < (m->raycast_near == 2 ? 32 : GMS_RAYCAST_NEAR_MIN_BEAMS)) return 0u;
+    return (uint32_t)((B + RCN_RAYS - 1) / RCN_RAYS);
+}
 
 template <bool TRACE, int RC_RAYS>
 __global__ void __launch_bounds__(RC_RAYS * 64)
@@ -1080,7 +1087,7 @@ void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t 
                              nullptr, nullptr, 0, nullptr);
     else
         rc_launch<false, 4>(m, dim3((B + 3) / 4, m->n_maps), d_beams, B, beam_stride, d_poses, pose_stride, nullptr, m->d_cnt, bb,
-                            nullptr, nullptr, 0, nullptr, m->raycast_near ? rc_near_blocks(B) : 0u);
+                            nullptr, nullptr, 0, nullptr, rc_near_blocks(m, B));
 }
 
 void gms_launch_trace_scan(gms_map *m, const gms_beam *d_beams, int32_t B, const float *d_pose, int32_t *d_cells,
@@ -1138,7 +1145,7 @@ void gms_launch_raycast_apply(gms_map *m, const gms_beam *d_beams, int32_t B, in
     const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
     const uint32_t n_apply = (uint32_t)(all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS);
     int32_t *pend = m->d_bbox + (size_t)m->bbox_cur * 4, *next = m->d_bbox + (size_t)(1 - m->bbox_cur) * 4;
-    const uint32_t n_near = m->raycast_near ? rc_near_blocks(B) : 0u;
+    const uint32_t n_near = rc_near_blocks(m, B);
     const size_t smem = rc_smem(m, 4, n_near);
     if (smem > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raycast_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
