@@ -752,6 +752,8 @@ def main() -> int:
     ap.add_argument("--exchange", default="auto", choices=["auto", "in-library", "torch-single", "torch-two"],
                     help="sharded runs: first exchange route to try (auto = in-library RCCL; later routes are fall-backs)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (all-gather) code path even with one rank")
+    ap.add_argument("--soak-seconds", type=float, default=6.0,
+                    help="default 1-GPU line: seconds of closed-loop steps back to back reported as secondary.soak (0 skips it)")
     ap.add_argument("--no-verify", action="store_true", help="sharded runs: skip the sharded == stand-alone check")
     ap.add_argument("--trace", default="", help="replay a recorded trace (DataRecorder format) frame by frame instead of the synthetic C3 step; "
                     "the JSON line then carries the replay under 'trace_replay' and value = particles x frames / s")
@@ -902,6 +904,34 @@ def main() -> int:
                 del w3
             except Exception as e:
                 sec[name] = {"error": repr(e)}
+        # a soak: the closed loop for several seconds on end -- long enough for any utilisation sampler to see the GPU busy, and
+        # long enough to show that the filter still knows where the robot is after ~10^5 scans on one map
+        if args.soak_seconds > 0:
+            try:
+                w4 = Workload("C3", args, torch, dist, 0, 1, local_rank, False, loop=True)
+                for i in range(10):
+                    w4.step(i)
+                w4.barrier()
+                t0 = time.perf_counter()
+                i = 10
+                while time.perf_counter() - t0 < args.soak_seconds:
+                    for _ in range(2000):                          # ~0.1 s of queued work between two waits
+                        w4.step(i)
+                        i += 1
+                    w4.barrier()
+                el = time.perf_counter() - t0
+                est = np.asarray(w4.pf.weighted_pose(), dtype=np.float64).reshape(-1)[:3]
+                truth = w4.tr.poses[(w4.T // 2 + i - 1) % w4.T].astype(np.float64)
+                st = w4.pf.stats()
+                st = st[0] if isinstance(st, list) else st
+                sec["soak"] = {"workload": "C3 closed loop (secondary.C3_loop), back to back", "seconds": el, "steps": i - 10,
+                               "ms_per_step": el / (i - 10) * 1e3, "value": w4.n_local * (i - 10) / el, "unit": "particle-scan evals/s",
+                               "pose_error_m": float(math.hypot(est[0] - truth[0], est[1] - truth[1])),
+                               "neff": st["neff"], "weight_sum_finite": bool(np.isfinite(st["weight_sum"]))}
+                w4.pf.close(); w4.m.close()
+                del w4
+            except Exception as e:
+                sec["soak"] = {"error": repr(e)}
         rec = os.path.join(ROOT, "tests", "golden", "recording_360.bin")
         if os.path.exists(rec):
             try:
