@@ -262,14 +262,17 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
         s_meta[lane] = mt;
         s_count[lane] = 0;
     }
-    if (!TRACE && first_blk == 0 && wave == 0) {
-        // the scan's dirty box from the rays' boxes, up front (with near-field workgroups in the launch, they raise it for their wedges)
+    __syncthreads();
+    GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 2);
+    if (!TRACE && first_blk == 0 && wave == (NWAVES > 1 ? 1 : 0)) {
+        // The scan's dirty box from the rays' boxes, up front (with near-field workgroups in the launch, they raise it for their
+        // wedges).  Behind the barrier and on a consumer wavefront: a barrier waits for the atomics in front of it to be
+        // acknowledged, and a few hundred workgroups raising the same four words queue up at the memory-side atomic unit --
+        // 3 us before the rays of a 360-beam scan could start when the producer's wavefront issued them in front of the barrier.
         int32_t hb[4] = { 0, 0, 0, 0 };
         if (lane < RC_RAYS) ray_box(g, s_meta[lane], hb);
         bbox_raise_wave(hb, lane, bbox + 4 * mi);
     }
-    __syncthreads();
-    GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 2);
     if (wave == 0) {
         if (lane < RC_RAYS) {
             RayWalk wk = ray_walk_begin(r);
