@@ -361,11 +361,6 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
         }
         my_nwords = min((mt.n_eff + 31) >> 5, 2);
         if (lane < RCN_RAYS) s_nmeta[lane] = mt;
-        {   // the scan's dirty box from the WHOLE walks of this wedge's rays (the far-field workgroups of these rays leave it to this one)
-            int32_t hb[4];
-            ray_box(g, mt, hb);
-            bbox_raise_wave(hb, lane, bbox + 4 * mi);
-        }
 #define GMS_STEP_(O) { bx0 = min(bx0, wave_xor<O>(bx0)); by0 = min(by0, wave_xor<O>(by0)); bx1 = max(bx1, wave_xor<O>(bx1)); by1 = max(by1, wave_xor<O>(by1)); }
         GMS_BUTTERFLY(GMS_STEP_)
 #undef GMS_STEP_
@@ -386,6 +381,13 @@ raycast_near_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t 
         RayWalk wk = ray_walk_begin(r);
         if (lane < RCN_RAYS && my_nwords > 0) ray_phase_a(wk, 0, my_nwords, s_slots, RCN_RAYS, lane);
     } else {
+        if (wave == 1) {
+            // the scan's dirty box from the WHOLE walks of this wedge's rays (the far-field workgroups of these rays leave it to this
+            // one), by a consumer wavefront behind the barriers: see raycast_body
+            int32_t hb[4] = { 0, 0, 0, 0 };
+            if (lane < RCN_RAYS) ray_box(g, s_nmeta[lane], hb);
+            bbox_raise_wave(hb, lane, bbox + 4 * mi);
+        }
         for (int32_t ray = wave - 1; ray < RCN_RAYS; ray += nwaves - 1) {
             RayMeta mt = s_nmeta[ray];
             if (mt.n_eff <= 0) continue;
@@ -497,11 +499,6 @@ k_raycast_tile(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t
         }
         my_nwords = (mt.n_eff + 31) >> 5;
         s_meta[lane] = mt;
-        {   // the map's dirty box from the rays' boxes, up front
-            int32_t hb[4];
-            ray_box(g, mt, hb);
-            bbox_raise_wave(hb, lane, bbox + 4 * mi);
-        }
         int32_t nwm = my_nwords;
 #define GMS_STEP_(O) { bx0 = min(bx0, wave_xor<O>(bx0)); by0 = min(by0, wave_xor<O>(by0)); bx1 = max(bx1, wave_xor<O>(bx1)); by1 = max(by1, wave_xor<O>(by1)); \
                        nwm = max(nwm, wave_xor<O>(nwm)); }
@@ -539,6 +536,13 @@ k_raycast_tile(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t
         __syncthreads();
     }
     if (nwords_max == 0) __syncthreads();
+    if (wave == 1) {
+        // the map's dirty box from the rays' boxes (ray_meta): behind the last barrier, so that nobody waits for the acknowledgement
+        // of atomics that every workgroup of the map sends to the same four words (see raycast_body)
+        int32_t hb[4] = { 0, 0, 0, 0 };
+        if (lane < RCT_RAYS) ray_box(g, s_meta[lane], hb);
+        bbox_raise_wave(hb, lane, bbox + 4 * mi);
+    }
     // flush: one atomic per touched cell, lanes on consecutive cells of a row
     uint32_t *mcnt = cnt + (size_t)mi * g.cells;
     for (int32_t ry = wave; ry < tile.h; ry += RCT_THREADS / 64) {     // a wavefront per tile row: no division per cell
