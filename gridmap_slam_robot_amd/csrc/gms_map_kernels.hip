@@ -266,9 +266,11 @@ raycast_body(const GridDev &g, const gms_beam *__restrict__ beams, int32_t B, in
     GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 2);
     if (!TRACE && first_blk == 0 && wave == (NWAVES > 1 ? 1 : 0)) {
         // The scan's dirty box from the rays' boxes, up front (with near-field workgroups in the launch, they raise it for their
-        // wedges).  Behind the barrier and on a consumer wavefront: a barrier waits for the atomics in front of it to be
-        // acknowledged, and a few hundred workgroups raising the same four words queue up at the memory-side atomic unit --
-        // 3 us before the rays of a 360-beam scan could start when the producer's wavefront issued them in front of the barrier.
+        // wedges).  On a CONSUMER wavefront, behind the set-up barrier: a few hundred workgroups raise the same four words, the
+        // requests queue up on their way to the memory-side atomic unit, and the wavefront that issues them is held up with them
+        // (the barrier itself waits for LDS only).  Issued by the producer's wavefront in front of the barrier they delayed the
+        // walk: measured 0.7 us of k_norm_raycast on a 360-beam scan (c2_step_timeline.txt of that build: rays set up 2.7-6 us
+        // after the pose).
         int32_t hb[4] = { 0, 0, 0, 0 };
         if (lane < RC_RAYS) ray_box(g, s_meta[lane], hb);
         bbox_raise_wave(hb, lane, bbox + 4 * mi);
@@ -537,8 +539,8 @@ k_raycast_tile(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t
     }
     if (nwords_max == 0) __syncthreads();
     if (wave == 1) {
-        // the map's dirty box from the rays' boxes (ray_meta): behind the last barrier, so that nobody waits for the acknowledgement
-        // of atomics that every workgroup of the map sends to the same four words (see raycast_body)
+        // the map's dirty box from the rays' boxes (ray_meta): by a consumer wavefront at the very end, where nobody is held up by
+        // atomics that every workgroup of the map sends to the same four words (see raycast_body; C5: 65.0 -> 62.3 us)
         int32_t hb[4] = { 0, 0, 0, 0 };
         if (lane < RCT_RAYS) ray_box(g, s_meta[lane], hb);
         bbox_raise_wave(hb, lane, bbox + 4 * mi);
