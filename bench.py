@@ -433,9 +433,18 @@ def measure(wl: Workload, steps: int, warmup: int):
     wl.barrier()
     prof = m.profile_get()
     m.profile(False)
+    # the steady-state step, un-bracketed: what the bracketed readings are calibrated against (the timed region of a short run
+    # carries ~50 us of first-launch and completion latency that belongs to no kernel: 2.5 us per step at 20 steps)
+    ns = max(nb, 200 if not wl.batched else 40)
+    wl.barrier()
+    t1 = time.perf_counter()
+    for i in range(ns):
+        wl.step(first + nb + i)
+    wl.barrier()
+    steady = (time.perf_counter() - t1) / ns
     compute = [k for k in prof if prof[k][1] > 0 and k != "exchange"]
     dominant = max(compute, key=lambda k: prof[k][0], default="score")
-    return dict(elapsed=elapsed, issue=issue, per_rank=per_rank, dominant=dominant, prof=prof, nb=nb,
+    return dict(elapsed=elapsed, issue=issue, per_rank=per_rank, dominant=dominant, prof=prof, nb=nb, steady=steady, steady_steps=ns,
                 bracket_us=bracket_ms * 1e3, noop_us=noop_ms * 1e3)
 
 
@@ -453,8 +462,8 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
     nb, prof = meas["nb"], meas["prof"]
     # The two event markers of a bracket are stream commands of their own, so a bracketed launch reads longer than the launch
     # costs in the un-bracketed step.  How much longer is taken from the run itself: the bracketed readings of one step add up to
-    # more than the un-bracketed step of the timed region took, and the excess, spread over the step's launches, is what a bracket
-    # adds (marker_us).  avg_launch_us = reading - marker_us: per-launch durations that TILE the timed step -- launch overhead and
+    # more than an un-bracketed step takes (the steady-state step: the timed region's, or that of a longer un-bracketed run right after
+    # the replay when the timed region is short), and the excess, spread over the step's launches, is what a bracket adds (marker_us).  avg_launch_us = reading - marker_us: per-launch durations that TILE the timed step -- launch overhead and
     # the gap to the next kernel included, which is also what `rocprofv3 --kernel-trace --stats` attributes to a kernel
     # (profiles/: k_score_c 20.0 us there).  The start-up calibration on empty kernels (gms_profile_calibrate2: a bracket around
     # an empty kernel minus an empty kernel back to back, ~5.1 us) overstates it: behind an empty kernel nothing overlaps the
@@ -462,7 +471,7 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
     marker_empty_us = max(0.0, meas["bracket_us"] - meas["noop_us"])
     launches_per_step = sum(n for _, n in prof.values()) / nb
     raw_us_per_step = sum(ms for ms, _ in prof.values()) / nb * 1e3
-    step_us = elapsed / steps * 1e6
+    step_us = min(elapsed / steps, meas.get("steady", elapsed / steps)) * 1e6      # the steady-state step (see measure)
     marker_us = min(max(0.0, (raw_us_per_step - step_us) / max(launches_per_step, 1.0)), marker_empty_us)
     # Long launches (C5's scoring launch: 210 us between markers, 220-230 in the un-bracketed step, 240 under rocprofv3) show the
     # opposite: the bracketed readings of a step add up to LESS than the un-bracketed step, the pauses the markers insert letting the
@@ -508,6 +517,7 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
                     "un-bracketed step of the timed region, per launch; when the readings add up to less than that step they are "
                     "scaled by tile_scale instead), so that the per-launch durations tile the timed step as a kernel trace's do",
         "event_markers_us": marker_us, "tile_scale": tile_scale, "event_markers_empty_kernel_us": marker_empty_us,
+        "steady_state_step_us": step_us, "steady_state_steps": meas.get("steady_steps"),
         "event_bracket_empty_kernel_us": meas["bracket_us"], "empty_kernel_back_to_back_us": meas["noop_us"],
         "step": {"algorithmic_bytes_per_step": step_bytes, "achieved": step_bytes / step_s / 1e9, "unit": "GB/s",
                  "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS, "launches_per_step": round(sum(v[1] for v in prof.values()) / nb, 2),
