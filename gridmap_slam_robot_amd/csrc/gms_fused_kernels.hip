@@ -256,8 +256,10 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
     const uint32_t n_res = (uint32_t)((pf->n + 255) / 256);
     const int32_t *bb = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4;
     const double *r01_maps = pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01_src;
-    const int32_t lik_mode = m->lik_lazy ? 2 : 3;             // the factor table only: likelihoodData follows on demand (gms_ensure_lik)
+    int32_t lik_mode = m->lik_lazy ? 2 : 3;                   // the factor table only: likelihoodData follows on demand (gms_ensure_lik)
     if (m->lik_lazy) m->lik_stale = 1;
+    if (m->fac_current && m->lik_skip) lik_mode |= 4;         // tiles whose codes this scan does not change are left alone (likelihood_body)
+    m->fac_current = 1;
 #define LR_LAUNCH(KH)                                                                                                     \
     do {                                                                                                                  \
         if (smem > 48 * 1024)                                                                                             \

@@ -351,7 +351,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     hipMemsetAsync(m->d_bbox, 0, (size_t)m->n_maps * 8 * sizeof(int32_t), m->stream);
     gms_launch_factors(m);        // likelihoodData == 0 everywhere (createMapData(null))
     HIPCHK(hipStreamSynchronize(m->stream));
-    m->need_full_build = 1;
+    m->need_full_build = 1; m->fac_current = 0;
     m->pair_launches = 1;
     {   // the tiled batched ray cast: 8 KiB of slots + a 64 KiB tile + static LDS
         int lds_max = 0;
@@ -364,6 +364,9 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     m->prof_stride = 1;
     m->lik_lazy = 1;
     if (const char *v = getenv("GMS_LIK_LAZY")) m->lik_lazy = atoi(v) != 0;
+    m->lik_skip = 1;
+    if (const char *v = getenv("GMS_LIK_SKIP")) m->lik_skip = atoi(v) != 0;
+    m->fac_current = 0;
     if (const char *v = getenv("GMS_PAIR_LAUNCHES")) m->pair_launches = atoi(v) != 0;
     *out = m;
     return GMS_OK;
@@ -406,7 +409,7 @@ int gms_map_reset(gms_map *m) {                                        // GridMa
     gms_ensure_lik(m);                 // likelihoodData keeps the last field (reset touches logData only)
     gms_flush_apply(m);
     HIPCHK(hipMemsetAsync(m->d_log, 0, (size_t)m->gd.cells * m->n_maps * sizeof(double), m->stream));
-    m->need_full_build = 1;
+    m->need_full_build = 1; m->fac_current = 0;
     return GMS_OK;
 }
 
@@ -423,7 +426,7 @@ int gms_map_upload_log(gms_map *m, const double *log_data) {
     REQUIRE(m && log_data, "null argument");
     gms_ensure_lik(m);
     gms_flush_apply(m);
-    m->need_full_build = 1;
+    m->need_full_build = 1; m->fac_current = 0;
     return map_xfer(m, m->d_log, const_cast<double *>(log_data), true);
 }
 int gms_map_download_log(gms_map *m, double *log_data) {
@@ -433,7 +436,7 @@ int gms_map_download_log(gms_map *m, double *log_data) {
 }
 int gms_map_upload_likelihood(gms_map *m, const double *lik) {
     REQUIRE(m && lik, "null argument");
-    m->need_full_build = 1;
+    m->need_full_build = 1; m->fac_current = 0;
     m->lik_stale = 0;                  // replaced wholesale
     int rc = map_xfer(m, m->d_lik, const_cast<double *>(lik), true);
     if (rc) return rc;
@@ -459,7 +462,7 @@ int gms_map_copy(gms_map *dst, const gms_map *src) {                  // GridMap
     HIPCHK(hipMemcpyAsync(dst->d_log, src->d_log, bytes, hipMemcpyDeviceToDevice, dst->stream));
     HIPCHK(hipMemcpyAsync(dst->d_lik, src->d_lik, bytes, hipMemcpyDeviceToDevice, dst->stream));
     gms_launch_factors(dst);
-    dst->need_full_build = 1;
+    dst->need_full_build = 1; dst->fac_current = 0;
     return GMS_OK;
 }
 
@@ -483,7 +486,7 @@ int gms_map_combine(gms_map *dst, gms_map *src) {                        // Grid
         if (e != hipSuccess) return fail(GMS_ERR_HIP, "gms_map_combine: stream hand-over: %s", hipGetErrorString(e));
     }
     gms_launch_combine(src, dst);
-    dst->need_full_build = 1;
+    dst->need_full_build = 1; dst->fac_current = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
 }

@@ -115,6 +115,8 @@ struct gms_map {
     int32_t raycast_tile;     // batched ray casts accumulate in LDS tiles (k_raycast_tile; GMS_RAYCAST_TILE=0 turns it off)
     int32_t lik_lazy;         // scan steps' dirty-tile rebuilds write the factor table only, likelihoodData on demand (GMS_LIK_LAZY=0 turns it off)
     int32_t lik_stale;        // likelihoodData is behind the factor table somewhere (gms_ensure_lik brings it up to date)
+    int32_t fac_current;      // the factor table is the field of logData + the pending counts as of the last rebuild, and logData has not moved since except by those counts
+    int32_t lik_skip;         // dirty-tile rebuilds leave tiles alone whose codes the scan does not change (GMS_LIK_SKIP=0 turns it off; same bits)
     int32_t raycast_near;     // single-map ray casts: the first 64 steps of every ray go through near-field workgroups with an LDS tile (0 never, 1 for scans of 512 beams or more, 2 for every scan of 32 or more: GMS_RAYCAST_NEAR=0 / unset / 1)
     int32_t pair_launches;    // scan steps pair independent kernels in one launch (GMS_PAIR_LAUNCHES=0 turns it off)
     gms_beam *h_beams;    // pinned staging (de-skew inputs, single-ray entry)

@@ -684,6 +684,11 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     // (GridMap.java:150-156,371-388 are its only readers: getLikelihood and the renderer), so it is brought up to date on demand by a
     // pass of mode 1 (gms_ensure_lik) -- half the stores of a rebuild, and half the dirty lines at the kernel's end.
     const bool wr_lik = (mode & 1) != 0, wr_fac = (mode & 2) != 0;
+    // bit 2: a tile none of whose staged cells changes its code under this scan's counts is left alone.  Its stored field is the
+    // blur of exactly these codes already -- the launcher sets the bit only when the factor table is current (every change of
+    // logData since the last rebuild went through that rebuild as pending counts: gms_map::fac_current) -- so only the staging and
+    // the comparison are spent on it.  A map that is explored changes codes along its frontier; a map that is revisited hardly at all.
+    const bool skip_unchanged = (mode & 4) != 0 && dirty_only && cnt_pending != nullptr;
     const int32_t k = KH > 0 ? KH : g.khalf;
     const int32_t ntaps = 2 * k + 1;
     const int32_t RW = LK_TW + 2 * k, RH = LK_TH + 2 * k;     // staged columns / rows
@@ -773,7 +778,12 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             smask = &s_mask[tile_iter % 3];
 #pragma unroll
             for (int q = 0; q < P1; q++)
-                if (cv[q]) lv[q] = lv[q] + ((double)(cv[q] & 0xffffu) * g.l_free + (double)(cv[q] >> 16) * g.l_occ);
+                if (cv[q]) {
+                    const double nv = lv[q] + ((double)(cv[q] & 0xffffu) * g.l_free + (double)(cv[q] >> 16) * g.l_occ);
+                    // (a clamped duplicate of a border cell counts too: conservative)
+                    if (skip_unchanged && ((nv > 0.0) != (lv[q] > 0.0) || (nv < 0.0) != (lv[q] < 0.0))) seen |= 16;
+                    lv[q] = nv;
+                }
 #pragma unroll
             for (int q = 0; q < P1; q++) {
                 const int32_t idx = (int32_t)threadIdx.x + q * 256;
@@ -825,8 +835,9 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             // a wavefront that is already OR-ing into it.)
             if (threadIdx.x == 0) s_mask[(tile_iter + 2) % 3] = 0;
             tile_iter++;
-            const bool uniform = mask == 1 || mask == 2 || mask == 4;
-            if (!uniform) {
+            const int32_t mk = mask & 15;
+            const bool uniform = mk == 1 || mk == 2 || mk == 4, unchanged = skip_unchanged && (mask & 16) == 0;
+            if (!uniform && !unchanged) {
                 // stage {0, 0.5, 1} (outside the map: 0.0).  Every thread passed the barrier above, so the previous
                 // tile's reads of in_s and hs are over.
 #pragma unroll
@@ -838,15 +849,17 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 }
             }
             if (t + (int32_t)gdx < ntiles) issue_loads(t + (int32_t)gdx);      // in flight during the rest of this tile
+            if (unchanged) continue;                                           // (one barrier, like a uniform tile)
             if (!uniform) __syncthreads();
         }
 
-        if (mask == 1 || mask == 2 || mask == 4) {
+        const int32_t mk = mask & 15;
+        if (mk == 1 || mk == 2 || mk == 4) {
             // ---- uniform tile: every in-order sum sees the same inputs
-            const uint8_t want = mask == 1 ? 1 : (mask == 2 ? 2 : 3);
+            const uint8_t want = mk == 1 ? 1 : (mk == 2 ? 2 : 3);
             if (wr_fac && tstate && tstate_old == want) continue;    // the tile already holds exactly these constants: no store (mode 3: both
                                                                     // arrays do -- a full rebuild invalidates the states first when likelihoodData is behind)
-            const double cval = mask == 1 ? 0.0 : (mask == 2 ? 0.5 : 1.0);
+            const double cval = mk == 1 ? 0.0 : (mk == 2 ? 0.5 : 1.0);
             double hc = 0.0;
             for (int32_t i = 0; i < ntaps; i++) hc += taps_g[i] * cval;           // Util.java:393-401
             double vc = 0.0;
@@ -1173,6 +1186,7 @@ void gms_launch_apply_counts(gms_map *m) {
     gms_flush_apply(m);
     apply_launch(m);
     m->bbox_dirty = 1;
+    m->fac_current = 0;            // logData moved on without a rebuild having seen these counts: the next rebuild leaves no tile alone
 }
 
 // dynamic LDS of a likelihood workgroup (likelihood_body's layout) and how many of them to launch per map
@@ -1214,6 +1228,10 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending, 
     else if (!dirty_only) {
         if (m->lik_stale) gms_invalidate_tile_state(m);       // the tile states speak for the factor table only: trust none of them for likelihoodData
         m->lik_stale = 0;
+    }
+    if (!materialize) {
+        if (dirty_only && counts_pending && m->fac_current && m->lik_skip) mode |= 4;     // unchanged tiles are left alone
+        m->fac_current = 1;                                   // after this launch the factor table is the field of logData + pending counts
     }
     ProfScope ps(m, GMS_K_LIKELIHOOD);
     const int32_t k = m->gd.khalf;

@@ -1,0 +1,58 @@
+"""A dirty-tile rebuild leaves a tile alone when none of its staged cells changes its thresholded code under the scan's counts
+(GridMap.java:239-244: the field is a blur of those codes, so it cannot have changed either).  With the switch off (GMS_LIK_SKIP=0)
+every tile of the dirty box is rebuilt as before: the field, the factor table (seen through the scores) and the map must agree bit
+for bit, while walls appear, while the same place is scanned over and over (nothing changes: almost every tile is left alone), and
+while walls disappear again (cells flip back, one scan after the other)."""
+import numpy as np
+import pytest
+
+from gridmap_slam_robot_amd import GridMap, ParticleFilter, synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _far(scan):
+    s = scan.copy()                                    # the same directions, nothing hit before 9 m: what was a wall is free space now
+    a = np.arctan2(s["local_y"], s["local_x"])
+    s["local_x"], s["local_y"], s["distance"], s["hit"] = 9.0 * np.cos(a), 9.0 * np.sin(a), 9.0, 0
+    return s
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_unchanged_tiles_left_alone_changes_nothing(monkeypatch, fused):
+    ext, res, B, N = 12.8, 0.05, 180, 512
+    tr = synth.make_trace(ext, res, B, T=16, seed=8, n_scans=16)
+    maps, pfs = {}, {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("GMS_LIK_SKIP", sw)
+        maps[sw] = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+        pfs[sw] = ParticleFilter(maps[sw], N)
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    # the drive: new walls; then the same scan from the same place twelve times; then the walls are gone, scan after scan;
+    # in between an integrateObservation WITHOUT a rebuild (GridMap.java:173-191): the next rebuild must not trust the table
+    plan = [(t, tr.scans[t], tr.poses[t]) for t in range(6)] + [(5, tr.scans[5], tr.poses[5])] * 12 + \
+           [(5, _far(tr.scans[5]), tr.poses[5])] * 8 + [(7, tr.scans[7], tr.poses[7])] * 3
+    probe = synth.make_particles(tr.poses[5], N, seed=4, sigma_xy=0.05, sigma_theta_deg=2.0)
+    for k, (t, scan, pose) in enumerate(plan):
+        for sw in ("1", "0"):
+            m, pf = maps[sw], pfs[sw]
+            if k == 9:
+                m.integrate_observation(tr.scans[9], tr.poses[9])
+            if fused:
+                P = synth.make_particles(pose, N, seed=k, sigma_xy=0.01, sigma_theta_deg=0.3)
+                pf.slam_update(P, scan, 0.31, 0.5, True)
+            else:
+                m.update(scan, pose)                                      # [ray cast | previous apply] -> dirty-tile rebuild
+        a, b = maps["1"], maps["0"]
+        if k % 3 == 2 or k >= len(plan) - 2:
+            la, lb = a.download_log(), b.download_log()
+            assert np.array_equal(la, lb), f"step {k}: logData"
+            assert np.array_equal(a.download_likelihood(), b.download_likelihood()), f"step {k}: likelihoodData"
+            assert np.array_equal(a.download_likelihood().reshape(-1), g.build_likelihood(la.reshape(-1))), f"step {k}: against the oracle"
+        # the factor table, as the scoring kernel reads it
+        for sw in ("1", "0"):
+            pfs[sw].set_poses(probe); pfs[sw].score(tr.scans[5])
+        assert np.array_equal(pfs["1"].get_weights(), pfs["0"].get_weights()), f"step {k}: scores (factor table)"
+    for sw in ("1", "0"):
+        pfs[sw].close(); maps[sw].close()
