@@ -164,7 +164,9 @@ class Workload:
             self.n_hit = int(trs[0].scans[T // 2]["hit"].sum())
             self.scan0 = trs[0].scans[T // 2]
             self.pose0 = trs[0].poses[T // 2]
-        self.r01 = np.random.default_rng(7).random((4096, M))
+        self.r01 = np.ascontiguousarray(np.random.default_rng(7).random((4096, M)))
+        self.pose_ptrs = [p.data_ptr() for p in self.pose_sets]         # (raw device addresses, taken once: the hot loop passes integers)
+        self.beam_ptrs = [x.data_ptr() for x in self.scans_dev]
 
         self.spf = self.comm = self.ops = None
         self.route = None
@@ -218,7 +220,7 @@ class Workload:
         self.torch.cuda.synchronize()
 
     def beams_ptr(self, t):
-        return self.scans_dev[t].data_ptr()
+        return self.beam_ptrs[t]
 
     # -- one scan step ------------------------------------------------------------------------------------------------
     def step(self, i: int):
@@ -235,12 +237,13 @@ class Workload:
         if self.batched:
             pf.slam_update_dev(self.pose_sets[s].data_ptr(), bp, B, r01, 0.5, True)      # one C-ABI call per batched scan
             return
+        r01v = r01                                           # (the [n_maps] row itself: no conversion on the hot path)
         r01 = float(r01[0])
         if a.host_inputs and self.spf is None:
             pf.slam_update(self.pose_sets_host[s], self.tr.scans[t], r01, 0.5, True)
             return
         if self.spf is None and not a.full_rebuild:
-            pf.slam_update_dev(self.pose_sets[s].data_ptr(), bp, B, r01, 0.5, True)       # one C-ABI call per scan
+            pf.slam_update_dev(self.pose_ptrs[s], bp, B, r01v, 0.5, True)                 # one C-ABI call per scan
             return
         if self.comm is not None:
             pf.slam_update_sharded_dev(self.comm, self.pose_sets[s].data_ptr(), bp, B, r01, 0.5, True)

@@ -452,16 +452,22 @@ class ParticleFilter:
     def score_dev(self, dev_beams: int, B: int):
         check(load().gms_pf_score_dev(self._h, C.c_void_p(dev_beams), B))
 
+    def _r01(self, r01):
+        """the draws as a contiguous float64 [n_maps] (an array of that shape passes through untouched: the hot loop's case)"""
+        if isinstance(r01, np.ndarray) and r01.dtype == np.float64 and r01.shape == (self.n_maps,) and r01.flags.c_contiguous:
+            return r01
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(r01, dtype=np.float64), (self.n_maps,)))
+
     def slam_update_dev(self, dev_xytheta: int, dev_beams: int, B: int, r01, fraction: float = 0.5, integrate: bool = True):
         """SLAM.update + `if (neff < fraction*N) resample()` in one call on device-resident inputs."""
-        r = np.ascontiguousarray(np.broadcast_to(np.asarray(r01, dtype=np.float64), (self.n_maps,)))
+        r = self._r01(r01)
         check(load().gms_slam_update_dev(self._h, C.c_void_p(dev_xytheta or 0), C.c_void_p(dev_beams), B, ptr(r), fraction,
                                          1 if integrate else 0))
 
     def slam_update_u_dev(self, d_center: float, d_theta: float, seed: int, sequence: int, dev_beams: int, B: int, r01,
                           fraction: float = 0.5, integrate: bool = True):
         """SLAM.update(z, u) with the motion-model sample inside the scoring launch (= sample_motion + slam_update_dev(0, ...))."""
-        r = np.ascontiguousarray(np.broadcast_to(np.asarray(r01, dtype=np.float64), (self.n_maps,)))
+        r = self._r01(r01)
         check(load().gms_slam_update_u_dev(self._h, d_center, d_theta, seed, sequence, C.c_void_p(dev_beams), B, ptr(r), fraction,
                                            1 if integrate else 0))
 
