@@ -93,3 +93,37 @@ def test_scan_step_on_an_edge_scan(k):
     assert np.max(np.abs(got[nz] - log[nz]) / np.abs(log[nz])) <= 1e-13, name
     assert np.array_equal(m.download_likelihood().reshape(-1), g.build_likelihood(got)), name
     pf.close(); m.close()
+
+
+@pytest.mark.parametrize("ext,res", [(3.5, 0.07), (4.13, 0.05), (6.5, 0.1)])
+def test_grids_that_are_not_a_multiple_of_anything(ext, res):
+    """widths that are no multiple of 4 (the apply pass's 16-byte path does not apply), of 64 or of 32 (ragged likelihood tiles):
+    map updates and fused steps against the oracle"""
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    m = GridMap(ext, ext, res, (-ext / 2, -ext / 2))
+    assert (m.W, m.H) == (g.W, g.H) and m.W % 4 != 0
+    B, N = 90, 300
+    tr = synth.make_trace(ext, res, B, T=12, seed=2)
+    log = g.new_log()
+    for t in range(4):
+        g.integrate(log, tr.scans[t], tr.poses[t]); m.update(tr.scans[t], tr.poses[t])
+    pf = ParticleFilter(m, N)
+    for t in range(4, 9):
+        got = m.download_log().reshape(-1)
+        assert np.array_equal(got != 0, log != 0)
+        nz = log != 0
+        assert np.max(np.abs(got[nz] - log[nz]) / np.abs(log[nz])) <= 1e-13
+        log = got.copy()                                                   # carried along from the device's state
+        lik = g.build_likelihood(log)
+        assert np.array_equal(m.download_likelihood().reshape(-1), lik)
+        P = synth.make_particles(tr.poses[t], N, seed=t, sigma_xy=0.03, sigma_theta_deg=1.0)
+        pf.slam_update(P, tr.scans[t], 0.2 + 0.1 * t, 0.5, True)
+        st, last = pf.stats(), pf.last_step()
+        w = g.score(lik, tr.scans[t], P)
+        ws, strongest = orc.normalize(w)
+        assert st["strongest"] == strongest and abs(st["weight_sum"] - ws) <= 1e-11 * ws
+        g.integrate(log, tr.scans[t], last["weighted_pose"])
+    got = m.download_log().reshape(-1)
+    assert np.array_equal(got != 0, log != 0)
+    assert np.array_equal(m.download_likelihood().reshape(-1), g.build_likelihood(got))
+    pf.close(); m.close()
