@@ -577,7 +577,10 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
                             (f"{wl.M} independent maps per rank x{wl.world}, no collective" if wl.batched else
                              f"particles sharded x{wl.world}, map replicated")),
             "exchange": wl.exchange_text(),
-            "likelihood_rebuild": "full" if a.full_rebuild else "dirty-rect (bit-identical to full)",
+            "likelihood_rebuild": "full" if a.full_rebuild else
+                                  ("dirty-rect (bit-identical to full)" if os.environ.get("GMS_LIK_SKIP") == "0" else
+                                   "dirty-rect; tiles whose thresholded codes the scan does not change are left alone (bit-identical to full; "
+                                   "GMS_LIK_SKIP=0 rebuilds every dirty tile)"),
             "inputs": "host buffers every step (PCIe-inclusive)" if a.host_inputs else "resident in HBM",
         },
         "value": value,
