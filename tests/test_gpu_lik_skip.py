@@ -56,3 +56,26 @@ def test_unchanged_tiles_left_alone_changes_nothing(monkeypatch, fused):
         assert np.array_equal(pfs["1"].get_weights(), pfs["0"].get_weights()), f"step {k}: scores (factor table)"
     for sw in ("1", "0"):
         pfs[sw].close(); maps[sw].close()
+
+
+def test_unchanged_tiles_at_the_bench_size(monkeypatch):
+    """BASELINE's C3 grid (2048 x 2048 at 2 cm, 720 beams): eight fused steps with the rule on and off, and batched (4 maps)"""
+    ext, res, B, N = 40.96, 0.02, 720, 2048
+    tr = synth.make_trace(ext, res, B, T=16, seed=1234, n_scans=12)
+    for n_maps in (1, 4):
+        out = {}
+        for sw in ("1", "0"):
+            monkeypatch.setenv("GMS_LIK_SKIP", sw)
+            m = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=n_maps, max_beams=1024)
+            pf = ParticleFilter(m, N)
+            rep = (lambda x: np.stack([x] * n_maps)) if n_maps > 1 else (lambda x: x)
+            for t in range(4):
+                m.update(rep(tr.scans[t]), rep(tr.poses[t]))
+            for k in range(8):
+                t = 4 + k % 4                                              # the same four places again and again
+                P = synth.make_particles(tr.poses[t], N, seed=k, sigma_xy=0.05, sigma_theta_deg=2.0)
+                pf.slam_update(rep(P), rep(tr.scans[t]), np.full(n_maps, 0.43), 0.5, True)
+            out[sw] = (m.download_log().copy(), m.download_likelihood().copy(), pf.get_weights().copy(), pf.get_poses().copy())
+            pf.close(); m.close()
+        for a, b in zip(out["1"], out["0"]):
+            assert np.array_equal(a, b)
