@@ -64,3 +64,34 @@ def test_near_field_equals_direct_atomics_and_the_oracle(monkeypatch, B):
         pf.close()
     for m in maps.values():
         m.close()
+
+
+def test_tiled_batched_ray_cast_equals_direct_atomics(monkeypatch):
+    """batched handles count in LDS tiles per 64-beam wedge (k_raycast_tile); GMS_RAYCAST_TILE=0 sends every count straight to the
+    grid: same maps, same fields, through map updates and fused steps"""
+    ext, res, B, M, N = 12.8, 0.05, 720, 8, 256
+    rng = np.random.default_rng(3)
+    maps = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("GMS_RAYCAST_TILE", sw)
+        maps[sw] = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M, max_beams=1024)
+    poses = np.stack([np.array([0.3 * i - 1.0, 0.2 * i - 0.5, 0.4 * i], np.float32) for i in range(M)])
+    for t in range(3):
+        scans = np.stack([_scan(rng, B, 9.0) for _ in range(M)])
+        for m in maps.values():
+            m.update(scans, poses)
+        assert np.array_equal(maps["1"].download_log(), maps["0"].download_log())
+        assert np.array_equal(maps["1"].download_likelihood(), maps["0"].download_likelihood())
+    pfs = {k: ParticleFilter(m, N) for k, m in maps.items()}
+    P = np.stack([synth.make_particles(poses[i], N, seed=i, sigma_xy=0.02, sigma_theta_deg=0.5) for i in range(M)])
+    for t in range(3):
+        scans = np.stack([_scan(rng, B, 6.0) for _ in range(M)])
+        for pf in pfs.values():
+            pf.slam_update(P, scans, np.full(M, 0.4), 0.5, True)
+    assert np.array_equal(maps["1"].download_log(), maps["0"].download_log())
+    assert np.array_equal(maps["1"].download_likelihood(), maps["0"].download_likelihood())
+    assert np.array_equal(pfs["1"].get_poses(), pfs["0"].get_poses())
+    for pf in pfs.values():
+        pf.close()
+    for m in maps.values():
+        m.close()
