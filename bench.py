@@ -7,17 +7,23 @@ One "step" = one LIDAR scan through the whole path, inputs already resident in H
   log-odds map at the weighted pose -> rebuild the likelihood field where it changed.
 
 Workload at 1 GPU = BASELINE.json configs[2] ("C3"): 16384 particles, 720 beams, 2048x2048 grid @ 2 cm, the
-configuration the metric is quoted on.  At N GPUs the particles are sharded, 16384 per GPU (weak scaling; configs[3],
-"C4", is the 4-GPU point of that series), one grouped RCCL all-gather per scan (raw weights + block partials); every
-rank keeps a replica of the map.  --config C5 is the batched-map throughput mode (64 maps x 4096 particles x 1080
-beams in one handle; at N GPUs every rank runs its own 64 maps, no collective); --config C2 the small single-map case.
-The default 1-GPU run also reports C5 and C2 in a "secondary" block (shorter runs of the same measurement).
+configuration the metric is quoted on.  At N > 1 GPUs the default is configs[3] ("C4"): a FIXED population of 65536
+particles split over the ranks (8192 per GPU at 8; "scaling": "strong"), one grouped RCCL all-gather per scan (raw
+weights + block partials), every rank keeping a replica of the map; the weak series (--config C3: 16384 particles per
+GPU whatever N) rides along as secondary.weak.  --config C5 is the batched-map throughput mode (64 maps x 4096
+particles x 1080 beams in one handle; at N GPUs every rank runs its own 64 maps, no collective); --config C2 the small
+single-map case.
+
+stdout carries ONE compact JSON line (< 4 KB: the contract's fields, roofline, cpu_baseline, a few figures beside them);
+the full report -- per-kernel table, the secondary runs (C5, C2, C4 on one GPU, eight batched maps of the C3 shape, the C3
+step on a map that is being explored, the closed loop, a soak, the replay of the shipped recording), notes -- goes to the
+file the line names under "report" (--report, default bench_report.json beside this file).
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
          bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  value = total particles x steps / max-over-ranks wall time of the K steps.
+value = total particles x steps / max-over-ranks wall time of the K steps.
 roofline = the dominant kernel's algorithmic bytes per launch / its average launch duration: HIP events on the library's
 stream around every launch of a REPLAY of the timed steps (the timed region itself carries no event brackets: they cost
 stream time), minus what the two event markers add (calibrated on an empty kernel); roofline.step is the whole step's
@@ -106,16 +112,29 @@ class Workload:
     """One BASELINE configuration on this rank: map pre-built from the first half of a synthetic trace, pose sets
     resident in HBM, the filter (stand-alone, or this rank's shard)."""
 
-    def __init__(self, name, args, torch, dist, rank, world, local_rank, sharded, keep_log=False, loop=False):
+    def __init__(self, name, args, torch, dist, rank, world, local_rank, sharded, keep_log=False, loop=False, comm=None,
+                 explore=False, n_maps=None):
         from gridmap_slam_robot_amd import GridMap, ParticleFilter, synth
         self.name, self.args, self.torch, self.dist = name, args, torch, dist
         self.rank, self.world = rank, world
         self.loop = loop        # closed loop: the particles are what the step before left, moved by the motion model on the device
-        cfg = dict(synth.CONFIGS["C3" if name == "C4" else name])
-        self.M = cfg["n_maps"]
-        self.n_local = args.particles or cfg["particles"]
+        self.explore = explore  # the map starts EMPTY and the timed scans are the drive's first ones: the frontier moves every step
+        cfg = dict(synth.CONFIGS[name])
+        self.M = n_maps or cfg["n_maps"]
         self.batched = self.M > 1
         self.sharded = sharded and not self.batched
+        # C4 is BASELINE.json configs[3]: a FIXED population of 65 536 particles split over the ranks (strong scaling; --particles
+        # overrides the population); every other configuration keeps the per-GPU work fixed as N grows (weak scaling; --particles
+        # overrides the particles per GPU and per map)
+        self.strong = name == "C4"
+        if self.strong:
+            total = args.particles or cfg["particles"]
+            parts = world if self.sharded else 1
+            if total % parts or (parts > 1 and (total // parts) % 256):
+                raise SystemExit(f"bench.py: {total} particles do not split into {parts} shards of a multiple of 256")
+            self.n_local = total // parts
+        else:
+            self.n_local = args.particles or cfg["particles"]
         self.n_global = self.n_local * (world if self.sharded else 1)
         self.B, self.ext, self.res = cfg["beams"], cfg["extent"], cfg["resolution"]
         self.T = T = 64 if not self.batched else 16
@@ -177,7 +196,9 @@ class Workload:
             self.stream = self.ops.stream
             self.spf = ShardedParticleFilter(self.n_global, self.ops)
             self.pf = self.ops.pf
-            if args.exchange in ("auto", "in-library"):
+            if comm is not None:
+                self.comm = comm                  # (one communicator per device: a second workload of the run shares the first's)
+            elif args.exchange in ("auto", "in-library"):
                 ok = 1
                 try:
                     self.comm = RcclComm(local_rank)
@@ -217,7 +238,7 @@ class Workload:
         self.torch.cuda.synchronize()
         if self.world > 1 and self.dist.is_initialized():
             self.dist.barrier()
-        self.torch.cuda.synchronize()
+            self.torch.cuda.synchronize()
 
     def beams_ptr(self, t):
         return self.beam_ptrs[t]
@@ -445,9 +466,20 @@ def measure(wl: Workload, steps: int, warmup: int):
         wl.step(first + nb + i)
     wl.barrier()
     steady = (time.perf_counter() - t1) / ns
+    # census of the likelihood tiles over nb more steps (counters in the rebuild's workgroups, off everywhere else): what the
+    # dirty-tile rebuilds of this workload rewrite and what they leave alone
+    tiles = None
+    try:
+        m.tile_stats(True, fetch=False)
+        for i in range(nb):
+            wl.step(first + nb + ns + i)
+        wl.barrier()
+        tiles = {k: v / nb for k, v in m.tile_stats(False).items()}
+    except Exception as e:
+        print(f"bench.py: tile census unavailable: {e!r}", file=sys.stderr)
     compute = [k for k in prof if prof[k][1] > 0 and k != "exchange"]
     dominant = max(compute, key=lambda k: prof[k][0], default="score")
-    return dict(elapsed=elapsed, issue=issue, per_rank=per_rank, dominant=dominant, prof=prof, nb=nb, steady=steady, steady_steps=ns,
+    return dict(elapsed=elapsed, issue=issue, per_rank=per_rank, dominant=dominant, prof=prof, nb=nb, steady=steady, steady_steps=ns, tiles=tiles,
                 bracket_us=bracket_ms * 1e3, noop_us=noop_ms * 1e3)
 
 
@@ -460,6 +492,13 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
     elapsed = meas["elapsed"]
     value = n_total * steps / elapsed
     paired = not a.full_rebuild and not a.host_inputs or wl.batched
+    # the likelihood rebuild is charged for the cells it REWRITES (16 B each: log-odds read, factor written): the census' written and
+    # blurred tiles; tiles the unchanged-tile rule leaves alone, and uniform tiles that already hold their constants, move nothing
+    # that the algorithm needs (their staging reads are overhead, not algorithmic bytes)
+    tiles = meas.get("tiles")
+    dirty_box_cells = dirty
+    if tiles is not None and not a.full_rebuild:
+        dirty = int(round((tiles["constants_written"] + tiles["blurred"]) * 64 * 32 / wl.M))
     kw = dict(n_particles=wl.n_local, n_hit=wl.n_hit, n_beams=wl.B, cells=m.W * m.H, visits=visits, dirty_cells=dirty, n_maps=wl.M,
               paired=bool(paired), full_rebuild=a.full_rebuild)
     nb, prof = meas["nb"], meas["prof"]
@@ -531,27 +570,25 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
         # caches, so `frac` can pass 1 (C5 with the particles in locality order)
         roof["note"] = ("%.0f %% of the algorithmic bytes reach the fabric (PMC): the working set is served by L2 / Infinity Cache, "
                         "frac is algorithmic bytes over the HBM peak and may exceed 1" % (100.0 * roof["traffic"] / alg))
+    roof["kernel_symbol"] = KERNEL_SYMBOLS.get(dom, dom)
+    if roof["traffic"]:
+        roof["traffic_over_algorithmic"] = roof["traffic"] / alg
     if dom == "score":
-        # what bounds this kernel (profiles/: the factor table is L2/Infinity-Cache resident, traffic is a fraction of the
-        # algorithmic bytes; tools/microbench/gather_coalesce.hip: the address pipe takes ~48 clocks per 64-lane 8-byte
-        # gather unless NEIGHBOURING lanes share a line)
+        # ONE pair of yardsticks for every configuration: `frac` is algorithmic bytes over the HBM peak (the contract's figure;
+        # it passes 1 when the factor tables never leave L2 / Infinity Cache, as at C5), and `lookup_ceiling_frac` is look-ups
+        # per second over the measured ceiling of the pipe that does bind the kernel (tools/microbench/gather_coalesce.hip: the L1
+        # address pipe takes ~48 clocks per 64-lane 8-byte gather of independent lines, ~25 when neighbouring lanes share
+        # lines -- the ceiling that applies when k_order has put the particles in locality order).
         roof["bound_measured"] = "l1-gather (texture-address pipe: ~48 clocks per 64-lane look-up, ~25 when neighbouring lanes share lines)"
         lookups = wl.n_local * wl.n_hit * wl.M
+        ordered = bool(prof.get("order", (0, 0))[1])
+        ceil = GATHER_CEILING_MERGED_PER_S if ordered else GATHER_CEILING_LANES_PER_S
         roof["lookups_per_s"] = lookups / dom_avg_s
-        roof["gather_ceiling_frac"] = lookups / dom_avg_s / GATHER_CEILING_LANES_PER_S
+        roof["lookup_ceiling_per_s"] = ceil
+        roof["lookup_ceiling_frac"] = lookups / dom_avg_s / ceil
+        roof["particles_in_locality_order"] = ordered
         roof["gather_ceilings"] = {"independent_lanes_per_s": GATHER_CEILING_LANES_PER_S, "neighbour_quads_lanes_per_s": GATHER_CEILING_MERGED_PER_S,
                                    "source": GATHER_CEILING_SOURCE}
-        if prof.get("order", (0, 0))[1]:
-            # k_order ran: neighbouring lanes share lines, which the pipe merges; the independent-lane ceiling no longer binds
-            roof["particles_in_locality_order"] = True
-            roof["gather_ceiling_merged_frac"] = lookups / dom_avg_s / GATHER_CEILING_MERGED_PER_S
-        if roof["traffic"] and roof["traffic"] < 0.5 * alg and roof["frac"] > 0.9:
-            # The table is cache-resident and the algorithmic-bytes figure runs past the HBM peak: a fraction above 1 says the
-            # yardstick is the wrong one.  The bound that holds is the look-up pipe's; frac is taken against it (the neighbour-lane
-            # ceiling when the particles are in locality order), the HBM-based figure is kept as hbm_equivalent_frac.
-            ceil = GATHER_CEILING_MERGED_PER_S if roof.get("particles_in_locality_order") else GATHER_CEILING_LANES_PER_S
-            roof.update({"hbm_equivalent_frac": roof["frac"], "hbm_equivalent_gb_per_s": roof["achieved"], "bound": "l1-gather",
-                         "achieved": lookups / dom_avg_s / 1e9, "peak": ceil / 1e9, "unit": "G look-ups/s", "frac": lookups / dom_avg_s / ceil})
     st = wl.pf.stats()
     st0 = st[0] if isinstance(st, list) else st
     # Neff recomputed on the host from the LOG-weights of the same scored population (no underflow there): if the raw
@@ -572,7 +609,7 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
                          if wl.batched else
                          f"{wl.name}: {wl.n_local} particles/GPU x {wl.B} beams ({wl.n_hit} hits), {m.W}x{m.H} grid @ {wl.res} m, ")
                         + "full scan step (score+normalise+resample+ray-cast+likelihood rebuild)",
-            "particles_total": n_total, "beams": wl.B, "grid": [m.W, m.H], "resolution_m": wl.res, "maps": wl.M,
+            "particles_total": n_total, "particles_per_gpu": wl.n_local * wl.M, "beams": wl.B, "grid": [m.W, m.H], "resolution_m": wl.res, "maps": wl.M,
             "parallelism": ("single GPU" if wl.world == 1 else
                             (f"{wl.M} independent maps per rank x{wl.world}, no collective" if wl.batched else
                              f"particles sharded x{wl.world}, map replicated")),
@@ -580,7 +617,8 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
             "likelihood_rebuild": "full" if a.full_rebuild else
                                   ("dirty-rect (bit-identical to full)" if os.environ.get("GMS_LIK_SKIP") == "0" else
                                    "dirty-rect; tiles whose thresholded codes the scan does not change are left alone (bit-identical to full; "
-                                   "GMS_LIK_SKIP=0 rebuilds every dirty tile)"),
+                                   "GMS_LIK_SKIP=0 rebuilds every dirty tile); the rebuilds write the scoring factor table only, likelihoodData is "
+                                   "materialised on demand outside the timed loop (gms_ensure_lik)"),
             "inputs": "host buffers every step (PCIe-inclusive)" if a.host_inputs else "resident in HBM",
         },
         "value": value,
@@ -592,7 +630,8 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
                            "counted); max_log_weight is the underflow-free companion", "max_log_weight": st0["max_log_weight"],
                    "neff_from_log_weights": neff_log},
         "roofline": roof,
-        "scan_footprint": {"visited_cells": visits, "dirty_rebuild_cells": dirty},
+        "scan_footprint": {"visited_cells": visits, "dirty_box_cells": dirty_box_cells, "rebuilt_cells_per_step_per_map": dirty,
+                           "likelihood_tiles_per_step": None if tiles is None else {k: round(v, 2) for k, v in tiles.items()}},
     }
     return out
 
@@ -707,8 +746,9 @@ def cpu_baseline(wl: Workload, budget_s: float, with_score_sweep: bool):
 # ---------------------------------------------------------------------------------------------------------------------
 def trace_replay(path: str, steps: int, warmup: int, particles: int, extent: float, res: float, local_rank: int, torch):
     """A recorded trace (DataRecorder format, gridmap_slam_robot_amd/trace.py) through the device path frame by frame, as
-    GridMapApp.onHandleData runs it (J/app/GridMapApp.java:133-192): read_trace -> gms_map_deskew (raw measurements handed over
-    as host arrays: 17 bytes per measurement over PCIe) -> gms_pf_sample_motion -> fused scan step.  The first frames only map
+    GridMapApp.onHandleData runs it (J/app/GridMapApp.java:133-192): read_trace -> ONE call per frame, gms_slam_frame (the raw
+    measurements handed over as host arrays, 17 bytes per measurement over PCIe; de-skew and motion-model sample in one launch,
+    then the fused scan step: five launches).  The first frames only map
     (dead-reckoned pose); `steps` frames are timed, the recording repeated as often as needed (its drive is a closed circle)."""
     from gridmap_slam_robot_amd import GridMap, ParticleFilter, synth
     from gridmap_slam_robot_amd.replay import TraceReplay
@@ -746,11 +786,198 @@ def trace_replay(path: str, steps: int, warmup: int, particles: int, extent: flo
            "grid": [m.W, m.H], "resolution_m": res, "bootstrap_frames": boot, "frames_timed": steps,
            "ms_per_frame": el / steps * 1e3, "host_issue_ms_per_frame": issue / steps * 1e3, "scans_per_s": steps / el,
            "particle_scan_evals_per_s": particles * steps / el,
-           "inputs": "raw polar measurements from host memory every frame (PCIe-inclusive); motion model, weights, resampling and map on the device",
-           "calls_per_frame": ["gms_map_deskew", "gms_pf_sample_motion", "gms_slam_update_dev"],
+           "inputs": "raw polar measurements from host memory every frame (PCIe-inclusive), one gms_slam_frame call per frame; de-skew, motion model, weights, resampling and map on the device",
+           "calls_per_frame": ["gms_slam_frame"] if rp.one_call else ["gms_map_deskew", "gms_pf_sample_motion", "gms_slam_update_dev"],
+           "launches_per_frame": 5 if rp.one_call else 6,
            "neff_last": st["neff"], "weighted_pose_last": [float(x) for x in est]}
     pf.close(); m.close()
     return out
+
+
+def explore_run(args, torch, local_rank: int, skip: bool, passes: int = 5):
+    """Config 3 on a map that is being EXPLORED: the map starts empty and the timed steps are the drive's first T/2 scans, so every
+    scan pushes the frontier on and the tiles along it change their thresholded codes (the headline step runs on a pre-built map
+    that is revisited, where the unchanged-tile rule leaves nearly every dirty tile alone).  `passes` passes of T/2 scan steps are
+    timed, the map reset (untimed) in front of each; one more pass runs with the tile census on (gms_map_tile_stats) and one with
+    the event brackets on.  skip = False: the same with GMS_LIK_SKIP=0, every dirty tile rebuilt.  The reference rebuilds the
+    whole field on every scan (J/slam/GridMap.java:233-250)."""
+    from gridmap_slam_robot_amd import GridMap, ParticleFilter, synth
+    cfg = synth.CONFIGS["C3"]
+    n, B, ext, res = cfg["particles"], cfg["beams"], cfg["extent"], cfg["resolution"]
+    T = 64
+    half = T // 2
+    dev = torch.device("cuda", local_rank)
+    tr = synth.make_trace(ext, res, B, T=T, seed=1234)
+    old = os.environ.get("GMS_LIK_SKIP")
+    os.environ["GMS_LIK_SKIP"] = "1" if skip else "0"           # read when the handle is created
+    try:
+        m = GridMap(ext, ext, res, (-ext / 2, -ext / 2), device=local_rank, max_beams=max(2048, B))
+    finally:
+        if old is None:
+            os.environ.pop("GMS_LIK_SKIP", None)
+        else:
+            os.environ["GMS_LIK_SKIP"] = old
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    pf = ParticleFilter(m, n)
+    scans = torch.from_numpy(tr.scans.view(np.uint8).reshape(T, -1).copy()).to(dev)
+    beam_ptrs = [scans[t].data_ptr() for t in range(T)]
+    sets = [torch.from_numpy(np.ascontiguousarray(synth.make_particles(tr.poses[t], n, seed=99 + t))).to(dev) for t in range(half)]
+    pose_ptrs = [p.data_ptr() for p in sets]
+    true_poses = torch.from_numpy(np.ascontiguousarray(tr.poses[:half], dtype=np.float32)).to(dev)
+    r01 = np.random.default_rng(11).random(half)
+
+    def fresh():
+        m.reset()
+        m.compute_likelihood_map()
+        torch.cuda.synchronize()
+
+    def scan_steps():
+        for t in range(half):
+            pf.slam_update_dev(pose_ptrs[t], beam_ptrs[t], B, float(r01[t]), 0.5, True)
+
+    def map_updates():
+        for t in range(half):
+            m.update_dev(beam_ptrs[t], B, true_poses[t].data_ptr())
+
+    out = {}
+    for name, body in (("step", scan_steps), ("map_update", map_updates)):
+        fresh(); body(); torch.cuda.synchronize()               # warm-up pass
+        tot = 0.0
+        for _ in range(passes):
+            fresh()
+            t0 = time.perf_counter()
+            body()
+            torch.cuda.synchronize()
+            tot += time.perf_counter() - t0
+        out[name + "_ms"] = tot / (passes * half) * 1e3
+        fresh()
+        m.tile_stats(True, fetch=False)
+        body()
+        ts = m.tile_stats(False)
+        out[name + "_tiles_per_scan"] = {k: round(v / half, 2) for k, v in ts.items()}
+    fresh()
+    m.profile(True); m.profile_reset()
+    scan_steps()
+    torch.cuda.synchronize()
+    prof = m.profile_get()
+    m.profile(False)
+    st = pf.stats()
+    res_ = {"workload": f"C3 on an EMPTY map, the drive's first {half} scans ({n} particles x {B} beams, {m.W}x{m.H} @ {res} m): the frontier moves "
+                        "every scan" + ("" if skip else "; GMS_LIK_SKIP=0: every dirty tile rebuilt"),
+            "steps_timed": passes * half, "ms_per_step": out["step_ms"], "value": n / (out["step_ms"] * 1e-3), "unit": "particle-scan evals/s",
+            "map_update_ms_per_scan": out["map_update_ms"],
+            "tiles_per_scan": {"scan_step": out["step_tiles_per_scan"], "map_update": out["map_update_tiles_per_scan"],
+                               "legend": "64x32-cell tiles of the dirty box per scan: left alone (no code changes) / uniform and already holding "
+                                         "its constants / uniform, constants written / blurred (both passes)"},
+            "bracketed_us_per_launch": {KERNEL_SYMBOLS.get(k, k): round(ms / nn * 1e3, 2) for k, (ms, nn) in prof.items() if nn},
+            "neff_last": st["neff"]}
+    pf.close(); m.close()
+    return res_
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the ONE stdout line: compact (a few KB), strict JSON; everything else goes to the report file it names
+# ---------------------------------------------------------------------------------------------------------------------
+KERNEL_SYMBOLS = {"score": "k_score_c", "reduce": "k_partials", "raycast": "k_norm_raycast", "likelihood": "k_lik_resample",
+                  "apply": "k_apply", "resample": "k_resample", "order": "k_order", "exchange": "ncclAllGather (grouped)"}
+LINE_LIMIT = 4096       # bytes; the driver reads the line from a bounded tail of stdout (round 3's 22 KB line was cut: parsed = null)
+
+
+def _sig(x, digits=6):
+    """numbers to `digits` significant figures (the report file keeps them in full)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if not math.isfinite(x):
+            return None                      # strict JSON has no NaN / Infinity
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_line(full: dict, report_file: str | None) -> str:
+    """The contract's fields and the few figures a reader needs beside them, as one JSON line below LINE_LIMIT bytes.
+    `full` is the complete report (what round 3 printed); it is written to `report_file`, which the line names."""
+    cfg = full.get("config") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg[k] for k in ("workload", "particles_total", "particles_per_gpu", "beams", "grid", "resolution_m", "maps",
+                                          "parallelism", "exchange", "inputs") if cfg.get(k) is not None}
+    for k in ("timed_region_s", "map_update_ms_per_scan", "map_update_ms_per_scan_exploring", "beam_evals_per_s", "scans_per_s", "per_rank_ms_per_step", "exchange_latency_us",
+              "sharded_equals_standalone", "rccl_ranks"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+    r = full.get("roofline")
+    if r:
+        rl = {k: r.get(k) for k in ("kernel", "kernel_symbol", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                    "algorithmic_bytes_per_launch", "avg_launch_us", "launches_timed")}
+        for k in ("lookup_ceiling_frac", "lookups_per_s", "lookup_ceiling_per_s", "traffic_over_algorithmic"):
+            if r.get(k) is not None:
+                rl[k] = r[k]
+        st = r.get("step") or {}
+        rl["step"] = {k: st.get(k) for k in ("frac", "achieved", "algorithmic_bytes_per_step", "launches_per_step", "kernel_us_per_step")}
+        line["roofline"] = rl
+    else:
+        line["roofline"] = None
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "seconds", "map_update_ms_per_scan")}
+    else:
+        line["cpu_baseline"] = None
+    kern = full.get("kernels") or {}
+    if kern:
+        line["kernel_us"] = {KERNEL_SYMBOLS.get(k, k): v.get("avg_launch_us") for k, v in kern.items()}
+    sec = full.get("secondary") or {}
+    if sec:
+        # one number per secondary run (ms per step / per frame); the runs themselves are in the report file
+        line["secondary_ms_per_step"] = {k: (v.get("ms_per_step", v.get("ms_per_frame")) if "error" not in v else None) for k, v in sec.items()}
+    if full.get("trace_replay"):
+        line["trace_replay"] = {k: full["trace_replay"].get(k) for k in ("recording", "frames_timed", "ms_per_frame", "particles", "beams")}
+    line["report"] = report_file
+    text = json.dumps(_sig(line), allow_nan=False, separators=(", ", ": "))
+    if len(text) > LINE_LIMIT:              # never print a line the driver cannot take: shed the optional blocks, longest first
+        for k in ("secondary_ms_per_step", "kernel_us", "per_rank_ms_per_step", "trace_replay"):
+            line.pop(k, None)
+            text = json.dumps(_sig(line), allow_nan=False, separators=(", ", ": "))
+            if len(text) <= LINE_LIMIT:
+                break
+    return text
+
+
+def _json_safe(x):
+    """the report file is strict JSON too: NaN / Infinity -> null, numpy scalars -> Python numbers"""
+    if isinstance(x, dict):
+        return {str(k): _json_safe(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_json_safe(v) for v in x]
+    if isinstance(x, (np.floating, float)):
+        x = float(x)
+        return x if math.isfinite(x) else None
+    if isinstance(x, np.integer):
+        return int(x)
+    if isinstance(x, np.bool_):
+        return bool(x)
+    if isinstance(x, np.ndarray):
+        return _json_safe(x.tolist())
+    return x
+
+
+def emit(full: dict, result_fd: int, report_path: str):
+    """writes the full report to `report_path` and the compact line to the saved stdout"""
+    full = _json_safe(full)
+    name = None
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(report_path)), exist_ok=True)
+        with open(report_path, "w") as f:
+            json.dump(full, f, indent=1, allow_nan=False)
+            f.write("\n")
+        name = os.path.relpath(os.path.abspath(report_path), ROOT)
+    except OSError as e:                     # a read-only tree must not cost the line
+        print(f"bench.py: could not write {report_path}: {e}", file=sys.stderr)
+    os.write(result_fd, (compact_line(full, name) + "\n").encode())
 
 
 def main() -> int:
@@ -758,8 +985,10 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="C3", help="C3 (default; C4 = the same per-GPU shape at 4 GPUs) | C2 | C5 (64 batched maps)")
-    ap.add_argument("--particles", type=int, default=0, help="override particles per GPU (per map)")
+    ap.add_argument("--config", default=None,
+                    help="C3 (default at 1 GPU: 16384 particles per GPU, weak scaling) | C4 (default at N > 1 GPUs: BASELINE's FIXED population of "
+                         "65536 particles split over the ranks, strong scaling) | C2 | C5 (64 batched maps per rank)")
+    ap.add_argument("--particles", type=int, default=0, help="override particles per GPU and per map (C4: the whole population)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C5 / C2 block of the default 1-GPU run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline's scan-step loop")
@@ -776,8 +1005,10 @@ def main() -> int:
     ap.add_argument("--trace-particles", type=int, default=1024)
     ap.add_argument("--trace-extent", type=float, default=25.6, help="map extent (m) for --trace")
     ap.add_argument("--trace-res", type=float, default=0.05, help="map resolution (m) for --trace")
+    ap.add_argument("--report", default=os.path.join(ROOT, "bench_report.json"),
+                    help="where the full report goes (kernel table, secondary runs, notes); stdout carries one compact line that names it")
     args = ap.parse_args()
-    if args.config not in ("C2", "C3", "C4", "C5"):
+    if args.config not in (None, "C2", "C3", "C4", "C5"):
         print("bench.py: --config must be C2, C3, C4 or C5", file=sys.stderr)
         return 2
 
@@ -818,30 +1049,64 @@ def main() -> int:
                "config": {"workload": f"trace replay: {tr['particles']} particles x {tr['beams']} beams, {tr['grid'][0]}x{tr['grid'][1]} grid @ {tr['resolution_m']} m, "
                                       "de-skew + motion model + full scan step per recorded frame"},
                "trace_replay": tr, "roofline": None, "cpu_baseline": None}
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        emit(out, result_fd, args.report)
         return 0
 
+    config = args.config or ("C3" if world == 1 else "C4")      # BASELINE.json configs[2] at one GPU, configs[3] over several
     sharded = world > 1 or args.force_sharded
     want_cpu = world == 1 and not args.no_cpu_baseline
-    wl = Workload(args.config, args, torch, dist, rank, world, local_rank, sharded, keep_log=(want_cpu and rank == 0))
-    verify = None
-    if wl.spf is not None:
-        wl.pick_route()
-        if not args.no_verify:
-            try:
-                verify = wl.verify_against_standalone()
-            except Exception as e:      # the check must never take the measurement down with it
-                print(f"bench.py: sharded-vs-standalone check failed to run: {e!r}", file=sys.stderr)
-                verify = {"sharded_equals_standalone": None, "error": repr(e)} if rank == 0 else None
 
-    meas = measure(wl, args.steps, args.warmup)
+    def run_sharded_or_single(name, steps, warmup, comm=None, keep_log=False):
+        """one configuration on this run's ranks: route, self-verification, measurement; rank 0 gets the report"""
+        w = Workload(name, args, torch, dist, rank, world, local_rank, sharded, keep_log=keep_log, comm=comm)
+        ver = None
+        if w.spf is not None:
+            w.pick_route()
+            if not args.no_verify:
+                try:
+                    ver = w.verify_against_standalone()
+                except Exception as e:      # the check must never take the measurement down with it
+                    print(f"bench.py: sharded-vs-standalone check failed to run: {e!r}", file=sys.stderr)
+                    ver = {"sharded_equals_standalone": None, "error": repr(e)} if rank == 0 else None
+        ms = measure(w, steps, warmup)
+        if rank != 0:
+            return w, None
+        r = report(w, ms, steps, warmup)
+        r["steps"], r["warmup"] = steps, warmup
+        r["scaling"] = "strong" if w.strong else "weak"
+        mu_ = map_update_ms(w, ms["nb"])
+        if mu_ is not None:
+            r["map_update_ms_per_scan"] = mu_
+        if world > 1 or w.spf is not None:
+            r["per_rank_ms_per_step"] = [round(t / steps * 1e3, 5) for t in ms["per_rank"]]
+            ex = r["kernels"].get("exchange")
+            r["exchange_latency_us"] = ex["avg_launch_us"] if ex else None     # the L of DESIGN.md section 7 (event-bracketed, in-library route)
+            if ver is not None:
+                r["verify"] = ver
+                r["sharded_equals_standalone"] = ver.get("sharded_equals_standalone")
+                r["rccl_ranks"] = ver.get("rccl_ranks")
+        return w, r
+
+    wl, rep = run_sharded_or_single(config, args.steps, args.warmup, keep_log=(want_cpu and rank == 0))
+    # N > 1 with the default configuration: the fixed population is the line; the weak series (16384 particles per GPU, the
+    # 1-GPU line's shape on every rank) rides along as secondary.weak -- every rank takes part in both
+    weak_rep = None
+    if world > 1 and args.config is None and not args.no_secondary and not args.particles:
+        try:
+            comm = wl.comm
+            wl.comm = None                   # (the communicator outlives the first workload: one per device)
+            wl.pf.close(); wl.m.close()
+            w2, weak_rep = run_sharded_or_single("C3", max(10, min(args.steps, 100)), max(2, min(args.warmup, 10)), comm=comm)
+            w2.pf.close(); w2.m.close()
+        except Exception as e:
+            print(f"bench.py: weak-scaling companion run failed: {e!r}", file=sys.stderr)
+            weak_rep = {"error": repr(e)} if rank == 0 else None
     if rank != 0:
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return 0
 
-    rep = report(wl, meas, args.steps, args.warmup)
     out = {
         "metric": "particle-scan evals/sec",
         "value": rep.pop("value"),
@@ -851,23 +1116,14 @@ def main() -> int:
         "warmup": args.warmup,
         "ms_per_step": rep.pop("ms_per_step"),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": rep.pop("scaling"),
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
     }
     out.update(rep)
-    mu = map_update_ms(wl, meas["nb"])
-    if mu is not None:
-        out["map_update_ms_per_scan"] = mu
-    if world > 1 or wl.spf is not None:
-        out["per_rank_ms_per_step"] = [round(t / args.steps * 1e3, 5) for t in meas["per_rank"]]
-        ex = out["kernels"].get("exchange")
-        out["exchange_latency_us"] = ex["avg_launch_us"] if ex else None     # the L of DESIGN.md section 7 (event-bracketed, in-library route)
-        if verify is not None:
-            out["verify"] = verify
-            out["sharded_equals_standalone"] = verify.get("sharded_equals_standalone")
-            out["rccl_ranks"] = verify.get("rccl_ranks")
+    if weak_rep is not None:
+        out["secondary"] = {"weak": weak_rep}
 
     if want_cpu:
         out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds, with_score_sweep=True)
@@ -875,24 +1131,38 @@ def main() -> int:
         out["cpu_baseline"] = None
 
     # ---- the other single-GPU configurations, shorter runs of the same measurement ------------------------------------
-    if world == 1 and not args.no_secondary and args.config == "C3" and not (args.full_rebuild or args.host_inputs or args.particles or args.force_sharded):
+    if world == 1 and not args.no_secondary and config == "C3" and not (args.full_rebuild or args.host_inputs or args.particles or args.force_sharded):
         sec = {}
-        for name, (k_steps, k_warm) in (("C5", (20, 3)), ("C2", (100, 10))):
+        # C5 and C2 as BASELINE states them; C4_1gpu = the N = 1 point of the fixed-population series (65536 particles on one GPU);
+        # C3x8_batched = eight maps of the headline shape in one batched handle (config 5's mode at 2 cm: what the chip does when the
+        # four-launch latency chain of a single map is amortised over eight)
+        for name, cfg_name, n_maps, (k_steps, k_warm) in (("C5", "C5", None, (20, 3)), ("C2", "C2", None, (100, 10)),
+                                                          ("C4_1gpu", "C4", None, (50, 5)), ("C3x8_batched", "C3", 8, (20, 3))):
             try:
-                w2 = Workload(name, args, torch, dist, 0, 1, local_rank, False, keep_log=want_cpu)
+                w2 = Workload(cfg_name, args, torch, dist, 0, 1, local_rank, False, keep_log=(want_cpu and n_maps is None and cfg_name != "C4"),
+                              n_maps=n_maps)
                 m2 = measure(w2, k_steps, k_warm)
                 r2 = report(w2, m2, k_steps, k_warm)
                 r2["steps"], r2["warmup"] = k_steps, k_warm
+                r2["scaling"] = "strong" if w2.strong else "weak"
                 mu2 = map_update_ms(w2, m2["nb"])
                 if mu2 is not None:
                     r2["map_update_ms_per_scan"] = mu2
-                if want_cpu:
+                if want_cpu and n_maps is None and cfg_name != "C4":
                     r2["cpu_baseline"] = cpu_baseline(w2, 3.0, with_score_sweep=False)
                 sec[name] = r2
                 w2.pf.close(); w2.m.close()
                 del w2
             except Exception as e:
                 sec[name] = {"error": repr(e)}
+        # the headline configuration on a map that is being explored (the timed region above revisits a pre-built map)
+        for name, skip in (("C3_explore", True), ("C3_explore_every_tile", False)):
+            try:
+                sec[name] = explore_run(args, torch, local_rank, skip)
+            except Exception as e:
+                sec[name] = {"error": repr(e)}
+        if "error" not in sec["C3_explore"]:
+            out["map_update_ms_per_scan_exploring"] = sec["C3_explore"]["map_update_ms_per_scan"]
         # the same configuration as a CLOSED LOOP: motion model and resampling on the device, the particles never leave it; once
         # with the caller's order (what the headline runs), once with the locality order forced on before every scoring launch
         for name, order in (("C3_loop", None), ("C3_loop_ordered", "1")):
@@ -954,9 +1224,9 @@ def main() -> int:
                 sec["trace_replay"] = trace_replay(rec, 200, 20, 1024, 25.6, 0.05, local_rank, torch)
             except Exception as e:
                 sec["trace_replay"] = {"error": repr(e)}
-        out["secondary"] = sec
+        out.setdefault("secondary", {}).update(sec)
 
-    os.write(result_fd, (json.dumps(out) + "\n").encode())
+    emit(out, result_fd, args.report)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

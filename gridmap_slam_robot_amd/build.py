@@ -24,14 +24,23 @@ def hipcc() -> str:
     return "hipcc"
 
 
+def extra_flags() -> list:
+    return os.environ.get("GMS_EXTRA_FLAGS", "").split()      # experiments only (e.g. -DRC_RAYS=4, -DGMS_STAMPS)
+
+
 def source_hash() -> str:
-    """sha256 (16 hex digits) over the library's sources: csrc/* and the public header, in name order."""
+    """sha256 (16 hex digits) over the library's sources -- csrc/* and the public header, in name order -- and, when
+    GMS_EXTRA_FLAGS is set, over those flags as well: an instrumented or experimental build carries another hash than the
+    product build of the same sources, so neither is ever taken for the other (gms_build_info(), the up-to-date check)."""
     import hashlib
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.join(ROOT, "include", "gridmapslam.h")]
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
+    extra = extra_flags()
+    if extra:
+        h.update(b"\0flags\0" + " ".join(extra).encode())
     return h.hexdigest()[:16]
 
 
@@ -57,7 +66,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(f"libgridmapslam: reused {want} (in-tree build of these sources)", file=sys.stderr)
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    extra = os.environ.get("GMS_EXTRA_FLAGS", "").split()      # experiments only (e.g. -DRC_RAYS=4)
+    extra = extra_flags()
     cmd = [hipcc()] + FLAGS + extra + [f'-DGMS_SOURCE_HASH="{want}"', "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:

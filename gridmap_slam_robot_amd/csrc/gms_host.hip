@@ -253,7 +253,7 @@ static int map_free(gms_map *m) {
     if (!m) return GMS_OK;
     prof_drain(m);
     for (ProfSlot &s : m->prof_free) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
-    hipFree(m->d_log); hipFree(m->d_lik); hipFree(m->d_fac); hipFree(m->d_cnt); hipFree(m->d_cnt_pend); hipFree(m->d_bbox); hipFree(m->d_taps); hipFree(m->d_tile_state);
+    hipFree(m->d_log); hipFree(m->d_lik); hipFree(m->d_fac); hipFree(m->d_cnt); hipFree(m->d_cnt_pend); hipFree(m->d_bbox); hipFree(m->d_taps); hipFree(m->d_tile_state); hipFree(m->d_tile_stats);
     hipFree(m->d_beams); hipFree(m->d_poses); hipFree(m->d_scratch);
     hipFree(m->d_trace_cells); hipFree(m->d_trace_cls); hipFree(m->d_trace_cnt);
     if (m->h_beams) hipHostFree(m->h_beams);
@@ -336,6 +336,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     ok = ok && hipMalloc(&m->d_bbox, (size_t)m->n_maps * 8 * sizeof(int32_t)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_taps, GMS_MAX_TAPS * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_tile_state, (size_t)((g.W + 63) / 64) * ((g.H + 31) / 32) * m->n_maps) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_tile_stats, 64 * 4 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_beams, (size_t)m->n_maps * m->max_beams * sizeof(gms_beam)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_poses, (size_t)m->n_maps * 3 * sizeof(float) + 16) == hipSuccess;   // (+16: copied in 16-byte units)
     ok = ok && hipMalloc(&m->d_scratch, 64 * sizeof(double)) == hipSuccess;
@@ -349,6 +350,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     hipMemsetAsync(m->d_cnt, 0, cells * sizeof(uint32_t), m->stream);
     hipMemsetAsync(m->d_cnt_pend, 0, cells * sizeof(uint32_t), m->stream);
     hipMemsetAsync(m->d_bbox, 0, (size_t)m->n_maps * 8 * sizeof(int32_t), m->stream);
+    hipMemsetAsync(m->d_tile_stats, 0, 64 * 4 * sizeof(uint32_t), m->stream);
     gms_launch_factors(m);        // likelihoodData == 0 everywhere (createMapData(null))
     HIPCHK(hipStreamSynchronize(m->stream));
     m->need_full_build = 1; m->fac_current = 0;
@@ -450,17 +452,36 @@ int gms_map_download_likelihood(gms_map *m, double *lik) {
     return map_xfer(m, m->d_lik, lik, false);
 }
 
+// `later` waits (stream order, no host synchronise) for everything enqueued on `earlier` so far
+static int stream_after(hipStream_t later, hipStream_t earlier, const char *what) {
+    if (later == earlier) return GMS_OK;
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, earlier);
+    if (e == hipSuccess) e = hipStreamWaitEvent(later, ev, 0);
+    hipEventDestroy(ev);                                             // released once the recorded work has completed
+    if (e != hipSuccess) return fail(GMS_ERR_HIP, "%s: stream hand-over: %s", what, hipGetErrorString(e));
+    return GMS_OK;
+}
+
 int gms_map_copy(gms_map *dst, const gms_map *src) {                  // GridMap.java:106-124
     REQUIRE(dst && src, "null argument");
     REQUIRE(dst->gd.W == src->gd.W && dst->gd.H == src->gd.H && dst->n_maps == src->n_maps, "gms_map_copy: shape mismatch");
     const size_t bytes = (size_t)src->gd.cells * src->n_maps * sizeof(double);
+    HIPCHK(hipSetDevice(dst->device));
     gms_ensure_lik(const_cast<gms_map *>(src));
     gms_flush_apply(const_cast<gms_map *>(src));
     gms_flush_apply(dst);
     dst->lik_stale = 0;
-    HIPCHK(hipStreamSynchronize(src->stream));
+    // The copies run on dst's stream and read src's arrays: dst's stream waits for what src's stream holds so far (the flushed
+    // apply pass among it), and src's stream waits for the copies before anything enqueued on it later may write those arrays
+    // again (a ray cast's apply pass, reset, upload): both directions in stream order, no host synchronise.
+    int rc = stream_after(dst->stream, src->stream, "gms_map_copy");
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(dst->d_log, src->d_log, bytes, hipMemcpyDeviceToDevice, dst->stream));
     HIPCHK(hipMemcpyAsync(dst->d_lik, src->d_lik, bytes, hipMemcpyDeviceToDevice, dst->stream));
+    rc = stream_after(src->stream, dst->stream, "gms_map_copy");
+    if (rc) return rc;
     gms_launch_factors(dst);
     dst->need_full_build = 1; dst->fac_current = 0;
     return GMS_OK;
@@ -473,19 +494,17 @@ int gms_map_combine(gms_map *dst, gms_map *src) {                        // Grid
     // src's deferred apply pass (a fused scan step or gms_map_update leaves the last scan's counts un-applied) is enqueued on
     // src's stream; the combine reads src's log-odds on dst's stream, so dst's stream must wait for it -- an event after the
     // flush, not a host synchronise before it (round 2 synchronised first and flushed afterwards: the combine could read
-    // pre-apply log-odds).
+    // pre-apply log-odds).  And the other way round: whatever src's stream is given after this call (the next scan's apply
+    // pass, a reset, an upload) writes the log-odds the combine reads, so src's stream waits for the combine (round 3 left
+    // that direction open: a write-after-read race whenever the two handles run on different streams).
     gms_ensure_lik(dst);               // the destination's likelihoodData keeps its last field (its logData is about to be replaced)
     gms_flush_apply(src);
     gms_flush_apply(dst);
-    if (src->stream != dst->stream) {
-        hipEvent_t ev;
-        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        hipError_t e = hipEventRecord(ev, src->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(dst->stream, ev, 0);
-        hipEventDestroy(ev);                                         // released once the recorded work has completed
-        if (e != hipSuccess) return fail(GMS_ERR_HIP, "gms_map_combine: stream hand-over: %s", hipGetErrorString(e));
-    }
+    int rc = stream_after(dst->stream, src->stream, "gms_map_combine");
+    if (rc) return rc;
     gms_launch_combine(src, dst);
+    rc = stream_after(src->stream, dst->stream, "gms_map_combine");
+    if (rc) return rc;
     dst->need_full_build = 1; dst->fac_current = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
@@ -800,6 +819,22 @@ int gms_map_update_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, gms_
 }
 
 // development: where instrumented builds (-DGMS_STAMPS) write their stage time stamps; GMS_ERR_STATE in a product build
+int gms_map_tile_stats(gms_map *m, int32_t enable, int64_t *out4) {
+    REQUIRE(m, "null map");
+    HIPCHK(hipSetDevice(m->device));
+    if (out4) {
+        uint32_t h[64 * 4];
+        HIPCHK(hipMemcpyAsync(h, m->d_tile_stats, sizeof(h), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        for (int k = 0; k < 4; k++) out4[k] = 0;
+        for (int r = 0; r < 64; r++)
+            for (int k = 0; k < 4; k++) out4[k] += h[4 * r + k];
+    }
+    HIPCHK(hipMemsetAsync(m->d_tile_stats, 0, 64 * 4 * sizeof(uint32_t), m->stream));
+    m->gd.tile_stats = enable ? m->d_tile_stats : nullptr;        // (the grid descriptor travels by value with every launch)
+    return GMS_OK;
+}
+
 int gms_debug_set_stamps(gms_map *m, void *dev_buffer) {
     REQUIRE(m, "null map");
     HIPCHK(hipSetDevice(m->device));

@@ -26,6 +26,7 @@ struct GridDev {
     int32_t ktaps, khalf;
     int32_t fpitch;       // factor table: row pitch W + 16; column W of every row and all of row H hold the neutral 1.0 (fac_index)
     uint32_t fneutral;    // factor table: index of one neutral entry (row H, column W)
+    uint32_t *tile_stats; // [64][4] likelihood-tile census (gms_map_tile_stats) or nullptr: {left alone, constants kept, constants written, blurred}
 };
 
 // one ray of a scan in grid coordinates (GridMap.integrateObservation's locals)
@@ -107,6 +108,7 @@ struct gms_map {
     int32_t bbox_dirty;   // an integrate ran since the last likelihood build
     double *d_taps;       // [ktaps]
     uint8_t *d_tile_state;  // [n_maps][likelihood tiles]: 0 unknown, 1..3 the tile of d_lik/d_fac holds the constants of a uniform tile of code 0 / 0.5 / 1
+    uint32_t *d_tile_stats; // [64][4] counters behind gd.tile_stats (always allocated; gd.tile_stats points at them while the census is on)
     gms_beam *d_beams;    // [n_maps][max_beams] staging
     float *d_poses;       // [n_maps][3] staging
     double *d_scratch;    // small device scratch

@@ -704,6 +704,9 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     double *taps_s = hs + (size_t)RH * PHS;                   // [ntaps] (generic path)
     __shared__ int32_t s_mask[3];
     int32_t tile_iter = 0;
+    // measurement (gms_map_tile_stats): what became of the tiles this workgroup walked, kept in thread 0's registers and added to
+    // one of 64 counter rows at the end (no store, no atomic per tile)
+    uint32_t ts_left = 0, ts_const_kept = 0, ts_const_written = 0, ts_blurred = 0;
 
     const int32_t mi = (int32_t)by;
     const double *mlog = logd + (size_t)mi * g.cells;
@@ -849,7 +852,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 }
             }
             if (t + (int32_t)gdx < ntiles) issue_loads(t + (int32_t)gdx);      // in flight during the rest of this tile
-            if (unchanged) continue;                                           // (one barrier, like a uniform tile)
+            if (unchanged) { ts_left++; continue; }                            // (one barrier, like a uniform tile)
             if (!uniform) __syncthreads();
         }
 
@@ -857,7 +860,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
         if (mk == 1 || mk == 2 || mk == 4) {
             // ---- uniform tile: every in-order sum sees the same inputs
             const uint8_t want = mk == 1 ? 1 : (mk == 2 ? 2 : 3);
-            if (wr_fac && tstate && tstate_old == want) continue;    // the tile already holds exactly these constants: no store (mode 3: both
+            if (wr_fac && tstate && tstate_old == want) { ts_const_kept++; continue; }    // the tile already holds exactly these constants: no store (mode 3: both
                                                                     // arrays do -- a full rebuild invalidates the states first when likelihoodData is behind)
             const double cval = mk == 1 ? 0.0 : (mk == 2 ? 0.5 : 1.0);
             double hc = 0.0;
@@ -872,9 +875,11 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 if (wr_fac) FAC_STORE(&mfac[(size_t)(ty0 + r) * g.fpitch + tx0 + c], fc);
             }
             if (wr_fac && tstate && threadIdx.x == 0) *tstate = want;
+            ts_const_written++;
             continue;
         }
         if (wr_fac && tstate && threadIdx.x == 0) *tstate = 0;
+        ts_blurred++;
 
         if (KH > 0) {
             // ---- phase 2: strips of LK_STRIP outputs along x
@@ -938,6 +943,13 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 }
             }
         }
+    }
+    if (g.tile_stats && threadIdx.x == 0) {
+        uint32_t *row = g.tile_stats + 4 * (bx & 63u);
+        if (ts_left) atomicAdd(row + 0, ts_left);
+        if (ts_const_kept) atomicAdd(row + 1, ts_const_kept);
+        if (ts_const_written) atomicAdd(row + 2, ts_const_written);
+        if (ts_blurred) atomicAdd(row + 3, ts_blurred);
     }
 }
 

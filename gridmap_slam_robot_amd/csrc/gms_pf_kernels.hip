@@ -1028,7 +1028,11 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
             int32_t oct = 0;
 #pragma unroll
             for (int k = 0; k < 8; k++) oct += (8 * k + 7 < len && U > base + cv[k]) ? 1 : 0;
-            if (oct > 7) oct = 7;
+            // U can exceed the chunk's last in-chunk value by a rounding (off[] comes from another association of the same sums): the
+            // octet is clamped to the last one that holds a particle -- also in a final partial chunk whose length is a multiple of
+            // 8 -- so that src's own octet is the one loaded below and c_prev is cm[src - 1]
+            const int32_t oct_max = (int32_t)((len - 1) >> 3);
+            if (oct > oct_max) oct = oct_max;
             const double before_oct = oct > 0 ? cv[oct - 1] : 0.0;      // in-chunk cumulative weight just before this octet (oct > 0)
 #pragma unroll
             for (int k = 0; k < 8; k++) cv[k] = cm[i0 + min((int64_t)(8 * oct + k), len - 1)];
@@ -1040,7 +1044,7 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
             // among the values already at hand (the octet's eight, the octet boundary before it, the previous chunk's end):
             // the same operands as loading them again, without the round trip.
             const double tol = N * 4.5e-16 * fabs(off[nchunks]);
-            const int32_t ki = (int32_t)(src - i0) - 8 * oct;           // 0..7: where cm[src] sits in cv[]
+            const int32_t ki = (int32_t)(src - i0) - 8 * oct;           // 0..7: where cm[src] sits in cv[] (src lies in octet `oct`: see the clamp above)
             double c_src = cv[0], c_prev = before_oct;
 #pragma unroll
             for (int k = 1; k < 8; k++) if (ki == k) { c_src = cv[k]; c_prev = cv[k - 1]; }

@@ -363,6 +363,13 @@ class GridMap:
             out[name] = (ms.value, n.value)
         return out
 
+    def tile_stats(self, enable: bool = True, fetch: bool = True):
+        """Census of the likelihood tiles the rebuilds walked since the last call (gms_map_tile_stats): a dict
+        {left_alone, constants_kept, constants_written, blurred}; reads and clears the counters, `enable` keeps counting."""
+        out = (C.c_int64 * 4)()
+        check(load().gms_map_tile_stats(self._h, 1 if enable else 0, out if fetch else None))
+        return dict(zip(("left_alone", "constants_kept", "constants_written", "blurred"), [int(v) for v in out])) if fetch else None
+
     def debug_f32(self, op: int, a: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.float32)
         out = np.empty_like(a)

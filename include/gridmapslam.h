@@ -374,6 +374,14 @@ int gms_profile_calibrate(gms_map *m, int32_t reps, double *bracket_ms);
  * add to a bracketed launch: subtract it from a bracketed duration to get what a kernel-trace profiler reports. */
 int gms_profile_calibrate2(gms_map *m, int32_t reps, double *bracket_ms, double *kernel_ms);
 
+/* Census of the likelihood-field tiles (64 x 32 cells) the rebuilds have walked since the last call, summed over the handle's
+ * maps: out4 (may be NULL) = {left alone: no cell changes its thresholded code under the scan's counts; constants kept: a
+ * uniform tile that already holds its constants; constants written: a uniform tile; blurred: both passes of
+ * Util.doGaussianBlurdSeparable (J/app/Util.java:378-426)}.  Reads and clears the counters (synchronises when out4 is given);
+ * enable != 0 keeps counting, 0 stops (the default: off).  The reference rebuilds every cell on every scan
+ * (J/slam/GridMap.java:233-250); the sum of the four is what a dirty-tile rebuild looked at. */
+int gms_map_tile_stats(gms_map *m, int32_t enable, int64_t *out4);
+
 /* ---- diagnostics ------------------------------------------------------------------------------- */
 /* The float-rounded device primitives the parity contract leans on, for tests: op 0 = (float)sqrt(a)
  * (GridMap.java:217), 1 = (float)cos((double)a), 2 = (float)sin((double)a) (J/math/MathUtil.java:30-40); 3 = self-check of the

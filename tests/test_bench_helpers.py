@@ -56,3 +56,56 @@ def test_committed_bench_lines_carry_the_contract_fields():
         assert k in cb
     assert cb["kind"] == "port" and cb["cores"] == 1
     assert set(main["secondary"]) == {"C5", "C2"}
+
+
+def _canned_full_report():
+    """the full report of a default 1-GPU run, as large as round 3's line was (six secondary blocks)"""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03", "bench.json")))
+    assert len(json.dumps(full)) > 20000           # the 22 KB line the driver could not take
+    return full
+
+
+def test_the_stdout_line_is_compact_strict_json_with_the_contract_fields():
+    b = _bench()
+    full = _canned_full_report()
+    full["secondary"]["bad"] = {"error": "x"}
+    full["roofline"]["lookup_ceiling_frac"] = 0.72
+    full["filter"]["neff"] = float("nan")           # NaN may not reach the line (strict JSON)
+    text = b.compact_line(b._json_safe(full), "bench_report.json")
+    assert "\n" not in text and len(text.encode()) < b.LINE_LIMIT <= 4096 < 8192
+    d = json.loads(text, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))        # NaN / Infinity would raise
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "report"):
+        assert k in d, k
+    assert d["report"] == "bench_report.json" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us", "step"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-3 * r["achieved"]
+    assert r["lookup_ceiling_frac"] == 0.72 and "frac" in r["step"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "seconds"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 1
+    assert d["secondary_ms_per_step"]["bad"] is None and d["secondary_ms_per_step"]["C5"] > 0
+    # value and ms_per_step survive the rounding to six significant figures
+    assert abs(d["value"] - full["value"]) < 1e-5 * full["value"] and abs(d["ms_per_step"] - full["ms_per_step"]) < 1e-5 * full["ms_per_step"]
+
+
+def test_an_oversized_line_sheds_its_optional_blocks_not_the_contract(tmp_path):
+    b = _bench()
+    full = _canned_full_report()
+    full["secondary"] = {f"run{i}_{'x' * 40}": {"ms_per_step": 0.1 * i} for i in range(200)}
+    text = b.compact_line(b._json_safe(full), "r.json")
+    d = json.loads(text)
+    assert len(text) <= b.LINE_LIMIT and "secondary_ms_per_step" not in d and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
+    # emit(): the report file holds everything, the line names it
+    rd, wr = os.pipe()
+    rep = tmp_path / "sub" / "report.json"
+    b.emit(full, wr, str(rep))
+    os.close(wr)
+    line = os.read(rd, 1 << 16).decode()
+    os.close(rd)
+    assert line.endswith("\n") and line.count("\n") == 1
+    assert len(json.load(open(rep))["secondary"]) == 200 and json.loads(line)["report"].endswith("report.json")

@@ -22,6 +22,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _line_and_report(out, report):
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    assert len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["report"] and os.path.samefile(os.path.join(ROOT, d["report"]), report)
+    return d, json.load(open(report))
+
+
 def _run(cmd_tail, timeout):
     """torch.distributed.run on a port that was free a moment ago; the rendezvous can still lose the port to another process
     (it then waits out its own ten-minute time-out): one more attempt on a fresh port before the test gives up."""
@@ -42,31 +51,45 @@ def _run(cmd_tail, timeout):
     return out
 
 
-def test_bench_with_two_ranks_on_one_gpu_falls_back_verifies_and_reports():
-    out = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--config", "C2", "--particles", "1024"], 240)
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+def test_bench_with_two_ranks_on_one_gpu_falls_back_verifies_and_reports(tmp_path):
+    rep = str(tmp_path / "report.json")
+    out = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--config", "C2", "--particles", "1024", "--report", rep], 240)
+    d, full = _line_and_report(out, rep)
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak"
     assert d["config"]["particles_total"] == 2048 and "sharded x2" in d["config"]["parallelism"]
     assert d["config"]["exchange"].startswith("torch.distributed")          # the in-library route cannot run here
-    assert d["sharded_equals_standalone"] is True, d.get("verify")
-    assert d["verify"]["population"] == 2048 and d["verify"]["mismatches"] is None
+    assert d["sharded_equals_standalone"] is True, full.get("verify")
+    assert full["verify"]["population"] == 2048 and full["verify"]["mismatches"] is None
     assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
     assert d["value"] > 0 and d["roofline"]["launches_timed"] >= 1 and d["cpu_baseline"] is None
 
 
-def test_bench_config5_with_two_ranks_shards_by_map_without_a_collective():
+def test_bench_default_configuration_with_two_ranks_is_the_fixed_population_with_the_weak_series_beside_it(tmp_path):
+    """No --config at N > 1 = BASELINE configs[3]: ONE population split over the ranks ("strong"); the weak series rides along.
+    (--particles would switch the companion run off, so the sizes here are the real ones: 2 x 32768 and 2 x 16384 on one GPU.)"""
+    rep = str(tmp_path / "report.json")
+    out = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--report", rep], 420)
+    d, full = _line_and_report(out, rep)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["particles_total"] == 65536 and d["config"]["particles_per_gpu"] == 32768
+    assert d["config"]["workload"].startswith("C4")
+    assert d["sharded_equals_standalone"] is True, full.get("verify")
+    weak = full["secondary"]["weak"]
+    assert weak["scaling"] == "weak" and weak["config"]["particles_total"] == 32768 and weak["config"]["particles_per_gpu"] == 16384
+    assert weak["sharded_equals_standalone"] is True and weak["value"] > 0
+    assert d["secondary_ms_per_step"]["weak"] == pytest.approx(weak["ms_per_step"], rel=1e-4)
+
+
+def test_bench_config5_with_two_ranks_shards_by_map_without_a_collective(tmp_path):
     """Config 5 (64 independent maps per handle) at N > 1: every rank runs its own 64 maps, nothing is exchanged on the data
     path; the line must carry the aggregate over both ranks and each rank's own time."""
-    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "C5", "--particles", "256"], 300)
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    rep = str(tmp_path / "report.json")
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "C5", "--particles", "256", "--report", rep], 300)
+    d, full = _line_and_report(out, rep)
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert d["config"]["maps"] == 64 and d["config"]["particles_total"] == 2 * 64 * 256
-    assert "no collective" in d["config"]["parallelism"] and d["config"]["exchange"] is None
+    assert "no collective" in d["config"]["parallelism"] and d["config"].get("exchange") is None and full["config"]["exchange"] is None
     assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
     # value = all ranks' particles x steps / the slowest rank's time
-    assert abs(d["value"] - 2 * 64 * 256 * 3 / (max(d["per_rank_ms_per_step"]) * 1e-3 * 3)) <= 1e-4 * d["value"]      # (per-rank times are printed to five decimals)
+    assert abs(d["value"] - 2 * 64 * 256 * 3 / (max(d["per_rank_ms_per_step"]) * 1e-3 * 3)) <= 1e-3 * d["value"]      # (per-rank times are printed to five decimals)
     assert d.get("sharded_equals_standalone") is None          # nothing is sharded: there is nothing to verify against
