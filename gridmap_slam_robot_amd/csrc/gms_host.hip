@@ -920,6 +920,8 @@ int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // Partic
     ok = ok && hipMalloc(&pf->d_ord, T * sizeof(float4)) == hipSuccess && hipMalloc(&pf->d_perm, T * 4) == hipSuccess;
     pf->order_mode = -1;
     if (const char *v = getenv("GMS_SCORE_ORDER")) pf->order_mode = atoi(v);
+    pf->score_threads = 0;
+    if (const char *v = getenv("GMS_SCORE_THREADS")) pf->score_threads = atoi(v);
     ok = ok && hipHostMalloc(&pf->h_stats, (size_t)m->n_maps * sizeof(PfStatsDev) + (size_t)m->n_maps * 8) == hipSuccess;
     ok = ok && hipHostMalloc(&pf->h_stage, T * 3 * sizeof(float)) == hipSuccess;
     ok = ok && ring_alloc(pf->pose_ring, T * 3 * sizeof(float)) == GMS_OK;

@@ -177,6 +177,7 @@ struct gms_pf {
     int32_t pending_nseg;           // > 0: d_w is stale, the weights are still d_part's segment products
     float4 *d_ord;                  // [n_maps][n] {x, y, cos, sin} of the particles in locality order (k_order)
     int32_t *d_perm;                // [n_maps][n] the particle at each position of that order
+    int32_t score_threads;          // 0 the launcher decides (the largest of 1024 / 512 / 256 lanes per scoring workgroup that still gives every CU one); GMS_SCORE_THREADS forces 64..1024
     int32_t order_mode;             // -1 the launcher decides (large launches only), 0 never, 1 always (GMS_SCORE_ORDER; results do not depend on it)
 };
 

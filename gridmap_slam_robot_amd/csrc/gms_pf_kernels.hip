@@ -1262,7 +1262,15 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
     }
     ProfScope ps(m, GMS_K_SCORE);
     pf->pending_nseg = 0;
-    const int32_t threads = pf->n >= 1024 ? 1024 : ((pf->n + 63) / 64) * 64;     // (512-thread workgroups: the same time at C3; 768: +40 %)
+    // Lanes per workgroup: 1024 (sixteen wavefronts sharing one segment's L1 patch) while that still gives every CU a workgroup;
+    // a smaller population -- one shard of eight of config 4's 65 536 particles, config 2 -- takes 512 or 256 lanes per workgroup
+    // instead, so that the look-ups spread over all the CUs' address pipes rather than queueing on half or an eighth of them
+    // (8192 particles x 720 beams: 128 workgroups of 1024 lanes on 256 CUs).  Which lanes share a workgroup does not enter the arithmetic.
+    // (At C3 512-lane workgroups measure the same as 1024; 768: +40 %.)
+    int32_t threads = pf->n >= 1024 ? 1024 : ((pf->n + 63) / 64) * 64;
+    if (pf->score_threads >= 64 && pf->score_threads <= 1024) threads = (pf->score_threads / 64) * 64;
+    else
+        while (threads > 256 && nseg * (((int64_t)pf->n + threads - 1) / threads) * pf->n_maps < m->n_cus) threads >>= 1;
     const int64_t groups = ((int64_t)pf->n + threads - 1) / threads;
     if (ordered)
         hipLaunchKernelGGL(k_score_c<3>, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,

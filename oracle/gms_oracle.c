@@ -193,6 +193,47 @@ void orc_pose_trig(float theta, double *cos_out, double *sin_out) {
     *sin_out = (double)(float)sin((double)theta);
 }
 
+/* the two float-rounded primitives every cell index leans on, over arrays (the exhaustive float-domain check of the device's
+ * versions, tests/test_gpu_exhaustive_float.py): orc_pose_trig element by element, and (float)Math.sqrt((double)s) of
+ * GridMap.java:217.  Returns how many of the n results differ from `got` (bit patterns; two NaNs count as equal). */
+static inline int f32_same(float a, float b) {
+    uint32_t x, y;
+    memcpy(&x, &a, 4); memcpy(&y, &b, 4);
+    return x == y || (a != a && b != b);
+}
+int64_t orc_count_trig_mismatches(const float *theta, const float *got_cos, const float *got_sin, int64_t n, int32_t threads,
+                                  int64_t *first_bad) {
+    int64_t bad = 0, first = -1;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(+ : bad)
+    for (int64_t i = 0; i < n; i++) {
+        double c, s;
+        orc_pose_trig(theta[i], &c, &s);
+        if (!f32_same((float)c, got_cos[i]) || !f32_same((float)s, got_sin[i])) {
+            bad++;
+#pragma omp critical
+            if (first < 0 || i < first) first = i;
+        }
+    }
+    if (first_bad) *first_bad = first;
+    return bad;
+}
+int64_t orc_count_sqrt_mismatches(const float *a, const float *got, int64_t n, int32_t threads, int64_t *first_bad) {
+    int64_t bad = 0, first = -1;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(+ : bad)
+    for (int64_t i = 0; i < n; i++) {
+        const float want = (float)sqrt((double)a[i]);                             /* GridMap.java:217 */
+        if (!f32_same(want, got[i])) {
+            bad++;
+#pragma omp critical
+            if (first < 0 || i < first) first = i;
+        }
+    }
+    if (first_bad) *first_bad = first;
+    return bad;
+}
+
 typedef struct xform { double c, s, px, py; } xform;
 
 static inline xform xform_from_pose(const float pose[3]) {

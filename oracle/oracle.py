@@ -112,6 +112,10 @@ def lib() -> C.CDLL:
         L.orc_point_index.argtypes = [C.POINTER(OrcGrid), C.c_float, C.c_float]
         L.orc_pose_trig.restype = None
         L.orc_pose_trig.argtypes = [C.c_float, dp, dp]
+        L.orc_count_trig_mismatches.restype = C.c_int64
+        L.orc_count_trig_mismatches.argtypes = [fp, fp, fp, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
+        L.orc_count_sqrt_mismatches.restype = C.c_int64
+        L.orc_count_sqrt_mismatches.argtypes = [fp, fp, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -270,6 +274,19 @@ def pose_trig(theta):
     s = C.c_double()
     lib().orc_pose_trig(np.float32(theta), C.byref(c), C.byref(s))
     return c.value, s.value
+
+
+def count_trig_mismatches(theta: np.ndarray, got_cos: np.ndarray, got_sin: np.ndarray, threads: int = 1):
+    """(mismatches, index of the first one or -1): got_* against (float)cos/sin((double)theta), glibc, element by element"""
+    first = C.c_int64(-1)
+    n = lib().orc_count_trig_mismatches(_fp(theta), _fp(got_cos), _fp(got_sin), len(theta), threads, C.byref(first))
+    return int(n), int(first.value)
+
+
+def count_sqrt_mismatches(a: np.ndarray, got: np.ndarray, threads: int = 1):
+    first = C.c_int64(-1)
+    n = lib().orc_count_sqrt_mismatches(_fp(a), _fp(got), len(a), threads, C.byref(first))
+    return int(n), int(first.value)
 
 
 def gaussian_kernel(sigma: float, size: int) -> np.ndarray:
