@@ -710,6 +710,24 @@ def cpu_baseline(wl: Workload, budget_s: float, with_score_sweep: bool):
         "map_update_ms_per_scan": upd_ms,
         "map_update_sample": f"{reps} x (integrateObservation + computeLikelihoodMap), C oracle, single thread",
     }
+    if not wl.batched and wl.spf is None:
+        # the checker's other job here: the device's resampling step against the sequential reference on the SAME normalised
+        # weights ("indices equal for fixed r"; the device scans in blocks and flags slots whose threshold lies
+        # within rounding distance of a boundary) -- as numbers
+        try:
+            pf = wl.pf
+            pf.set_poses(wl.pose_sets_host[0])
+            pf.score_dev(wl.beams_ptr(T // 2), wl.B)
+            pf.normalize()
+            wn = np.asarray(pf.get_weights(), dtype=np.float64).reshape(-1)
+            idx, amb = pf.resample(float(r01[0]), want_indices=True)
+            want, _ = orc.resample_indices(wn, float(r01[0]))
+            idx = np.asarray(idx, dtype=np.int64).reshape(-1)
+            out["resample_agreement"] = {"slots": int(idx.size), "slots_differing": int((idx != want).sum()),
+                                         "max_index_distance": int(np.abs(idx - want).max()), "n_ambiguous": int(amb),
+                                         "against": "SLAM.resample's running sum (oracle) over the device's normalised weights, same r"}
+        except Exception as e:
+            out["resample_agreement"] = {"error": repr(e)}
     if with_score_sweep:
         # extra information: scoring alone (a pure function) over host threads with OpenMP; the thread count that does
         # best is reported (containers often expose more CPUs than they may use)
@@ -1191,33 +1209,43 @@ def main() -> int:
             except Exception as e:
                 sec[name] = {"error": repr(e)}
         # a soak: the closed loop for several seconds on end -- long enough for any utilisation sampler to see the GPU busy, and
-        # long enough to show that the filter still knows where the robot is after ~10^5 scans on one map
-        if args.soak_seconds > 0:
+        # long enough to show that the filter still knows where the robot is after ~10^5 scans on one map; then the same loop, shorter,
+        # with the opt-in log-normalisation (gms_pf_set_log_normalize): how many particles stay alive and where the filter ends up
+        for name, seconds, log_norm in (("soak", args.soak_seconds, False), ("soak_log_normalize", min(args.soak_seconds, 2.0), True)):
+            if seconds <= 0:
+                continue
             try:
                 w4 = Workload("C3", args, torch, dist, 0, 1, local_rank, False, loop=True)
+                if log_norm:
+                    w4.pf.set_log_normalize(True)
                 for i in range(10):
                     w4.step(i)
                 w4.barrier()
                 t0 = time.perf_counter()
                 i = 10
-                while time.perf_counter() - t0 < args.soak_seconds:
+                neffs = []
+                while time.perf_counter() - t0 < seconds:
                     for _ in range(2000):                          # ~0.1 s of queued work between two waits
                         w4.step(i)
                         i += 1
                     w4.barrier()
+                    st = w4.pf.stats()                             # (outside the steps' own work: one read-back per 2000 steps)
+                    neffs.append((st[0] if isinstance(st, list) else st)["neff"])
                 el = time.perf_counter() - t0
                 est = np.asarray(w4.pf.weighted_pose(), dtype=np.float64).reshape(-1)[:3]
                 truth = w4.tr.poses[(w4.T // 2 + i - 1) % w4.T].astype(np.float64)
                 st = w4.pf.stats()
                 st = st[0] if isinstance(st, list) else st
-                sec["soak"] = {"workload": "C3 closed loop (secondary.C3_loop), back to back", "seconds": el, "steps": i - 10,
-                               "ms_per_step": el / (i - 10) * 1e3, "value": w4.n_local * (i - 10) / el, "unit": "particle-scan evals/s",
-                               "pose_error_m": float(math.hypot(est[0] - truth[0], est[1] - truth[1])),
-                               "neff": st["neff"], "weight_sum_finite": bool(np.isfinite(st["weight_sum"]))}
+                sec[name] = {"workload": "C3 closed loop (secondary.C3_loop), back to back" + (", log-normalisation on (not the reference's arithmetic)" if log_norm else ""),
+                             "seconds": el, "steps": i - 10,
+                             "ms_per_step": el / (i - 10) * 1e3, "value": w4.n_local * (i - 10) / el, "unit": "particle-scan evals/s",
+                             "pose_error_m": float(math.hypot(est[0] - truth[0], est[1] - truth[1])),
+                             "neff": st["neff"], "neff_median_of_samples": float(np.median(neffs)) if neffs else None,
+                             "n_zero_weights": st["n_zero"], "weight_sum_finite": bool(np.isfinite(st["weight_sum"]))}
                 w4.pf.close(); w4.m.close()
                 del w4
             except Exception as e:
-                sec["soak"] = {"error": repr(e)}
+                sec[name] = {"error": repr(e)}
         rec = os.path.join(ROOT, "tests", "golden", "recording_360.bin")
         if os.path.exists(rec):
             try:

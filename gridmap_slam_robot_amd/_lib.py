@@ -190,6 +190,7 @@ def load() -> C.CDLL:
     sig("gms_profile_calibrate", C.c_int, vp, i32, C.POINTER(C.c_double))
     sig("gms_profile_calibrate2", C.c_int, vp, i32, vp, vp)
     sig("gms_map_tile_stats", C.c_int, vp, i32, vp)
+    sig("gms_pf_set_log_normalize", C.c_int, vp, i32)
     sig("gms_debug_f32", C.c_int, vp, i32, vp, vp, i64)
     sig("gms_debug_set_stamps", C.c_int, vp, vp)
     _lib = L

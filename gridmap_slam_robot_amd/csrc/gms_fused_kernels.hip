@@ -79,9 +79,9 @@ __global__ void __launch_bounds__(256)
 k_partials_apply(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n, int64_t offset,
                  int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part, int32_t part_nseg,
                  GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
-                 int32_t *__restrict__ bbox_idle) {
+                 int32_t *__restrict__ bbox_idle, const double *__restrict__ blockmax) {
     if (blockIdx.x < (uint32_t)nblk_global)
-        partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y);
+        partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y, blockmax);
     else
         apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - (uint32_t)nblk_global, blockIdx.y, gridDim.x - (uint32_t)nblk_global);
 }
@@ -230,10 +230,11 @@ void gms_launch_partials_apply(gms_pf *pf, double *d_partials, bool apply_rides_
     const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
     const uint32_t n_apply = (uint32_t)(all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS);
     int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4;
+    const double *blockmax = gms_launch_pf_logmax(pf);
     hipLaunchKernelGGL(k_partials_apply, dim3((uint32_t)nblk + n_apply, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw,
                        pf->d_pose, pf->n, pf->offset, nblk, d_partials,
                        pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg, m->gd, m->d_log,
-                       m->d_cnt_pend, cur, idle);
+                       m->d_cnt_pend, cur, idle, blockmax);
     pf->pending_nseg = 0;
     gms_apply_done(m);
 }

@@ -860,7 +860,8 @@ static int64_t nblk_of(int64_t n) { return (n + GMS_BLOCK - 1) / GMS_BLOCK; }
 static int64_t nchunks_of(int64_t n) { return (n + 63) / 64; }
 
 static void pf_free_global(gms_pf *pf) {
-    hipFree(pf->d_partials); hipFree(pf->d_p2); hipFree(pf->d_global_own); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum);
+    hipFree(pf->d_partials); hipFree(pf->d_p2); hipFree(pf->d_global_own); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum); hipFree(pf->d_blockmax);
+    pf->d_blockmax = nullptr;
     pf->d_partials = pf->d_p2 = nullptr; pf->d_global = pf->d_global_own = nullptr; pf->d_chunk_tot = pf->d_cum = nullptr;
 }
 
@@ -870,6 +871,7 @@ static int pf_alloc_global(gms_pf *pf) {
     const size_t nblk = nblk_of(pf->n_global), nch = nchunks_of(pf->n_global);
     HIPCHK(hipMalloc(&pf->d_partials, M * nblk * GMS_PARTIAL_STRIDE * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_p2, M * nblk * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&pf->d_blockmax, M * nblk * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_global_own, M * pf->n_global * sizeof(PackedParticle)));
     pf->d_global = pf->d_global_own;
     HIPCHK(hipMalloc(&pf->d_chunk_tot, M * (nch + 1 + nch * 8) * sizeof(double)));     // chunk totals of all maps, then every chunk's eight octet boundaries (chunk_sub_of)
@@ -942,6 +944,7 @@ int gms_pf_set_shard(gms_pf *pf, int64_t offset, int64_t n_global) {
     pf->offset = offset;
     pf->n_global = n_global;
     pf->have_global = 0;
+    if (offset != 0 || n_global != pf->n) pf->log_norm = 0;           // (stand-alone filters only: gms_pf_set_log_normalize)
     return pf_alloc_global(pf);
 }
 
@@ -1422,6 +1425,14 @@ int gms_pf_did_resample(gms_pf *pf, int32_t *flags) {
     int rc = pull_stats(pf);
     if (rc) return rc;
     for (int32_t mi = 0; mi < pf->n_maps; mi++) flags[mi] = pf->h_stats[mi].did_resample;
+    return GMS_OK;
+}
+
+int gms_pf_set_log_normalize(gms_pf *pf, int32_t on) {
+    REQUIRE(pf, "null filter");
+    if (on && (pf->offset != 0 || pf->n_global != pf->n))
+        return fail(GMS_ERR_STATE, "gms_pf_set_log_normalize: stand-alone filters only (a shard does not know the other shards' largest log-weight)");
+    pf->log_norm = on ? 1 : 0;
     return GMS_OK;
 }
 

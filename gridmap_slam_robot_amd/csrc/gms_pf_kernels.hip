@@ -518,12 +518,31 @@ struct RedLds {
 
 // part != nullptr: the weights are still per-segment products from k_score_c: combine them here (and
 // store weight and log-weight) instead of in a launch of their own.
+// blockmax != nullptr (gms_pf_set_log_normalize): the weights of this pass are exp(logw - M), M the largest log-weight of the
+// map's population, folded here from the per-block maxima k_logmax left (nblk of them, block order; a maximum does not depend
+// on the order) -- the underflow-free normalisation SURVEY 9.6 asks for beside the reference's plain product.  The weights are
+// stored, and everything downstream (weight sum, weighted pose, Neff, the cumulative sums, the resampling) runs on them unchanged.
 __device__ __forceinline__ void block_partials(double *__restrict__ w, double *__restrict__ logw,
                                                const float *__restrict__ pose, int64_t cnt, int64_t base,
                                                double out[GMS_PARTIAL_STRIDE], RedLds &L,
                                                const double *__restrict__ part = nullptr, int32_t part_mi = 0,
-                                               int32_t part_n = 0, int32_t part_nseg = 0, int64_t part_p0 = 0) {
+                                               int32_t part_n = 0, int32_t part_nseg = 0, int64_t part_p0 = 0,
+                                               const double *__restrict__ blockmax = nullptr, int64_t nblk = 0) {
     const int32_t tl = threadIdx.x & (GRP - 1);
+    double log_ref = 0.0;
+    if (blockmax) {                                                    // (uniform)
+        double mloc = -INFINITY;
+        for (int64_t b = tl; b < nblk; b += GRP) { const double v2 = blockmax[b]; if (v2 > mloc) mloc = v2; }
+#define GMS_STEP_(O) { const double v2 = wave_xor<O>(mloc); if (v2 > mloc) mloc = v2; }
+        GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
+        const int32_t wv = threadIdx.x >> 6, g4 = (wv >> 2) << 2;
+        if ((threadIdx.x & 63) == 0) L.b[wv] = mloc;
+        __syncthreads();
+        log_ref = L.b[g4];
+        for (int k = 1; k < 4; k++) if (L.b[g4 + k] > log_ref) log_ref = L.b[g4 + k];
+        if (!(log_ref > -INFINITY)) log_ref = 0.0;                     // every product is 0 (or NaN): nothing to rescale by
+    }
     double s = 0.0, nz = 0.0, mv = -INFINITY, mx = 9.0e15, ml = -INFINITY, sq = 0.0, xw = 0.0, yw = 0.0, tw = 0.0;
 #pragma unroll
     for (int e0 = 0; e0 < EPT; e0 += EPB) {
@@ -543,6 +562,7 @@ __device__ __forceinline__ void block_partials(double *__restrict__ w, double *_
                 v[e] = in ? w[i] : 0.0;
                 lw[e] = in ? logw[i] : -INFINITY;
             }
+            if (blockmax && in) { v[e] = exp(lw[e] - log_ref); w[i] = v[e]; }
             px[e] = in ? pose[3 * i] : 0.0f; py[e] = in ? pose[3 * i + 1] : 0.0f; pt[e] = in ? pose[3 * i + 2] : 0.0f;
         }
 #pragma unroll
@@ -709,7 +729,7 @@ k_fold_neff(const double *__restrict__ p2_all, int64_t nblk, PfStatsDev *__restr
 __device__ __forceinline__ void
 partials_body(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n,
               int64_t offset, int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part,
-              int32_t part_nseg, uint32_t bx, uint32_t by) {
+              int32_t part_nseg, uint32_t bx, uint32_t by, const double *__restrict__ blockmax = nullptr) {
     __shared__ RedLds L;
     const int32_t mi = (int32_t)by;
     const int64_t gb = bx;
@@ -723,7 +743,7 @@ partials_body(double *__restrict__ w, double *__restrict__ logw, const float *__
     double out[GMS_PARTIAL_STRIDE];
     const size_t o = (size_t)mi * n + lb * GMS_BLOCK;
     block_partials(w + o, logw + o, pose + 3 * o, block_count(n, lb), offset + lb * GMS_BLOCK, out, L, part, mi, n,
-                   part_nseg, lb * GMS_BLOCK);
+                   part_nseg, lb * GMS_BLOCK, blockmax ? blockmax + (size_t)mi * nblk_global : nullptr, nblk_global);
     if (threadIdx.x == 0)
         for (int k = 0; k < GMS_PARTIAL_STRIDE; k++) p[k] = out[k];
 }
@@ -731,10 +751,43 @@ partials_body(double *__restrict__ w, double *__restrict__ logw, const float *__
 __global__ void __launch_bounds__(256)
 k_partials(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n,
            int64_t offset, int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part,
-           int32_t part_nseg) {
+           int32_t part_nseg, const double *__restrict__ blockmax) {
     GMS_STAMP(GMS_STAMP_ROW(1, blockIdx.x), 0);
-    partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y);
+    partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y, blockmax);
     GMS_STAMP(GMS_STAMP_ROW(1, blockIdx.x), 1);
+}
+
+// Log-normalisation, first pass (gms_pf_set_log_normalize; stand-alone filters): the segment products are combined (weight and
+// log-weight stored, as k_score_combine does) and every reduction block leaves the largest log-weight of its 256 particles;
+// block_partials folds those maxima and rescales.  grid = (blocks, maps).
+__global__ void __launch_bounds__(256)
+k_logmax(double *__restrict__ w, double *__restrict__ logw, int32_t n, int64_t nblk, const double *__restrict__ part, int32_t part_nseg,
+         double *__restrict__ blockmax) {
+    __shared__ double s_m[4];
+    const int32_t mi = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * GMS_BLOCK + threadIdx.x;
+    double lw = -INFINITY;
+    if (i < n) {
+        const size_t o = (size_t)mi * n + i;
+        if (part) {
+            double wv;
+            combine_segments(part, mi, n, part_nseg, i, wv, lw);
+            w[o] = wv; logw[o] = lw;
+        } else {
+            lw = logw[o];
+        }
+        if (!(lw == lw)) lw = -INFINITY;                                // a NaN product does not set the scale
+    }
+#define GMS_STEP_(O) { const double v2 = wave_xor<O>(lw); if (v2 > lw) lw = v2; }
+    GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = lw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double mx = s_m[0];
+        for (int k = 1; k < 4; k++) if (s_m[k] > mx) mx = s_m[k];
+        blockmax[(size_t)mi * nblk + blockIdx.x] = mx;
+    }
 }
 
 // Level 0 of the cumulative weights: one wavefront = one 64-particle chunk, lane = particle, inclusive scan by
@@ -1282,6 +1335,7 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
                            pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pose_dst, cs_dst, (const float4 *)nullptr,
                            (const int32_t *)nullptr, mo, pf->offset);
     if (motion) { std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); }
+    pf->score_fresh = 1;
     if (nseg > 1) pf->pending_nseg = (int32_t)nseg;               // combined by the next consumer of the weights
 }
 
@@ -1295,13 +1349,27 @@ void gms_launch_pf_combine(gms_pf *pf) {
     pf->pending_nseg = 0;
 }
 
+// log-normalisation's first pass: combined weights / log-weights and the per-block maxima (no-op unless the option is on)
+const double *gms_launch_pf_logmax(gms_pf *pf) {
+    // only the weights of a scoring pass are rescaled: weights the caller set, or the copies a resampling left, are taken as they are
+    if (!pf->log_norm || !pf->score_fresh) return nullptr;
+    pf->score_fresh = 0;
+    gms_map *m = pf->map;
+    const int64_t nblk = nblk_global_of(pf);
+    hipLaunchKernelGGL(k_logmax, dim3((unsigned)nblk, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw, pf->n, nblk,
+                       pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg, pf->d_blockmax);
+    pf->pending_nseg = 0;
+    return pf->d_blockmax;
+}
+
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
+    const double *blockmax = gms_launch_pf_logmax(pf);
     hipLaunchKernelGGL(k_partials, dim3((unsigned)nblk, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw,
                        pf->d_pose, pf->n, pf->offset, nblk, d_partials,
-                       pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg);
+                       pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg, blockmax);
     pf->pending_nseg = 0;                                             // k_partials stored the combined weights
 }
 

@@ -522,6 +522,11 @@ class ParticleFilter:
         check(load().gms_pf_weighted_pose(self._h, ptr(out)))
         return out[0] if self.n_maps == 1 else out
 
+    def set_log_normalize(self, on: bool = True):
+        """Opt-in (not in the reference): normalise from the log-weights, weight = exp(logw - max logw), instead of the plain
+        product that underflows at hundreds of beams (gms_pf_set_log_normalize)."""
+        check(load().gms_pf_set_log_normalize(self._h, 1 if on else 0))
+
     def resample(self, r01=None, want_indices: bool = False):
         """resample() (SLAM.java:133-153); r01 stands for Math.random()."""
         if r01 is None:

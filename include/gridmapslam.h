@@ -248,6 +248,16 @@ int gms_pf_refine_poses(gms_pf *pf, const gms_beam *beams, int32_t B);
  * Default off (the search is 1210 probabilityOf evaluations per particle). */
 int gms_pf_set_refine(gms_pf *pf, int32_t on);
 
+/* Opt-in robust normalisation (not in the reference).  The reference's weight is the plain product of up
+ * to 720 factors in [0.01, 0.91] (GridMap.java:262-288), which underflows for all but a handful of particles of a wide cloud: the
+ * filter then runs on one survivor.  on != 0: the normalise step of this filter (gms_pf_normalize, the scan steps) takes
+ * weight[i] = exp(logw[i] - max_j logw[j]) from the log-weights gms_pf_score keeps beside the products, and everything after it
+ * -- weight sum, strongest, weighted pose, Neff, resampling -- runs on those weights as before (same blocked reductions; one more
+ * launch in front of the block partials).  gms_pf_stats.weight_sum is then the sum of the rescaled weights (the largest is 1),
+ * max_log_weight the scale.  Default off: the parity outputs are the reference's arithmetic.  Stand-alone filters only
+ * (GMS_ERR_STATE on a shard); gms_pf_set_shard turns it off. */
+int gms_pf_set_log_normalize(gms_pf *pf, int32_t on);
+
 /* ---- device-resident inputs ---------------------------------------------------------------------
  * The same entry points for callers whose scans / poses already live in HBM (a trace staged once, a
  * torch tensor, the output of a device-side motion model).  dev_beams is [n_maps][B] gms_beam,

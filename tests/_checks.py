@@ -2,7 +2,10 @@
 import numpy as np
 
 
-def assert_resample_indices(idx, want, n_ambiguous):
+AGREEMENT = []      # one record per checked resampling step: conftest writes them to gpurun_out/resample_agreement.json at session end
+
+
+def assert_resample_indices(idx, want, n_ambiguous, label=None):
     """Source indices of a resampling step (SLAM.java:133-153) against the sequential oracle's.
 
     The device forms the cumulative weights as a blocked scan, the reference as one running sum; a slot whose threshold
@@ -17,6 +20,13 @@ def assert_resample_indices(idx, want, n_ambiguous):
     assert (np.abs(idx - want) <= 1).all(), f"{int((np.abs(idx - want) > 1).sum())} slots further than a neighbour from the oracle's"
     assert int(diff.sum()) <= int(n_ambiguous), f"{int(diff.sum())} slots differ, {int(n_ambiguous)} flagged ambiguous"
     assert (np.diff(idx) >= 0).all()                      # systematic resampling is order-preserving (SLAM.java:140-149)
+    if label is None:
+        import inspect
+        f = inspect.stack()[1]
+        label = f"{f.filename.rsplit('/', 1)[-1]}::{f.function}"
+    # BASELINE.md asks for "indices equal for fixed r": how far from that a blocked scan is, as numbers
+    AGREEMENT.append({"where": label, "slots": int(idx.size), "slots_differing": int(diff.sum()), "n_ambiguous": int(n_ambiguous)})
+    return int(diff.sum())
 
 
 def near_boundary_slots(wn, r01, rel_tol=1e-9):

@@ -52,3 +52,34 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Resample agreement as numbers ("indices equal for fixed r"; the device's blocked scan may pick a neighbour
+    where U lies within rounding distance of a boundary): every checked resampling step's slots, differing slots and flagged
+    slots, summed per test, printed and -- on the GPU box -- left in gpurun_out/resample_agreement.json."""
+    try:
+        import _checks
+    except Exception:
+        return
+    if not _checks.AGREEMENT:
+        return
+    per = {}
+    for r in _checks.AGREEMENT:
+        e = per.setdefault(r["where"], {"steps": 0, "slots": 0, "slots_differing": 0, "n_ambiguous": 0, "largest_population": 0})
+        e["steps"] += 1
+        e["slots"] += r["slots"]
+        e["slots_differing"] += r["slots_differing"]
+        e["n_ambiguous"] += r["n_ambiguous"]
+        e["largest_population"] = max(e["largest_population"], r["slots"])
+    tot = {k: sum(e[k] for e in per.values()) for k in ("steps", "slots", "slots_differing", "n_ambiguous")}
+    tr = session.config.pluginmanager.get_plugin("terminalreporter")
+    line = (f"resample agreement with the sequential oracle: {tot['slots_differing']} of {tot['slots']} slots differ over {tot['steps']} "
+            f"resampling steps ({tot['n_ambiguous']} slots flagged ambiguous by the device)")
+    if tr is not None:
+        tr.write_line(line)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        with open(os.path.join(out, "resample_agreement.json"), "w") as f:
+            json.dump({"total": tot, "per_test": per}, f, indent=1)

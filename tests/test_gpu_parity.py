@@ -291,6 +291,36 @@ def test_resample_indices_equal_the_sequential_reference(N, seed):
         pf.close()
 
 
+@pytest.mark.parametrize("tail", [8, 16, 24, 32, 40, 48, 56])
+def test_resample_last_partial_chunk_of_a_multiple_of_eight_with_the_draw_close_to_one(tail):
+    """A population whose last 64-particle chunk holds a multiple of 8 particles, r01 just below 1: the highest slots' U lies at or
+    beyond the last chunk's end, where the search's octet is clamped to the last octet that holds a particle (round 3 derived the
+    neighbour test's boundary from one octet too far there).  Indices equal to the oracle's wherever the device flags nothing."""
+    m = GridMap(3.2, 3.2, 0.05, (-1.6, -1.6))
+    N = 3 * 64 + tail
+    rng = np.random.default_rng(100 + tail)
+    P = rng.normal(0, 1, (N, 3)).astype(np.float32)
+    for kind in ("uniform", "heavy head", "heavy tail"):
+        w = rng.uniform(0.5, 1.0, N)
+        if kind == "heavy head":
+            w[: N // 2] *= 1e6
+        if kind == "heavy tail":
+            w[-3:] *= 1e6
+        for r in (1.0 - 2.0 ** -53, 0.9999999, 0.999):
+            pf = ParticleFilter(m, N)
+            pf.set_poses(P)
+            pf.set_weights(w)
+            pf.normalize()
+            wn = w.copy()
+            orc.normalize(wn)
+            idx, amb = pf.resample(r, want_indices=True)
+            want, _ = orc.resample_indices(wn, r)
+            assert_resample_indices(idx, want, amb)
+            assert amb <= 4, f"{amb} slots flagged ambiguous in a population of {N} ({kind}, r01 = {r!r})"
+            assert np.array_equal(pf.get_poses(), P[idx])
+            pf.close()
+
+
 def test_resample_if_follows_neff():
     m = GridMap(3.2, 3.2, 0.05, (-1.6, -1.6))
     N = 512
