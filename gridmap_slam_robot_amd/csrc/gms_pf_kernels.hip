@@ -279,7 +279,7 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
           int32_t B, int32_t beam_stride, const float *__restrict__ pose, const float *__restrict__ cs, int32_t n,
           int32_t nseg, double *__restrict__ part, double *__restrict__ w, double *__restrict__ logw,
           const float *__restrict__ pose_src, float *__restrict__ pose_dst, float *__restrict__ cs_dst,
-          const float4 *__restrict__ ord, const int32_t *__restrict__ perm, MotionArgs mo, int64_t offset) {
+          const float4 *__restrict__ ord, const int32_t *__restrict__ perm, MotionArgs mo, int64_t offset, int32_t spread) {
     __shared__ double2 s_beam[128 + U];        // this segment's beams with wasHit, in order
     __shared__ int32_t s_nb;
     // Workgroup -> (beam segment, particle group), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs
@@ -290,16 +290,29 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     const int32_t mi = blockIdx.z;
     int32_t seg, grp;
     {
-        const int32_t i = blockIdx.x, ngrp = gridDim.x / nseg;
+        const int32_t i = blockIdx.x;
         if ((nseg & 7) == 0) {
+            // an XCD's workgroups in dispatch order (j) alternate between its segments.  (Round 4 measured the other order -- all
+            // particle groups of the XCD's first segment, then of its next, so that two workgroups sharing a CU walk the same L1
+            // patch: 65 536 particles 87.5 -> 104.3 us, 512-lane workgroups at C3 20 -> 30.6 us: thirty-two CUs gathering from one
+            // segment's few hundred L2 lines at once queue on those lines' channels.)
             const int32_t spx = nseg >> 3, j = i >> 3;
             seg = (i & 7) * spx + j % spx;
             grp = j / spx;
+            const int32_t ngrp = gridDim.x / nseg;
+            if (spread && (ngrp & 1) == 0) {
+                // launches of several workgroups per CU (config 4 on one or two GPUs): an XCD takes the first half of the particle
+                // groups of its own nseg / 8 segments and the second half of the next XCD's, i.e. twice the segments with half the
+                // CUs on each -- fewer CUs queue on one patch's L2 lines, at the price of every patch being fetched into two L2s
+                // (65 536 particles: 86.2 -> 79.8 us; at one workgroup per CU, config 3, it costs a microsecond: 19.35 -> 20.3)
+                const int32_t k = j % (2 * spx), h = j / (2 * spx);
+                seg = ((i & 7) * spx + k) % nseg;
+                grp = h + (k >= spx ? ngrp / 2 : 0);
+            }
         } else {
             seg = i % nseg;
             grp = i / nseg;
         }
-        (void)ngrp;
     }
     const int32_t L = (B + nseg - 1) / nseg;          // <= 128 (launcher)
     const int32_t j0 = seg * L, j1 = min(B, j0 + L);
@@ -1325,15 +1338,18 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
     else
         while (threads > 256 && nseg * (((int64_t)pf->n + threads - 1) / threads) * pf->n_maps < m->n_cus) threads >>= 1;
     const int64_t groups = ((int64_t)pf->n + threads - 1) / threads;
+    // two or more workgroups per CU (see k_score_c's workgroup map; 24 576 particles, 1.5 per CU: 35.5 us without, 37.5 with; 32 768: 48.7 / 43.3)
+    int32_t spread = nseg * groups >= 2 * (int64_t)m->n_cus ? 1 : 0;
+    if (const char *v = getenv("GMS_SCORE_SPREAD")) spread = atoi(v) != 0;
     if (ordered)
         hipLaunchKernelGGL(k_score_c<3>, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
                            m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
-                           pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pose_dst, cs_dst, pf->d_ord, pf->d_perm, mo, pf->offset);
+                           pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pose_dst, cs_dst, pf->d_ord, pf->d_perm, mo, pf->offset, 0);
     else
         hipLaunchKernelGGL(k_score_c<1>, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
                            m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
                            pf->d_part, pf->d_w, pf->d_logw, d_pose_src, pose_dst, cs_dst, (const float4 *)nullptr,
-                           (const int32_t *)nullptr, mo, pf->offset);
+                           (const int32_t *)nullptr, mo, pf->offset, spread);
     if (motion) { std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); }
     pf->score_fresh = 1;
     if (nseg > 1) pf->pending_nseg = (int32_t)nseg;               // combined by the next consumer of the weights
