@@ -570,7 +570,14 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
         # caches, so `frac` can pass 1 (C5 with the particles in locality order)
         roof["note"] = ("%.0f %% of the algorithmic bytes reach the fabric (PMC): the working set is served by L2 / Infinity Cache, "
                         "frac is algorithmic bytes over the HBM peak and may exceed 1" % (100.0 * roof["traffic"] / alg))
-    roof["kernel_symbol"] = KERNEL_SYMBOLS.get(dom, dom)
+    symbols = dict(KERNEL_SYMBOLS)
+    if wl.batched:
+        symbols.update({"raycast": "k_raycast_tile", "reduce": "k_partials + k_normalize_pack"})
+    elif a.full_rebuild or (a.host_inputs and False):
+        symbols.update({"raycast": "k_raycast", "likelihood": "k_likelihood"})
+    if wl.spf is not None:
+        symbols.update({"raycast": "k_raycast_norm_chunks", "reduce": "k_partials_pack_apply"})
+    roof["kernel_symbol"] = symbols.get(dom, dom)
     if roof["traffic"]:
         roof["traffic_over_algorithmic"] = roof["traffic"] / alg
     if dom == "score":
@@ -625,6 +632,7 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
         "beam_evals_per_s": value * wl.n_hit,
         "scans_per_s": steps * wl.M * (wl.world if wl.batched else 1) / elapsed,
         "kernels": kernels,
+        "kernel_symbols": {k: symbols.get(k, k) for k in kernels},
         "filter": {"neff": st0["neff"], "n_zero_weights": st0["n_zero"], "weight_sum": st0["weight_sum"],
                    "note": "the reference's plain product of <= 720 factors: most raw weights underflow at this cloud (reproduced, "
                            "counted); max_log_weight is the underflow-free companion", "max_log_weight": st0["max_log_weight"],
@@ -947,7 +955,8 @@ def compact_line(full: dict, report_file: str | None) -> str:
         line["cpu_baseline"] = None
     kern = full.get("kernels") or {}
     if kern:
-        line["kernel_us"] = {KERNEL_SYMBOLS.get(k, k): v.get("avg_launch_us") for k, v in kern.items()}
+        sym = full.get("kernel_symbols") or KERNEL_SYMBOLS
+        line["kernel_us"] = {sym.get(k, KERNEL_SYMBOLS.get(k, k)): v.get("avg_launch_us") for k, v in kern.items()}
     sec = full.get("secondary") or {}
     if sec:
         # one number per secondary run (ms per step / per frame); the runs themselves are in the report file

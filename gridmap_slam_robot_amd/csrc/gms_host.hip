@@ -360,6 +360,8 @@ int gms_map_create(const gms_params *p, gms_map **out) {
         if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, m->device) != hipSuccess) lds_max = 64 * 1024;
         m->raycast_tile = lds_max >= 80 * 1024;
         if (const char *v = getenv("GMS_RAYCAST_TILE")) m->raycast_tile = m->raycast_tile && atoi(v) != 0;
+        m->raycast_tile_min = 4096;
+        if (const char *v = getenv("GMS_RAYCAST_TILE_MIN")) m->raycast_tile_min = atoi(v);
         m->raycast_near = lds_max >= 40 * 1024;                       // 25 KiB tile + slots + static LDS
         if (const char *v = getenv("GMS_RAYCAST_NEAR")) m->raycast_near = !m->raycast_near ? 0 : (atoi(v) != 0 ? 2 : 0);   // 1: for every scan of 32 beams or more
     }
@@ -1316,7 +1318,7 @@ static int slam_update_impl(gms_pf *pf, const float *dev_xytheta, const MotionMo
         // batched maps: the ray cast runs 16 rays per workgroup (1024 threads), so only the other two pairs apply:
         // [partials | previous apply] -> normalise -> ray cast -> [likelihood | resample]
         pf->d_global = pf->d_global_own;
-        const bool ride = (int64_t)B * m->n_maps > 4096 && m->raycast_tile;     // the tiled ray cast takes the pending apply pass along
+        const bool ride = gms_raycast_tiled(m, B);     // the tiled ray cast takes the pending apply pass along
         gms_launch_partials_apply(pf, pf->d_partials, ride);
         gms_launch_pf_apply_partials(pf, pf->d_partials, pf->d_global, true);
         pf->have_global = 1;

@@ -115,6 +115,7 @@ struct gms_map {
     int32_t need_full_build;  // likelihood field must be rebuilt everywhere (upload/reset/copy)
     int32_t apply_pending;    // the last scan's counts are not in logData yet (deferred apply pass, gms_flush_apply)
     int32_t raycast_tile;     // batched ray casts accumulate in LDS tiles (k_raycast_tile; GMS_RAYCAST_TILE=0 turns it off)
+    int32_t raycast_tile_min; // ... when the launch has more rays than this in all (default 4096; GMS_RAYCAST_TILE_MIN)
     int32_t lik_lazy;         // scan steps' dirty-tile rebuilds write the factor table only, likelihoodData on demand (GMS_LIK_LAZY=0 turns it off)
     int32_t lik_stale;        // likelihoodData is behind the factor table somewhere (gms_ensure_lik brings it up to date)
     int32_t fac_current;      // the factor table is the field of logData + the pending counts as of the last rebuild, and logData has not moved since except by those counts
@@ -200,6 +201,7 @@ struct gms_comm {
 
 void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
                         int32_t pose_stride, bool take_pending_apply = false);
+bool gms_raycast_tiled(const gms_map *m, int32_t B);
 void gms_launch_trace_scan(gms_map *m, const gms_beam *d_beams, int32_t B, const float *d_pose,
                            int32_t *d_cells, uint8_t *d_cls, int32_t cap, int32_t *d_counts);
 void gms_launch_trace_ray(gms_map *m, float x0, float y0, float x1, float y1, int32_t extra,

@@ -1087,9 +1087,12 @@ static void rc_launch(gms_map *m, dim3 grid, const gms_beam *d_beams, int32_t B,
                        pose_stride, single, cnt, bbox, t_cells, t_cls, cap, t_counts, rc_nw_max(m), n_near);
 }
 
+// batched ray casts of more than raycast_tile_min rays in all go through LDS tiles (k_raycast_tile)
+bool gms_raycast_tiled(const gms_map *m, int32_t B) { return (int64_t)B * m->n_maps > m->raycast_tile_min && m->raycast_tile; }
+
 void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
                         int32_t pose_stride, bool take_pending_apply) {
-    const bool tile = (int64_t)B * m->n_maps > 4096 && m->raycast_tile;
+    const bool tile = gms_raycast_tiled(m, B);
     // take_pending_apply: a deferred apply pass rides in this launch (tiled form only) instead of a launch of its own: the ray
     // cast then raises the other box half (cleared by the previous likelihood launch) and fills the other count grid
     const bool riding = take_pending_apply && tile && m->apply_pending;
@@ -1116,7 +1119,7 @@ void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t 
         hipLaunchKernelGGL(k_raycast_tile, dim3(n_ray + n_apply, m->n_maps), dim3(RCT_THREADS), smem, m->stream, m->gd,
                            d_beams, B, beam_stride, d_poses, pose_stride, m->d_cnt, next, n_ray, m->d_log, m->d_cnt_pend, bb);
         if (riding) gms_apply_done(m);
-    } else if ((int64_t)B * m->n_maps > 4096)       // (GMS_RAYCAST_TILE=0, or not enough LDS: 16 rays per workgroup, direct atomics)
+    } else if ((int64_t)B * m->n_maps > m->raycast_tile_min)       // (GMS_RAYCAST_TILE=0, or not enough LDS: 16 rays per workgroup, direct atomics)
         rc_launch<false, 16>(m, dim3((B + 15) / 16, m->n_maps), d_beams, B, beam_stride, d_poses, pose_stride, nullptr, m->d_cnt, bb,
                              nullptr, nullptr, 0, nullptr);
     else

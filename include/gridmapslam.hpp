@@ -20,6 +20,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <array>
 #include <vector>
 
 #include "gridmapslam.h"
@@ -126,6 +127,14 @@ public:
     /** findBestPose(map, obs, startPose) (:319-346) */
     Pose findBestPose(const Observation &obs, const Pose &start);
 
+    /** what the dirty-tile rebuilds of computeLikelihoodMap did since the last call: 64 x 32-cell tiles {left alone, constants
+     *  kept, constants written, blurred}; keepCounting = false stops the census (gms_map_tile_stats) */
+    std::array<int64_t, 4> tileStats(bool keepCounting = true) {
+        std::array<int64_t, 4> o{};
+        check(gms_map_tile_stats(h_, keepCounting ? 1 : 0, o.data()));
+        return o;
+    }
+
     std::vector<double> logData() { std::vector<double> v((size_t)w_ * hgt_); check(gms_map_download_log(h_, v.data())); return v; }
     std::vector<double> likelihoodData() { std::vector<double> v((size_t)w_ * hgt_); check(gms_map_download_likelihood(h_, v.data())); return v; }
     void setLogData(const std::vector<double> &v) { check(gms_map_upload_log(h_, v.data())); }
@@ -180,6 +189,9 @@ public:
     /** resample() (ParticleFilter.java:59-82 surface, SLAM.java:133-153 semantics); r01 stands for Math.random() */
     void resample(double r01) { check(gms_pf_resample(h_, &r01, nullptr, nullptr)); }
     void refinePoses(const Observation &obs) { check(gms_pf_refine_poses(h_, obs.getMeasurements().data(), obs.getNumberOfMeasurements())); }
+    /** opt-in, not in the reference: normalise from the log-weights (exp(logw - max logw)) instead of the plain product of up to
+     *  720 factors, which underflows for nearly every particle of a wide cloud (gms_pf_set_log_normalize) */
+    void setLogNormalize(bool on) { check(gms_pf_set_log_normalize(h_, on ? 1 : 0)); }
     Pose getWeightedPose() { float o[3]; check(gms_pf_weighted_pose(h_, o)); return Pose(o[0], o[1], o[2]); }
     int size() const { return n_; }
     gms_pf *handle() { return h_; }

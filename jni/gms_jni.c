@@ -187,6 +187,7 @@ JNIEXPORT jlong JNICALL CLS(pfCreate)(JNIEnv *env, jclass c, jlong m, jint n) {
 JNIEXPORT void JNICALL CLS(pfDestroy)(JNIEnv *env, jclass c, jlong pf) { throw_gms(env, gms_pf_destroy(PF(pf))); }
 JNIEXPORT void JNICALL CLS(pfSetShard)(JNIEnv *env, jclass c, jlong pf, jlong offset, jlong nGlobal) { throw_gms(env, gms_pf_set_shard(PF(pf), offset, nGlobal)); }
 JNIEXPORT void JNICALL CLS(pfSetRefine)(JNIEnv *env, jclass c, jlong pf, jboolean on) { throw_gms(env, gms_pf_set_refine(PF(pf), on ? 1 : 0)); }
+JNIEXPORT void JNICALL CLS(pfSetLogNormalize)(JNIEnv *env, jclass c, jlong pf, jboolean on) { throw_gms(env, gms_pf_set_log_normalize(PF(pf), on ? 1 : 0)); }
 JNIEXPORT void JNICALL CLS(pfSetPoses)(JNIEnv *env, jclass c, jlong pf, jfloatArray xyt, jint n) {
     int ok;
     if (!particle_count_ok(env, pf, n, 0)) return;

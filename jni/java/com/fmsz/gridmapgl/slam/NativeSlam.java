@@ -21,6 +21,7 @@ final class NativeSlam {
     static native void pfDestroy(long pf);
     static native void pfSetShard(long pf, long offset, long nGlobal);
     static native void pfSetRefine(long pf, boolean on);
+    static native void pfSetLogNormalize(long pf, boolean on);
     static native void pfSetPoses(long pf, float[] xytheta, int n);
     static native void pfGetParticles(long pf, float[] xytheta, double[] weights, int n);
     static native void pfScore(long pf, double[] beams, int B);

@@ -45,6 +45,10 @@ public class ParticleFilterGpu extends ParticleFilter {
     /** findBestPose on every particle before it is weighted (SLAM.java:96-97) */
     public void setRefine(boolean on) { NativeSlam.pfSetRefine(handle, on); }
 
+    /** opt-in, not in the reference: weights from the log-weights (exp(logw - max logw)) instead of the plain product, which
+     *  underflows at several hundred beams (gms_pf_set_log_normalize) */
+    public void setLogNormalize(boolean on) { NativeSlam.pfSetLogNormalize(handle, on); }
+
     /**
      * SLAM.update(z, u) (SLAM.java:80-131) followed by its caller's `if (neff < fraction * N) resample()`
      * (GridMapApp.java:185-186) in ONE native call.  `sampled` are the motion-model samples (sampleMotionModel stays on

@@ -3,7 +3,7 @@
 # of bench.py (C3 default, C5) and of the dense-map likelihood rebuild; raw output under gpurun_out/prof/, the summaries
 # that are kept go to profiles/<round>/ afterwards (tools/kstats.py, tools/pmc_summary.py).
 # usage: collect_profiles.sh <round dir name, e.g. r02>
-R=${1:-r03}
+R=${1:-r04}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/prof_$R"
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -47,14 +47,23 @@ cp gpurun_out/microbench/persistent_step.txt "$OUT/keep/persistent_step_model_ru
 # the bench lines below quote this collection's own PMC traffic and look-up ceilings: install them where bench.py reads them
 mkdir -p "profiles/$R"
 cp "$OUT/keep/pmc_traffic.json" "$OUT/keep/microbench.json" "profiles/$R/" 2>/dev/null
-# un-profiled bench lines
-python3 bench.py > "$OUT/keep/bench.json" 2> "$OUT/bench.stderr"
-python3 bench.py --force-sharded --no-cpu-baseline --no-secondary > "$OUT/keep/bench_sharded_one_rank.json" 2>> "$OUT/bench.stderr"
-python3 bench.py --host-inputs --no-cpu-baseline --no-secondary > "$OUT/keep/bench_host_inputs.json" 2>> "$OUT/bench.stderr"
-python3 bench.py --full-rebuild --no-cpu-baseline --no-secondary > "$OUT/keep/bench_full_rebuild.json" 2>> "$OUT/bench.stderr"
-python3 bench.py --config C5 --steps 50 --warmup 5 > "$OUT/keep/bench_c5.json" 2>> "$OUT/bench.stderr"
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$OUT/keep/bench_steps20.json" 2>> "$OUT/bench.stderr"
-python3 bench.py --trace tests/golden/recording_360.bin --steps 300 --warmup 20 > "$OUT/keep/bench_trace_replay.json" 2>> "$OUT/bench.stderr"
+# un-profiled bench lines (stdout = the one compact line; --report = the full report)
+python3 bench.py --report "$OUT/keep/bench_report.json" > "$OUT/keep/bench.json" 2> "$OUT/bench.stderr"
+python3 bench.py --steps 20 --warmup 5 --report "$OUT/keep/bench_steps20_report.json" > "$OUT/keep/bench_steps20.json" 2>> "$OUT/bench.stderr"
+Q="--no-cpu-baseline --no-secondary"
+python3 bench.py --force-sharded $Q --report "$OUT/keep/bench_sharded_one_rank_report.json" > "$OUT/keep/bench_sharded_one_rank.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --config C4 --force-sharded $Q --steps 50 --warmup 5 --report "$OUT/keep/bench_c4_sharded_one_rank_report.json" > "$OUT/keep/bench_c4_sharded_one_rank.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --host-inputs $Q --report "$OUT/keep/bench_host_inputs_report.json" > "$OUT/keep/bench_host_inputs.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --full-rebuild $Q --report "$OUT/keep/bench_full_rebuild_report.json" > "$OUT/keep/bench_full_rebuild.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --config C5 --steps 50 --warmup 5 --report "$OUT/keep/bench_c5_report.json" > "$OUT/keep/bench_c5.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --trace tests/golden/recording_360.bin --steps 300 --warmup 20 --report "$OUT/keep/bench_trace_replay_report.json" > "$OUT/keep/bench_trace_replay.json" 2>> "$OUT/bench.stderr"
+# the per-GPU step of the fixed-population series (config 4) at 1 / 2 / 4 / 8 GPUs' shard sizes, on one GPU (no exchange): DESIGN.md section 7's curve
+for n in 65536 32768 16384 8192; do
+  python3 bench.py --config C4 --particles $n $Q --steps 100 --warmup 10 --report "$OUT/keep/bench_c4_shard_${n}_report.json" > "$OUT/keep/bench_c4_shard_${n}.json" 2>> "$OUT/bench.stderr"
+done
+# the float domain of the rounded primitives, exhausted, with the record kept
+GMS_EXHAUSTIVE=1 python3 -m pytest tests/test_gpu_exhaustive_float.py -m gpu -q > "$OUT/exhaustive.stdout" 2>&1
+cp gpurun_out/exhaustive_float.json "$OUT/keep/" 2>/dev/null
 # stage timeline of a C3 step from the instrumented build, when it was shipped along (lib/exp_stamps.so)
 if [ -f gridmap_slam_robot_amd/lib/exp_stamps.so ]; then
   GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/stamps.py > "$OUT/keep/c3_step_timeline.txt" 2>> "$OUT/bench.stderr"

@@ -3,8 +3,6 @@
 //   form 1  global_load_dwordx2 v, v_off32, s[base]          (scalar base + 32-bit byte offset per lane)
 //   form 2  buffer_load_dwordx2 v, v_off32, s[rsrc], 0 offen (buffer resource + 32-bit byte offset per lane)
 //   form 3  form 2 with a 4-byte element (buffer_load_dword): half the bytes returned
-//   form 4  two look-ups per lane returned by ONE instruction is not possible for unrelated cells; instead: global_load_dwordx4
-//           of 16 bytes at the cell (what a 16-byte cell would cost)
 // Access pattern: every lane its own random cell inside a 64x64 patch of the workgroup (the scoring kernel's case), and the
 // same with quads of neighbouring lanes on one line.
 //   hipcc --offload-arch=gfx950 -O3 tools/microbench/gather_addr.hip -o /tmp/ga && /tmp/ga
@@ -44,14 +42,9 @@ k_gather(const double *__restrict__ table, uint32_t W, int iters, int g, double 
             } else if (FORM == 2) {
                 const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(idx[u] * 8u), 0, 0);
                 v[u] = __builtin_bit_cast(double, r);
-            } else if (FORM == 3) {
+            } else {
                 const uint32_t r = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(idx[u] * 8u), 0, 0);
                 v[u] = (double)__uint_as_float(r);
-            } else {
-                const double *p = table + (idx[u] & ~1u);
-                double2 t;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(p) : "memory");
-                v[u] = t.x * t.y;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -95,7 +88,6 @@ int main() {
         run<1>("form 1: global_load_dwordx2, scalar base + 32-bit offset", g);
         run<2>("form 2: buffer_load_dwordx2 offen", g);
         run<3>("form 3: buffer_load_dword offen (4 bytes)", g);
-        run<4>("form 4: global_load_dwordx4 (16 bytes)", g);
     }
     return 0;
 }

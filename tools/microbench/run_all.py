@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 OUT = os.path.join(ROOT, "gpurun_out", "microbench")
 os.makedirs(OUT, exist_ok=True)
 res = {"source": "tools/microbench/*.hip on MI355X (gfx950), hipcc -O3"}
-for name, args in (("gather_coalesce", []), ("gather8", []), ("dda_chain", []), ("persistent_step", ["-1"])):
+for name, args in (("gather_coalesce", []), ("gather8", []), ("gather_addr", []), ("dda_chain", []), ("persistent_step", ["-1"])):
     src = os.path.join(ROOT, "tools", "microbench", name + ".hip")
     exe = os.path.join("/tmp", "mb_" + name)
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", src, "-o", exe])
