@@ -234,6 +234,40 @@ int64_t orc_count_sqrt_mismatches(const float *a, const float *got, int64_t n, i
     return bad;
 }
 
+/* How close does the double a libm returns for cos / sin of a widened float come to a ROUNDING BOUNDARY of the float it is narrowed
+ * to (the midpoint of two adjacent floats)?  Transform.java:15-16 narrows FastMath's double to float; another libm whose double
+ * differs by less than an ulp narrows to the same float unless such a boundary lies between the two doubles.  Sweeps the bit
+ * patterns lo..hi (inclusive, sign OR-ed in) and records every (theta, which: 0 cos / 1 sin) whose glibc double lies within
+ * `window` ulps(double) of a boundary; returns how many there are (at most cap are stored).  tests/golden/make_trig_fragile.py settles
+ * each with multi-precision arithmetic; tests/golden/trig_fragile.json is the result. */
+int64_t orc_trig_near_float_boundary(uint32_t lo, uint32_t hi, uint32_t sign, double window, float *out_theta, int32_t *out_which,
+                                     double *out_dist, int64_t cap, int32_t threads) {
+    int64_t n = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t b = (int64_t)lo; b <= (int64_t)hi; b++) {
+        const uint32_t bits = (uint32_t)b | sign;
+        float th;
+        memcpy(&th, &bits, 4);
+        for (int which = 0; which < 2; which++) {
+            const double d = which ? sin((double)th) : cos((double)th);
+            if (!(d == d) || d == 0.0) continue;
+            const float f = (float)d;
+            const float other = (double)f <= d ? nextafterf(f, INFINITY) : nextafterf(f, -INFINITY);
+            const double mid = ((double)f + (double)other) * 0.5;               /* exact: a 25-bit significand */
+            const double ulp = nextafter(fabs(d), INFINITY) - fabs(d);
+            const double dist = fabs(d - mid) / ulp;
+            if (dist <= window) {
+                int64_t k;
+#pragma omp atomic capture
+                k = n++;
+                if (k < cap) { out_theta[k] = th; out_which[k] = which; out_dist[k] = dist; }
+            }
+        }
+    }
+    return n;
+}
+
 typedef struct xform { double c, s, px, py; } xform;
 
 static inline xform xform_from_pose(const float pose[3]) {

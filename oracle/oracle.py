@@ -114,6 +114,8 @@ def lib() -> C.CDLL:
         L.orc_pose_trig.argtypes = [C.c_float, dp, dp]
         L.orc_count_trig_mismatches.restype = C.c_int64
         L.orc_count_trig_mismatches.argtypes = [fp, fp, fp, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
+        L.orc_trig_near_float_boundary.restype = C.c_int64
+        L.orc_trig_near_float_boundary.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, fp, ip, dp, C.c_int64, C.c_int32]
         L.orc_count_sqrt_mismatches.restype = C.c_int64
         L.orc_count_sqrt_mismatches.argtypes = [fp, fp, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         _lib = L
@@ -281,6 +283,19 @@ def count_trig_mismatches(theta: np.ndarray, got_cos: np.ndarray, got_sin: np.nd
     first = C.c_int64(-1)
     n = lib().orc_count_trig_mismatches(_fp(theta), _fp(got_cos), _fp(got_sin), len(theta), threads, C.byref(first))
     return int(n), int(first.value)
+
+
+def trig_near_float_boundary(lo_bits: int, hi_bits: int, negative: bool, window_ulps: float, threads: int = 1, cap: int = 1 << 16):
+    """[(theta, 'cos' | 'sin', distance in ulps)] for the float bit patterns lo..hi whose glibc cos / sin lies within window_ulps of a
+    rounding boundary of the float it is narrowed to (orc_trig_near_float_boundary)."""
+    th = np.empty(cap, dtype=np.float32)
+    wh = np.empty(cap, dtype=np.int32)
+    ds = np.empty(cap, dtype=np.float64)
+    n = lib().orc_trig_near_float_boundary(lo_bits, hi_bits, 0x80000000 if negative else 0, window_ulps, _fp(th), _ip(wh), _dp(ds), cap, threads)
+    if n > cap:
+        raise RuntimeError(f"{n} candidates exceed the buffer of {cap}")
+    order = np.lexsort((wh[:n], th[:n].view(np.uint32)))
+    return [(float(th[i]), "sin" if wh[i] else "cos", float(ds[i])) for i in order]
 
 
 def count_sqrt_mismatches(a: np.ndarray, got: np.ndarray, threads: int = 1):
