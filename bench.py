@@ -450,7 +450,9 @@ def measure(wl: Workload, steps: int, warmup: int):
     # bracketed replay: the same steps again (the same pose sets, scans and draws), every launch timed
     m.profile(True)
     m.profile_reset()
-    nb = max(1, min(steps, 200))
+    # (a short timed region is replayed several times over, to at least 100 steps: the first bracketed launches behind a barrier run
+    # cold and, at the driver's 20 steps, would be a fifth of the sample)
+    nb = max(1, min(max(steps, 100 if not wl.batched else 20), 200))
     first = warmup + (steps if wl.loop else 0)           # a closed loop cannot go back: its replay is the NEXT nb steps of the drive
     for i in range(nb):
         wl.step(first + i)
