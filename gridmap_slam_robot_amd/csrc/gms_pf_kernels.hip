@@ -345,12 +345,20 @@ k_score_c(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, con
     } else if (pose_src) {
         float x = pose_src[3 * gi], y = pose_src[3 * gi + 1], th = pose_src[3 * gi + 2];
         float c, sn;
+#ifdef GMS_STAMPS
+        if (th != th) x = 0.0f;                 // (the stamp below waits for the pose)
+        GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 3);
+#endif
         if (mo.on)                                                     // (uniform) the motion-model sample happens here: SLAM.java:90
             motion_apply(x, y, th, c, sn, (uint64_t)(offset + op) + ((uint64_t)mi << 40), mo.d_center, mo.d_theta, mo.d_center_sd,
                          mo.d_theta_sd, mo.seed, mo.sequence);
         else
             pose_trig(th, c, sn);                                      // Transform.java:15-16
         t.c = (double)c; t.s = (double)sn; t.px = (double)x; t.py = (double)y;
+#ifdef GMS_STAMPS
+        if (c != c) x = 0.0f;
+        GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 4);
+#endif
         if (seg == 0 && p < n) {
             pose_dst[3 * gi] = x; pose_dst[3 * gi + 1] = y; pose_dst[3 * gi + 2] = th;
             cs_dst[2 * gi] = c; cs_dst[2 * gi + 1] = sn;

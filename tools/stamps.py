@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 STAGES = {
-    0: ("k_score_c", {0: "entered", 1: "beams compacted, trig done", 2: "products stored"}),
+    0: ("k_score_c", {0: "entered", 3: "pose loaded (thread 0)", 4: "trig done (thread 0)", 1: "beams compacted, trig done", 2: "products stored"}),
     1: ("k_partials", {0: "entered", 2: "weights combined, sums accumulated (thread 0)", 3: "butterflies done", 4: "waves combined", 1: "left"}),
     2: ("k_norm_raycast", {0: "entered", 1: "ray: pose folded", 2: "far: rays set up", 3: "far: recurrence done (producer)", 4: "far: first consumer done",
                            5: "far: box committed", 9: "near: tile cleared", 10: "near: 64 steps counted", 11: "near: tile flushed", 12: "near: box committed",
