@@ -155,3 +155,33 @@ def test_weights_the_caller_sets_are_never_rescaled_and_shards_refuse_the_option
         sh.set_log_normalize(True)
     assert e.value.code == GMS_ERR_STATE
     sh.set_log_normalize(False)                                       # turning it off is always allowed
+
+
+@pytest.mark.parametrize("beams", [96, 400])
+def test_batched_maps_and_short_scans(beams):
+    """Three maps in one handle (every kernel carries a map index; the scale is per map) and a scan short enough for a single
+    scoring segment (96 beams: the weights come out of the scoring launch directly, no segment products to combine)."""
+    M, ext, res, n = 3, 6.4, 0.05, 700
+    traces = [synth.make_trace(ext, res, beams, T=8, seed=70 + i) for i in range(M)]
+    mb = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M, max_beams=beams)
+    for t in range(4):
+        mb.update(np.stack([tr.scans[t] for tr in traces]), np.stack([tr.poses[t] for tr in traces]))
+    pf = ParticleFilter(mb, n)
+    pf.set_log_normalize(True)
+    P = np.stack([synth.make_particles(tr.poses[4], n, seed=5 + i) for i, tr in enumerate(traces)])
+    pf.set_poses(P)
+    pf.score(np.stack([tr.scans[4] for tr in traces]))
+    st = pf.normalize()
+    lw = pf.get_log_weights().reshape(M, n)
+    w = pf.get_weights().reshape(M, n)
+    for i in range(M):
+        Mx, v, S, wn = _reference(lw[i], P[i])
+        assert st[i]["max_log_weight"] == Mx and abs(st[i]["weight_sum"] - S) <= 1e-12 * S
+        big = wn > 1e-280
+        assert np.max(np.abs(w[i][big] - wn[big]) / wn[big]) <= 1e-12
+        assert st[i]["strongest"] == int(np.argmax(lw[i]))
+    # the fused batched step takes the same route
+    pf2 = ParticleFilter(mb, n)
+    pf2.set_log_normalize(True)
+    pf2.slam_update(P, np.stack([tr.scans[4] for tr in traces]), np.full(M, 0.4), -1.0, False)
+    assert np.array_equal(pf2.get_weights(), pf.get_weights())
