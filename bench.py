@@ -575,7 +575,7 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
     symbols = dict(KERNEL_SYMBOLS)
     if wl.batched:
         symbols.update({"raycast": "k_raycast_tile", "reduce": "k_partials + k_normalize_pack"})
-    elif a.full_rebuild or (a.host_inputs and False):
+    elif a.full_rebuild:
         symbols.update({"raycast": "k_raycast", "likelihood": "k_likelihood"})
     if wl.spf is not None:
         symbols.update({"raycast": "k_raycast_norm_chunks", "reduce": "k_partials_pack_apply"})
