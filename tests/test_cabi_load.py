@@ -67,6 +67,10 @@ def test_bad_arguments_are_reported_not_crashed():
     p.ktaps = 4      # even
     h = C.c_void_p()
     assert L.gms_map_create(C.byref(p), C.byref(h)) == _lib.GMS_ERR_INVALID
+    # round-4 entry points: a null handle is an argument error, not a crash
+    out = (C.c_int64 * 4)()
+    assert L.gms_map_tile_stats(None, 1, out) == _lib.GMS_ERR_INVALID
+    assert L.gms_pf_set_log_normalize(None, 1) == _lib.GMS_ERR_INVALID and b"null" in L.gms_last_error()
 
 
 def test_fails_loudly_without_a_device(have_gpu):
