@@ -50,4 +50,5 @@ def test_bench_over_rccl_shards_the_fixed_population_and_equals_the_standalone_f
     assert d["config"]["exchange"].startswith("in-library RCCL")
     assert d["sharded_equals_standalone"] is True, full.get("verify")
     assert full["verify"]["population"] == 65536 and full["verify"]["mismatches"] is None
-    assert len(d["per_rank_ms_per_step"]) == world and d["exchange_latency_us"] is not None and d["value"] > 0
+    assert len(d["per_rank_ms_per_step"]) == world and d["value"] > 0
+    assert d.get("exchange_latency_us") is not None and d["exchange_latency_us"] > 0      # the grouped all-gather, event-bracketed
