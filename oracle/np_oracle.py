@@ -287,3 +287,91 @@ def resample_indices(weights, r01):
             c += float(weights[i])
         out.append(i)
     return np.array(out, dtype=np.int32)
+
+
+# ---------------------------------------------------------------- J/slam/SLAM.java as a class, J/slam/Odometry.java:77-96
+def odometry_apply(pose, d_center, d_theta, z0, z1):
+    """Odometry.apply(p) (Odometry.java:77-96) given the two standard normal variates of its draws (the reference's unseeded
+    Well1024a stream is not reproducible: the variates are an input, see orc_philox_normals)."""
+    d_center_sd = (0.01 + abs(d_center) * 0.05) / 2                  # :63
+    d_theta_sd = 5 * (math.pi / 180.0) + 0.1 * abs(d_theta)          # :64
+    d = d_center + d_center_sd * z0                                  # :80
+    theta = d_theta + d_theta_sd * z1                                # :81
+    th = f32(angle_constrain(float(f32(pose[2])) + theta))           # :92
+    c, s = NpGrid.trig(th)                                           # MathUtil.cos(float) / sin(float)
+    x = f32(float(f32(pose[0])) + c * d)                             # :93 (float += double: widened, added, narrowed)
+    y = f32(float(f32(pose[1])) + s * d)                             # :94
+    return np.array([x, y, th], dtype=np.float32)
+
+
+class NpSlam:
+    """SLAM.java:26-204, one object per Particle as in the reference (a dict {weight, pose, log, lik}); findBestPoseOptim (:97) is
+    left out (see gms_oracle.h).  normals(i, sequence) -> (z0, z1) supplies the motion model's variates."""
+
+    def __init__(self, grid: NpGrid, n: int, normals=None):
+        self.g = grid
+        self.n = n
+        self.normals = normals
+        self.strongest = None
+        self.reset()
+
+    def _new_map(self, other=None):
+        # GridMap.createMapData (GridMap.java:106-124)
+        cells = self.g.W * self.g.H
+        if other is None:
+            return np.full(cells, self.g.l[1], dtype=np.float64), np.zeros(cells, dtype=np.float64)
+        return other[0].copy(), other[1].copy()
+
+    def reset(self):
+        # :65-77
+        self.particles = []
+        for _ in range(self.n):
+            log, lik = self._new_map()
+            self.particles.append({"weight": 1.0 / self.n, "pose": np.zeros(3, dtype=np.float32), "log": log, "lik": lik})
+        self.strongest = self.particles[0]
+
+    def update(self, beams, odometry=None, sequence=0):
+        # :80-131
+        d_theta = odometry[1] if odometry is not None else 0.0
+        skip_update = abs(d_theta) > (math.pi / 180.0) * 30          # :82
+        self.strongest = None
+        weight_sum = 0.0
+        for i, p in enumerate(self.particles):
+            if odometry is not None:                                 # :90, :155-163
+                z0, z1 = self.normals(i, sequence)
+                p["pose"] = odometry_apply(p["pose"], odometry[0], odometry[1], z0, z1)
+            p["lik"] = self.g.build_likelihood(p["log"])             # :93
+            p["weight"] = float(self.g.score(p["lik"], beams, p["pose"].reshape(1, 3))[0])     # :99
+            weight_sum += p["weight"]                                # :100
+            if not skip_update:
+                self.g.integrate(p["log"], beams, p["pose"])         # :105
+            if self.strongest is None or p["weight"] > self.strongest["weight"]:   # :110-115
+                self.strongest = p
+        for p in self.particles:                                     # :120-121
+            p["weight"] /= weight_sum
+        return self.neff()
+
+    def resample(self, r01):
+        # :133-153
+        new = []
+        r = r01 * 1.0 / self.n
+        c = self.particles[0]["weight"]
+        i = 0
+        idx = []
+        for m in range(1, self.n + 1):
+            U = r + (m - 1) * 1.0 / self.n
+            while U > c and i < self.n - 1:
+                i += 1
+                c += self.particles[i]["weight"]
+            src = self.particles[i]
+            log, lik = self._new_map((src["log"], src["lik"]))       # :41-45
+            new.append({"weight": src["weight"], "pose": src["pose"].copy(), "log": log, "lik": lik})
+            idx.append(i)
+        self.particles = new
+        return np.array(idx, dtype=np.int32)
+
+    def neff(self):
+        return neff([p["weight"] for p in self.particles])           # :180-190
+
+    def weighted_pose(self):
+        return weighted_pose(np.stack([p["pose"] for p in self.particles]), [p["weight"] for p in self.particles])   # :165-178

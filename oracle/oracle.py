@@ -118,6 +118,32 @@ def lib() -> C.CDLL:
         L.orc_trig_near_float_boundary.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, fp, ip, dp, C.c_int64, C.c_int32]
         L.orc_count_sqrt_mismatches.restype = C.c_int64
         L.orc_count_sqrt_mismatches.argtypes = [fp, fp, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
+        L.orc_slam_new.restype = vp
+        L.orc_slam_new.argtypes = [gp, C.c_int32]
+        L.orc_slam_free.restype = None
+        L.orc_slam_free.argtypes = [vp]
+        L.orc_slam_reset.restype = None
+        L.orc_slam_reset.argtypes = [vp]
+        L.orc_slam_count.restype = C.c_int32
+        L.orc_slam_count.argtypes = [vp]
+        L.orc_slam_poses.restype = fp
+        L.orc_slam_poses.argtypes = [vp]
+        L.orc_slam_weights.restype = dp
+        L.orc_slam_weights.argtypes = [vp]
+        L.orc_slam_log.restype = dp
+        L.orc_slam_log.argtypes = [vp, C.c_int32]
+        L.orc_slam_lik.restype = dp
+        L.orc_slam_lik.argtypes = [vp, C.c_int32]
+        L.orc_slam_strongest.restype = C.c_int32
+        L.orc_slam_strongest.argtypes = [vp]
+        L.orc_slam_update.restype = C.c_double
+        L.orc_slam_update.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int32]
+        L.orc_slam_resample.restype = C.c_int32
+        L.orc_slam_resample.argtypes = [vp, C.c_double, ip]
+        L.orc_slam_neff.restype = C.c_double
+        L.orc_slam_neff.argtypes = [vp]
+        L.orc_slam_weighted_pose.restype = None
+        L.orc_slam_weighted_pose.argtypes = [vp, fp]
         _lib = L
     return _lib
 
@@ -354,3 +380,78 @@ def deskew(angle, distance, hit, d_center: float, d_theta: float) -> np.ndarray:
     lib().orc_deskew(_dp(angle), _dp(distance), hit.ctypes.data_as(C.POINTER(C.c_uint8)), len(angle), d_center, d_theta,
                      out.ctypes.data)
     return out
+
+
+class Slam:
+    """SLAM (J/slam/SLAM.java): n particles, each with a pose, a weight and its own GridMapData -- the reference's filter shape
+    (orc_slam_* in gms_oracle.c).  poses / weights / log(i) / lik(i) are COPIES of the oracle's state."""
+
+    def __init__(self, grid: "Grid", n: int):
+        self.grid = grid
+        self.n = int(n)
+        self._h = lib().orc_slam_new(C.byref(grid.g), self.n)
+        if not self._h:
+            raise MemoryError("orc_slam_new")
+        self.cells = grid.W * grid.H
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_slam_free(self._h)
+            self._h = None
+
+    def reset(self):
+        lib().orc_slam_reset(self._h)
+
+    @property
+    def poses(self) -> np.ndarray:
+        return np.ctypeslib.as_array(lib().orc_slam_poses(self._h), shape=(self.n, 3)).copy()
+
+    def set_poses(self, poses):
+        np.ctypeslib.as_array(lib().orc_slam_poses(self._h), shape=(self.n, 3))[:] = np.asarray(poses, dtype=np.float32).reshape(self.n, 3)
+
+    @property
+    def weights(self) -> np.ndarray:
+        return np.ctypeslib.as_array(lib().orc_slam_weights(self._h), shape=(self.n,)).copy()
+
+    def set_weights(self, w):
+        np.ctypeslib.as_array(lib().orc_slam_weights(self._h), shape=(self.n,))[:] = np.asarray(w, dtype=np.float64)
+
+    def log(self, i: int) -> np.ndarray:
+        return np.ctypeslib.as_array(lib().orc_slam_log(self._h, int(i)), shape=(self.cells,)).copy()
+
+    def lik(self, i: int) -> np.ndarray:
+        return np.ctypeslib.as_array(lib().orc_slam_lik(self._h, int(i)), shape=(self.cells,)).copy()
+
+    def set_log(self, i: int, log):
+        np.ctypeslib.as_array(lib().orc_slam_log(self._h, int(i)), shape=(self.cells,))[:] = np.asarray(log, dtype=np.float64).reshape(-1)
+
+    def logs(self) -> np.ndarray:
+        return np.stack([self.log(i) for i in range(self.n)])
+
+    def liks(self) -> np.ndarray:
+        return np.stack([self.lik(i) for i in range(self.n)])
+
+    @property
+    def strongest(self) -> int:
+        return int(lib().orc_slam_strongest(self._h))
+
+    def update(self, beams: np.ndarray, odometry=None, seed: int = 0, sequence: int = 0, refine: bool = False) -> float:
+        """SLAM.update(z, u) (SLAM.java:80-131); odometry = (dCenter, dTheta) or None; returns Neff"""
+        have = odometry is not None
+        dc, dt = (odometry if have else (0.0, 0.0))
+        return float(lib().orc_slam_update(self._h, beams.ctypes.data, len(beams), int(have), float(dc), float(dt), int(seed), int(sequence),
+                                           int(bool(refine))))
+
+    def resample(self, r01: float):
+        """SLAM.resample() (SLAM.java:133-153); returns (source index per slot, clamped slots)"""
+        idx = np.empty(self.n, dtype=np.int32)
+        clamped = lib().orc_slam_resample(self._h, float(r01), _ip(idx))
+        return idx, int(clamped)
+
+    def neff(self) -> float:
+        return float(lib().orc_slam_neff(self._h))
+
+    def weighted_pose(self) -> np.ndarray:
+        out = np.empty(3, dtype=np.float32)
+        lib().orc_slam_weighted_pose(self._h, _fp(out))
+        return out
