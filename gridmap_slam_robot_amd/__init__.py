@@ -6,7 +6,7 @@ include/gridmapslam.h.  This package is the thin host side: a ctypes binding (_l
 the reference's GridMap / ParticleFilter / SLAM class surface (gridmap), particle sharding over
 torch.distributed (distributed) and the synthetic trace generator used by tests and bench (synth).
 """
-from .gridmap import GridMap, Observation, ParticleFilter, Pose, SLAM  # noqa: F401
+from .gridmap import GridMap, Observation, ParticleFilter, Pose, SLAM, SLAMParticleMaps  # noqa: F401
 from ._lib import BEAM_DTYPE, GmsError, load  # noqa: F401
 
 __version__ = "0.1.0"

@@ -192,6 +192,19 @@ def load() -> C.CDLL:
     sig("gms_map_tile_stats", C.c_int, vp, i32, vp)
     sig("gms_pf_set_log_normalize", C.c_int, vp, i32)
     sig("gms_debug_f32", C.c_int, vp, i32, vp, vp, i64)
+    sig("gms_slam_create", C.c_int, pp, i32, C.POINTER(vp))
+    sig("gms_slam_destroy", C.c_int, vp)
+    sig("gms_slam_reset", C.c_int, vp)
+    sig("gms_slam_count", C.c_int, vp, vp, vp, vp)
+    sig("gms_slam_handles", C.c_int, vp, C.POINTER(vp), C.POINTER(vp))
+    sig("gms_slam_update_per_particle", C.c_int, vp, vp, i32, i32, f64, f64, C.c_uint64, C.c_uint64, sp)
+    sig("gms_slam_update_per_particle_dev", C.c_int, vp, vp, i32, i32, f64, f64, C.c_uint64, C.c_uint64, sp)
+    sig("gms_slam_resample_maps", C.c_int, vp, f64, vp, vp)
+    sig("gms_slam_download_map", C.c_int, vp, i32, vp, vp)
+    sig("gms_slam_upload_map", C.c_int, vp, i32, vp, vp)
+    sig("gms_slam_download_maps", C.c_int, vp, vp, vp)
+    sig("gms_slam_combined", C.c_int, vp)
+    sig("gms_slam_copies", C.c_int, vp, C.POINTER(C.c_int64))
     sig("gms_debug_set_stamps", C.c_int, vp, vp)
     _lib = L
     return L

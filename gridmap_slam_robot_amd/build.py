@@ -10,8 +10,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgridmapslam.so")
-# gms_fused_kernels.hip is the device translation unit: it includes gms_map_kernels.hip and gms_pf_kernels.hip
-SOURCES = ["gms_host.hip", "gms_fused_kernels.hip"]
+# gms_fused_kernels.hip is the device translation unit: it includes gms_map_kernels.hip, gms_pf_kernels.hip and gms_slam_kernels.hip
+SOURCES = ["gms_host.hip", "gms_slam_host.hip", "gms_fused_kernels.hip"]
 # -ffp-contract=off: the reference (JVM) never fuses a multiply with an add; parity depends on it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
          "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

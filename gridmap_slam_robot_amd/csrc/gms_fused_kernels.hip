@@ -13,6 +13,7 @@
 // This file is the device translation unit of the library: it includes the two kernel files.
 #include "gms_map_kernels.hip"
 #include "gms_pf_kernels.hip"
+#include "gms_slam_kernels.hip"
 
 // 256-thread workgroups of a deferred apply pass that rides beside a ray cast (128 to 2048 measure alike at C3)
 #ifndef GMS_APPLY_BLOCKS_RIDING

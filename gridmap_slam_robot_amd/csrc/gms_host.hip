@@ -24,6 +24,14 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+int gms_fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -372,6 +380,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     if (const char *v = getenv("GMS_LIK_SKIP")) m->lik_skip = atoi(v) != 0;
     m->fac_current = 0;
     if (const char *v = getenv("GMS_PAIR_LAUNCHES")) m->pair_launches = atoi(v) != 0;
+    if (const char *v = getenv("GMS_SLAM_TILE_CELLS")) m->slam_tile_cells = atoi(v);
     *out = m;
     return GMS_OK;
 }
@@ -602,6 +611,10 @@ static int stage_beams(gms_map *m, const gms_beam *beams, int32_t B) {
     gms_launch_copy(m, m->d_beams, h, (m->n_maps == 1 ? (size_t)B : (size_t)m->n_maps * m->max_beams) * sizeof(gms_beam));
     return ring_commit(m->beam_ring, m->stream);
 }
+
+}  // extern "C"
+int gms_stage_beams(gms_map *m, const gms_beam *beams, int32_t B) { return stage_beams(m, beams, B); }
+extern "C" {
 
 static int stage_poses(gms_map *m, const float *poses) {
     REQUIRE(poses, "null poses");

@@ -122,6 +122,7 @@ struct gms_map {
     int32_t lik_skip;         // dirty-tile rebuilds leave tiles alone whose codes the scan does not change (GMS_LIK_SKIP=0 turns it off; same bits)
     int32_t raycast_near;     // single-map ray casts: the first 64 steps of every ray go through near-field workgroups with an LDS tile (0 never, 1 for scans of 512 beams or more, 2 for every scan of 32 or more: GMS_RAYCAST_NEAR=0 / unset / 1)
     int32_t pair_launches;    // scan steps pair independent kernels in one launch (GMS_PAIR_LAUNCHES=0 turns it off)
+    int32_t slam_tile_cells;  // per-particle maps: cap on the LDS count tile of k_slam_particle in cells (0 = what the LDS allows; GMS_SLAM_TILE_CELLS, for tests of the band walk)
     gms_beam *h_beams;    // pinned staging (de-skew inputs, single-ray entry)
     StageRing beam_ring;  // pinned staging of scans handed over as host buffers
     float *h_poses;       // pinned staging
@@ -197,6 +198,23 @@ struct gms_comm {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
+// SLAM as the reference has it (J/slam/SLAM.java): N particles, each with its own GridMapData (gms_slam_host.hip, gms_slam_kernels.hip)
+struct gms_slam {
+    gms_map *map;                   // ONE map's worth of handle: the GridMap (geometry, constants, taps), the stream, staging, profiling; its own
+                                    // logData / likelihoodData receive the combined map (gms_slam_combined, GridMapApp.calculateCombined)
+    gms_pf *pf;                     // the N particles' poses, weights, statistics and resampling indices (one "map" of N particles)
+    int32_t n;
+    double *d_log[2], *d_lik[2];    // [n][H][W] every particle's GridMapData, double-buffered for resample()'s deep copies
+    int32_t cur;                    // the buffer that holds the current generation
+    int32_t reference_order;        // gms_slam_set_reference_order: weightSum / the cumulative weights as ONE sequential chain (SLAM.java:100,137-144)
+    int64_t copies;                 // maps copied by resampling steps so far (measurement)
+};
+
+// the thread's last-error text + code (gms_host.hip); every C-ABI file reports through it
+int gms_fail(int code, const char *fmt, ...);
+// host beams [n_maps][B] -> the map's device staging buffer [n_maps][max_beams] through the pinned ring (gms_host.hip)
+int gms_stage_beams(gms_map *m, const gms_beam *beams, int32_t B);
+
 // ---- kernel launchers (gms_map_kernels.hip / gms_pf_kernels.hip) -----------------------------
 
 void gms_launch_raycast(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses,
@@ -259,6 +277,12 @@ void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedPa
 void gms_launch_pf_stats_only(gms_pf *pf, const double *d_partials, PfStatsDev *d_stats_out);
 void gms_launch_pf_resample(gms_pf *pf, double fraction /* <0: unconditional */);
 void gms_launch_pf_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);
+// one GridMapData per particle (gms_slam_kernels.hip)
+void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, int32_t n);
+void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, double *d_log, const double *d_lik, const MotionModel *motion,
+                              int32_t integrate);
+void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik);
+void gms_launch_slam_combine(gms_map *dst, const double *d_logs, int32_t n);
 
 // profiling brackets
 void gms_prof_begin(gms_map *m, int32_t k);

@@ -1,0 +1,194 @@
+// gms_slam_host.hip -- C-ABI of the reference's own filter shape: SLAM (J/slam/SLAM.java), every particle with its own GridMapData.
+// Handle lifetime and the launch sequences of SLAM.update / SLAM.resample; the kernels are in gms_slam_kernels.hip.  No CPU path.
+#include <math.h>
+#include <string.h>
+
+#include <new>
+
+#include "gms_internal.h"
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return gms_fail(GMS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+#define REQUIRE(cond, msg)                                         \
+    do {                                                           \
+        if (!(cond)) return gms_fail(GMS_ERR_INVALID, "%s", msg);  \
+    } while (0)
+
+extern "C" {
+
+int gms_slam_destroy(gms_slam *s) {
+    if (!s) return GMS_OK;
+    if (s->map) { hipSetDevice(s->map->device); hipStreamSynchronize(s->map->stream); }
+    for (int k = 0; k < 2; k++) { hipFree(s->d_log[k]); hipFree(s->d_lik[k]); }
+    if (s->pf) gms_pf_destroy(s->pf);
+    if (s->map) gms_map_destroy(s->map);
+    delete s;
+    return GMS_OK;
+}
+
+int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out) {            // SLAM.java:56-62
+    REQUIRE(p && out, "gms_slam_create: null argument");
+    *out = nullptr;
+    REQUIRE(p->n_maps == 1, "gms_slam_create: gms_params.n_maps must be 1 (every particle gets a map of its own)");
+    REQUIRE(n_particles >= 1 && n_particles <= 65535, "gms_slam_create: particle count out of range (1 .. 65535)");
+    gms_slam *s = new (std::nothrow) gms_slam();
+    if (!s) return gms_fail(GMS_ERR_NOMEM, "out of host memory");
+    s->n = n_particles;
+    int rc = gms_map_create(p, &s->map);                                                   // new GridMap(...) :57
+    if (!rc) rc = gms_pf_create(s->map, n_particles, &s->pf);                              // the particle list :59
+    if (rc) { gms_slam_destroy(s); return rc; }
+    gms_map *m = s->map;
+    // the per-particle kernel keeps one row of the count tile at the very least (gms_launch_slam_particle)
+    if ((size_t)m->max_beams * 8 + 16384 + (size_t)m->gd.W * 4 + 4096 > (size_t)m->lds_per_cu) {
+        gms_slam_destroy(s);
+        return gms_fail(GMS_ERR_INVALID, "gms_slam_create: %d beams and rows of %d cells do not fit a workgroup's LDS", m->max_beams, m->gd.W);
+    }
+    const size_t bytes = (size_t)n_particles * (size_t)m->gd.cells * sizeof(double);
+    bool ok = true;
+    for (int k = 0; k < 2; k++)
+        ok = ok && hipMalloc(&s->d_log[k], bytes) == hipSuccess && hipMalloc(&s->d_lik[k], bytes) == hipSuccess;
+    if (!ok) {
+        gms_slam_destroy(s);
+        return gms_fail(GMS_ERR_NOMEM, "gms_slam_create: device allocation failed (%d particles x %lld cells x 32 bytes)", n_particles, (long long)m->gd.cells);
+    }
+    *out = s;
+    return gms_slam_reset(s);
+}
+
+int gms_slam_reset(gms_slam *s) {                                                           // SLAM.java:65-77
+    REQUIRE(s, "null handle");
+    gms_map *m = s->map;
+    HIPCHK(hipSetDevice(m->device));
+    const size_t bytes = (size_t)s->n * (size_t)m->gd.cells * sizeof(double);
+    // createMapData(null) per particle (GridMap.java:106-117): logData = logOdds(0.5) = 0.0, likelihoodData a fresh double[] = 0.0
+    HIPCHK(hipMemsetAsync(s->d_log[s->cur], 0, bytes, m->stream));
+    HIPCHK(hipMemsetAsync(s->d_lik[s->cur], 0, bytes, m->stream));
+    gms_launch_pf_init(s->pf);                                                               // Pose(0, 0, 0), weight 1 / numParticles (:68-71)
+    s->pf->pending_nseg = 0; s->pf->have_global = 0; s->pf->stats_current = 0; s->pf->score_fresh = 0;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_slam_handles(gms_slam *s, gms_map **map, gms_pf **pf) {
+    REQUIRE(s, "null handle");
+    if (map) *map = s->map;
+    if (pf) *pf = s->pf;
+    return GMS_OK;
+}
+
+int gms_slam_count(const gms_slam *s, int32_t *n, int32_t *W, int32_t *H) {
+    REQUIRE(s, "null handle");
+    if (n) *n = s->n;
+    if (W) *W = s->map->gd.W;
+    if (H) *H = s->map->gd.H;
+    return GMS_OK;
+}
+
+// SLAM.update(z, u) on a device-resident scan (SLAM.java:80-131)
+int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                                     uint64_t seed, uint64_t sequence, gms_pf_stats *stats) {
+    REQUIRE(s && dev_beams, "null argument");
+    gms_map *m = s->map;
+    gms_pf *pf = s->pf;
+    REQUIRE(B >= 0 && B <= m->max_beams, "beam count exceeds gms_params.max_beams");
+    HIPCHK(hipSetDevice(m->device));
+    const bool skip_update = fabs(d_theta) > (3.141592653589793 / 180.0) * 30;                              // :82
+    MotionModel mo;
+    mo.d_center = d_center; mo.d_theta = d_theta; mo.seed = seed; mo.sequence = sequence;
+    gms_launch_slam_likelihood(m, s->d_log[s->cur], s->d_lik[s->cur], s->n);                                // :93 for every particle
+    gms_launch_slam_particle(pf, dev_beams, B, s->d_log[s->cur], s->d_lik[s->cur], sample_motion ? &mo : nullptr, skip_update ? 0 : 1);   // :90, :99, :102-107
+    pf->have_global = 0;
+    pf->stats_current = 0;
+    HIPCHK(hipGetLastError());
+    return gms_pf_normalize(pf, stats);                                                                    // :100, :110-124 (stats: synchronises)
+}
+
+int gms_slam_update_per_particle(gms_slam *s, const gms_beam *beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                                 uint64_t seed, uint64_t sequence, gms_pf_stats *stats) {
+    REQUIRE(s && beams, "null argument");
+    int rc = gms_stage_beams(s->map, beams, B);
+    if (rc) return rc;
+    return gms_slam_update_per_particle_dev(s, s->map->d_beams, B, sample_motion, d_center, d_theta, seed, sequence, stats);
+}
+
+// SLAM.resample() (SLAM.java:133-153): the systematic draw over the particles' weights, then every slot's deep copy
+int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n_ambiguous) {
+    REQUIRE(s, "null handle");
+    gms_map *m = s->map;
+    HIPCHK(hipSetDevice(m->device));
+    int rc = gms_pf_resample(s->pf, &r01, indices, n_ambiguous);                                           // :136-145 + pose, weight (:42-43)
+    if (rc) return rc;
+    gms_launch_slam_gather_maps(s->pf, s->d_log[s->cur], s->d_lik[s->cur], s->d_log[1 - s->cur], s->d_lik[1 - s->cur]);   // :44
+    s->cur = 1 - s->cur;                                                                                   // :152
+    s->copies += s->n;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+static int slam_map_xfer(gms_slam *s, int32_t i, int32_t count, double *dev_base, double *host, bool to_device) {
+    gms_map *m = s->map;
+    const size_t cells = (size_t)m->gd.cells;
+    double *dev = dev_base + (size_t)i * cells;
+    const size_t bytes = (size_t)count * cells * sizeof(double);
+    if (to_device) HIPCHK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, m->stream));
+    else HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, m->stream));
+    return GMS_OK;
+}
+
+int gms_slam_download_map(gms_slam *s, int32_t i, double *log_data, double *lik) {          // Particle.m (SLAM.java:33)
+    REQUIRE(s && i >= 0 && i < s->n, "gms_slam_download_map: particle index out of range");
+    HIPCHK(hipSetDevice(s->map->device));
+    int rc = GMS_OK;
+    if (log_data) rc = slam_map_xfer(s, i, 1, s->d_log[s->cur], log_data, false);
+    if (!rc && lik) rc = slam_map_xfer(s, i, 1, s->d_lik[s->cur], lik, false);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(s->map->stream));
+    return GMS_OK;
+}
+
+int gms_slam_download_maps(gms_slam *s, double *log_all, double *lik_all) {
+    REQUIRE(s, "null handle");
+    HIPCHK(hipSetDevice(s->map->device));
+    int rc = GMS_OK;
+    if (log_all) rc = slam_map_xfer(s, 0, s->n, s->d_log[s->cur], log_all, false);
+    if (!rc && lik_all) rc = slam_map_xfer(s, 0, s->n, s->d_lik[s->cur], lik_all, false);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(s->map->stream));
+    return GMS_OK;
+}
+
+int gms_slam_upload_map(gms_slam *s, int32_t i, const double *log_data, const double *lik) {
+    REQUIRE(s && i >= 0 && i < s->n, "gms_slam_upload_map: particle index out of range");
+    HIPCHK(hipSetDevice(s->map->device));
+    int rc = GMS_OK;
+    if (log_data) rc = slam_map_xfer(s, i, 1, s->d_log[s->cur], const_cast<double *>(log_data), true);
+    if (!rc && lik) rc = slam_map_xfer(s, i, 1, s->d_lik[s->cur], const_cast<double *>(lik), true);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(s->map->stream));
+    return GMS_OK;
+}
+
+// GridMapApp.calculateCombined (J/app/GridMapApp.java:439-458) over the particles' maps, into the handle's own GridMap:
+// read it with gms_map_download_log / gms_map_download_likelihood on the map of gms_slam_handles.
+int gms_slam_combined(gms_slam *s) {
+    REQUIRE(s, "null handle");
+    gms_map *m = s->map;
+    HIPCHK(hipSetDevice(m->device));
+    gms_ensure_lik(m);
+    gms_flush_apply(m);
+    gms_launch_slam_combine(m, s->d_log[s->cur], s->n);                                       // :441-455
+    m->need_full_build = 1; m->fac_current = 0;
+    HIPCHK(hipGetLastError());
+    return gms_map_build_likelihood(m);                                                       // :457
+}
+
+int gms_slam_copies(const gms_slam *s, int64_t *maps_copied) {
+    REQUIRE(s && maps_copied, "null argument");
+    *maps_copied = s->copies;
+    return GMS_OK;
+}
+
+}  // extern "C"

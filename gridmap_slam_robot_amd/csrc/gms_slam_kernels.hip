@@ -1,0 +1,358 @@
+// gms_slam_kernels.hip -- the reference's own filter shape: SLAM (J/slam/SLAM.java), N particles, each with ITS OWN GridMapData.
+//
+// In the reference every Particle owns a map (SLAM.java:30-47): update() rebuilds the particle's likelihood field, scores the
+// scan against it and integrates the scan into the particle's map at the particle's pose (:88-107); resample() deep-copies both
+// arrays of the surviving particle's map (:41-45 -> GridMap.createMapData(other), J/slam/GridMap.java:106-124).  The shared-map
+// filter of gms_pf_kernels.hip is what BASELINE's configurations need (16 384 poses against one 2048^2 map); this file is what
+// SLAM.update / SLAM.resample literally do, at the reference's own operating point (500 particles x 120^2 cells, SLAM.java:50,57)
+// and beyond (thousands of particles x 256^2).
+//
+// HBM layout: logData / likelihoodData of all particles as two arrays [N][H][W] of doubles (a particle's map is GridMapData's two
+// arrays as they are, row-major x + y * W), double-buffered for the resampling copy.  Poses, weights and every statistic live in a
+// gms_pf of N particles (one "map" of particles): the normalisation, Neff, weighted pose and the systematic resampling's index search
+// are the kernels of gms_pf_kernels.hip, unchanged.
+//
+//   k_slam_likelihood   computeLikelihoodMap(p.m) for every particle (SLAM.java:93): likelihood_body over [tiles][N] workgroups,
+//                       likelihoodData only (16 bytes per cell: the streaming kernel of this mode)
+//   k_slam_particle     one workgroup per particle: the motion-model sample (:90), probabilityOf(p.m, z, p.pose) with the product
+//                       taken by ONE lane in beam order -- the reference's own association, bit for bit, underflow included (:99,
+//                       GridMap.java:262-288) -- and integrateObservation(p.m, z, p.pose) (:105): all rays of the scan walked by
+//                       producer wavefronts (RayIterator's float recurrence, ray_phase_a), their cells counted by consumer wavefronts
+//                       in an LDS tile of the scan's bounding box, and `logData[c] += ...` (GridMap.java:223) applied from that tile
+//                       straight to the particle's rows: no count grid in memory, no global atomic, touched cells read and written once
+//   k_slam_gather_maps  resample()'s deep copies: map[m] <- map[idx[m]] for both arrays, a pure HBM stream (32 bytes per cell)
+#include "gms_device.h"
+
+#define PS_WORDS 8                      // decision words per ray and round of k_slam_particle (256 steps of the walk)
+
+// likelihoodData of every particle's map from its logData (mode 1 of likelihood_body: no factor table, no tile states, every tile)
+template <int KH>
+__global__ void __launch_bounds__(256)
+k_slam_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, const double *__restrict__ taps_g,
+                  int32_t tiles_x, int32_t tiles_y) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    likelihood_body<KH>(g, logd, lik, lik, 0, taps_g, nullptr, 0, tiles_x, tiles_y, blockIdx.x, blockIdx.y, gridDim.x, smem, nullptr,
+                        nullptr, 1);
+}
+
+// GridMap.integrateObservation's per-beam locals (GridMap.java:175-188) from a transform that is already at hand (make_ray takes
+// the pose and its trig)
+__device__ __forceinline__ RayIn ps_make_ray(const GridDev &g, const XformDev &t, const gms_beam &m) {
+    RayIn r;
+    r.sx = (float)((xform_x(t, 0.0, 0.0) - g.posx) / g.res);                  // :178
+    r.sy = (float)((xform_y(t, 0.0, 0.0) - g.posy) / g.res);                  // :179
+    r.ex = (float)((xform_x(t, m.local_x, m.local_y) - g.posx) / g.res);      // :185
+    r.ey = (float)((xform_y(t, m.local_x, m.local_y) - g.posy) / g.res);      // :186
+    r.measured = (float)m.distance / g.resf;                                  // :188
+    r.hit = m.hit != 0;
+    return r;
+}
+
+// phase B of the ray cast (ray_phase_b) for an LDS tile of 32-bit cells n_free | n_occ << 16 -- a whole scan's visits of one cell fit
+// (gms_map_create: (1 + extra) * beams < 65536) -- covering [tx0, tx0 + tw) x [ty0, ty0 + th); cells outside it belong to another band
+__device__ __forceinline__ void ps_phase_b(const GridDev &g, const RayMeta &mt, const uint64_t *__restrict__ slots, int32_t stride, int32_t slot,
+                                           int32_t blk, int32_t lane, uint32_t *__restrict__ tile, int32_t tx0, int32_t ty0, int32_t tw,
+                                           int32_t th, int32_t w_base) {
+    const int32_t nwords = (mt.n_eff + 31) >> 5;
+    const int32_t w0 = 2 * blk - w_base, w1 = min(2 * blk + 1, nwords - 1) - w_base;
+    uint64_t a, c;
+    for (;;) {                                         // wave-uniform: every lane reads the same two slots
+        lds_poll_2xu64(&slots[w0 * stride + slot], &slots[w1 * stride + slot], a, c);
+        if (((a & c) >> 63) != 0u) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    const int32_t k = blk * 64 + lane;
+    if (k >= mt.n_eff) return;
+    const uint64_t sl = lane < 32 ? a : c;
+    const int32_t j = lane & 31;
+    const int32_t ny = (int32_t)(((uint32_t)(sl >> 32) & ~RC_VALID) + __popc((uint32_t)sl & ((1u << j) - 1u)));
+    const int32_t nx = k - ny;
+    const int32_t cx = mt.x0 + mt.x_inc * nx, cy = mt.y0 + mt.y_inc * ny;
+    if (cx < 0 || cx >= g.W || cy < 0 || cy >= g.H) return;                                // RayIterator.java:108
+    const float d = cell_distance(mt.sx, mt.sy, cx, cy);                                   // GridMap.java:215-217
+    const int32_t cls = sensor_class(d, mt.measured, mt.hit, g.half_tol);                  // :223
+    if (cls == 1) return;                                                                  // += logOdds(0.5) = 0.0
+    const uint32_t ux = (uint32_t)(cx - tx0), uy = (uint32_t)(cy - ty0);
+    if (ux < (uint32_t)tw && uy < (uint32_t)th)
+        __hip_atomic_fetch_add((gms_lds_u32 *)(tile) + (uy * (uint32_t)tw + ux), cls == 0 ? 1u : 0x10000u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One workgroup per particle.  NT threads, NP producer wavefronts (64 * NP rays walked at a time), the rest consumers.
+// Dynamic LDS: factors [Bpad] f64 | decision slots [PS_WORDS][64 NP] u64 | ray records [64 NP] | count tile [tile_cap] u32.
+template <int NT, int NP>
+__global__ void __launch_bounds__(NT)
+k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, double *__restrict__ log_all,
+                const double *__restrict__ lik_all, float *__restrict__ pose, float *__restrict__ cs, double *__restrict__ w,
+                double *__restrict__ logw, MotionArgs mo, int32_t integrate, int32_t tile_cap) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NW = NT / 64, GR = 64 * NP, NC = NW - NP;
+    static_assert(NC >= 1, "at least one consumer wavefront");
+    double *s_fac = reinterpret_cast<double *>(smem);                          // [Bpad]
+    uint64_t *s_slots = reinterpret_cast<uint64_t *>(s_fac + Bpad);            // [PS_WORDS][GR]
+    RayMeta *s_meta = reinterpret_cast<RayMeta *>(s_slots + PS_WORDS * GR);    // [GR]
+    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_meta + GR);              // [tile_cap]
+    __shared__ float s_pose[5];                                                // x, y, theta, (float)cos, (float)sin
+    __shared__ int32_t s_box[4];                                               // the scan's box x0, y0, x1, y1 (inclusive)
+    __shared__ int32_t s_grp_words[NP];
+    __shared__ double s_red[NW];
+    const int32_t p = blockIdx.x;
+    const int32_t lane = threadIdx.x & 63;
+    const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6));
+
+    // ---- the particle's pose: sampleMotionModel (SLAM.java:90, Odometry.java:77-96) or the pose as it stands
+    if (wave == 0) {
+        float x = pose[3 * (size_t)p], y = pose[3 * (size_t)p + 1], th = pose[3 * (size_t)p + 2], c, sn;
+        if (mo.on) {                                                           // (uniform)
+            motion_apply(x, y, th, c, sn, (uint64_t)p, mo.d_center, mo.d_theta, mo.d_center_sd, mo.d_theta_sd, mo.seed, mo.sequence);
+        } else {
+            c = cs[2 * (size_t)p]; sn = cs[2 * (size_t)p + 1];                 // (cs[] always matches pose[]: k_pose_trig)
+        }
+        if (lane == 0) {
+            s_pose[0] = x; s_pose[1] = y; s_pose[2] = th; s_pose[3] = c; s_pose[4] = sn;
+            if (mo.on) {
+                pose[3 * (size_t)p] = x; pose[3 * (size_t)p + 1] = y; pose[3 * (size_t)p + 2] = th;
+                cs[2 * (size_t)p] = c; cs[2 * (size_t)p + 1] = sn;
+            }
+        }
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 68) s_box[threadIdx.x - 64] = threadIdx.x < 66 ? INT32_MAX : INT32_MIN;
+    __syncthreads();
+    XformDev t;
+    t.px = (double)s_pose[0]; t.py = (double)s_pose[1]; t.c = (double)s_pose[3]; t.s = (double)s_pose[4];      // Transform.java:13-21
+
+    // ---- probabilityOf(p.m, z, p.pose): the factors in parallel, the product by one lane in beam order (GridMap.java:262-288);
+    //      beside it every beam's ray box (GridMap.java:175-188 + ray_meta) for the count tile
+    const double *lik = lik_all + (size_t)p * (size_t)g.cells;
+    double lsum = 0.0;
+    int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
+    for (int32_t b = (int32_t)threadIdx.x; b < B; b += NT) {
+        const gms_beam bm = beams[b];
+        double f = 1.0;                                                        // a beam that is skipped leaves the product as it is: x * 1.0 == x
+        if (bm.hit) {                                                          // :269
+            const int32_t gx = j_cell_exact(xform_x(t, bm.local_x, bm.local_y) - g.posx, g.res);      // :273
+            const int32_t gy = j_cell_exact(xform_y(t, bm.local_x, bm.local_y) - g.posy, g.res);      // :274
+            if (!(gx < 0 || gy < 0 || gx >= g.W || gy >= g.H))                                        // :276
+                f = lik_factor(g, lik[(size_t)gy * g.W + gx]);                                        // :277-288
+        }
+        s_fac[b] = f;
+        lsum += log(f);
+        if (integrate) {
+            RayDev r;
+            const RayMeta mt = ray_meta(g, ps_make_ray(g, t, bm), r);
+            if (mt.n_eff > 0) {
+                bx0 = min(bx0, min(mt.x0, mt.hx)); bx1 = max(bx1, max(mt.x0, mt.hx));
+                by0 = min(by0, min(mt.y0, mt.hy)); by1 = max(by1, max(mt.y0, mt.hy));
+            }
+        }
+    }
+    lsum = wave_sum_f64(lsum);
+    if (lane == 0) s_red[wave] = lsum;
+    if (integrate) {
+#define GMS_STEP_(O) { bx0 = min(bx0, wave_xor<O>(bx0)); by0 = min(by0, wave_xor<O>(by0)); bx1 = max(bx1, wave_xor<O>(bx1)); by1 = max(by1, wave_xor<O>(by1)); }
+        GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
+        if (lane == 0 && bx1 >= bx0) {
+            atomicMin(&s_box[0], bx0); atomicMin(&s_box[1], by0); atomicMax(&s_box[2], bx1); atomicMax(&s_box[3], by1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == NT - 64) {
+        // the last wavefront's first lane, while the others set up the ray cast: product *= factor, beam by beam (:262, :286-288)
+        double prod = 1.0;
+        int32_t b = 0;
+        for (; b + 8 <= B; b += 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = s_fac[b + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) prod *= v[k];
+        }
+        for (; b < B; b++) prod *= s_fac[b];
+        double ls = 0.0;
+        for (int k = 0; k < NW; k++) ls += s_red[k];
+        w[p] = prod;                                                           // p.weight (SLAM.java:99)
+        logw[p] = ls;                                                          // sum of log factors: the underflow-free companion
+    }
+    if (!integrate) return;                                                    // skipUpdate (SLAM.java:82,102)
+
+    // ---- integrateObservation(p.m, z, p.pose) (SLAM.java:105, GridMap.java:173-228)
+    const int32_t X0 = s_box[0], Y0 = s_box[1], X1 = s_box[2], Y1 = s_box[3];
+    if (X1 < X0) return;                                                       // no ray touches the map
+    const int32_t tw = X1 - X0 + 1, th_all = Y1 - Y0 + 1;
+    const int32_t band_rows = max(1, min(th_all, tile_cap / tw));              // (the launcher guarantees tile_cap >= W)
+    double *mlog = log_all + (size_t)p * (size_t)g.cells;
+    for (int32_t ty0 = Y0; ty0 <= Y1; ty0 += band_rows) {
+        const int32_t th = min(band_rows, Y1 - ty0 + 1);
+        for (int32_t i = threadIdx.x; i < tw * th; i += NT) s_tile[i] = 0u;
+        for (int32_t g0 = 0; g0 < B; g0 += GR) {
+            // this group's rays: a producer lane per ray (the same arithmetic as the box pass above: same values)
+            RayDev r;
+            r.dx = r.dy = r.error = 0.0f; r.x = r.y = r.x_inc = r.y_inc = r.n = 0;
+            int32_t my_nwords = 0;
+            if (wave < NP) {
+                const int32_t ri = g0 + wave * 64 + lane;
+                RayMeta mt;
+                mt.n_eff = 0; mt.x0 = mt.y0 = mt.x_inc = mt.y_inc = mt.hit = 0; mt.sx = mt.sy = mt.measured = 0.0f; mt.hx = mt.hy = 0;
+                if (ri < B) mt = ray_meta(g, ps_make_ray(g, t, beams[ri]), r);
+                // a ray that never enters this band's rows is not walked for it (its box says so)
+                if (mt.n_eff > 0 && (max(mt.y0, mt.hy) < ty0 || min(mt.y0, mt.hy) >= ty0 + th)) mt.n_eff = 0;
+                s_meta[wave * 64 + lane] = mt;
+                my_nwords = (mt.n_eff + 31) >> 5;
+                int32_t nwm = my_nwords;
+#define GMS_STEP_(O) nwm = max(nwm, wave_xor<O>(nwm));
+                GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
+                if (lane == 0) s_grp_words[wave] = nwm;
+            }
+            __syncthreads();
+            int32_t nwords_max = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++) nwords_max = max(nwords_max, s_grp_words[k]);
+            RayWalk wk = ray_walk_begin(r);
+            for (int32_t wb = 0; wb < nwords_max; wb += PS_WORDS) {            // one round = up to 256 steps of every ray of the group
+                for (int32_t i = threadIdx.x; i < PS_WORDS * GR; i += NT) s_slots[i] = 0ull;
+                __syncthreads();                                               // (also: the tile is cleared, the previous round consumed)
+                if (wave < NP) {
+                    if (wb < my_nwords) ray_phase_a(wk, wb, min(my_nwords, wb + PS_WORDS), s_slots, GR, wave * 64 + lane);
+                } else {
+                    const int32_t blk0 = wb >> 1, nblk = min(PS_WORDS / 2, (nwords_max - wb + 1) >> 1);
+                    for (int32_t q = wave - NP; q < nblk * GR; q += NC) {
+                        const int32_t blk = blk0 + q / GR, slot = q % GR;
+                        const RayMeta mt = s_meta[slot];
+                        if (blk * 64 >= mt.n_eff) continue;
+                        ps_phase_b(g, mt, s_slots, GR, slot, blk, lane, s_tile, X0, ty0, tw, th, wb);
+                    }
+                }
+                __syncthreads();
+            }
+            if (nwords_max == 0) __syncthreads();                              // (s_meta / s_grp_words are rewritten by the next group)
+        }
+        // logData[c] += n_free * logOdds(P_FREE) + n_occ * logOdds(P_OCC): the expression of apply_body (GridMap.java:223)
+        for (int32_t ry = wave; ry < th; ry += NW) {
+            const size_t row = (size_t)(ty0 + ry) * g.W + X0;
+            for (int32_t rx = lane; rx < tw; rx += 64) {
+                const uint32_t c = s_tile[ry * tw + rx];
+                if (c) mlog[row + rx] = mlog[row + rx] + ((double)(c & 0xffffu) * g.l_free + (double)(c >> 16) * g.l_occ);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// resample()'s deep copies (SLAM.java:147 -> :41-45 -> GridMap.java:106-124): slot m of the new generation receives both arrays of
+// particle idx[m]'s map.  grid = (chunks, N); a workgroup streams its chunk of both arrays, 16 bytes per lane, four loads in flight.
+__global__ void __launch_bounds__(256)
+k_slam_gather_maps(const double *__restrict__ src_log, const double *__restrict__ src_lik, double *__restrict__ dst_log,
+                   double *__restrict__ dst_lik, const int32_t *__restrict__ idx, int64_t cells) {
+    const int32_t m = blockIdx.y;
+    const int32_t i = idx[m];
+    const size_t so = (size_t)i * (size_t)cells, dof = (size_t)m * (size_t)cells;
+    if ((cells & 1) == 0) {                            // every map starts on a 16-byte boundary
+        const int64_t n2 = cells >> 1;
+        const double2 *sl = reinterpret_cast<const double2 *>(src_log + so), *sk = reinterpret_cast<const double2 *>(src_lik + so);
+        double2 *dl = reinterpret_cast<double2 *>(dst_log + dof), *dk = reinterpret_cast<double2 *>(dst_lik + dof);
+        const int64_t stride = (int64_t)gridDim.x * 256;
+        for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < n2; e0 += 2 * stride) {
+            const int64_t e1 = e0 + stride;
+            const bool two = e1 < n2;
+            const double2 a0 = sl[e0], b0 = sk[e0];
+            double2 a1 = a0, b1 = b0;
+            if (two) { a1 = sl[e1]; b1 = sk[e1]; }
+            dl[e0] = a0; dk[e0] = b0;
+            if (two) { dl[e1] = a1; dk[e1] = b1; }
+        }
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < cells; e += (int64_t)gridDim.x * 256) {
+            dst_log[dof + e] = src_log[so + e];
+            dst_lik[dof + e] = src_lik[so + e];
+        }
+    }
+}
+
+// createMapData(null) for every particle (SLAM.reset, SLAM.java:65-77): logData = logOdds(0.5) = 0.0, likelihoodData = 0.0
+// (hipMemsetAsync does it: both are all-zero bit patterns)
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, int32_t n) {
+    ProfScope ps(m, GMS_K_LIKELIHOOD);
+    const int32_t k = m->gd.khalf;
+    const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
+    const size_t smem = gms_likelihood_lds_bytes(k);
+    // a workgroup per tile while that stays a few rounds of the chip; beyond it persistent workgroups walk a map's tiles
+    int32_t blocks = tiles_x * tiles_y;
+    int32_t per_cu = (int32_t)((size_t)m->lds_per_cu / (smem + 256));
+    if (per_cu > GMS_LIK_WG_PER_CU) per_cu = GMS_LIK_WG_PER_CU;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t resident = (int64_t)per_cu * m->n_cus;
+    while (blocks > 1 && (int64_t)blocks * n > 64 * resident) blocks = (blocks + 1) / 2;
+    dim3 grid((unsigned)blocks, (unsigned)n);
+#define SLK_LAUNCH(KH)                                                                                                          \
+    do {                                                                                                                          \
+        if (smem > 48 * 1024)                                                                                                     \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_likelihood<KH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((k_slam_likelihood<KH>), grid, dim3(256), smem, m->stream, m->gd, d_log, d_lik, m->d_taps, tiles_x, tiles_y); \
+    } while (0)
+    if (k == 3) SLK_LAUNCH(3);
+    else if (k == 5) SLK_LAUNCH(5);
+    else SLK_LAUNCH(0);
+#undef SLK_LAUNCH
+}
+
+// dynamic LDS of k_slam_particle<NT, NP> without its count tile
+static inline size_t slam_particle_fixed_lds(int32_t Bpad, int np) {
+    return (size_t)Bpad * sizeof(double) + (size_t)PS_WORDS * 64 * np * sizeof(uint64_t) + (size_t)64 * np * sizeof(RayMeta);
+}
+
+// SLAM.update's per-particle body for all n particles of pf (one map each, d_log / d_lik [n][cells]); motion may be NULL
+void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, double *d_log, const double *d_lik, const MotionModel *motion,
+                              int32_t integrate) {
+    gms_map *m = pf->map;
+    MotionArgs mo;
+    mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0;
+    if (motion) {
+        mo.on = 1; mo.d_center = motion->d_center; mo.d_theta = motion->d_theta; mo.seed = motion->seed; mo.sequence = motion->sequence;
+        mo.d_center_sd = (0.01 + fabs(motion->d_center) * 0.05) / 2;             // Odometry.java:63
+        mo.d_theta_sd = 5 * (3.141592653589793 / 180.0) + 0.1 * fabs(motion->d_theta);   // :64
+    }
+    ProfScope ps(m, GMS_K_SCORE);
+    const int32_t Bpad = (B + 7) & ~7;
+    constexpr int NP = 2;
+    const size_t fixed = slam_particle_fixed_lds(Bpad, NP);
+    // the count tile: the whole map when two workgroups then still share a CU's LDS, else whatever one workgroup can have (the kernel
+    // walks the scan's box in bands of rows when it is larger)
+    const size_t lds_wg = (size_t)m->lds_per_cu - 2048;                         // (static LDS of the kernel, allocation granularity)
+    size_t cells = (size_t)m->gd.cells;
+    size_t tile = cells;
+    if (fixed + tile * 4 > lds_wg / 2) {
+        const size_t room = lds_wg > fixed ? (lds_wg - fixed) / 4 : 0;
+        if (tile > room) tile = room;
+    }
+    if (m->slam_tile_cells > 0 && tile > (size_t)m->slam_tile_cells) tile = (size_t)m->slam_tile_cells;
+    if (tile < (size_t)m->gd.W) tile = (size_t)m->gd.W;                         // one row at least (refused at creation if even that cannot fit)
+    const size_t smem = fixed + tile * 4;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_particle<1024, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((k_slam_particle<1024, NP>), dim3((unsigned)pf->n), dim3(1024), smem, m->stream, m->gd, d_beams, B, Bpad, d_log, d_lik,
+                       pf->d_pose, pf->d_cs, pf->d_w, pf->d_logw, mo, integrate, (int32_t)tile);
+    pf->pending_nseg = 0;
+    pf->score_fresh = 1;
+}
+
+void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik) {
+    gms_map *m = pf->map;
+    ProfScope ps(m, GMS_K_RESAMPLE);
+    const int64_t cells = m->gd.cells;
+    // 256 lanes x 16 bytes x 2 in flight per array = 8 KiB of each array per workgroup pass
+    int64_t chunks = (cells / 2 + 511) / 512;
+    if (chunks < 1) chunks = 1;
+    while (chunks > 1 && chunks * pf->n > 65536) chunks = (chunks + 1) / 2;
+    hipLaunchKernelGGL(k_slam_gather_maps, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, src_log, src_lik, dst_log, dst_lik,
+                       pf->d_idx, cells);
+}
+
+// GridMapApp.calculateCombined over the particles' maps (J/app/GridMapApp.java:439-458) into a single map's logData
+void gms_launch_slam_combine(gms_map *dst, const double *d_logs, int32_t n) {
+    hipLaunchKernelGGL(k_combine, dim3(2048), dim3(256), 0, dst->stream, d_logs, n, dst->gd.cells, dst->d_log);
+}

@@ -692,3 +692,161 @@ class SLAM:
     getParticles = get_particles
     getStrongestParticle = get_strongest_particle
     getGridMap = get_grid_map
+
+
+class _Borrowed:
+    """a handle owned by another object (never destroyed from here)"""
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+class _BorrowedMap(_Borrowed, GridMap):
+    def __init__(self, handle, params):
+        self.params = params
+        self._h = handle
+        W, H, M = C.c_int32(), C.c_int32(), C.c_int32()
+        check(load().gms_map_get_size(self._h, C.byref(W), C.byref(H), C.byref(M)))
+        self.W, self.H, self.n_maps = W.value, H.value, M.value
+        self._filters = weakref.WeakSet()
+
+
+class _BorrowedFilter(_Borrowed, ParticleFilter):
+    def __init__(self, handle, grid_map, n):
+        self.map = grid_map
+        self.n = n
+        self.n_maps = 1
+        self._h = handle
+        self.offset, self.n_global = 0, n
+
+
+class SLAMParticleMaps:
+    """SLAM as the reference has it (J/slam/SLAM.java:26-204): num_particles particles, each with its own pose, weight AND
+    GridMapData -- update() scores a particle against its own likelihood field and integrates the scan into its own map at its own
+    pose (:88-107), resample() deep-copies the surviving particles' maps (:41-45).  (`SLAM` above is the shared-map filter that
+    BASELINE's configurations need.)  findBestPoseOptim (:97) is left out; the motion-model draw is Philox(seed; particle, sequence)."""
+
+    def __init__(self, width=6.0, height=6.0, resolution=0.05, position=(-3.0, -3.0), num_particles=500, device: int = 0,
+                 max_beams: int = 0, kernel=None):
+        L = load()
+        p = GmsParams()
+        check(L.gms_params_default(C.byref(p), width, height, resolution, position[0], position[1]))   # SLAM.java:57
+        p.device = device
+        p.max_beams = max_beams
+        if kernel is not None:
+            k = np.asarray(kernel, dtype=np.float64)
+            p.ktaps = k.size
+            for i, t in enumerate(k):
+                p.kernel[i] = float(t)
+        self.params = p
+        self.num_particles = int(num_particles)                                                          # :50
+        self._h = C.c_void_p()
+        check(L.gms_slam_create(C.byref(p), self.num_particles, C.byref(self._h)))
+        mh, ph = C.c_void_p(), C.c_void_p()
+        check(L.gms_slam_handles(self._h, C.byref(mh), C.byref(ph)))
+        self.grid_map = _BorrowedMap(mh, p)                     # getGridMap() (:200); its GridMapData receives calculate_combined()
+        self.pf = _BorrowedFilter(ph, self.grid_map, self.num_particles)
+        self.W, self.H = self.grid_map.W, self.grid_map.H
+        self.strongest = 0
+        self.neff = float(num_particles)
+        self.sequence = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.grid_map.close(); self.pf.close()
+            check(load().gms_slam_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        check(load().gms_slam_reset(self._h))                                                            # :65-77
+
+    def update(self, z, odometry=None, seed: int = 0, sequence: Optional[int] = None, fetch: bool = True, sample_motion: bool = True):
+        """update(z, u) (:80-131); odometry = (dCenter, dTheta) or None (= (0, 0) and no motion sample: `u == null` in
+        sampleMotionModel, :159); sample_motion = False keeps the poses (dTheta still decides skipUpdate, :82); returns Neff"""
+        b = _beams_of(z)
+        have = odometry is not None and sample_motion
+        dc, dt = (odometry if odometry is not None else (0.0, 0.0))
+        if sequence is None:
+            sequence = self.sequence
+            self.sequence += 1
+        st = GmsPfStats()
+        check(load().gms_slam_update_per_particle(self._h, ptr(b), len(b), int(have), float(dc), float(dt), int(seed), int(sequence),
+                                                  C.byref(st) if fetch else None))
+        if fetch:
+            self.strongest, self.neff = st.strongest, st.neff
+            self.last_stats = {"weight_sum": st.weight_sum, "neff": st.neff, "strongest": st.strongest, "n_zero": st.n_zero,
+                               "max_log_weight": st.max_log_weight}
+            return st.neff
+        return None
+
+    def update_dev(self, dev_beams: int, B: int, odometry=None, seed: int = 0, sequence: int = 0, sample_motion: bool = True):
+        have = odometry is not None and sample_motion
+        dc, dt = (odometry if odometry is not None else (0.0, 0.0))
+        check(load().gms_slam_update_per_particle_dev(self._h, C.c_void_p(dev_beams), B, int(have), float(dc), float(dt), int(seed),
+                                                      int(sequence), None))
+
+    def resample(self, r01: Optional[float] = None, want_indices: bool = False):
+        """resample() (:133-153): r01 stands for Math.random()"""
+        r = float(np.random.random() if r01 is None else r01)
+        idx = np.empty(self.num_particles, dtype=np.int32) if want_indices else None
+        amb = C.c_int32(0)
+        check(load().gms_slam_resample_maps(self._h, r, ptr(idx) if want_indices else None, C.byref(amb) if want_indices else None))
+        return (idx, amb.value) if want_indices else None
+
+    def get_weighted_pose(self) -> np.ndarray:
+        return self.pf.weighted_pose()                                                                   # :165-178
+
+    def calculate_neff(self) -> float:
+        return self.pf.stats()["neff"]                                                                   # :180-190
+
+    def get_particles(self):
+        """(poses [n][3], weights [n]); the maps: map_of(i) / maps()"""
+        return self.pf.get_particles()                                                                   # :192
+
+    def set_poses(self, xytheta):
+        self.pf.set_poses(xytheta)
+
+    def map_of(self, i: int, likelihood: bool = False) -> np.ndarray:
+        """Particle i's logData (or likelihoodData) as [H][W] (Particle.m, :33)"""
+        out = np.empty((self.H, self.W), dtype=np.float64)
+        check(load().gms_slam_download_map(self._h, int(i), None if likelihood else ptr(out), ptr(out) if likelihood else None))
+        return out
+
+    def maps(self, likelihood: bool = False) -> np.ndarray:
+        out = np.empty((self.num_particles, self.H, self.W), dtype=np.float64)
+        check(load().gms_slam_download_maps(self._h, None if likelihood else ptr(out), ptr(out) if likelihood else None))
+        return out
+
+    def set_map(self, i: int, log=None, lik=None):
+        lg = None if log is None else np.ascontiguousarray(log, dtype=np.float64)
+        lk = None if lik is None else np.ascontiguousarray(lik, dtype=np.float64)
+        check(load().gms_slam_upload_map(self._h, int(i), None if lg is None else ptr(lg), None if lk is None else ptr(lk)))
+
+    def calculate_combined(self) -> np.ndarray:
+        """GridMapApp.calculateCombined (J/app/GridMapApp.java:439-458): the combined logData [H][W]; the likelihood field of it is
+        grid_map.download_likelihood()"""
+        check(load().gms_slam_combined(self._h))
+        return self.grid_map.download_log()
+
+    def maps_copied(self) -> int:
+        v = C.c_int64(0)
+        check(load().gms_slam_copies(self._h, C.byref(v)))
+        return int(v.value)
+
+    def get_strongest_particle(self) -> int:
+        return self.strongest                                                                            # :196
+
+    def get_grid_map(self) -> GridMap:
+        return self.grid_map                                                                             # :200
+
+    getWeightedPose = get_weighted_pose
+    calculateNeff = calculate_neff
+    getParticles = get_particles
+    getStrongestParticle = get_strongest_particle
+    getGridMap = get_grid_map

@@ -258,6 +258,50 @@ int gms_pf_set_refine(gms_pf *pf, int32_t on);
  * (GMS_ERR_STATE on a shard); gms_pf_set_shard turns it off. */
 int gms_pf_set_log_normalize(gms_pf *pf, int32_t on);
 
+/* ---- SLAM as the reference has it: one GridMapData per particle --------------------------------------------------------------
+ * J/slam/SLAM.java keeps a map in every Particle (:30-47): update() scores a particle against ITS OWN likelihood field and
+ * integrates the scan into ITS OWN map at ITS OWN pose (:88-107), resample() deep-copies both arrays of the surviving particle's
+ * map (:41-45 -> GridMap.createMapData(other), J/slam/GridMap.java:106-124).  The gms_pf entry points above score N poses against
+ * ONE shared map (what BASELINE's configurations need); this handle is the reference's filter literally, at its own operating
+ * point (500 particles x 120 x 120 cells, SLAM.java:50,57) and beyond.  Not the reference's: findBestPoseOptim (:97; BOBYQA on an
+ * objective that is 0 / NaN) is left out, and the motion-model draw (:90) comes from Philox keyed by the particle's
+ * slot index (see gms_pf_sample_motion). */
+typedef struct gms_slam gms_slam;
+/* new SLAM() (SLAM.java:56-62) + reset() (:65-77): n_particles particles at Pose(0, 0, 0) with weight 1 / n and a blank map each
+ * (createMapData(null)).  p as for gms_map_create, with p->n_maps == 1 (the GridMap whose GridMapData every particle instantiates). */
+int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out);
+int gms_slam_destroy(gms_slam *s);
+int gms_slam_reset(gms_slam *s);                                    /* SLAM.reset() (SLAM.java:65-77) */
+int gms_slam_count(const gms_slam *s, int32_t *n_particles, int32_t *W, int32_t *H);
+/* The handles behind it, owned by the gms_slam (do not destroy them): *map = SLAM.getGridMap() (:200) -- geometry, constants, the
+ * stream every call of this handle runs on, and a GridMapData of its own that receives gms_slam_combined; *pf = getParticles()
+ * (:192) without the maps: poses, weights and statistics through gms_pf_get_poses / gms_pf_set_poses / gms_pf_get_weights /
+ * gms_pf_set_weights / gms_pf_get_stats / gms_pf_weighted_pose (getWeightedPose, :165-178) / gms_pf_last_step (strongest particle). */
+int gms_slam_handles(gms_slam *s, gms_map **map, gms_pf **pf);
+/* SLAM.update(z, u) (SLAM.java:80-131) for all particles: sampleMotionModel (:90; sample_motion == 0 is its `u == null` branch,
+ * :159: the particles keep their poses, e.g. because the caller has set the samples with gms_pf_set_poses),
+ * computeLikelihoodMap(p.m) (:93), p.weight = probabilityOf(p.m, z, p.pose) (:99; the product taken in beam order by one lane: the
+ * reference's bits, underflow included), integrateObservation(p.m, z, p.pose) unless |dTheta| > 30 degrees (:82,102-107), weightSum,
+ * strongest, weight /= weightSum (:100,110-121), calculateNeff (:124).  beams[B]; stats (may be NULL; when given the call
+ * synchronises) receives update()'s return value as stats->neff, the weight sum and the strongest particle's index. */
+int gms_slam_update_per_particle(gms_slam *s, const gms_beam *beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                                 uint64_t seed, uint64_t sequence, gms_pf_stats *stats);
+int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                                     uint64_t seed, uint64_t sequence, gms_pf_stats *stats);
+/* SLAM.resample() (SLAM.java:133-153) with Math.random() = r01: the systematic draw over the particles' weights, then every slot's
+ * deep copy -- pose, weight (:42-43) and both arrays of the map (:44, GridMap.java:118-121): map[m] <- map[idx[m]], double-buffered,
+ * a pure HBM stream of 32 bytes per cell.  indices [n] / n_ambiguous as gms_pf_resample (either may be NULL). */
+int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n_ambiguous);
+/* Particle i's GridMapData (SLAM.java:33; GridMap.java:72-74): W * H doubles each, either pointer may be NULL. */
+int gms_slam_download_map(gms_slam *s, int32_t i, double *log_data, double *lik);
+int gms_slam_upload_map(gms_slam *s, int32_t i, const double *log_data, const double *lik);
+int gms_slam_download_maps(gms_slam *s, double *log_all, double *lik_all);        /* all particles: [n][H][W] */
+/* GridMapApp.calculateCombined (J/app/GridMapApp.java:439-458) over the particles' maps, likelihood field included (:457), into the
+ * GridMapData of the handle's own map (gms_slam_handles -> gms_map_download_log / gms_map_download_likelihood). */
+int gms_slam_combined(gms_slam *s);
+/* maps copied by resampling steps since creation (measurement: bytes moved = copies * W * H * 32) */
+int gms_slam_copies(const gms_slam *s, int64_t *maps_copied);
+
 /* ---- device-resident inputs ---------------------------------------------------------------------
  * The same entry points for callers whose scans / poses already live in HBM (a trace staged once, a
  * torch tensor, the output of a device-side motion model).  dev_beams is [n_maps][B] gms_beam,

@@ -8,6 +8,9 @@
 #include "gms_oracle.h"
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -647,33 +650,54 @@ int32_t orc_slam_strongest(const orc_slam *s) { return s->strongest; }
 double orc_slam_neff(const orc_slam *s) { return orc_neff(s->weight, s->n); }                       /* :180-190 */
 void orc_slam_weighted_pose(const orc_slam *s, float out[3]) { orc_weighted_pose(s->pose, s->weight, s->n, out); }   /* :165-178 */
 
-/* SLAM.update(z, u) :80-131.  have_u = 0 is `u == null` in sampleMotionModel (:159); update() itself dereferences u.dTheta (:82),
- * so the reference can only be called with an Odometry: have_u = 0 stands for an Odometry the caller does not want applied (the
- * skip test then sees dTheta = 0). */
-double orc_slam_update(orc_slam *s, const orc_beam *z, int32_t B, int32_t have_u, double d_center, double d_theta,
-                       uint64_t seed, uint64_t sequence, int32_t refine) {
+/* SLAM.update(z, u) :80-131.  sample_motion = 0: the particles keep the poses they have -- the caller has set the motion-model
+ * samples itself (sampleMotionModel's `u == null` branch, :159) -- while u.dTheta still decides skipUpdate (:82), as update()
+ * reads it whatever sampleMotionModel does. */
+double orc_slam_update_mt(orc_slam *s, const orc_beam *z, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                          uint64_t seed, uint64_t sequence, int32_t refine, int32_t threads) {
     const size_t cells = (size_t)s->g.W * (size_t)s->g.H;
-    const int skip_update = fabs(have_u ? d_theta : 0.0) > (M_PI / 180.0) * 30;        /* :82 */
+    const int have_u = sample_motion;
+    const int skip_update = fabs(d_theta) > (M_PI / 180.0) * 30;                        /* :82 */
     s->strongest = -1;                                                                  /* :84 */
-    double weight_sum = 0;                                                              /* :87 */
+    /* The body of the particle loop (:88-107) touches nothing but its own particle -- and the shared scratch arrays probData /
+     * tempArray, which are per thread here -- so the particles may be taken by several host threads (threads > 1: a faster checker,
+     * same values); the two loop-carried quantities, weightSum (:100) and strongestParticle (:110-115), are folded in particle
+     * order afterwards, operation for operation what the sequential loop does. */
+    if (threads < 1) threads = 1;
+    double *scratch_all = threads > 1 ? (double *)malloc((size_t)threads * 2 * cells * sizeof(double)) : NULL;
+    if (threads > 1 && !scratch_all) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4) if (threads > 1)
     for (int32_t i = 0; i < s->n; i++) {                                                /* :88 */
+        double *scratch = s->scratch;
+#ifdef _OPENMP
+        if (scratch_all) scratch = scratch_all + (size_t)omp_get_thread_num() * 2 * cells;
+#endif
         float *pose = s->pose + 3 * (size_t)i;
         double *log_data = s->log_data + (size_t)i * cells, *lik = s->lik_data + (size_t)i * cells;
         if (have_u) orc_sample_motion(pose, 1, i, d_center, d_theta, seed, sequence);   /* :90 -> :155-163 */
-        orc_build_likelihood(&s->g, log_data, lik, s->scratch);                         /* :93 */
+        orc_build_likelihood(&s->g, log_data, lik, scratch);                            /* :93 */
         if (refine) {                                                                   /* :96 (the lattice search; :97 is BOBYQA) */
             float best[3];
             orc_find_best_pose(&s->g, lik, z, B, pose, best, NULL);
             pose[0] = best[0]; pose[1] = best[1]; pose[2] = best[2];
         }
         s->weight[i] = orc_probability_of(&s->g, lik, z, B, pose);                      /* :99 */
-        weight_sum += s->weight[i];                                                     /* :100 */
         if (!skip_update) orc_integrate(&s->g, log_data, z, B, pose);                   /* :102-107 */
+    }
+    free(scratch_all);
+    double weight_sum = 0;                                                              /* :87 */
+    for (int32_t i = 0; i < s->n; i++) {
+        weight_sum += s->weight[i];                                                     /* :100 */
         if (s->strongest < 0) s->strongest = i;                                         /* :110-111 */
         else if (s->weight[i] > s->weight[s->strongest]) s->strongest = i;              /* :113-114 */
     }
     for (int32_t i = 0; i < s->n; i++) s->weight[i] /= weight_sum;                      /* :120-121 */
     return orc_slam_neff(s);                                                            /* :124,129 */
+}
+
+double orc_slam_update(orc_slam *s, const orc_beam *z, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                       uint64_t seed, uint64_t sequence, int32_t refine) {
+    return orc_slam_update_mt(s, z, B, sample_motion, d_center, d_theta, seed, sequence, refine, 1);
 }
 
 /* SLAM.resample() :133-153 with Math.random() = r01: every slot receives a deep copy of a particle (pose, weight, both map

@@ -138,6 +138,8 @@ def lib() -> C.CDLL:
         L.orc_slam_strongest.argtypes = [vp]
         L.orc_slam_update.restype = C.c_double
         L.orc_slam_update.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int32]
+        L.orc_slam_update_mt.restype = C.c_double
+        L.orc_slam_update_mt.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]
         L.orc_slam_resample.restype = C.c_int32
         L.orc_slam_resample.argtypes = [vp, C.c_double, ip]
         L.orc_slam_neff.restype = C.c_double
@@ -435,12 +437,14 @@ class Slam:
     def strongest(self) -> int:
         return int(lib().orc_slam_strongest(self._h))
 
-    def update(self, beams: np.ndarray, odometry=None, seed: int = 0, sequence: int = 0, refine: bool = False) -> float:
-        """SLAM.update(z, u) (SLAM.java:80-131); odometry = (dCenter, dTheta) or None; returns Neff"""
+    def update(self, beams: np.ndarray, odometry=None, seed: int = 0, sequence: int = 0, refine: bool = False,
+               sample_motion: bool = True, threads: int = 1) -> float:
+        """SLAM.update(z, u) (SLAM.java:80-131); odometry = (dCenter, dTheta) or None (= (0, 0), no motion sample); sample_motion =
+        False keeps the poses as they are (the caller has set the samples) while dTheta still decides skipUpdate (:82); returns Neff"""
         have = odometry is not None
         dc, dt = (odometry if have else (0.0, 0.0))
-        return float(lib().orc_slam_update(self._h, beams.ctypes.data, len(beams), int(have), float(dc), float(dt), int(seed), int(sequence),
-                                           int(bool(refine))))
+        return float(lib().orc_slam_update_mt(self._h, beams.ctypes.data, len(beams), int(have and sample_motion), float(dc), float(dt),
+                                              int(seed), int(sequence), int(bool(refine)), int(threads)))
 
     def resample(self, r01: float):
         """SLAM.resample() (SLAM.java:133-153); returns (source index per slot, clamped slots)"""

@@ -1,0 +1,187 @@
+"""The reference's own filter shape on the device -- SLAM (J/slam/SLAM.java) with one GridMapData per particle: update() scores a
+particle against ITS OWN likelihood field and integrates the scan into ITS OWN map at ITS OWN pose (:88-107), resample() deep-copies
+the surviving particles' maps (:41-45 -> GridMap.java:106-124) -- against the oracle's literal restatement of the loop
+(orc_slam_update / orc_slam_resample, tests/test_oracle_slam.py), frame by frame over a recording: every particle's pose, weight and
+both arrays of its map.  The motion-model draw is not the reference's (unseeded Well1024a): both sides take Philox variates; the
+device's double-precision log / sin / cos may round the last ulp of a float pose differently from glibc, so after that is checked the
+oracle continues from the device's poses (as tests/test_gpu_trace_replay.py does)."""
+import os
+
+import numpy as np
+import pytest
+
+from gridmap_slam_robot_amd import SLAMParticleMaps, synth
+from gridmap_slam_robot_amd.trace import read_trace
+from oracle import oracle as orc
+
+from _checks import assert_resample_indices
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+THREADS = min(16, os.cpu_count() or 1)
+
+
+def _frames_to_scans(frames):
+    return [(orc.deskew(f.angle, f.distance, f.hit, f.d_center, f.d_theta), (f.d_center, f.d_theta)) for f in frames]
+
+
+def _compare_weights(w, wo, where):
+    """normalised weights: the raw products are the reference's bits (one lane multiplies in beam order), the weight sum is a blocked
+    sum on the device: zeros are zeros, everything else agrees to 1e-13"""
+    assert np.isfinite(wo).all(), f"{where}: the oracle's weights must be finite for this check"
+    assert np.array_equal(w == 0, wo == 0), f"{where}: {int((w == 0).sum())} zero weights on the device, {int((wo == 0).sum())} in the oracle"
+    big = wo > 1e-290
+    assert big.any() and np.max(np.abs(w[big] - wo[big]) / wo[big]) <= 1e-13, f"{where}: weights off by {np.max(np.abs(w[big] - wo[big]) / wo[big]):.3e}"
+    assert (np.abs(w[~big] - wo[~big]) <= 1e-300).all()
+
+
+def _compare_maps(dev, o, where):
+    """logData: the same cells changed, values to 1e-13 relative (the device adds a scan's increments of one cell as one sum:
+    DESIGN.md section 5); likelihoodData: equal."""
+    n = o.n
+    logs, liks = dev.maps().reshape(n, -1), dev.maps(likelihood=True).reshape(n, -1)
+    for i in range(n):
+        lo, ko = o.log(i), o.lik(i)
+        assert np.array_equal(logs[i] != 0, lo != 0), f"{where}: particle {i}: another set of cells touched"
+        err = np.abs(logs[i] - lo)
+        assert (err <= 1e-13 * np.maximum(np.abs(lo), 1.0)).all(), f"{where}: particle {i}: log-odds off by {err.max():.3e}"
+        assert np.array_equal(liks[i], ko), f"{where}: particle {i}: likelihood field differs in {int((liks[i] != ko).sum())} cells"
+
+
+def _run(dev, o, scans, start, seed, rng, check_maps_at, resample_rule=True, label=""):
+    """frames through both; returns the number of resampling steps"""
+    n = o.n
+    P0 = np.tile(np.asarray(start, np.float32), (n, 1))
+    dev.set_poses(P0)
+    o.set_poses(P0)
+    resampled = 0
+    for k, (z, u) in enumerate(scans):
+        prev = o.poses
+        neff = dev.update(z, u, seed=seed, sequence=k)                                   # SLAM.update(z, u): SLAM.java:80-131
+        P = dev.get_particles()[0]
+        Po = orc.sample_motion(prev, u[0], u[1], seed=seed, sequence=k)                  # :90 -> Odometry.java:77-96
+        assert (np.all(P == Po, axis=1)).mean() > 0.99 and np.max(np.abs(P - Po)) <= 2e-6, f"{label} frame {k}: motion samples"
+        o.set_poses(P)
+        neff_o = o.update(z, u, sample_motion=False, threads=THREADS)
+        st = dev.last_stats
+        w, wo = dev.get_particles()[1], o.weights
+        _compare_weights(w, wo, f"{label} frame {k}")
+        assert st["strongest"] == o.strongest and st["n_zero"] == int((wo == 0).sum())
+        assert abs(neff - neff_o) <= 1e-11 * neff_o
+        assert np.allclose(dev.get_weighted_pose(), o.weighted_pose(), rtol=0, atol=2e-6)
+        if k in check_maps_at:
+            _compare_maps(dev, o, f"{label} frame {k}")
+        if resample_rule and neff_o < n // 2:                                            # GridMapApp.java:185-186
+            r01 = float(rng.random())
+            idx, amb = dev.resample(r01, want_indices=True)
+            want, clamped = o.resample(r01)
+            assert clamped == 0
+            assert_resample_indices(idx, want, amb)
+            assert np.array_equal(idx, want), f"{label} frame {k}: the draw {r01} sits on a rounding boundary; pick another seed"
+            resampled += 1
+            assert np.array_equal(dev.get_particles()[0], o.poses)
+            _compare_weights(dev.get_particles()[1], o.weights, f"{label} frame {k} after resampling")
+            if k in check_maps_at or resampled == 1:
+                _compare_maps(dev, o, f"{label} frame {k} after the resampling copy")
+    return resampled
+
+
+def test_the_reference_operating_point_500_particles_of_120x120_cells():
+    """SLAM.java:50,57: 500 particles, GridMap(6 m, 6 m, 0.05 m, (-3, -3)); 90 beams per revolution; thirty revolutions of a drive
+    through a 4.8 m room, the caller's `if (neff < N / 2) resample()` (GridMapApp.java:185-186) included."""
+    N, B, T = 500, 90, 30
+    frames, truth = synth.make_recording(6.0, B, T=48, seed=77, n_frames=T)
+    scans = _frames_to_scans(frames)
+    start = synth.true_pose(synth.make_world(6.0, 77), -1, 48)
+    dev = SLAMParticleMaps(6.0, 6.0, 0.05, (-3.0, -3.0), num_particles=N, max_beams=128)
+    assert (dev.W, dev.H) == (120, 120)
+    g = orc.Grid(6.0, 6.0, 0.05, -3.0, -3.0)
+    o = orc.Slam(g, N)
+    # reset(): uniform weights, poses 0, blank maps (SLAM.java:65-77)
+    P, w = dev.get_particles()
+    assert np.array_equal(P, np.zeros((N, 3), np.float32)) and np.array_equal(w, np.full(N, 1.0 / N))
+    assert not dev.maps().any() and not dev.maps(likelihood=True).any()
+    resampled = _run(dev, o, scans, start, seed=2024, rng=np.random.default_rng(11), check_maps_at={0, 1, 7, 15, 22, T - 1}, label="500x120^2")
+    assert resampled >= 1, "the drive must trigger at least one resampling step"
+    assert dev.maps_copied() == resampled * N
+    # getWeightedPose follows the drive (the filter works, not only matches)
+    wp = dev.get_weighted_pose()
+    assert np.hypot(wp[0] - truth[T - 1][0], wp[1] - truth[T - 1][1]) < 1.0          # (the reference filter without its pose refinement drifts: a sanity bound, not a quality claim)
+    # calculateCombined over the particles' maps (GridMapApp.java:439-458)
+    comb = dev.calculate_combined().reshape(-1)
+    want = orc.combine_maps(o.logs())
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(comb), fin) and np.max(np.abs(comb[fin] - want[fin])) <= 1e-9 * max(1.0, np.abs(want[fin]).max())
+
+
+def test_4096_particles_of_256x256_cells_on_the_committed_recording():
+    """tests/golden/recording_360.bin (the reference's DataRecorder format; synthetic: the reference ships no recording), every
+    other measurement of its 360 per revolution -- the reference's scans hold 90 to 180 (one per 2-4 degrees); at 360 the plain
+    product over a blank map, 0.1^360, is 0 for every particle and update() divides 0 by 0 -- and 4096 particles with
+    a 12.8 m map each: 4 GiB of GridMapData on the device."""
+    N = 4096
+    frames = read_trace(os.path.join(HERE, "golden", "recording_360.bin"))[:6]
+    for f in frames:
+        f.angle, f.distance, f.hit = f.angle[::2].copy(), f.distance[::2].copy(), f.hit[::2].copy()
+    scans = _frames_to_scans(frames)
+    start = synth.true_pose(synth.make_world(25.6, 4321), -1, 64)
+    ext = 12.8
+    dev = SLAMParticleMaps(ext, ext, 0.05, (-ext / 2, -ext / 2), num_particles=N, max_beams=512)
+    assert (dev.W, dev.H) == (256, 256)
+    g = orc.Grid(ext, ext, 0.05, -ext / 2, -ext / 2)
+    o = orc.Slam(g, N)
+    rng = np.random.default_rng(3)
+    _run(dev, o, scans[:5], start, seed=7, rng=rng, check_maps_at={0, 4}, resample_rule=False, label="4096x256^2")
+    # resample() whatever Neff says (the GUI's button: GridMapApp.java:306), then one more revolution on the copies
+    r01 = 0.4242
+    idx, amb = dev.resample(r01, want_indices=True)
+    want, _ = o.resample(r01)
+    assert_resample_indices(idx, want, amb)
+    assert np.array_equal(idx, want)
+    _compare_maps(dev, o, "4096x256^2 after the resampling copy")
+    z, u = scans[5]
+    dev.update(z, u, seed=7, sequence=5)
+    o.set_poses(dev.get_particles()[0])
+    o.update(z, u, sample_motion=False, threads=THREADS)
+    _compare_weights(dev.get_particles()[1], o.weights, "4096x256^2 one revolution after the copy")
+    _compare_maps(dev, o, "4096x256^2 one revolution after the copy")
+
+
+def test_edge_scans_the_band_walk_and_the_skip_rule(monkeypatch):
+    """no beam at all; a scan of misses only; particles outside the map (a ray whose start cell is outside emits nothing,
+    RayIterator.java:108); |dTheta| > 30 degrees skips integrateObservation but not computeLikelihoodMap (SLAM.java:82,102); and the
+    count tile forced down to a few rows, so that the scan's box is walked in bands."""
+    ext, res, B, N = 6.4, 0.05, 72, 24
+    tr = synth.make_trace(ext, res, B, T=8, seed=21)
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    for tile_cells in (0, 1000):
+        if tile_cells:
+            monkeypatch.setenv("GMS_SLAM_TILE_CELLS", str(tile_cells))
+        dev = SLAMParticleMaps(ext, ext, res, (-ext / 2, -ext / 2), num_particles=N, max_beams=128)
+        o = orc.Slam(g, N)
+        P = synth.make_particles(tr.poses[0], N, seed=8, sigma_xy=0.05, sigma_theta_deg=3.0)
+        P[3] = [40.0, 1.0, 0.3]                   # far outside the map
+        P[4] = [-3.3, 0.0, 0.0]                   # just outside: rays would enter the map, but the walk never starts
+        P[5] = [3.19, 3.19, 0.7]                  # in the corner cell
+        dev.set_poses(P); o.set_poses(P)
+        z = tr.scans[0]
+        dev.update(z, None); o.update(z, None)
+        _compare_maps(dev, o, f"tile {tile_cells}: first scan")
+        _compare_weights(dev.get_particles()[1], o.weights, f"tile {tile_cells}: first scan")
+        # misses only
+        zm = tr.scans[1].copy()
+        zm["hit"] = 0
+        zm["distance"] = 10.0
+        dev.update(zm, None); o.update(zm, None)
+        assert np.array_equal(dev.get_particles()[1], np.full(N, 1.0 / N))     # no beam hit: every product is 1
+        _compare_maps(dev, o, f"tile {tile_cells}: misses only")
+        # no beam at all
+        dev.update(z[:0], None); o.update(z[:0], None)
+        _compare_maps(dev, o, f"tile {tile_cells}: empty scan")
+        # the skip rule
+        before = dev.maps()
+        dev.update(tr.scans[2], (0.0, np.radians(31.0)), seed=5, sequence=9)
+        o.set_poses(dev.get_particles()[0]); o.update(tr.scans[2], (0.0, np.radians(31.0)), sample_motion=False)
+        assert np.array_equal(dev.maps(), before)
+        _compare_maps(dev, o, f"tile {tile_cells}: skipped update")
+        dev.close()
