@@ -822,6 +822,98 @@ def trace_replay(path: str, steps: int, warmup: int, particles: int, extent: flo
     return out
 
 
+def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res: float, beams: int, steps: int, warm_frames: int = 12,
+                      cpu_seconds: float = 0.0):
+    """The reference's own filter shape (SLAM.java: one GridMapData per particle; gms_slam_*): `particles` particles with a map of
+    extent x extent metres each, scans of `beams` measurements of a synthetic drive through a room that fits the map.  Timed, inputs
+    resident in HBM, nothing read back: `steps` SLAM.update calls (motion model inside, no resampling: the maps keep growing), then
+    SLAM.resample's deep copies (`steps` draws back to back); then the same with HIP-event brackets around every launch for the
+    per-kernel table.  Rooflines by algorithmic bytes: computeLikelihoodMap 16 B per cell and particle; the resampling copy 32 B per
+    cell and particle (both arrays read and written, GridMap.java:118-121)."""
+    from gridmap_slam_robot_amd import SLAMParticleMaps, synth
+    from gridmap_slam_robot_amd._lib import BEAM_DTYPE
+    T = 48
+    frames, truth = synth.make_recording(extent, beams, T=T, seed=77)
+    start = synth.true_pose(synth.make_world(extent, 77), -1, T)
+    dev = torch.device("cuda", local_rank)
+    s = SLAMParticleMaps(extent, extent, res, (-extent / 2, -extent / 2), num_particles=particles, device=local_rank, max_beams=max(128, beams))
+    s.grid_map.set_stream(torch.cuda.current_stream().cuda_stream)
+    s.set_poses(np.tile(np.asarray(start, np.float32), (particles, 1)))
+    scans, odo = [], []
+    for f in frames:
+        obs = s.grid_map.deskew(f.angle, f.distance, f.hit, f.d_center, f.d_theta)
+        scans.append(torch.from_numpy(obs.beams.view(np.uint8).reshape(-1).copy()).to(dev))
+        odo.append((f.d_center, f.d_theta))
+    cells = s.W * s.H
+    k = 0
+    def step(seq):
+        nonlocal k
+        s.update_dev(scans[k].data_ptr(), beams, odo[k], seed=11, sequence=seq)
+        k = (k + 1) % T
+    r01 = np.random.default_rng(5).random(4096)
+    for i in range(warm_frames):                       # the maps are partly explored when the timed region starts
+        step(i)
+        if i % 4 == 3:
+            s.resample(float(r01[i]))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm_frames + i)
+    torch.cuda.synchronize()
+    upd = (time.perf_counter() - t0) / steps
+    st = s.pf.stats()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        s.resample(float(r01[(17 + i) % 4096]))
+    torch.cuda.synchronize()
+    rsm = (time.perf_counter() - t0) / steps
+    # per kernel: event brackets (they cost ~2 us each on the stream: these durations are upper bounds of the un-bracketed ones)
+    s.grid_map.profile(True)
+    s.grid_map.profile_reset()
+    for i in range(steps):
+        step(warm_frames + steps + i)
+        s.resample(float(r01[(99 + i) % 4096]))
+    torch.cuda.synchronize()
+    prof = s.grid_map.profile_get()
+    s.grid_map.profile(False)
+    kern = {name: {"avg_launch_us": ms / n * 1e3, "launches": n} for name, (ms, n) in prof.items() if n}
+    lik_b, copy_b = 16.0 * cells * particles, 32.0 * cells * particles
+    if "likelihood" in kern:
+        kern["likelihood"].update(algorithmic_bytes_per_launch=lik_b, achieved_TBps=lik_b / (kern["likelihood"]["avg_launch_us"] * 1e-6) / 1e12,
+                                  hbm_frac=lik_b / (kern["likelihood"]["avg_launch_us"] * 1e-6) / 8e12, what="computeLikelihoodMap of every particle's map (GridMap.java:233-250): 16 B per cell",
+                                  us_per_map=kern["likelihood"]["avg_launch_us"] / particles)
+    if "mapcopy" in kern:
+        kern["mapcopy"].update(algorithmic_bytes_per_launch=copy_b, achieved_TBps=copy_b / (kern["mapcopy"]["avg_launch_us"] * 1e-6) / 1e12,
+                               hbm_frac=copy_b / (kern["mapcopy"]["avg_launch_us"] * 1e-6) / 8e12, what="resample()'s deep copies, map[m] <- map[idx[m]] for both arrays (SLAM.java:41-45, GridMap.java:118-121): 32 B per cell")
+    if "score" in kern:
+        kern["score"]["what"] = "k_slam_particle: motion sample, probabilityOf against the particle's own field (one lane's product in beam order), integrateObservation into the particle's own map through an LDS count tile"
+    out = {"workload": f"SLAM.java's own shape: {particles} particles x one {s.W}x{s.H} map each @ {res} m, {beams} beams per scan; SLAM.update per particle "
+                       "(motion model, computeLikelihoodMap, probabilityOf, integrateObservation), SLAM.resample with deep copies of both map arrays",
+           "particles": particles, "grid": [s.W, s.H], "beams": beams, "steps": steps,
+           "update_ms": upd * 1e3, "updates_per_s": 1.0 / upd, "particle_scan_evals_per_s": particles / upd,
+           "resample_ms": rsm * 1e3, "resample_copy_TBps_algorithmic": copy_b / rsm / 1e12, "resample_copy_hbm_frac": copy_b / rsm / 8e12,
+           "gridmapdata_bytes_on_device": 4.0 * 8 * cells * particles, "neff_last": st["neff"], "n_zero_weights": st["n_zero"],
+           "kernels": kern}
+    if cpu_seconds > 0:
+        from oracle import oracle as orc                  # the reported CPU baseline of this mode: the oracle's SLAM loop, one thread
+        g = orc.Grid(extent, extent, res, -extent / 2, -extent / 2)
+        o = orc.Slam(g, particles)
+        o.set_poses(np.tile(np.asarray(start, np.float32), (particles, 1)))
+        zs = [orc.deskew(f.angle, f.distance, f.hit, f.d_center, f.d_theta) for f in frames]
+        t0 = time.perf_counter()
+        n = 0
+        while n < 2 or (time.perf_counter() - t0 < cpu_seconds and n < T):
+            o.update(zs[n % T], odo[n % T], seed=11, sequence=n)
+            n += 1
+        el = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        o.resample(0.37)
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "update_ms": el / n * 1e3, "resample_ms": (time.perf_counter() - t1) * 1e3,
+                               "sample": f"{n} SLAM.update calls of the same recording (oracle/gms_oracle.c::orc_slam_update)"}
+    s.close()
+    return out
+
+
 def explore_run(args, torch, local_rank: int, skip: bool, passes: int = 5):
     """Config 3 on a map that is being EXPLORED: the map starts empty and the timed steps are the drive's first T/2 scans, so every
     scan pushes the frontier on and the tiles along it change their thresholded codes (the headline step runs on a pre-built map
@@ -1034,6 +1126,7 @@ def main() -> int:
     ap.add_argument("--trace-particles", type=int, default=1024)
     ap.add_argument("--trace-extent", type=float, default=25.6, help="map extent (m) for --trace")
     ap.add_argument("--trace-res", type=float, default=0.05, help="map resolution (m) for --trace")
+    ap.add_argument("--particle-maps", default="", help="run only the per-particle-map mode (SLAM.java's own shape): PARTICLES,EXTENT_M,BEAMS e.g. 500,6,90")
     ap.add_argument("--report", default=os.path.join(ROOT, "bench_report.json"),
                     help="where the full report goes (kernel table, secondary runs, notes); stdout carries one compact line that names it")
     args = ap.parse_args()
@@ -1069,6 +1162,16 @@ def main() -> int:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+
+    if args.particle_maps:
+        n_, ext_, b_ = args.particle_maps.split(",")
+        pm = particle_maps_run(torch, local_rank, int(n_), float(ext_), 0.05, int(b_), args.steps, cpu_seconds=0.0 if args.no_cpu_baseline else 5.0)
+        out = {"metric": "particle-scan evals/sec", "value": pm["particle_scan_evals_per_s"], "unit": "particle-scan evals/s", "n_gpus": 1,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": pm["update_ms"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": pm["workload"]},
+               "per_particle_maps": pm, "roofline": None, "cpu_baseline": pm.get("cpu_baseline")}
+        emit(out, result_fd, args.report)
+        return 0
 
     if args.trace:
         tr = trace_replay(args.trace, args.steps, args.warmup, args.trace_particles, args.trace_extent, args.trace_res, local_rank, torch)

@@ -22,8 +22,8 @@ GMS_PARTIAL_STRIDE = 9
 PACKED_BYTES = 24
 
 GMS_OK, GMS_ERR_INVALID, GMS_ERR_NO_DEVICE, GMS_ERR_HIP, GMS_ERR_NOMEM, GMS_ERR_STATE = 0, -1, -2, -3, -4, -5
-K_RAYCAST, K_APPLY, K_LIKELIHOOD, K_SCORE, K_REDUCE, K_RESAMPLE, K_REFINE, K_EXCHANGE, K_ORDER, K_COUNT = range(10)   # enum of gridmapslam.h (GMS_K_*)
-KERNEL_NAMES = ["raycast", "apply", "likelihood", "score", "reduce", "resample", "refine", "exchange", "order"]
+K_RAYCAST, K_APPLY, K_LIKELIHOOD, K_SCORE, K_REDUCE, K_RESAMPLE, K_REFINE, K_EXCHANGE, K_ORDER, K_MAPCOPY, K_COUNT = range(11)   # enum of gridmapslam.h (GMS_K_*)
+KERNEL_NAMES = ["raycast", "apply", "likelihood", "score", "reduce", "resample", "refine", "exchange", "order", "mapcopy"]
 assert len(KERNEL_NAMES) == K_COUNT
 
 BEAM_DTYPE = np.dtype(

@@ -158,6 +158,47 @@ __device__ __forceinline__ int32_t sensor_class(float cur, float measured, int32
     return 2;
 }
 
+// ---- the sensor class without a square root per cell ------------------------------------------------------------------------
+// inverseSensorModel compares distance = (float) Math.sqrt(s), s = dX * dX + dY * dY (GridMap.java:215-217, a correctly rounded
+// float square root of a float), with measured -+ hitTolerance / 2 (SensorModel.java:31-41).  A correctly rounded square root is
+// monotonic, so for a threshold t the set {s : sqrt(s) >= t} is an upper set of the floats: d < t <=> s < sq_lower(t), its smallest
+// element, and d > t <=> s > sq_upper(t), the largest s whose root is still <= t.  The two thresholds are found once per RAY (t * t,
+// then a step or two along the floats, checked with the same square root), and every cell of the ray is classified by two compares:
+// the same classes, bit for bit (tests/test_gpu_slam_particle_maps.py::test_squared_thresholds...), ~20 instructions per cell less.
+__device__ __forceinline__ float f32_up(float c) { return __uint_as_float(__float_as_uint(c) + 1u); }       // c >= +0, finite
+__device__ __forceinline__ float f32_down(float c) { return __uint_as_float(__float_as_uint(c) - 1u); }     // c > 0
+// smallest float s >= 0 with (float)sqrt(s) >= t;  d < t <=> s < result  (NaN for a NaN t: never true, as in the reference)
+__device__ __forceinline__ float sq_lower(float t) {
+    if (t != t) return t;
+    if (!(t > 0.0f)) return 0.0f;                      // d < t never holds for d >= 0
+    float c = t * t;
+    if (!(c < INFINITY)) return INFINITY;              // t = +Inf, or beyond sqrt(FLT_MAX): every finite s lies below
+    for (int i = 0; i < 8 && c > 0.0f && j_sqrtf(f32_down(c)) >= t; i++) c = f32_down(c);
+    for (int i = 0; i < 8 && j_sqrtf(c) < t; i++) c = f32_up(c);
+    return c;
+}
+// largest float s with (float)sqrt(s) <= t;  d > t <=> s > result
+__device__ __forceinline__ float sq_upper(float t) {
+    if (t != t) return t;
+    if (t < 0.0f) return -1.0f;                        // d > t always holds for d >= 0 (and never for a NaN s, as in the reference)
+    if (t == INFINITY) return INFINITY;
+    float c = t * t;
+    if (!(c < INFINITY)) return 3.4028234663852886e38f;   // beyond sqrt(FLT_MAX): only s = +Inf has a larger root
+    for (int i = 0; i < 8 && j_sqrtf(c) > t; i++) c = f32_down(c);           // (c > 0 here: sqrt(0) = 0 <= t)
+    for (int i = 0; i < 8 && j_sqrtf(f32_up(c)) <= t; i++) c = f32_up(c);
+    return c;
+}
+struct RayThr { float s_free, s_prior; };              // class 0 iff s < s_free; of a hit ray: class 1 iff s > s_prior, else 2; of a miss: else 1
+__device__ __forceinline__ RayThr ray_thresholds(float measured, int32_t hit, float half_tol) {
+    RayThr t;
+    if (hit) { t.s_free = sq_lower(measured - half_tol); t.s_prior = sq_upper(measured + half_tol); }     // SensorModel.java:36-40
+    else { t.s_free = sq_lower(measured); t.s_prior = 0.0f; }                                              // :33-34
+    return t;
+}
+__device__ __forceinline__ int32_t sensor_class_sq(float s, const RayThr &t, int32_t hit) {
+    return s < t.s_free ? 0 : (hit ? (s > t.s_prior ? 1 : 2) : 1);
+}
+
 // distance from the (un-shifted) ray start to the centre of cell (cx,cy), GridMap.java:215-217
 __device__ __forceinline__ float cell_distance(float sx, float sy, int32_t cx, int32_t cy) {
     float dX = sx - ((float)cx + 0.5f);

@@ -381,6 +381,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     m->fac_current = 0;
     if (const char *v = getenv("GMS_PAIR_LAUNCHES")) m->pair_launches = atoi(v) != 0;
     if (const char *v = getenv("GMS_SLAM_TILE_CELLS")) m->slam_tile_cells = atoi(v);
+    if (const char *v = getenv("GMS_SLAM_THREADS")) m->slam_threads = atoi(v);
     *out = m;
     return GMS_OK;
 }
@@ -857,7 +858,7 @@ int gms_debug_set_stamps(gms_map *m, void *dev_buffer) {
 }
 
 int gms_debug_f32(gms_map *m, int32_t op, const float *in, float *out, int64_t n) {
-    REQUIRE(m && in && out && n > 0 && op >= 0 && op <= 3 && (op != 3 || n % 64 == 0), "gms_debug_f32: bad arguments");
+    REQUIRE(m && in && out && n > 0 && op >= 0 && op <= 5 && (op != 3 || n % 64 == 0), "gms_debug_f32: bad arguments");
     HIPCHK(hipSetDevice(m->device));
     float *d_a = nullptr, *d_o = nullptr;
     HIPCHK(hipMalloc(&d_a, n * sizeof(float)));

@@ -122,6 +122,7 @@ struct gms_map {
     int32_t lik_skip;         // dirty-tile rebuilds leave tiles alone whose codes the scan does not change (GMS_LIK_SKIP=0 turns it off; same bits)
     int32_t raycast_near;     // single-map ray casts: the first 64 steps of every ray go through near-field workgroups with an LDS tile (0 never, 1 for scans of 512 beams or more, 2 for every scan of 32 or more: GMS_RAYCAST_NEAR=0 / unset / 1)
     int32_t pair_launches;    // scan steps pair independent kernels in one launch (GMS_PAIR_LAUNCHES=0 turns it off)
+    int32_t slam_threads;     // per-particle maps: lanes per workgroup of k_slam_particle (0 = the launcher decides; GMS_SLAM_THREADS = 512 / 1024)
     int32_t slam_tile_cells;  // per-particle maps: cap on the LDS count tile of k_slam_particle in cells (0 = what the LDS allows; GMS_SLAM_TILE_CELLS, for tests of the band walk)
     gms_beam *h_beams;    // pinned staging (de-skew inputs, single-ray entry)
     StageRing beam_ring;  // pinned staging of scans handed over as host buffers

@@ -1061,6 +1061,8 @@ __global__ void k_debug_f32(int32_t op, const float *__restrict__ a, float *__re
 #undef GMS_STEP_
             out[i] = (float)code;
         }
+        else if (op == 4) out[i] = sq_lower(a[i]);
+        else if (op == 5) out[i] = sq_upper(a[i]);
         else { pose_trig(a[i], c, s); out[i] = op == 1 ? c : s; }
     }
 }

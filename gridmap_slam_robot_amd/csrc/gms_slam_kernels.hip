@@ -16,14 +16,13 @@
 //                       likelihoodData only (16 bytes per cell: the streaming kernel of this mode)
 //   k_slam_particle     one workgroup per particle: the motion-model sample (:90), probabilityOf(p.m, z, p.pose) with the product
 //                       taken by ONE lane in beam order -- the reference's own association, bit for bit, underflow included (:99,
-//                       GridMap.java:262-288) -- and integrateObservation(p.m, z, p.pose) (:105): all rays of the scan walked by
-//                       producer wavefronts (RayIterator's float recurrence, ray_phase_a), their cells counted by consumer wavefronts
-//                       in an LDS tile of the scan's bounding box, and `logData[c] += ...` (GridMap.java:223) applied from that tile
-//                       straight to the particle's rows: no count grid in memory, no global atomic, touched cells read and written once
+//                       GridMap.java:262-288) -- and integrateObservation(p.m, z, p.pose) (:105): producer wavefronts walk the scan's
+//                       rays (RayIterator's float recurrence, ray_phase_a), every wavefront counts their cells in an LDS tile of the
+//                       scan's bounding box (the sensor class from two thresholds per ray, no square root per cell), and
+//                       `logData[c] += ...` (GridMap.java:223) is applied from that tile straight to the particle's rows: no count grid
+//                       in memory, no global atomic, touched cells read and written once
 //   k_slam_gather_maps  resample()'s deep copies: map[m] <- map[idx[m]] for both arrays, a pure HBM stream (32 bytes per cell)
 #include "gms_device.h"
-
-#define PS_WORDS 8                      // decision words per ray and round of k_slam_particle (256 steps of the walk)
 
 // likelihoodData of every particle's map from its logData (mode 1 of likelihood_body: no factor table, no tile states, every tile)
 template <int KH>
@@ -48,9 +47,15 @@ __device__ __forceinline__ RayIn ps_make_ray(const GridDev &g, const XformDev &t
     return r;
 }
 
+#define PS_WORDS 8                      // decision words per ray and round of k_slam_particle (256 steps of the walk)
+struct PsRay {                          // what a consumer needs of a ray
+    int32_t x0, y0, x_inc, y_inc, n_eff, hit;
+    float sx, sy, s_free, s_prior;
+};
+
 // phase B of the ray cast (ray_phase_b) for an LDS tile of 32-bit cells n_free | n_occ << 16 -- a whole scan's visits of one cell fit
 // (gms_map_create: (1 + extra) * beams < 65536) -- covering [tx0, tx0 + tw) x [ty0, ty0 + th); cells outside it belong to another band
-__device__ __forceinline__ void ps_phase_b(const GridDev &g, const RayMeta &mt, const uint64_t *__restrict__ slots, int32_t stride, int32_t slot,
+__device__ __forceinline__ void ps_phase_b(const GridDev &g, const PsRay &mt, const uint64_t *__restrict__ slots, int32_t stride, int32_t slot,
                                            int32_t blk, int32_t lane, uint32_t *__restrict__ tile, int32_t tx0, int32_t ty0, int32_t tw,
                                            int32_t th, int32_t w_base) {
     const int32_t nwords = (mt.n_eff + 31) >> 5;
@@ -62,36 +67,37 @@ __device__ __forceinline__ void ps_phase_b(const GridDev &g, const RayMeta &mt, 
         __builtin_amdgcn_s_sleep(2);
     }
     const int32_t k = blk * 64 + lane;
-    if (k >= mt.n_eff) return;
     const uint64_t sl = lane < 32 ? a : c;
-    const int32_t j = lane & 31;
-    const int32_t ny = (int32_t)(((uint32_t)(sl >> 32) & ~RC_VALID) + __popc((uint32_t)sl & ((1u << j) - 1u)));
+    const int32_t ny = (int32_t)(((uint32_t)(sl >> 32) & ~RC_VALID) + __popc((uint32_t)sl & ((1u << (lane & 31)) - 1u)));
     const int32_t nx = k - ny;
-    const int32_t cx = mt.x0 + mt.x_inc * nx, cy = mt.y0 + mt.y_inc * ny;
-    if (cx < 0 || cx >= g.W || cy < 0 || cy >= g.H) return;                                // RayIterator.java:108
-    const float d = cell_distance(mt.sx, mt.sy, cx, cy);                                   // GridMap.java:215-217
-    const int32_t cls = sensor_class(d, mt.measured, mt.hit, g.half_tol);                  // :223
-    if (cls == 1) return;                                                                  // += logOdds(0.5) = 0.0
+    const int32_t cx = mt.x0 + __mul24(mt.x_inc, nx), cy = mt.y0 + __mul24(mt.y_inc, ny);     // (|n| <= W + H + 1 < 2^23: gms_map_create)
+    const float dX = mt.sx - ((float)cx + 0.5f), dY = mt.sy - ((float)cy + 0.5f);            // GridMap.java:215-216
+    const int32_t cls = sensor_class_sq(dX * dX + dY * dY, RayThr{mt.s_free, mt.s_prior}, mt.hit);   // :217, :223
     const uint32_t ux = (uint32_t)(cx - tx0), uy = (uint32_t)(cy - ty0);
-    if (ux < (uint32_t)tw && uy < (uint32_t)th)
-        __hip_atomic_fetch_add((gms_lds_u32 *)(tile) + (uy * (uint32_t)tw + ux), cls == 0 ? 1u : 0x10000u, __ATOMIC_RELAXED,
+    // inside the map (RayIterator.java:108; the tile lies inside it), of this band, and not `+= logOdds(0.5)` = 0.0
+    if (k < mt.n_eff && (uint32_t)cx < (uint32_t)g.W && (uint32_t)cy < (uint32_t)g.H && ux < (uint32_t)tw && uy < (uint32_t)th && cls != 1)
+        __hip_atomic_fetch_add((gms_lds_u32 *)(tile) + (__umul24(uy, (uint32_t)tw) + ux), cls == 0 ? 1u : 0x10000u, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// One workgroup per particle.  NT threads, NP producer wavefronts (64 * NP rays walked at a time), the rest consumers.
-// Dynamic LDS: factors [Bpad] f64 | decision slots [PS_WORDS][64 NP] u64 | ray records [64 NP] | count tile [tile_cap] u32.
+// One workgroup per particle.  NT threads; wavefronts 0 .. NP-1 walk 64 rays each (RayIterator's float recurrence, ray_phase_a), then
+// join the others in the cell work.  Dynamic LDS: factors [Bpad] f64 | decision slots [PS_WORDS][64 NP] u64 | ray records [64 NP] |
+// count tile [tile_cap] u32.
+// (A lane per ray running the reference's loop as it stands -- walk, distance, class, count -- was built and measured: 80 instructions
+// per step on one or two wavefronts per SIMD, which issue one instruction per ~4.6 clocks: 29 us of walking for 90 rays against 17 for
+// this split form, whose cell work spreads over every wavefront of the workgroup.)
 template <int NT, int NP>
 __global__ void __launch_bounds__(NT)
 k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, double *__restrict__ log_all,
                 const double *__restrict__ lik_all, float *__restrict__ pose, float *__restrict__ cs, double *__restrict__ w,
                 double *__restrict__ logw, MotionArgs mo, int32_t integrate, int32_t tile_cap) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int NW = NT / 64, GR = 64 * NP, NC = NW - NP;
-    static_assert(NC >= 1, "at least one consumer wavefront");
+    constexpr int NW = NT / 64, GR = 64 * NP;
+    static_assert(NW > NP, "at least one wavefront that only consumes");
     double *s_fac = reinterpret_cast<double *>(smem);                          // [Bpad]
     uint64_t *s_slots = reinterpret_cast<uint64_t *>(s_fac + Bpad);            // [PS_WORDS][GR]
-    RayMeta *s_meta = reinterpret_cast<RayMeta *>(s_slots + PS_WORDS * GR);    // [GR]
-    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_meta + GR);              // [tile_cap]
+    PsRay *s_ray = reinterpret_cast<PsRay *>(s_slots + PS_WORDS * GR);         // [GR]
+    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_ray + GR);               // [tile_cap]
     __shared__ float s_pose[5];                                                // x, y, theta, (float)cos, (float)sin
     __shared__ int32_t s_box[4];                                               // the scan's box x0, y0, x1, y1 (inclusive)
     __shared__ int32_t s_grp_words[NP];
@@ -99,6 +105,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     const int32_t p = blockIdx.x;
     const int32_t lane = threadIdx.x & 63;
     const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6));
+    GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 0);
 
     // ---- the particle's pose: sampleMotionModel (SLAM.java:90, Odometry.java:77-96) or the pose as it stands
     if (wave == 0) {
@@ -118,6 +125,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     }
     if (threadIdx.x >= 64 && threadIdx.x < 68) s_box[threadIdx.x - 64] = threadIdx.x < 66 ? INT32_MAX : INT32_MIN;
     __syncthreads();
+    GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 1);
     XformDev t;
     t.px = (double)s_pose[0]; t.py = (double)s_pose[1]; t.c = (double)s_pose[3]; t.s = (double)s_pose[4];      // Transform.java:13-21
 
@@ -157,6 +165,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
         }
     }
     __syncthreads();
+    GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 2);
     if (threadIdx.x == NT - 64) {
         // the last wavefront's first lane, while the others set up the ray cast: product *= factor, beam by beam (:262, :286-288)
         double prod = 1.0;
@@ -173,6 +182,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
         for (int k = 0; k < NW; k++) ls += s_red[k];
         w[p] = prod;                                                           // p.weight (SLAM.java:99)
         logw[p] = ls;                                                          // sum of log factors: the underflow-free companion
+        GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(0, blockIdx.x), 3);
     }
     if (!integrate) return;                                                    // skipUpdate (SLAM.java:82,102)
 
@@ -192,13 +202,18 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
             int32_t my_nwords = 0;
             if (wave < NP) {
                 const int32_t ri = g0 + wave * 64 + lane;
-                RayMeta mt;
-                mt.n_eff = 0; mt.x0 = mt.y0 = mt.x_inc = mt.y_inc = mt.hit = 0; mt.sx = mt.sy = mt.measured = 0.0f; mt.hx = mt.hy = 0;
-                if (ri < B) mt = ray_meta(g, ps_make_ray(g, t, beams[ri]), r);
-                // a ray that never enters this band's rows is not walked for it (its box says so)
-                if (mt.n_eff > 0 && (max(mt.y0, mt.hy) < ty0 || min(mt.y0, mt.hy) >= ty0 + th)) mt.n_eff = 0;
-                s_meta[wave * 64 + lane] = mt;
-                my_nwords = (mt.n_eff + 31) >> 5;
+                PsRay pr;
+                pr.n_eff = 0; pr.x0 = pr.y0 = pr.x_inc = pr.y_inc = pr.hit = 0; pr.sx = pr.sy = pr.s_free = pr.s_prior = 0.0f;
+                if (ri < B) {
+                    const RayMeta mt = ray_meta(g, ps_make_ray(g, t, beams[ri]), r);
+                    // a ray that never enters this band's rows is not walked for it (its box says so)
+                    const bool in_band = mt.n_eff > 0 && !(max(mt.y0, mt.hy) < ty0 || min(mt.y0, mt.hy) >= ty0 + th);
+                    const RayThr thr = ray_thresholds(mt.measured, mt.hit, g.half_tol);
+                    pr.x0 = mt.x0; pr.y0 = mt.y0; pr.x_inc = mt.x_inc; pr.y_inc = mt.y_inc; pr.n_eff = in_band ? mt.n_eff : 0; pr.hit = mt.hit;
+                    pr.sx = mt.sx; pr.sy = mt.sy; pr.s_free = thr.s_free; pr.s_prior = thr.s_prior;
+                }
+                s_ray[wave * 64 + lane] = pr;
+                my_nwords = (pr.n_eff + 31) >> 5;
                 int32_t nwm = my_nwords;
 #define GMS_STEP_(O) nwm = max(nwm, wave_xor<O>(nwm));
                 GMS_BUTTERFLY(GMS_STEP_)
@@ -206,6 +221,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                 if (lane == 0) s_grp_words[wave] = nwm;
             }
             __syncthreads();
+            if (g0 == 0 && ty0 == Y0) GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 4);
             int32_t nwords_max = 0;
 #pragma unroll
             for (int k = 0; k < NP; k++) nwords_max = max(nwords_max, s_grp_words[k]);
@@ -215,28 +231,44 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                 __syncthreads();                                               // (also: the tile is cleared, the previous round consumed)
                 if (wave < NP) {
                     if (wb < my_nwords) ray_phase_a(wk, wb, min(my_nwords, wb + PS_WORDS), s_slots, GR, wave * 64 + lane);
-                } else {
-                    const int32_t blk0 = wb >> 1, nblk = min(PS_WORDS / 2, (nwords_max - wb + 1) >> 1);
-                    for (int32_t q = wave - NP; q < nblk * GR; q += NC) {
-                        const int32_t blk = blk0 + q / GR, slot = q % GR;
-                        const RayMeta mt = s_meta[slot];
-                        if (blk * 64 >= mt.n_eff) continue;
-                        ps_phase_b(g, mt, s_slots, GR, slot, blk, lane, s_tile, X0, ty0, tw, th, wb);
-                    }
+                    if (g0 == 0 && ty0 == Y0 && wb == 0) GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 5);
+                }
+                // the cell work: every wavefront, the producers once their words are out (block-major: the order of publication)
+                const int32_t blk0 = wb >> 1, nblk = min(PS_WORDS / 2, (nwords_max - wb + 1) >> 1);
+                for (int32_t q = wave; q < nblk * GR; q += NW) {
+                    const int32_t blk = blk0 + q / GR, slot = q % GR;
+                    const int32_t n_eff = s_ray[slot].n_eff;
+                    if (blk * 64 >= n_eff) continue;
+                    ps_phase_b(g, s_ray[slot], s_slots, GR, slot, blk, lane, s_tile, X0, ty0, tw, th, wb);
                 }
                 __syncthreads();
             }
-            if (nwords_max == 0) __syncthreads();                              // (s_meta / s_grp_words are rewritten by the next group)
+            if (nwords_max == 0) __syncthreads();                              // (s_ray / s_grp_words are rewritten by the next group)
         }
-        // logData[c] += n_free * logOdds(P_FREE) + n_occ * logOdds(P_OCC): the expression of apply_body (GridMap.java:223)
-        for (int32_t ry = wave; ry < th; ry += NW) {
-            const size_t row = (size_t)(ty0 + ry) * g.W + X0;
-            for (int32_t rx = lane; rx < tw; rx += 64) {
-                const uint32_t c = s_tile[ry * tw + rx];
-                if (c) mlog[row + rx] = mlog[row + rx] + ((double)(c & 0xffffu) * g.l_free + (double)(c >> 16) * g.l_occ);
+        // logData[c] += n_free * logOdds(P_FREE) + n_occ * logOdds(P_OCC): the expression of apply_body (GridMap.java:223).  Eight
+        // cells per thread and pass, every load issued before the first store: a read-modify-write per iteration is one memory round
+        // trip each (the first form of this loop: 14 of them in a row on a 100 x 100 box)
+        const int32_t ncell = tw * th;
+        if (ty0 == Y0) GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 6);
+        for (int32_t base = 0; base < ncell; base += NT * 8) {
+            uint32_t c[8];
+            size_t o[8];
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int32_t i = base + u * NT + (int32_t)threadIdx.x;
+                c[u] = i < ncell ? s_tile[i] : 0u;
+                const int32_t ry = i / tw, rx = i - ry * tw;
+                o[u] = (size_t)(ty0 + ry) * g.W + X0 + rx;
             }
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = c[u] ? mlog[o[u]] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (c[u]) mlog[o[u]] = v[u] + ((double)(c[u] & 0xffffu) * g.l_free + (double)(c[u] >> 16) * g.l_occ);
         }
         __syncthreads();
+        if (ty0 == Y0) GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 7);
     }
 }
 
@@ -303,7 +335,7 @@ void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, 
 
 // dynamic LDS of k_slam_particle<NT, NP> without its count tile
 static inline size_t slam_particle_fixed_lds(int32_t Bpad, int np) {
-    return (size_t)Bpad * sizeof(double) + (size_t)PS_WORDS * 64 * np * sizeof(uint64_t) + (size_t)64 * np * sizeof(RayMeta);
+    return (size_t)Bpad * sizeof(double) + (size_t)PS_WORDS * 64 * np * sizeof(uint64_t) + (size_t)64 * np * sizeof(PsRay);
 }
 
 // SLAM.update's per-particle body for all n particles of pf (one map each, d_log / d_lik [n][cells]); motion may be NULL
@@ -333,16 +365,25 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, do
     if (m->slam_tile_cells > 0 && tile > (size_t)m->slam_tile_cells) tile = (size_t)m->slam_tile_cells;
     if (tile < (size_t)m->gd.W) tile = (size_t)m->gd.W;                         // one row at least (refused at creation if even that cannot fit)
     const size_t smem = fixed + tile * 4;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_particle<1024, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((k_slam_particle<1024, NP>), dim3((unsigned)pf->n), dim3(1024), smem, m->stream, m->gd, d_beams, B, Bpad, d_log, d_lik,
-                       pf->d_pose, pf->d_cs, pf->d_w, pf->d_logw, mo, integrate, (int32_t)tile);
+    // Workgroup shape: 512 lanes when two workgroups then share a CU (their latency chains -- pose, factors, the product, the walks,
+    // the read-modify-write of the touched cells -- overlap), 1024 when the tile leaves room for one only.  GMS_SLAM_THREADS forces one.
+    int32_t threads = smem <= lds_wg / 2 ? 512 : 1024;
+    if (m->slam_threads == 512 || m->slam_threads == 1024) threads = m->slam_threads;
+#define PS_LAUNCH(NT)                                                                                                                   \
+    do {                                                                                                                                \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_particle<NT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((k_slam_particle<NT, NP>), dim3((unsigned)pf->n), dim3(NT), smem, m->stream, m->gd, d_beams, B, Bpad, d_log, d_lik, \
+                           pf->d_pose, pf->d_cs, pf->d_w, pf->d_logw, mo, integrate, (int32_t)tile);                                   \
+    } while (0)
+    if (threads == 512) PS_LAUNCH(512); else PS_LAUNCH(1024);
+#undef PS_LAUNCH
     pf->pending_nseg = 0;
     pf->score_fresh = 1;
 }
 
 void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik) {
     gms_map *m = pf->map;
-    ProfScope ps(m, GMS_K_RESAMPLE);
+    ProfScope ps(m, GMS_K_MAPCOPY);
     const int64_t cells = m->gd.cells;
     // 256 lanes x 16 bytes x 2 in flight per array = 8 KiB of each array per workgroup pass
     int64_t chunks = (cells / 2 + 511) / 512;

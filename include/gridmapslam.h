@@ -408,7 +408,8 @@ int gms_slam_update_sharded_end_dev(gms_pf *pf, const gms_beam *dev_beams, int32
 enum {
     GMS_K_RAYCAST = 0, GMS_K_APPLY = 1, GMS_K_LIKELIHOOD = 2, GMS_K_SCORE = 3, GMS_K_REDUCE = 4,
     GMS_K_RESAMPLE = 5, GMS_K_REFINE = 6, GMS_K_EXCHANGE = 7 /* the grouped RCCL launch of a sharded scan step */,
-    GMS_K_ORDER = 8 /* the locality order of the particles ahead of a large scoring launch */, GMS_K_COUNT = 9
+    GMS_K_ORDER = 8 /* the locality order of the particles ahead of a large scoring launch */,
+    GMS_K_MAPCOPY = 9 /* resample()'s deep copies of the particles' maps (gms_slam_resample_maps) */, GMS_K_COUNT = 10
 };
 /* Bracket kernel launches of this map handle (and its filters) with HIP events on its stream:
  * bit k of `mask` enables kernel class k (GMS_K_*); 0 turns profiling off. */
@@ -440,7 +441,9 @@ int gms_map_tile_stats(gms_map *m, int32_t enable, int64_t *out4);
 /* The float-rounded device primitives the parity contract leans on, for tests: op 0 = (float)sqrt(a)
  * (GridMap.java:217), 1 = (float)cos((double)a), 2 = (float)sin((double)a) (J/math/MathUtil.java:30-40); 3 = self-check of the
  * wavefront butterflies every reduction uses (n a multiple of 64): out[i] = a bit code, bits 0-5 set where the exchange with lane
- * (i ^ 32, 16, 8, 4, 2, 1) does not deliver that lane's value (must be 0), bits 6-11 the same for the mirrored reading (must be 63 << 6 for the half-wave, row and quad-of-four steps that have one). */
+ * (i ^ 32, 16, 8, 4, 2, 1) does not deliver that lane's value (must be 0), bits 6-11 the same for the mirrored reading (must be 63 << 6 for the half-wave, row and quad-of-four steps that have one);
+ * 4 / 5 = the squared thresholds the per-particle-map ray cast classifies cells with instead of a square root per cell: the smallest float s with
+ * (float)sqrt(s) >= a, resp. the largest with (float)sqrt(s) <= a (SensorModel.java:31-41 compares (float)Math.sqrt(s) with a). */
 int gms_debug_f32(gms_map *m, int32_t op, const float *in, float *out, int64_t n);
 /* Development: instrumented builds (-DGMS_STAMPS) write wall-clock stamps of their kernels' stages to dev_buffer
  * ([workgroup][16] uint64, 10 ns units; NULL turns it off); a product build returns GMS_ERR_STATE.  tools/stamps.py. */

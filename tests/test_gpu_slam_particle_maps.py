@@ -185,3 +185,40 @@ def test_edge_scans_the_band_walk_and_the_skip_rule(monkeypatch):
         assert np.array_equal(dev.maps(), before)
         _compare_maps(dev, o, f"tile {tile_cells}: skipped update")
         dev.close()
+
+
+def test_squared_thresholds_classify_like_the_square_root():
+    """inverseSensorModel compares (float) Math.sqrt(s) with measured -+ 1 (GridMap.java:217, SensorModel.java:31-41); the per-particle
+    ray cast compares s with two thresholds per ray instead (gms_device.h: sq_lower / sq_upper).  For thousands of thresholds t --
+    random, integers and halves (cell distances cluster there), tiny, huge, zero, negative, infinite, NaN -- the device's thresholds are
+    checked against their definition with numpy's correctly rounded float32 sqrt: d < t <=> s < sq_lower(t), d > t <=> s > sq_upper(t)
+    for every float s within a few ulps of the boundary (and at the domain's ends)."""
+    from gridmap_slam_robot_amd import GridMap
+    m = GridMap(3.2, 3.2, 0.05, (-1.6, -1.6))
+    rng = np.random.default_rng(12)
+    t = np.concatenate([
+        rng.uniform(0, 600, 4000), np.arange(0, 400, 0.5), rng.uniform(0, 2, 500), 10.0 ** rng.uniform(-30, 19, 500),
+        [0.0, -0.0, -1.0, -1e-30, 1e-45, 1.17549435e-38, 3.4e38, 1.8446744e19, 1.8446743e19, 1.8446746e19, np.inf, -np.inf, np.nan]]).astype(np.float32)
+    lo, hi = m.debug_f32(4, t), m.debug_f32(5, t)
+    one = np.uint32(1)
+
+    def nbrs(c):
+        """floats within 3 ulps of c (c >= 0 finite), plus 0, the largest float and inf"""
+        out = [np.float32(0), np.float32(3.4028235e38), np.float32(np.inf)]
+        if np.isfinite(c) and c >= 0:
+            u = np.float32(c).view(np.uint32)
+            for d in range(-3, 4):
+                v = int(u) + d
+                if 0 <= v <= 0x7f800000:
+                    out.append(np.uint32(v).view(np.float32))
+        return np.array(out, dtype=np.float32)
+
+    with np.errstate(invalid="ignore"):
+        for ti, l, h in zip(t, lo, hi):
+            for c in (l, h):
+                s = nbrs(c)
+                d = np.sqrt(s)                                   # float32 in, float32 out: correctly rounded
+                assert np.array_equal(d < ti, s < l), (ti, l, s)
+                assert np.array_equal(d > ti, s > h), (ti, h, s)
+    # a NaN s (a NaN pose) is neither below nor above anything, as NaN distance in the reference
+    assert np.isnan(lo[-1]) and np.isnan(hi[-1])
