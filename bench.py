@@ -617,7 +617,10 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
             "workload": (f"{wl.name}: {wl.M} maps x {m.W}x{m.H} @ {wl.res} m x {wl.n_local} particles x {wl.B} beams ({wl.n_hit} hits), batched handle, "
                          if wl.batched else
                          f"{wl.name}: {wl.n_local} particles/GPU x {wl.B} beams ({wl.n_hit} hits), {m.W}x{m.H} grid @ {wl.res} m, ")
-                        + "full scan step (score+normalise+resample+ray-cast+likelihood rebuild)",
+                        + "full scan step (score+normalise+resample+ray-cast+likelihood rebuild"
+                        + (": every cell, likelihoodData written, as the reference does)" if a.full_rebuild else
+                           "; the rebuild is dirty-tile / factor-table-only: bit-identical results, likelihoodData on demand -- the reference's own "
+                           "every-cell rebuild is cpu_baseline.gpu_like_for_like_ms_per_step)"),
             "particles_total": n_total, "particles_per_gpu": wl.n_local * wl.M, "beams": wl.B, "grid": [m.W, m.H], "resolution_m": wl.res, "maps": wl.M,
             "parallelism": ("single GPU" if wl.world == 1 else
                             (f"{wl.M} independent maps per rank x{wl.world}, no collective" if wl.batched else
@@ -1044,7 +1047,8 @@ def compact_line(full: dict, report_file: str | None) -> str:
         line["roofline"] = None
     cb = full.get("cpu_baseline")
     if cb:
-        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "seconds", "map_update_ms_per_scan")}
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "seconds", "map_update_ms_per_scan",
+                                                       "gpu_like_for_like_ms_per_step")}
     else:
         line["cpu_baseline"] = None
     kern = full.get("kernels") or {}
@@ -1101,6 +1105,31 @@ def emit(full: dict, result_fd: int, report_path: str):
     os.write(result_fd, (compact_line(full, name) + "\n").encode())
 
 
+def launch_command(n_gpus: int, argv, port: int):
+    """the command line that runs this file on n_gpus ranks of one node (what the driver's launcher line is)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus: int, argv) -> int:
+    """Runs the ranks as a child process (never an exec: this process may not have touched the GPU, the child does) and forwards its
+    stdout -- rank 0's one JSON line -- and exit code.  GMS_BENCH_LAUNCH_DRYRUN=1 prints the command instead (tests)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = launch_command(n_gpus, argv, port)
+    if os.environ.get("GMS_BENCH_LAUNCH_DRYRUN", "") not in ("", "0"):
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1134,6 +1163,13 @@ def main() -> int:
         print("bench.py: --config must be C2, C3, C4 or C5", file=sys.stderr)
         return 2
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver's command line does
+    # (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>), as a CHILD process and before
+    # this process has touched the GPU (nothing above imports torch or loads the library): rank 0's single JSON line reaches our
+    # stdout through the child's, and we leave with the child's exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, sys.argv[1:])
+
     # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner on C stdout when a
     # communicator is created, so everything but the result goes to stderr
     sys.stdout.flush()
@@ -1146,8 +1182,8 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run", file=sys.stderr)
+    if args.gpus != world and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         return 2
     # Test hooks (tests/test_gpu_bench_two_ranks.py): several ranks on ONE GPU with gloo collectives, to exercise the
     # N > 1 control flow (route fall-back, self-verification, per-rank timing) where no multi-GPU node exists.  RCCL
@@ -1261,6 +1297,23 @@ def main() -> int:
         out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds, with_score_sweep=True)
     else:
         out["cpu_baseline"] = None
+    # The like-for-like pair of the CPU baseline: the C port rebuilds all cells of the likelihood field on every scan (as the
+    # reference does, GridMap.java:233-250); the headline step rebuilds the dirty tiles only.  The same step with every cell
+    # rebuilt and likelihoodData written (--full-rebuild's path) is timed here and stated beside the baseline.
+    if want_cpu and out["cpu_baseline"] and config == "C3" and not (args.full_rebuild or args.host_inputs or args.force_sharded):
+        try:
+            fr_args = argparse.Namespace(**vars(args))
+            fr_args.full_rebuild = True
+            wf = Workload("C3", fr_args, torch, dist, 0, 1, local_rank, False)
+            mf = measure(wf, 60, 8)
+            out["cpu_baseline"]["gpu_like_for_like_ms_per_step"] = mf["steady"] * 1e3
+            out["cpu_baseline"]["gpu_like_for_like_what"] = ("the same scan step through the separate entry points with computeLikelihoodMap over ALL cells and "
+                                                             "likelihoodData written every scan (bench.py --full-rebuild), as the CPU port does")
+            wf.pf.close(); wf.m.close()
+            del wf
+        except Exception as e:
+            out["cpu_baseline"]["gpu_like_for_like_ms_per_step"] = None
+            print(f"bench.py: like-for-like (full rebuild) run failed: {e!r}", file=sys.stderr)
 
     # ---- the other single-GPU configurations, shorter runs of the same measurement ------------------------------------
     if world == 1 and not args.no_secondary and config == "C3" and not (args.full_rebuild or args.host_inputs or args.particles or args.force_sharded):
@@ -1358,6 +1411,15 @@ def main() -> int:
                              "n_zero_weights": st["n_zero"], "weight_sum_finite": bool(np.isfinite(st["weight_sum"]))}
                 w4.pf.close(); w4.m.close()
                 del w4
+            except Exception as e:
+                sec[name] = {"error": repr(e)}
+        # the reference's own filter shape (SLAM.java: one GridMapData per particle) at its operating point and at a size that
+        # no longer fits the caches
+        for name, (n_, ext_, b_, k_) in (("per_particle_maps", (500, 6.0, 90, 50)), ("per_particle_maps_4096x256", (4096, 12.8, 180, 10))):
+            try:
+                pm = particle_maps_run(torch, local_rank, n_, ext_, 0.05, b_, k_, cpu_seconds=(3.0 if (want_cpu and n_ <= 1000) else 0.0))
+                pm["ms_per_step"] = pm["update_ms"]
+                sec[name] = pm
             except Exception as e:
                 sec[name] = {"error": repr(e)}
         rec = os.path.join(ROOT, "tests", "golden", "recording_360.bin")

@@ -191,6 +191,7 @@ def load() -> C.CDLL:
     sig("gms_profile_calibrate2", C.c_int, vp, i32, vp, vp)
     sig("gms_map_tile_stats", C.c_int, vp, i32, vp)
     sig("gms_pf_set_log_normalize", C.c_int, vp, i32)
+    sig("gms_pf_set_reference_order", C.c_int, vp, i32)
     sig("gms_debug_f32", C.c_int, vp, i32, vp, vp, i64)
     sig("gms_slam_create", C.c_int, pp, i32, C.POINTER(vp))
     sig("gms_slam_destroy", C.c_int, vp)

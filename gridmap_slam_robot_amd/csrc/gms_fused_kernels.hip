@@ -298,6 +298,7 @@ void gms_launch_partials_pack_apply(gms_pf *pf, bool apply_rides_later) {
                        pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg,
                        pf->d_global_own + pf->offset, n_local, m->gd, m->d_log, m->d_cnt_pend, cur, idle);
     pf->pending_nseg = 0;
+    pf->score_fresh = 0;               // the scoring pass has been consumed (raw weights packed for the exchange)
     if (n_apply) gms_apply_done(m);
 }
 

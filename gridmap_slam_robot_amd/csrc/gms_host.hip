@@ -479,6 +479,7 @@ static int stream_after(hipStream_t later, hipStream_t earlier, const char *what
 int gms_map_copy(gms_map *dst, const gms_map *src) {                  // GridMap.java:106-124
     REQUIRE(dst && src, "null argument");
     REQUIRE(dst->gd.W == src->gd.W && dst->gd.H == src->gd.H && dst->n_maps == src->n_maps, "gms_map_copy: shape mismatch");
+    REQUIRE(dst->device == src->device, "gms_map_copy: both handles must live on the same device (the copies and their stream hand-over are device-local)");
     const size_t bytes = (size_t)src->gd.cells * src->n_maps * sizeof(double);
     HIPCHK(hipSetDevice(dst->device));
     gms_ensure_lik(const_cast<gms_map *>(src));
@@ -502,6 +503,7 @@ int gms_map_copy(gms_map *dst, const gms_map *src) {                  // GridMap
 int gms_map_combine(gms_map *dst, gms_map *src) {                        // GridMapApp.java:439-458
     REQUIRE(dst && src, "null argument");
     REQUIRE(dst->n_maps == 1 && dst->gd.W == src->gd.W && dst->gd.H == src->gd.H, "gms_map_combine: dst must be one map of the same size");
+    REQUIRE(dst->device == src->device, "gms_map_combine: both handles must live on the same device");
     HIPCHK(hipSetDevice(dst->device));
     // src's deferred apply pass (a fused scan step or gms_map_update leaves the last scan's counts un-applied) is enqueued on
     // src's stream; the combine reads src's log-odds on dst's stream, so dst's stream must wait for it -- an event after the
@@ -834,7 +836,6 @@ int gms_map_update_at_dev(gms_map *m, const gms_beam *dev_beams, int32_t B, gms_
     return finish_likelihood(m, m->need_full_build ? 0 : 1);
 }
 
-// development: where instrumented builds (-DGMS_STAMPS) write their stage time stamps; GMS_ERR_STATE in a product build
 int gms_map_tile_stats(gms_map *m, int32_t enable, int64_t *out4) {
     REQUIRE(m, "null map");
     HIPCHK(hipSetDevice(m->device));
@@ -851,6 +852,7 @@ int gms_map_tile_stats(gms_map *m, int32_t enable, int64_t *out4) {
     return GMS_OK;
 }
 
+// development: where instrumented builds (-DGMS_STAMPS) write their stage time stamps; GMS_ERR_STATE in a product build
 int gms_debug_set_stamps(gms_map *m, void *dev_buffer) {
     REQUIRE(m, "null map");
     HIPCHK(hipSetDevice(m->device));
@@ -940,6 +942,8 @@ int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // Partic
     if (const char *v = getenv("GMS_SCORE_ORDER")) pf->order_mode = atoi(v);
     pf->score_threads = 0;
     if (const char *v = getenv("GMS_SCORE_THREADS")) pf->score_threads = atoi(v);
+    pf->score_spread = -1;
+    if (const char *v = getenv("GMS_SCORE_SPREAD")) pf->score_spread = atoi(v) != 0;
     ok = ok && hipHostMalloc(&pf->h_stats, (size_t)m->n_maps * sizeof(PfStatsDev) + (size_t)m->n_maps * 8) == hipSuccess;
     ok = ok && hipHostMalloc(&pf->h_stage, T * 3 * sizeof(float)) == hipSuccess;
     ok = ok && ring_alloc(pf->pose_ring, T * 3 * sizeof(float)) == GMS_OK;
@@ -960,7 +964,7 @@ int gms_pf_set_shard(gms_pf *pf, int64_t offset, int64_t n_global) {
     pf->offset = offset;
     pf->n_global = n_global;
     pf->have_global = 0;
-    if (offset != 0 || n_global != pf->n) pf->log_norm = 0;           // (stand-alone filters only: gms_pf_set_log_normalize)
+    if (offset != 0 || n_global != pf->n) { pf->log_norm = 0; pf->reference_order = 0; }      // (stand-alone filters only)
     return pf_alloc_global(pf);
 }
 
@@ -1014,6 +1018,7 @@ int gms_pf_set_weights(gms_pf *pf, const double *w) {
     pf->pending_nseg = 0;
     pf->have_global = 0;
     pf->stats_current = 0;
+    pf->score_fresh = 0;                // d_w no longer belongs to d_logw: a log-normalising filter takes these weights as they are
     return pf_copy_f64(pf, pf->d_w, const_cast<double *>(w), true);
 }
 int gms_pf_get_weights(gms_pf *pf, double *w) {
@@ -1110,6 +1115,16 @@ int gms_pf_normalize(gms_pf *pf, gms_pf_stats *stats) {                 // SLAM.
     if (pf->offset != 0 || pf->n_global != pf->n)
         return fail(GMS_ERR_STATE, "sharded filter: use gms_pf_local_partials / apply_partials / import_global");
     HIPCHK(hipSetDevice(pf->map->device));
+    if (pf->reference_order) {                         // the audit path: one lane, the reference's own loops
+        gms_launch_pf_combine(pf);
+        gms_launch_pf_normalize_seq(pf, pf->d_stats, true);
+        pf->have_global = 0;
+        pf->stats_current = 1;
+        pf->score_fresh = 0;
+        HIPCHK(hipGetLastError());
+        if (stats) { int rc_ = pull_stats(pf); if (rc_) return rc_; fill_stats(pf, stats); }
+        return GMS_OK;
+    }
     pf->d_global = pf->d_global_own;
     gms_launch_pf_partials(pf, pf->d_partials);
     gms_launch_pf_apply_partials(pf, pf->d_partials, pf->d_global, true);
@@ -1195,8 +1210,13 @@ int gms_pf_weighted_pose(gms_pf *pf, float *out) {                      // SLAM.
         // recomputes the pose from whatever the particles are now (J/app/GridMapApp.java:192)
         if (pf->offset != 0 || pf->n_global != pf->n)
             return fail(GMS_ERR_STATE, "sharded filter: gms_pf_local_partials -> all-reduce -> gms_pf_stats_from_partials first");
-        gms_launch_pf_partials(pf, pf->d_partials);
-        gms_launch_pf_stats_only(pf, pf->d_partials, pf->d_stats + pf->n_maps);
+        if (pf->reference_order) {
+            gms_launch_pf_combine(pf);
+            gms_launch_pf_normalize_seq(pf, pf->d_stats + pf->n_maps, false);
+        } else {
+            gms_launch_pf_partials(pf, pf->d_partials);
+            gms_launch_pf_stats_only(pf, pf->d_partials, pf->d_stats + pf->n_maps);
+        }
         pf->stats_current = 2;
     }
     const PfStatsDev *src = pf->d_stats + (pf->stats_current == 2 ? pf->n_maps : 0);
@@ -1234,16 +1254,20 @@ static int do_resample(gms_pf *pf, const double *r01, double fraction, int32_t *
     REQUIRE(pf && r01, "null argument");
     gms_map *m = pf->map;
     HIPCHK(hipSetDevice(m->device));
-    int rc = ensure_global(pf);
+    int rc = GMS_OK;
+    if (!pf->reference_order) rc = ensure_global(pf);
+    else gms_launch_pf_combine(pf);
     if (rc) return rc;
     rc = stage_r01(pf, r01);
     if (rc) return rc;
-    gms_launch_pf_resample(pf, fraction);
+    if (pf->reference_order) gms_launch_pf_resample_seq(pf, fraction);      // the audit path: the reference's own loop on one lane
+    else gms_launch_pf_resample(pf, fraction);
     rc = commit_r01(pf);
     if (rc) return rc;
     std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);
     pf->have_global = 0;
     pf->stats_current = 0;
+    pf->score_fresh = 0;                // the copies' weights are not the log-weights' (d_logw is not permuted): never rescale them from those
     HIPCHK(hipGetLastError());
     if (indices) {
         HIPCHK(hipMemcpyAsync(indices, pf->d_idx, (size_t)pf->n * pf->n_maps * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
@@ -1280,6 +1304,7 @@ static int paired_likelihood_resample(gms_pf *pf, const double *r01, double frac
         std::swap(pf->d_pose, pf->d_pose2); std::swap(pf->d_cs, pf->d_cs2); std::swap(pf->d_w, pf->d_w2);
         pf->have_global = 0;
         pf->stats_current = 0;
+        pf->score_fresh = 0;
         gms_defer_apply(m);
     } else {                                // no resample to pair with: the immediate protocol
         gms_launch_apply_counts(m);
@@ -1318,7 +1343,7 @@ static int slam_update_impl(gms_pf *pf, const float *dev_xytheta, const MotionMo
         return fail(GMS_ERR_STATE, "sharded filter: the collectives belong to the caller (see distributed.py)");
     int rc = GMS_OK;
     rc = set_poses_and_score_dev(pf, dev_xytheta, dev_beams, B, pf->refine != 0, motion);   // SLAM.java:90, :96-97, :99
-    if (!rc && integrate && gms_can_pair_launches(pf, B)) {
+    if (!rc && integrate && !pf->reference_order && gms_can_pair_launches(pf, B)) {
         // The weight branch and the map branch are independent once the partials exist: they share launches
         // (gms_fused_kernels.hip).  (Two streams were measured: the event fork/join costs more than it hides.)
         pf->d_global = pf->d_global_own;
@@ -1328,7 +1353,7 @@ static int slam_update_impl(gms_pf *pf, const float *dev_xytheta, const MotionMo
         pf->stats_current = 1;
         return paired_likelihood_resample(pf, r01, resample_fraction);           // :105 | GridMapApp.java:185-186
     }
-    if (!rc && integrate && pf->n_maps > 1 && B > 0 && !m->need_full_build && m->pair_launches) {
+    if (!rc && integrate && !pf->reference_order && pf->n_maps > 1 && B > 0 && !m->need_full_build && m->pair_launches) {
         // batched maps: the ray cast runs 16 rays per workgroup (1024 threads), so only the other two pairs apply:
         // [partials | previous apply] -> normalise -> ray cast -> [likelihood | resample]
         pf->d_global = pf->d_global_own;
@@ -1448,7 +1473,19 @@ int gms_pf_set_log_normalize(gms_pf *pf, int32_t on) {
     REQUIRE(pf, "null filter");
     if (on && (pf->offset != 0 || pf->n_global != pf->n))
         return fail(GMS_ERR_STATE, "gms_pf_set_log_normalize: stand-alone filters only (a shard does not know the other shards' largest log-weight)");
+    if (on && pf->reference_order) return fail(GMS_ERR_STATE, "gms_pf_set_log_normalize: the reference-order audit path is on (gms_pf_set_reference_order)");
     pf->log_norm = on ? 1 : 0;
+    return GMS_OK;
+}
+
+int gms_pf_set_reference_order(gms_pf *pf, int32_t on) {
+    REQUIRE(pf, "null filter");
+    if (on && (pf->offset != 0 || pf->n_global != pf->n))
+        return fail(GMS_ERR_STATE, "gms_pf_set_reference_order: stand-alone filters only (the audit path adds up on ONE lane of ONE device)");
+    if (on && pf->log_norm) return fail(GMS_ERR_STATE, "gms_pf_set_reference_order: log-normalisation is on (not the reference's arithmetic): turn it off first");
+    pf->reference_order = on ? 1 : 0;
+    pf->have_global = 0;
+    pf->stats_current = 0;
     return GMS_OK;
 }
 
@@ -1661,6 +1698,9 @@ int gms_pf_normalize_sharded_end(gms_pf *pf, gms_comm *c) {
 // (the owner's division, w / weightSum, repeated on the gathered copy: same operands, same bits), ray cast, resample.
 static int sharded_shape_ok(const gms_pf *pf) {
     if (pf->n_maps != 1) return fail(GMS_ERR_STATE, "sharded filters hold one map per handle");
+    if (pf->reference_order) return fail(GMS_ERR_STATE, "gms_pf_set_reference_order is on: stand-alone scan steps only");
+    if (pf->log_norm)
+        return fail(GMS_ERR_STATE, "gms_pf_set_log_normalize is on: the sharded scan steps exchange raw weights and do not rescale them; turn it off (stand-alone steps only)");
     if (pf->n_global != pf->n && pf->n % GMS_BLOCK)
         return fail(GMS_ERR_INVALID, "shard size %d must be a multiple of GMS_BLOCK=%d", pf->n, GMS_BLOCK);
     if (pf->n_global % pf->n || pf->offset % pf->n)

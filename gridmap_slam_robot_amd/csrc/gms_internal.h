@@ -184,6 +184,9 @@ struct gms_pf {
     int32_t score_fresh;            // d_w / d_logw (or the segment products) come from a scoring pass nothing has consumed yet
     double *d_blockmax;             // [n_maps][nblk_global] per-block maxima of the log-weights (log-normalisation's first pass)
     int32_t score_threads;          // 0 the launcher decides (the largest of 1024 / 512 / 256 lanes per scoring workgroup that still gives every CU one); GMS_SCORE_THREADS forces 64..1024
+    int32_t reference_order;        // gms_pf_set_reference_order: the audit path -- every re-associated chain (the scan's product, weightSum, the
+                                    // cumulative weights) as ONE chain in the reference's order (tests; slow)
+    int32_t score_spread;           // -1 the launcher decides (launches of two or more workgroups per CU), 0 / 1 forced (GMS_SCORE_SPREAD, read at creation)
     int32_t order_mode;             // -1 the launcher decides (large launches only), 0 never, 1 always (GMS_SCORE_ORDER; results do not depend on it)
 };
 
@@ -278,6 +281,8 @@ void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedPa
 void gms_launch_pf_stats_only(gms_pf *pf, const double *d_partials, PfStatsDev *d_stats_out);
 void gms_launch_pf_resample(gms_pf *pf, double fraction /* <0: unconditional */);
 void gms_launch_pf_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);
+void gms_launch_pf_normalize_seq(gms_pf *pf, PfStatsDev *d_stats_out, bool normalise);
+void gms_launch_pf_resample_seq(gms_pf *pf, double fraction);
 // one GridMapData per particle (gms_slam_kernels.hip)
 void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, int32_t n);
 void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, double *d_log, const double *d_lik, const MotionModel *motion,

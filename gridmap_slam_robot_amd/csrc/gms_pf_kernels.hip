@@ -1239,6 +1239,171 @@ k_refine(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, cons
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Reference-order audit (gms_pf_set_reference_order; tests, slow on purpose).  The default kernels re-associate three chains of the
+// reference: the product of a scan's factors (16 segment products, combine_segments), weightSum (blocked sums) and the cumulative
+// weights of resample() (a three-level scan).  Here each is ONE chain in the reference's own order -- so that a test can demand
+// equality with the oracle, bit for bit, zeros and denormals included, and then compare the default path with THIS path: whatever
+// differs between the two is association and nothing else.
+// ---------------------------------------------------------------------------------------------
+// probabilityOf (GridMap.java:261-294): lane = particle, the product of ALL hit beams' factors in one register, in beam order.  The
+// beams pass through the LDS table 128 at a time; log-weight = sum over those chunks of log(chunk product) (every chunk product is
+// a normal double: >= 0.01^128).
+__global__ void __launch_bounds__(256)
+k_score_seq(GridDev g, const double *__restrict__ fac_all, int64_t fac_stride, const gms_beam *__restrict__ beams, int32_t B,
+            int32_t beam_stride, const float *__restrict__ pose, const float *__restrict__ cs, int32_t n, double *__restrict__ w,
+            double *__restrict__ logw) {
+    __shared__ double2 s_beam[128];
+    __shared__ int32_t s_nb;
+    const int32_t mi = blockIdx.y;
+    const int32_t p = blockIdx.x * 256 + threadIdx.x;
+    const size_t gi = (size_t)mi * n + (p < n ? p : 0);
+    const gms_beam *mb = beams + (size_t)mi * beam_stride;
+    const double *fac = fac_all + (size_t)mi * fac_stride;
+    XformDev t;
+    t.c = (double)cs[2 * gi]; t.s = (double)cs[2 * gi + 1]; t.px = (double)pose[3 * gi]; t.py = (double)pose[3 * gi + 1];
+    double prod = 1.0, lsum = 0.0;                                     // GridMap.java:262
+    for (int32_t j0 = 0; j0 < B; j0 += 128) {
+        __syncthreads();                                               // the previous chunk has been consumed
+        if (threadIdx.x < 64) {                                        // order-preserving compaction of the chunk's hit beams (:269)
+            const int32_t j1 = min(B, j0 + 128);
+            int32_t base = 0;
+            for (int32_t b0 = j0; b0 < j1; b0 += 64) {
+                const int32_t b = b0 + (int32_t)threadIdx.x;
+                const bool hit = b < j1 && mb[b].hit != 0;
+                const unsigned long long mask = __ballot(hit);
+                if (hit) s_beam[base + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = make_double2(mb[b].local_x, mb[b].local_y);
+                base += __popcll(mask);
+            }
+            if (threadIdx.x == 0) s_nb = base;
+        }
+        __syncthreads();
+        const int32_t nb = s_nb;
+        double cp = 1.0;
+        for (int32_t k = 0; k < nb; k++) {
+            const double2 bm = s_beam[k];
+            const double f = fac[beam_cell(g, t, bm.x, bm.y)];         // the reference's own quotients (:273-288)
+            prod *= f;                                                 // product *= ... (:286-288)
+            cp *= f;
+        }
+        int e;
+        const double mnt = frexp(cp, &e);
+        lsum += log(mnt) + (double)e * 0.6931471805599453;
+    }
+    if (p < n) { w[gi] = prod; logw[gi] = lsum; }
+}
+
+// SLAM.update's bookkeeping as the reference's own loops (SLAM.java:87-124, calculateNeff :180-190, getWeightedPose :165-178): ONE
+// lane adds in particle order.  The weights pass through LDS 2048 at a time (every thread loads, lane 0 adds).  normalise = 0: the
+// statistics of the weights as they stand (nothing rewritten).  One workgroup per map.
+#define SEQ_CHUNK 2048
+__global__ void __launch_bounds__(256)
+k_normalize_seq(double *__restrict__ w_all, const double *__restrict__ logw_all, const float *__restrict__ pose_all, int32_t n,
+                PfStatsDev *__restrict__ stats_all, int32_t normalise) {
+    __shared__ double s_w[SEQ_CHUNK];
+    __shared__ double s_l[SEQ_CHUNK];
+    __shared__ float s_p[SEQ_CHUNK * 3];
+    __shared__ double s_sum;
+    const int32_t mi = blockIdx.x;
+    double *w = w_all + (size_t)mi * n;
+    const double *lw = logw_all + (size_t)mi * n;
+    const float *pose = pose_all + (size_t)mi * n * 3;
+    PfStatsDev *st = stats_all + mi;
+    double weight_sum = 0.0, max_w = 0.0, max_l = -INFINITY;
+    int32_t strongest = -1, nz = 0;
+    for (int32_t c0 = 0; c0 < n; c0 += SEQ_CHUNK) {                    // :88-117
+        const int32_t len = min(SEQ_CHUNK, n - c0);
+        __syncthreads();
+        for (int32_t i = threadIdx.x; i < len; i += 256) { s_w[i] = w[c0 + i]; s_l[i] = lw[c0 + i]; }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int32_t i = 0; i < len; i++) {
+                const double v = s_w[i];
+                weight_sum += v;                                       // :100
+                if (strongest < 0) { strongest = c0 + i; max_w = v; }  // :110-111
+                else if (v > max_w) { strongest = c0 + i; max_w = v; } // :113-114 (strict)
+                if (v == 0.0) nz++;
+                if (s_l[i] > max_l) max_l = s_l[i];
+            }
+    }
+    if (threadIdx.x == 0) s_sum = weight_sum;
+    __syncthreads();
+    const double sum = s_sum;
+    if (normalise)
+        for (int32_t i = threadIdx.x; i < n; i += 256) w[i] = w[i] / sum;          // :120-121
+    __syncthreads();
+    // calculateNeff's `sum` (:181-183) and getWeightedPose's four sums (:167-174), then Neff's squares (:185-187)
+    double norm_sum = 0.0, xs = 0.0, ys = 0.0, ts = 0.0, sq = 0.0;
+    for (int pass = 0; pass < 2; pass++)
+        for (int32_t c0 = 0; c0 < n; c0 += SEQ_CHUNK) {
+            const int32_t len = min(SEQ_CHUNK, n - c0);
+            __syncthreads();
+            for (int32_t i = threadIdx.x; i < len; i += 256) s_w[i] = w[c0 + i];
+            if (pass == 0) for (int32_t i = threadIdx.x; i < 3 * len; i += 256) s_p[i] = pose[3 * (size_t)c0 + i];
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (int32_t i = 0; i < len; i++) {
+                    const double v = s_w[i];
+                    if (pass == 0) {
+                        xs += (double)s_p[3 * i] * v;                                  // :170
+                        ys += (double)s_p[3 * i + 1] * v;                              // :171
+                        ts += angle_constrain((double)s_p[3 * i + 2]) * v;             // :172
+                        norm_sum += v;                                                 // :173 == :183
+                    } else {
+                        sq += (v / norm_sum) * (v / norm_sum);                         // :187
+                    }
+                }
+        }
+    if (threadIdx.x == 0) {
+        st->weight_sum = weight_sum; st->max_w = max_w; st->max_logw = max_l; st->strongest = strongest < 0 ? 0 : strongest; st->n_zero = nz;
+        st->norm_sum = norm_sum; st->sq_sum = sq; st->xs = xs; st->ys = ys; st->ts = ts;
+        st->wpose[0] = (float)(xs / norm_sum); st->wpose[1] = (float)(ys / norm_sum); st->wpose[2] = (float)(ts / norm_sum);   // :176
+        const int32_t sp = strongest < 0 ? 0 : strongest;
+        st->spose[0] = pose[3 * (size_t)sp]; st->spose[1] = pose[3 * (size_t)sp + 1]; st->spose[2] = pose[3 * (size_t)sp + 2];
+        st->n_ambiguous = 0;
+    }
+}
+
+// resample() (SLAM.java:133-153) as the reference's own loop: ONE lane, c += weight in particle order.  One thread per map.
+__global__ void k_resample_seq_idx(const double *__restrict__ w_all, int32_t n, const double *__restrict__ r01_maps, double r01_scalar,
+                                   double fraction, int32_t *__restrict__ idx_all, PfStatsDev *__restrict__ stats_all) {
+    const int32_t mi = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const double *w = w_all + (size_t)mi * n;
+    int32_t *idx = idx_all + (size_t)mi * n;
+    PfStatsDev *st = stats_all + mi;
+    const bool go = fraction < 0.0 || (1.0 / st->sq_sum) < fraction * (double)n;        // GridMapApp.java:185
+    st->did_resample = go ? 1 : 0;
+    st->n_ambiguous = 0;
+    if (!go) { for (int32_t m = 0; m < n; m++) idx[m] = m; return; }
+    const double N = (double)n;
+    const double r = (r01_maps ? r01_maps[mi] : r01_scalar) * 1.0 / N;                  // :136
+    double c = w[0];                                                                    // :137
+    int32_t i = 0;
+    for (int32_t m = 1; m <= n; m++) {                                                  // :140
+        const double U = r + (double)(m - 1) * 1.0 / N;                                 // :141
+        while (U > c) {                                                                 // :142
+            if (i >= n - 1) break;                                                      // (Java: IndexOutOfBoundsException; clamped as the oracle does)
+            i++;
+            c += w[i];                                                                  // :144
+        }
+        idx[m - 1] = i;                                                                 // :147
+    }
+}
+// ... and the copies (:147 -> :41-43): pose, trig, weight of slot m from particle idx[m]
+__global__ void __launch_bounds__(256)
+k_resample_seq_gather(const int32_t *__restrict__ idx_all, const float *__restrict__ pose, const float *__restrict__ cs,
+                      const double *__restrict__ w, int32_t n, float *__restrict__ pose2, float *__restrict__ cs2, double *__restrict__ w2) {
+    const int32_t mi = blockIdx.y;
+    const int32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= n) return;
+    const size_t o = (size_t)mi * n + m, sidx = (size_t)mi * n + idx_all[o];
+    pose2[3 * o] = pose[3 * sidx]; pose2[3 * o + 1] = pose[3 * sidx + 1]; pose2[3 * o + 2] = pose[3 * sidx + 2];
+    cs2[2 * o] = cs[2 * sidx]; cs2[2 * o + 1] = cs[2 * sidx + 1];
+    w2[o] = w[sidx];
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -1307,6 +1472,17 @@ static int64_t score_segments(int32_t B, bool batched) {
 void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_pose_src,
                          const MotionModel *motion) {
     gms_map *m = pf->map;
+    if (pf->reference_order) {
+        // the audit path: poses first (launches of their own), then the whole scan's product in one register per particle
+        if (d_pose_src) gms_launch_pf_pose_trig(pf, d_pose_src);
+        if (motion) gms_launch_pf_motion(pf, motion->d_center, motion->d_theta, motion->seed, motion->sequence);
+        ProfScope ps(m, GMS_K_SCORE);
+        hipLaunchKernelGGL(k_score_seq, dim3((unsigned)((pf->n + 255) / 256), pf->n_maps), dim3(256), 0, m->stream, m->gd, m->d_fac, m->fac_stride,
+                           d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, pf->d_w, pf->d_logw);
+        pf->pending_nseg = 0;
+        pf->score_fresh = 1;
+        return;
+    }
     MotionArgs mo;
     mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0;
     const int64_t nseg = score_segments(B, pf->n_maps > 1);
@@ -1343,12 +1519,14 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
     // (At C3 512-lane workgroups measure the same as 1024; 768: +40 %.)
     int32_t threads = pf->n >= 1024 ? 1024 : ((pf->n + 63) / 64) * 64;
     if (pf->score_threads >= 64 && pf->score_threads <= 1024) threads = (pf->score_threads / 64) * 64;
-    else
+    else {
         while (threads > 256 && nseg * (((int64_t)pf->n + threads - 1) / threads) * pf->n_maps < m->n_cus) threads >>= 1;
+        threads = ((threads + 63) / 64) * 64;                     // whole wavefronts (700 particles: 704 -> 352 -> 384 lanes, not 352)
+    }
     const int64_t groups = ((int64_t)pf->n + threads - 1) / threads;
     // two or more workgroups per CU (see k_score_c's workgroup map; 24 576 particles, 1.5 per CU: 35.5 us without, 37.5 with; 32 768: 48.7 / 43.3)
     int32_t spread = nseg * groups >= 2 * (int64_t)m->n_cus ? 1 : 0;
-    if (const char *v = getenv("GMS_SCORE_SPREAD")) spread = atoi(v) != 0;
+    if (pf->score_spread >= 0) spread = pf->score_spread;
     if (ordered)
         hipLaunchKernelGGL(k_score_c<3>, dim3((unsigned)(nseg * groups), 1, pf->n_maps), dim3(threads), 0, m->stream, m->gd,
                            m->d_fac, m->fac_stride, d_beams, B, beam_stride, pf->d_pose, pf->d_cs, pf->n, (int32_t)nseg,
@@ -1477,4 +1655,19 @@ void gms_launch_pf_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_
                             (int)smem);
     hipLaunchKernelGGL(k_refine, dim3(pf->n, pf->n_maps), dim3(256), smem, m->stream, m->gd, m->d_fac, m->fac_stride,
                        pf->d_hitbeams, pf->d_nhit, m->max_beams, pf->d_pose, pf->d_cs, pf->n);
+}
+
+// ---- the reference-order audit path (gms_pf_set_reference_order) ----
+void gms_launch_pf_normalize_seq(gms_pf *pf, PfStatsDev *d_stats_out, bool normalise) {
+    gms_map *m = pf->map;
+    ProfScope ps(m, GMS_K_REDUCE);
+    hipLaunchKernelGGL(k_normalize_seq, dim3(pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw, pf->d_pose, pf->n, d_stats_out, normalise ? 1 : 0);
+}
+void gms_launch_pf_resample_seq(gms_pf *pf, double fraction) {
+    gms_map *m = pf->map;
+    ProfScope ps(m, GMS_K_RESAMPLE);
+    hipLaunchKernelGGL(k_resample_seq_idx, dim3(pf->n_maps), dim3(64), 0, m->stream, pf->d_w, pf->n,
+                       pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01_src, pf->r01_scalar, fraction, pf->d_idx, pf->d_stats);
+    hipLaunchKernelGGL(k_resample_seq_gather, dim3((unsigned)((pf->n + 255) / 256), pf->n_maps), dim3(256), 0, m->stream, pf->d_idx, pf->d_pose,
+                       pf->d_cs, pf->d_w, pf->n, pf->d_pose2, pf->d_cs2, pf->d_w2);
 }

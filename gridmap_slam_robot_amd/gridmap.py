@@ -527,6 +527,11 @@ class ParticleFilter:
         product that underflows at hundreds of beams (gms_pf_set_log_normalize)."""
         check(load().gms_pf_set_log_normalize(self._h, 1 if on else 0))
 
+    def set_reference_order(self, on: bool = True):
+        """the audit path (gms_pf_set_reference_order): the scan's product, weightSum and the cumulative weights each as ONE chain in
+        the reference's order (tests; slow)"""
+        check(load().gms_pf_set_reference_order(self._h, 1 if on else 0))
+
     def resample(self, r01=None, want_indices: bool = False):
         """resample() (SLAM.java:133-153); r01 stands for Math.random()."""
         if r01 is None:

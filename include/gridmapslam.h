@@ -258,6 +258,15 @@ int gms_pf_set_refine(gms_pf *pf, int32_t on);
  * (GMS_ERR_STATE on a shard); gms_pf_set_shard turns it off. */
 int gms_pf_set_log_normalize(gms_pf *pf, int32_t on);
 
+/* Reference-order audit (tests; slow on purpose).  The default kernels re-associate three chains of the reference's arithmetic: the
+ * product of a scan's factors (GridMap.java:262-288: segment products, combined), weightSum (SLAM.java:100: blocked sums) and the
+ * cumulative weights of resample() (SLAM.java:137-144: a three-level scan).  on != 0: gms_pf_score, gms_pf_normalize, gms_pf_resample[_if],
+ * gms_pf_weighted_pose and the scan steps of this filter (which then take the separate launches) run each of them as ONE chain in
+ * the reference's own order -- one register per particle for the product, one lane for the sums -- so that raw weights (zeros and
+ * denormals included), the weight sum, Neff, the weighted pose and the resampling indices can be compared with the oracle for
+ * EQUALITY, and the default path with this one: what differs between the two is association and nothing else.  Stand-alone filters. */
+int gms_pf_set_reference_order(gms_pf *pf, int32_t on);
+
 /* ---- SLAM as the reference has it: one GridMapData per particle --------------------------------------------------------------
  * J/slam/SLAM.java keeps a map in every Particle (:30-47): update() scores a particle against ITS OWN likelihood field and
  * integrates the scan into ITS OWN map at ITS OWN pose (:88-107), resample() deep-copies both arrays of the surviving particle's

@@ -10,6 +10,7 @@
 //   gms::GridMap          J/slam/GridMap.java:47-432       (one object = GridMap + its GridMapData)
 //   gms::ParticleFilter   J/slam/ParticleFilter.java:19-84 (resample semantics of SLAM.resample)
 //   gms::SLAM             J/slam/SLAM.java:26-204          (one shared map, N poses: SURVEY.md fact 3)
+//   gms::SlamParticleMaps J/slam/SLAM.java:26-204          (the reference's own shape: every Particle owns a GridMapData)
 //
 // Java signals nothing on this path except ArrayIndexOutOfBounds from getRawAt; here every failing
 // C-ABI call throws gms::Error carrying gms_last_error().
@@ -273,6 +274,83 @@ public:
 private:
     GridMap gridMap_;
     ParticleFilter pf_;
+    int strongest_ = 0;
+};
+
+/** SLAM as the reference has it (J/slam/SLAM.java:26-204): every Particle owns a pose, a weight AND a GridMapData.  update() scores a
+ *  particle against its own likelihood field and integrates the scan into its own map at its own pose (:88-107); resample()
+ *  deep-copies the surviving particles' maps (:41-45 -> GridMap.createMapData(other), GridMap.java:106-124).  findBestPoseOptim (:97)
+ *  is left out; the motion-model draw of Odometry.apply is Philox(seed; particle slot, sequence). */
+class SlamParticleMaps {
+public:
+    struct Odometry { double dCenter = 0, dTheta = 0; };                                   // J/slam/Odometry.java:31
+    struct Particle { double weight; Pose pose; };                                          // SLAM.Particle without its map: mapOf(i)
+
+    explicit SlamParticleMaps(int numParticles = 500, float width = 6.0f, float height = 6.0f, float resolution = 0.05f,
+                              float posX = -3.0f, float posY = -3.0f, int maxBeams = 0) : n_(numParticles) {   // SLAM.java:50,57
+        gms_params p{};
+        check(gms_params_default(&p, width, height, resolution, posX, posY));
+        p.max_beams = maxBeams;
+        check(gms_slam_create(&p, numParticles, &h_));
+        check(gms_slam_handles(h_, &map_, &pf_));
+        check(gms_slam_count(h_, nullptr, &w_, &hgt_));
+    }
+    ~SlamParticleMaps() { gms_slam_destroy(h_); }
+    SlamParticleMaps(const SlamParticleMaps &) = delete;
+    SlamParticleMaps &operator=(const SlamParticleMaps &) = delete;
+
+    void reset() { check(gms_slam_reset(h_)); }                                             // :65-77
+    /** update(z, u) (:80-131); returns Neff.  seed / sequence select the motion model's variates (one sequence per frame). */
+    double update(const Observation &z, const Odometry &u, uint64_t seed, uint64_t sequence, bool sampleMotion = true) {
+        gms_pf_stats st{};
+        check(gms_slam_update_per_particle(h_, z.getMeasurements().data(), z.getNumberOfMeasurements(), sampleMotion ? 1 : 0, u.dCenter, u.dTheta,
+                                           seed, sequence, &st));
+        strongest_ = st.strongest;
+        return st.neff;
+    }
+    /** resample() (:133-153); r01 stands for Math.random() */
+    void resample(double r01) { check(gms_slam_resample_maps(h_, r01, nullptr, nullptr)); }
+    Pose getWeightedPose() { float o[3]; check(gms_pf_weighted_pose(pf_, o)); return Pose(o[0], o[1], o[2]); }      // :165-178
+    double calculateNeff() { gms_pf_stats s{}; check(gms_pf_get_stats(pf_, &s)); return s.neff; }                    // :180-190
+    std::vector<Particle> getParticles() {                                                  // :192
+        std::vector<float> p((size_t)n_ * 3);
+        std::vector<double> w(n_);
+        check(gms_pf_get_poses(pf_, p.data()));
+        check(gms_pf_get_weights(pf_, w.data()));
+        std::vector<Particle> out(n_);
+        for (int i = 0; i < n_; i++) out[i] = Particle{w[i], Pose(p[3 * i], p[3 * i + 1], p[3 * i + 2])};
+        return out;
+    }
+    void setPoses(const std::vector<Pose> &poses) {
+        std::vector<float> p((size_t)n_ * 3);
+        for (int i = 0; i < n_; i++) { p[3 * i] = poses[i].x; p[3 * i + 1] = poses[i].y; p[3 * i + 2] = poses[i].theta; }
+        check(gms_pf_set_poses(pf_, p.data()));
+    }
+    int getStrongestParticle() const { return strongest_; }                                 // :196
+    /** Particle i's GridMapData.logData (or .likelihoodData), W * H doubles, row-major x + y * W (SLAM.java:33, GridMap.java:72-74) */
+    std::vector<double> mapOf(int i, bool likelihood = false) {
+        std::vector<double> out((size_t)w_ * hgt_);
+        check(gms_slam_download_map(h_, i, likelihood ? nullptr : out.data(), likelihood ? out.data() : nullptr));
+        return out;
+    }
+    /** GridMapApp.calculateCombined (J/app/GridMapApp.java:439-458): the combined logData */
+    std::vector<double> calculateCombined() {
+        check(gms_slam_combined(h_));
+        std::vector<double> out((size_t)w_ * hgt_);
+        check(gms_map_download_log(map_, out.data()));
+        return out;
+    }
+    int size() const { return n_; }
+    int width() const { return w_; }
+    int height() const { return hgt_; }
+    gms_slam *handle() { return h_; }
+
+private:
+    gms_slam *h_ = nullptr;
+    gms_map *map_ = nullptr;     // owned by h_
+    gms_pf *pf_ = nullptr;       // owned by h_
+    int n_;
+    int32_t w_ = 0, hgt_ = 0;
     int strongest_ = 0;
 };
 

@@ -28,6 +28,7 @@
 #define MAP(h) ((gms_map *)(intptr_t)(h))
 #define PF(h) ((gms_pf *)(intptr_t)(h))
 #define COMM(h) ((gms_comm *)(intptr_t)(h))
+#define SLAM(h) ((gms_slam *)(intptr_t)(h))
 
 static void throw_named(JNIEnv *env, const char *cls, const char *msg) {
     jclass ex = (*env)->FindClass(env, cls);
@@ -315,5 +316,94 @@ JNIEXPORT void JNICALL CLS(slamUpdateSharded)(JNIEnv *env, jclass c, jlong pf, j
     const int rc = gms_slam_update_sharded(PF(pf), COMM(cm), p, buf, B, &r01, resampleFraction, integrate ? 1 : 0, &st);
     free(p); free(buf);
     if (!rc) stats_out(env, out3, &st);
+    throw_gms(env, rc);
+}
+
+/* ---- SLAM as the reference has it: one GridMapData per particle (J/slam/SLAM.java:26-204; gms_slam_* of gridmapslam.h) -------- */
+/* new SLAM() (SLAM.java:56-62): the GridMap's constants come from the JVM as for mapCreate */
+JNIEXPORT jlong JNICALL CLS(pmCreate)(JNIEnv *env, jclass c, jfloat w, jfloat h, jfloat res, jfloat px, jfloat py, jdouble lFree, jdouble lOcc,
+                                      jdoubleArray kernel, jint maxBeams, jint device, jint numParticles) {
+    gms_params p;
+    int rc = gms_params_default(&p, w, h, res, px, py);
+    if (rc) { throw_gms(env, rc); return 0; }
+    p.l_free = lFree; p.l_occ = lOcc; p.max_beams = maxBeams; p.device = device;
+    jsize k = (*env)->GetArrayLength(env, kernel);
+    if (k > GMS_MAX_TAPS) { throw_named(env, "java/lang/IllegalArgumentException", "likelihood kernel longer than GMS_MAX_TAPS"); return 0; }
+    (*env)->GetDoubleArrayRegion(env, kernel, 0, k, p.kernel);
+    p.ktaps = k;
+    gms_slam *s = NULL;
+    rc = gms_slam_create(&p, numParticles, &s);
+    throw_gms(env, rc);
+    return (jlong)(intptr_t)s;
+}
+JNIEXPORT void JNICALL CLS(pmDestroy)(JNIEnv *env, jclass c, jlong s) { throw_gms(env, gms_slam_destroy(SLAM(s))); }
+JNIEXPORT void JNICALL CLS(pmReset)(JNIEnv *env, jclass c, jlong s) { throw_gms(env, gms_slam_reset(SLAM(s))); }     /* SLAM.reset() :65-77 */
+/* SLAM.update(z, u) (:80-131): out3 = {weightSum, neff, strongest}; the motion-model variates are Philox(seed; particle, sequence) */
+JNIEXPORT void JNICALL CLS(pmUpdate)(JNIEnv *env, jclass c, jlong s, jdoubleArray beams, jint B, jboolean sampleMotion, jdouble dCenter,
+                                     jdouble dTheta, jlong seed, jlong sequence, jdoubleArray out3) {
+    gms_beam *buf = beams_from(env, beams, B);
+    if (!buf) return;
+    gms_pf_stats st;
+    const int rc = gms_slam_update_per_particle(SLAM(s), buf, B, sampleMotion ? 1 : 0, dCenter, dTheta, (uint64_t)seed, (uint64_t)sequence, &st);
+    free(buf);
+    if (!rc) stats_out(env, out3, &st);
+    throw_gms(env, rc);
+}
+/* SLAM.resample() (:133-153) with r = Math.random() drawn on the Java side */
+JNIEXPORT void JNICALL CLS(pmResample)(JNIEnv *env, jclass c, jlong s, jdouble r01) { throw_gms(env, gms_slam_resample_maps(SLAM(s), r01, NULL, NULL)); }
+/* getParticles() without the maps: {x, y, theta} and weight of every particle */
+JNIEXPORT void JNICALL CLS(pmGetParticles)(JNIEnv *env, jclass c, jlong s, jfloatArray xyt, jdoubleArray w, jint n) {
+    gms_pf *pf = NULL;
+    int32_t have = 0;
+    int rc = gms_slam_handles(SLAM(s), NULL, &pf);
+    if (!rc) rc = gms_slam_count(SLAM(s), &have, NULL, NULL);
+    if (rc) { throw_gms(env, rc); return; }
+    if (have != n) { throw_named(env, "java/lang/IllegalArgumentException", "particle count differs from the native filter's"); return; }
+    float *p = (float *)malloc((size_t)n * 3 * sizeof(float));
+    double *ww = (double *)malloc((size_t)n * sizeof(double));
+    if (!p || !ww) { free(p); free(ww); throw_named(env, "java/lang/OutOfMemoryError", "particle buffers"); return; }
+    rc = gms_pf_get_poses(pf, p);
+    if (!rc) rc = gms_pf_get_weights(pf, ww);
+    if (!rc) { (*env)->SetFloatArrayRegion(env, xyt, 0, 3 * n, p); (*env)->SetDoubleArrayRegion(env, w, 0, n, ww); }
+    free(p); free(ww);
+    throw_gms(env, rc);
+}
+/* getWeightedPose() (:165-178) */
+JNIEXPORT void JNICALL CLS(pmWeightedPose)(JNIEnv *env, jclass c, jlong s, jfloatArray out3) {
+    gms_pf *pf = NULL;
+    float o[3];
+    int rc = gms_slam_handles(SLAM(s), NULL, &pf);
+    if (!rc) rc = gms_pf_weighted_pose(pf, o);
+    if (!rc) (*env)->SetFloatArrayRegion(env, out3, 0, 3, o);
+    throw_gms(env, rc);
+}
+/* Particle i's GridMapData into the Java arrays (either may be null); the download synchronises, so it goes through heap buffers */
+JNIEXPORT void JNICALL CLS(pmDownloadMap)(JNIEnv *env, jclass c, jlong s, jint i, jdoubleArray logData, jdoubleArray likelihoodData) {
+    int32_t W = 0, H = 0;
+    int rc = gms_slam_count(SLAM(s), NULL, &W, &H);
+    if (rc) { throw_gms(env, rc); return; }
+    const size_t n = (size_t)W * H;
+    double *a = logData ? (double *)malloc(n * sizeof(double)) : NULL, *b = likelihoodData ? (double *)malloc(n * sizeof(double)) : NULL;
+    if ((logData && !a) || (likelihoodData && !b)) { free(a); free(b); throw_named(env, "java/lang/OutOfMemoryError", "map buffer"); return; }
+    rc = gms_slam_download_map(SLAM(s), i, a, b);
+    if (!rc && a) (*env)->SetDoubleArrayRegion(env, logData, 0, (jsize)n, a);
+    if (!rc && b) (*env)->SetDoubleArrayRegion(env, likelihoodData, 0, (jsize)n, b);
+    free(a); free(b);
+    throw_gms(env, rc);
+}
+/* GridMapApp.calculateCombined (J/app/GridMapApp.java:439-458) into the Java arrays of the combined GridMapData */
+JNIEXPORT void JNICALL CLS(pmCombined)(JNIEnv *env, jclass c, jlong s, jdoubleArray logData, jdoubleArray likelihoodData) {
+    gms_map *m = NULL;
+    int32_t W = 0, H = 0;
+    int rc = gms_slam_handles(SLAM(s), &m, NULL);
+    if (!rc) rc = gms_slam_count(SLAM(s), NULL, &W, &H);
+    if (!rc) rc = gms_slam_combined(SLAM(s));
+    if (rc) { throw_gms(env, rc); return; }
+    const size_t n = (size_t)W * H;
+    double *tmp = (double *)malloc(n * sizeof(double));
+    if (!tmp) { throw_named(env, "java/lang/OutOfMemoryError", "map buffer"); return; }
+    if (logData) { rc = gms_map_download_log(m, tmp); if (!rc) (*env)->SetDoubleArrayRegion(env, logData, 0, (jsize)n, tmp); }
+    if (!rc && likelihoodData) { rc = gms_map_download_likelihood(m, tmp); if (!rc) (*env)->SetDoubleArrayRegion(env, likelihoodData, 0, (jsize)n, tmp); }
+    free(tmp);
     throw_gms(env, rc);
 }

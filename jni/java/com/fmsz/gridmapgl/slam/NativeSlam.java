@@ -40,6 +40,17 @@ final class NativeSlam {
     static native void slamUpdateSharded(long pf, long comm, float[] xythetaOrNull, int n, double[] beams, int B, double r01,
                                          double resampleFraction, boolean integrate, double[] weightSumNeffStrongest);
 
+    // SLAM with one GridMapData per particle (SLAM.java:26-204): SLAMGpu
+    static native long pmCreate(float w, float h, float res, float px, float py, double lFree, double lOcc, double[] kernel, int maxBeams, int device, int numParticles);
+    static native void pmDestroy(long s);
+    static native void pmReset(long s);
+    static native void pmUpdate(long s, double[] beams, int B, boolean sampleMotion, double dCenter, double dTheta, long seed, long sequence, double[] weightSumNeffStrongest);
+    static native void pmResample(long s, double r01);
+    static native void pmGetParticles(long s, float[] xytheta, double[] weights, int n);
+    static native void pmWeightedPose(long s, float[] out3);
+    static native void pmDownloadMap(long s, int i, double[] logDataOrNull, double[] likelihoodDataOrNull);
+    static native void pmCombined(long s, double[] logDataOrNull, double[] likelihoodDataOrNull);
+
     /** Observation -> double[4*B] {localX, localY, distance, wasHit} (Observation.java:37-41). */
     static double[] flatten(Observation obs) {
         java.util.List<Observation.Measurement> ms = obs.getMeasurements();

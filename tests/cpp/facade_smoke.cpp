@@ -22,6 +22,20 @@ int main() {
         bool threw = false;
         try { slam.getGridMap().getRawAt(100000, 0); } catch (const gms::Error &) { threw = true; }
         if (!threw) { std::printf("no error on bad index\n"); return 1; }
+        // the reference's own shape: every particle with a map of its own (SLAM.java:30-47)
+        gms::SlamParticleMaps pm(64, 6.0f, 6.0f, 0.05f, -3.0f, -3.0f, 128);
+        gms::SlamParticleMaps::Odometry u;
+        u.dCenter = 0.05; u.dTheta = 0.02;
+        double neff2 = 0.0;
+        for (int k = 0; k < 3; k++) neff2 = pm.update(z, u, 7, (uint64_t)k);
+        pm.resample(0.3);
+        const std::vector<double> m0 = pm.mapOf(0), comb = pm.calculateCombined();
+        bool touched = false;
+        for (double v : m0) touched = touched || v != 0.0;
+        if (!(neff2 >= 1.0 && neff2 <= 64.0) || !touched || m0.size() != 120u * 120u || comb.size() != m0.size() || pm.getParticles().size() != 64u) {
+            std::printf("bad per-particle-map values\n");
+            return 1;
+        }
         std::printf("ok %.6f %.6e\n", neff, p0);
         return 0;
     } catch (const gms::Error &e) {

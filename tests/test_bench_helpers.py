@@ -109,3 +109,26 @@ def test_an_oversized_line_sheds_its_optional_blocks_not_the_contract(tmp_path):
     os.close(rd)
     assert line.endswith("\n") and line.count("\n") == 1
     assert len(json.load(open(rep))["secondary"]) == 200 and json.loads(line)["report"].endswith("report.json")
+
+
+def test_plain_gpus_n_launches_the_ranks_itself(tmp_path):
+    """`python bench.py --gpus N` with no launcher around it (the form the driver uses for its 1-GPU line) must not exit with rc 2:
+    it starts N ranks as a child `python -m torch.distributed.run ... bench.py <same arguments>` before touching the GPU.  Here the
+    dry run: the command it would start (GMS_BENCH_LAUNCH_DRYRUN=1; the real thing runs in tests/test_gpu_bench_two_ranks.py)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, GMS_BENCH_LAUNCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "2"], capture_output=True,
+                         text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    # under a launcher (WORLD_SIZE set) nothing is re-launched: the mismatch is reported instead
+    env2 = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", GMS_BENCH_LAUNCH_DRYRUN="1")
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('return self_launch(args.gpus, sys.argv[1:])') < src.index("import torch\n    import torch.distributed as dist")

@@ -93,3 +93,19 @@ def test_bench_config5_with_two_ranks_shards_by_map_without_a_collective(tmp_pat
     # value = all ranks' particles x steps / the slowest rank's time
     assert abs(d["value"] - 2 * 64 * 256 * 3 / (max(d["per_rank_ms_per_step"]) * 1e-3 * 3)) <= 1e-3 * d["value"]      # (per-rank times are printed to five decimals)
     assert d.get("sharded_equals_standalone") is None          # nothing is sharded: there is nothing to verify against
+
+
+def test_plain_python_bench_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py starts the two ranks itself (a child torch.distributed.run,
+    before this process touches the GPU) and hands rank 0's line and the exit code through."""
+    rep = str(tmp_path / "report.json")
+    env = dict(os.environ, GMS_BENCH_DIST_BACKEND="gloo", GMS_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--config", "C2",
+                          "--particles", "1024", "--report", rep], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d, full = _line_and_report(out, rep)
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["config"]["particles_total"] == 2048
+    assert d["sharded_equals_standalone"] is True and len(d["per_rank_ms_per_step"]) == 2
+    assert "rccl_ranks" in d or d["config"]["exchange"].startswith("torch.distributed")     # (gloo here: no RCCL communicator spans two ranks on one GPU)

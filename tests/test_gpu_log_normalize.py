@@ -185,3 +185,34 @@ def test_batched_maps_and_short_scans(beams):
     pf2.set_log_normalize(True)
     pf2.slam_update(P, np.stack([tr.scans[4] for tr in traces]), np.full(M, 0.4), -1.0, False)
     assert np.array_equal(pf2.get_weights(), pf.get_weights())
+
+
+def test_only_an_unconsumed_scoring_pass_is_rescaled():
+    """(round-4 advisor finding) weights the caller sets AFTER a scoring pass, and the copies a resampling leaves, are not the
+    log-weights' any more: the next normalise / getWeightedPose must take them as they are, not rebuild them from the stale log-weights."""
+    tr, g, m, log, lik = _world()
+    n = 1024
+    P = synth.make_particles(tr.poses[6], n, seed=21)
+    pf = ParticleFilter(m, n)
+    pf.set_log_normalize(True)
+    pf.set_poses(P)
+    pf.score(tr.scans[6])                                             # a scoring pass nobody consumes ...
+    w = np.random.default_rng(1).uniform(0.1, 1.0, n)
+    pf.set_weights(w)                                                 # ... because the caller replaces its weights
+    st = pf.normalize()
+    wn = w.copy()
+    ws, strongest = orc.normalize(wn)
+    assert abs(st["weight_sum"] - ws) <= 1e-12 * ws and st["strongest"] == strongest
+    assert np.max(np.abs(pf.get_weights() - wn) / wn) <= 1e-12
+    # score -> normalise -> resample -> getWeightedPose (GridMapApp.java:186-192): the pose of the COPIES with the weights they kept
+    pf.set_poses(P)
+    pf.score(tr.scans[6])
+    pf.normalize()
+    wn = pf.get_weights()
+    idx, amb = pf.resample(0.61, want_indices=True)
+    want, _ = orc.resample_indices(wn.copy(), 0.61)
+    assert_resample_indices(idx, want, amb)
+    got = pf.weighted_pose()
+    ref = orc.weighted_pose(P[idx], wn[idx])
+    assert np.allclose(got, ref, rtol=0, atol=2e-6), (got, ref)
+    assert np.max(np.abs(pf.get_weights() - wn[idx])) == 0           # the copies' weights are untouched by the read-out
