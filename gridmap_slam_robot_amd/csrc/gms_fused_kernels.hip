@@ -28,6 +28,8 @@
 // ---- A: normalise + pack  |  ray cast at the weighted pose --------------------------------------------------
 // The ray-cast workgroups fold the weighted pose from the partial vector themselves (the arithmetic of
 // fold_stats: SLAM.java:165-178), because the workgroup that publishes it runs beside them.
+template <bool LOGNORM>   // (the log-normalising form is a separate instantiation: the default kernel is exactly what it was -- as one kernel
+                          // with a uniform branch its ray blocks ran 1.1 us longer, measured A/B on one box)
 __global__ void __launch_bounds__(256)
 k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_t *__restrict__ cnt, int32_t *__restrict__ bbox,
                int32_t nw_max, uint32_t n_ray_blocks,
@@ -35,9 +37,10 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
                int32_t n, int64_t offset, PackedParticle *__restrict__ packed, double *__restrict__ cum,
                double *__restrict__ chunk_tot, int64_t nchunks, double *__restrict__ p2, PfStatsDev *__restrict__ stats,
                uint32_t n_norm_blocks, double *__restrict__ logd, uint32_t *__restrict__ cnt_pend, const int32_t *__restrict__ bbox_pend,
-               uint32_t n_near_blocks) {
+               uint32_t n_near_blocks, const double *__restrict__ logw_lognorm) {
     extern __shared__ __align__(16) unsigned char smem[];
     // workgroups: [far-field ray blocks | near-field ray blocks) = n_ray_blocks, then normalise, then the riding apply pass
+    // logw_lognorm != nullptr: the partial vector is block-relative (gms_pf_set_log_normalize, block_partials)
     GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 0);
     if (blockIdx.x >= n_ray_blocks + n_norm_blocks) {
         // The PREVIOUS scan's `logData[c] += ...` (GridMap.java:223) from the other count grid: it needs nothing of this launch
@@ -53,7 +56,11 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
         __shared__ float s_pose[3];
         const int cols[4] = { COL_SUM, COL_XW, COL_YW, COL_TW };
         double f[4];
-        fold_sums<4>(partials, nblk_global, cols, f, L);               // one round trip, one barrier pair
+        if (LOGNORM) {                                                 // the population's reference, then the rescaled sums
+            fold_lognorm<4>(partials, nblk_global, cols, f, L);
+        } else {
+            fold_sums<4>(partials, nblk_global, cols, f, L);           // one round trip, one barrier pair
+        }
         if (threadIdx.x == 0) {
             s_pose[0] = (float)(f[1] / f[0]);                          // SLAM.java:176
             s_pose[1] = (float)(f[2] / f[0]);
@@ -68,7 +75,7 @@ k_norm_raycast(GridDev g, const gms_beam *__restrict__ beams, int32_t B, uint32_
                                              smem, s_pose, n_near_blocks ? 1 : 0);
     } else {
         normalize_pack_body(partials, nblk_global, w, pose, n, offset, packed, cum, chunk_tot, nchunks, p2, stats,
-                            blockIdx.x - n_ray_blocks, 0);
+                            blockIdx.x - n_ray_blocks, 0, LOGNORM ? logw_lognorm : (const double *)nullptr);
         GMS_STAMP(GMS_STAMP_ROW(2, blockIdx.x), 14);
     }
 }
@@ -80,9 +87,9 @@ __global__ void __launch_bounds__(256)
 k_partials_apply(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n, int64_t offset,
                  int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part, int32_t part_nseg,
                  GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const int32_t *__restrict__ bbox,
-                 int32_t *__restrict__ bbox_idle, const double *__restrict__ blockmax) {
+                 int32_t *__restrict__ bbox_idle, PfStatsDev *__restrict__ lognorm_stats) {
     if (blockIdx.x < (uint32_t)nblk_global)
-        partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y, blockmax);
+        partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y, lognorm_stats);
     else
         apply_body(g, logd, cnt, bbox, bbox_idle, blockIdx.x - (uint32_t)nblk_global, blockIdx.y, gridDim.x - (uint32_t)nblk_global);
 }
@@ -210,12 +217,20 @@ void gms_launch_norm_raycast(gms_pf *pf, const double *d_partials, PackedParticl
     }
     int32_t *pend = m->d_bbox + (size_t)m->bbox_cur * 4;
     int32_t *bb = n_apply ? m->d_bbox + (size_t)(1 - m->bbox_cur) * 4 : pend;
-    if (smem > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_norm_raycast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k_norm_raycast, dim3(n_ray + n_norm + n_apply), dim3(256), smem, m->stream, m->gd, d_beams, B, m->d_cnt, bb,
-                       rc_nw_max(m), n_ray, d_partials, nblk_global_of(pf), pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local,
-                       own ? pf->d_cum : (double *)nullptr, own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf),
-                       own ? pf->d_p2 : (double *)nullptr, pf->d_stats, n_norm, m->d_log, m->d_cnt_pend, pend, n_near);
+    const bool lognorm = gms_pf_lognorm_now(pf);
+#define NR_LAUNCH(LN)                                                                                                                 \
+    do {                                                                                                                              \
+        if (smem > 48 * 1024)                                                                                                         \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_norm_raycast<LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL(k_norm_raycast<LN>, dim3(n_ray + n_norm + n_apply), dim3(256), smem, m->stream, m->gd, d_beams, B, m->d_cnt, bb, \
+                           rc_nw_max(m), n_ray, d_partials, nblk_global_of(pf), pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local, \
+                           own ? pf->d_cum : (double *)nullptr, own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf),          \
+                           own ? pf->d_p2 : (double *)nullptr, pf->d_stats, n_norm, m->d_log, m->d_cnt_pend, pend, n_near,          \
+                           LN ? (const double *)pf->d_logw : (const double *)nullptr);                                              \
+    } while (0)
+    if (lognorm) NR_LAUNCH(true); else NR_LAUNCH(false);
+#undef NR_LAUNCH
+    pf->score_fresh = 0;                                              // the scoring pass has been consumed
     if (n_apply) gms_apply_done(m);
     pf->chunks_ready = own ? 1 : 0;
     pf->neff_folded = 0;
@@ -231,11 +246,11 @@ void gms_launch_partials_apply(gms_pf *pf, double *d_partials, bool apply_rides_
     const int32_t all = ((m->gd.W + APPLY_TW - 1) / APPLY_TW) * ((m->gd.H + APPLY_TH - 1) / APPLY_TH);
     const uint32_t n_apply = (uint32_t)(all < GMS_APPLY_BLOCKS ? all : GMS_APPLY_BLOCKS);
     int32_t *cur = m->d_bbox + (size_t)m->bbox_cur * m->n_maps * 4, *idle = m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4;
-    const double *blockmax = gms_launch_pf_logmax(pf);
+    PfStatsDev *lognorm_stats = gms_pf_lognorm_now(pf) ? pf->d_stats : (PfStatsDev *)nullptr;
     hipLaunchKernelGGL(k_partials_apply, dim3((uint32_t)nblk + n_apply, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw,
                        pf->d_pose, pf->n, pf->offset, nblk, d_partials,
                        pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg, m->gd, m->d_log,
-                       m->d_cnt_pend, cur, idle, blockmax);
+                       m->d_cnt_pend, cur, idle, lognorm_stats);
     pf->pending_nseg = 0;
     gms_apply_done(m);
 }

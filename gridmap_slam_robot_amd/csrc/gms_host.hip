@@ -878,8 +878,7 @@ static int64_t nblk_of(int64_t n) { return (n + GMS_BLOCK - 1) / GMS_BLOCK; }
 static int64_t nchunks_of(int64_t n) { return (n + 63) / 64; }
 
 static void pf_free_global(gms_pf *pf) {
-    hipFree(pf->d_partials); hipFree(pf->d_p2); hipFree(pf->d_global_own); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum); hipFree(pf->d_blockmax);
-    pf->d_blockmax = nullptr;
+    hipFree(pf->d_partials); hipFree(pf->d_p2); hipFree(pf->d_global_own); hipFree(pf->d_chunk_tot); hipFree(pf->d_cum);
     pf->d_partials = pf->d_p2 = nullptr; pf->d_global = pf->d_global_own = nullptr; pf->d_chunk_tot = pf->d_cum = nullptr;
 }
 
@@ -889,7 +888,6 @@ static int pf_alloc_global(gms_pf *pf) {
     const size_t nblk = nblk_of(pf->n_global), nch = nchunks_of(pf->n_global);
     HIPCHK(hipMalloc(&pf->d_partials, M * nblk * GMS_PARTIAL_STRIDE * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_p2, M * nblk * 2 * sizeof(double)));
-    HIPCHK(hipMalloc(&pf->d_blockmax, M * nblk * sizeof(double)));
     HIPCHK(hipMalloc(&pf->d_global_own, M * pf->n_global * sizeof(PackedParticle)));
     pf->d_global = pf->d_global_own;
     HIPCHK(hipMalloc(&pf->d_chunk_tot, M * (nch + 1 + nch * 8) * sizeof(double)));     // chunk totals of all maps, then every chunk's eight octet boundaries (chunk_sub_of)

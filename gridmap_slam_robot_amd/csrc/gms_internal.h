@@ -182,7 +182,6 @@ struct gms_pf {
     int32_t *d_perm;                // [n_maps][n] the particle at each position of that order
     int32_t log_norm;               // gms_pf_set_log_normalize: weights = exp(logw - max logw) instead of the plain product (stand-alone filters)
     int32_t score_fresh;            // d_w / d_logw (or the segment products) come from a scoring pass nothing has consumed yet
-    double *d_blockmax;             // [n_maps][nblk_global] per-block maxima of the log-weights (log-normalisation's first pass)
     int32_t score_threads;          // 0 the launcher decides (the largest of 1024 / 512 / 256 lanes per scoring workgroup that still gives every CU one); GMS_SCORE_THREADS forces 64..1024
     int32_t reference_order;        // gms_pf_set_reference_order: the audit path -- every re-associated chain (the scan's product, weightSum, the
                                     // cumulative weights) as ONE chain in the reference's order (tests; slow)
@@ -275,7 +274,7 @@ struct MotionModel {            // one odometry step for gms_launch_pf_score's m
 void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_pose_src = nullptr,
                          const MotionModel *motion = nullptr);   // d_pose_src: set the poses in the same launch
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials);
-const double *gms_launch_pf_logmax(gms_pf *pf);
+bool gms_pf_lognorm_now(const gms_pf *pf);
 void gms_launch_pf_pack(gms_pf *pf, PackedParticle *d_packed);
 void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedParticle *d_packed_local, bool own);
 void gms_launch_pf_stats_only(gms_pf *pf, const double *d_partials, PfStatsDev *d_stats_out);

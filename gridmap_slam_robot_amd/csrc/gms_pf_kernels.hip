@@ -539,31 +539,23 @@ struct RedLds {
 
 // part != nullptr: the weights are still per-segment products from k_score_c: combine them here (and
 // store weight and log-weight) instead of in a launch of their own.
-// blockmax != nullptr (gms_pf_set_log_normalize): the weights of this pass are exp(logw - M), M the largest log-weight of the
-// map's population, folded here from the per-block maxima k_logmax left (nblk of them, block order; a maximum does not depend
-// on the order) -- the underflow-free normalisation SURVEY 9.6 asks for beside the reference's plain product.  The weights are
-// stored, and everything downstream (weight sum, weighted pose, Neff, the cumulative sums, the resampling) runs on them unchanged.
+// lognorm (gms_pf_set_log_normalize): the underflow-free normalisation SURVEY 9.6 asks for beside the reference's plain product,
+// weight = exp(logw - M) / sum, M the largest log-weight of the map's population, WITHOUT a pass of its own in front: this block's
+// columns are taken relative to the block's OWN largest log-weight m_b (column COL_MLW) -- v = exp(logw - m_b) -- and whoever folds
+// the partial vector rescales every block by exp(m_b - M) (fold_sums_scaled: the online-softmax rearrangement; the sums differ from
+// sum exp(logw - M) by a few ulps).  The weights themselves are formed from the log-weights where they are normalised
+// (normalize_pack_body), exp(logw - M) / sum: nothing block-relative is ever stored.  COL_MAX / COL_ARG then hold the largest
+// LOG-weight and its first index (the strongest particle is the first maximum of the log-weights: two different log-weights may
+// round to the same weight).  (Round 4 took M from a launch of its own, k_logmax, in front of this one: +4 us per step.)
+static_assert(EPT == 1, "the log-normalising form of block_partials takes one particle per thread");
+__device__ __forceinline__ double lognorm_ref(double m) { return m > -INFINITY ? m : 0.0; }      // a block (or a population) whose products are all 0 or NaN: nothing to rescale by
 __device__ __forceinline__ void block_partials(double *__restrict__ w, double *__restrict__ logw,
                                                const float *__restrict__ pose, int64_t cnt, int64_t base,
                                                double out[GMS_PARTIAL_STRIDE], RedLds &L,
                                                const double *__restrict__ part = nullptr, int32_t part_mi = 0,
                                                int32_t part_n = 0, int32_t part_nseg = 0, int64_t part_p0 = 0,
-                                               const double *__restrict__ blockmax = nullptr, int64_t nblk = 0) {
+                                               bool lognorm = false) {
     const int32_t tl = threadIdx.x & (GRP - 1);
-    double log_ref = 0.0;
-    if (blockmax) {                                                    // (uniform)
-        double mloc = -INFINITY;
-        for (int64_t b = tl; b < nblk; b += GRP) { const double v2 = blockmax[b]; if (v2 > mloc) mloc = v2; }
-#define GMS_STEP_(O) { const double v2 = wave_xor<O>(mloc); if (v2 > mloc) mloc = v2; }
-        GMS_BUTTERFLY(GMS_STEP_)
-#undef GMS_STEP_
-        const int32_t wv = threadIdx.x >> 6, g4 = (wv >> 2) << 2;
-        if ((threadIdx.x & 63) == 0) L.b[wv] = mloc;
-        __syncthreads();
-        log_ref = L.b[g4];
-        for (int k = 1; k < 4; k++) if (L.b[g4 + k] > log_ref) log_ref = L.b[g4 + k];
-        if (!(log_ref > -INFINITY)) log_ref = 0.0;                     // every product is 0 (or NaN): nothing to rescale by
-    }
     double s = 0.0, nz = 0.0, mv = -INFINITY, mx = 9.0e15, ml = -INFINITY, sq = 0.0, xw = 0.0, yw = 0.0, tw = 0.0;
 #pragma unroll
     for (int e0 = 0; e0 < EPT; e0 += EPB) {
@@ -583,8 +575,20 @@ __device__ __forceinline__ void block_partials(double *__restrict__ w, double *_
                 v[e] = in ? w[i] : 0.0;
                 lw[e] = in ? logw[i] : -INFINITY;
             }
-            if (blockmax && in) { v[e] = exp(lw[e] - log_ref); w[i] = v[e]; }
             px[e] = in ? pose[3 * i] : 0.0f; py[e] = in ? pose[3 * i + 1] : 0.0f; pt[e] = in ? pose[3 * i + 2] : 0.0f;
+        }
+        if (lognorm) {                                                     // (uniform; one particle per thread)
+            double mloc = lw[0] == lw[0] ? lw[0] : -INFINITY;              // a NaN product does not set the scale
+#define GMS_STEP_(O) { const double v2 = wave_xor<O>(mloc); if (v2 > mloc) mloc = v2; }
+            GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
+            const int32_t wv = threadIdx.x >> 6, g4 = (wv >> 2) << 2;
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) L.b[wv] = mloc;
+            __syncthreads();
+            double mb = L.b[g4];
+            for (int k = 1; k < 4; k++) if (L.b[g4 + k] > mb) mb = L.b[g4 + k];
+            if (tl < cnt) v[0] = exp(lw[0] - lognorm_ref(mb));
         }
 #pragma unroll
         for (int e = 0; e < EPB; e++) {
@@ -596,8 +600,9 @@ __device__ __forceinline__ void block_partials(double *__restrict__ w, double *_
                 yw += (double)py[e] * v[e];                               // :171
                 tw += angle_constrain((double)pt[e]) * v[e];              // :172
                 if (v[e] == 0.0) nz += 1.0;
-                if (v[e] > mv) { mv = v[e]; mx = (double)(base + i); }    // ascending index: strict > keeps the first
-                else if (mx > 8.0e15 && v[e] == v[e]) { mv = v[e]; mx = (double)(base + i); }
+                const double key = lognorm ? lw[e] : v[e];                // (log-normalising: the strongest is the first maximum of the log-weights)
+                if (key > mv) { mv = key; mx = (double)(base + i); }      // ascending index: strict > keeps the first
+                else if (mx > 8.0e15 && key == key) { mv = key; mx = (double)(base + i); }
                 if (lw[e] > ml) ml = lw[e];
             }
         }
@@ -674,6 +679,80 @@ __device__ __forceinline__ void fold_sums(const double *__restrict__ p, int64_t 
     for (int c = 0; c < NC; c++) out[c] = ((L.m[c][g4] + L.m[c][g4 + 1]) + L.m[c][g4 + 2]) + L.m[c][g4 + 3];
 }
 
+// The same fold over block-relative columns of a log-normalising pass (block_partials): block b's entries are multiplied by
+// exp(m_b - M), m_b its own reference (COL_MLW), M the population's.  Same shape, same order.
+template <int NC>
+__device__ __forceinline__ void fold_sums_scaled(const double *__restrict__ p, int64_t nblk, const int (&col)[NC], double (&out)[NC],
+                                                 RedLds &L, double M) {
+    static_assert(NC <= GMS_PARTIAL_STRIDE, "RedLds::m has GMS_PARTIAL_STRIDE rows");
+    const double R = lognorm_ref(M);
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] = 0.0;
+    for (int64_t b = threadIdx.x & (GRP - 1); b < nblk; b += GRP) {
+        double v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) v[c] = p[b * GMS_PARTIAL_STRIDE + col[c]];
+        const double sc = exp(lognorm_ref(p[b * GMS_PARTIAL_STRIDE + COL_MLW]) - R);
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc[c] += v[c] * sc;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] = wave_sum_f64(acc[c]);
+    const int32_t wave = threadIdx.x >> 6, g4 = (wave >> 2) << 2;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) L.m[c][wave] = acc[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; c++) out[c] = ((L.m[c][g4] + L.m[c][g4 + 1]) + L.m[c][g4 + 2]) + L.m[c][g4 + 3];
+}
+
+__device__ __forceinline__ void fold_argmax(const double *__restrict__ p, int64_t nblk, int colv, int coli, double &mv,
+                                            double &mx, RedLds &L);
+// The log-normalising fold in one piece: the population's reference M = max_b m_b, then the rescaled sums.  Up to GRP blocks
+// (65 536 particles) every thread holds its block's entries from ONE round trip to memory -- this fold sits in front of the ray
+// cast's pose, on the step's critical path --; more blocks take the two passes.  Every caller gets the same bits (one function).
+template <int NC>
+__device__ __forceinline__ double fold_lognorm(const double *__restrict__ p, int64_t nblk, const int (&col)[NC], double (&out)[NC], RedLds &L) {
+    if (nblk > GRP) {
+        double ml, mli;
+        fold_argmax(p, nblk, COL_MLW, -1, ml, mli, L);
+        fold_sums_scaled<NC>(p, nblk, col, out, L, ml);
+        return ml;
+    }
+    const int64_t b = threadIdx.x & (GRP - 1);
+    const bool in = b < nblk;
+    double v[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) v[c] = in ? p[b * GMS_PARTIAL_STRIDE + col[c]] : 0.0;
+    const double mb = in ? p[b * GMS_PARTIAL_STRIDE + COL_MLW] : -INFINITY;
+    double mloc = mb == mb ? mb : -INFINITY;
+#define GMS_STEP_(O) { const double v2 = wave_xor<O>(mloc); if (v2 > mloc) mloc = v2; }
+    GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
+    const int32_t wave = threadIdx.x >> 6, g4 = (wave >> 2) << 2;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) L.b[wave] = mloc;
+    __syncthreads();
+    double M = L.b[g4];
+    for (int k = 1; k < 4; k++) if (L.b[g4 + k] > M) M = L.b[g4 + k];
+    const double sc = in ? exp(lognorm_ref(mb) - lognorm_ref(M)) : 0.0;
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] = wave_sum_f64(0.0 + v[c] * sc);       // (0.0 + x: the strided accumulation of fold_sums_scaled, one term)
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) L.m[c][wave] = acc[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; c++) out[c] = ((L.m[c][g4] + L.m[c][g4 + 1]) + L.m[c][g4 + 2]) + L.m[c][g4 + 3];
+    return M;
+}
+
 __device__ __forceinline__ void fold_argmax(const double *__restrict__ p, int64_t nblk, int colv, int coli, double &mv,
                                             double &mx, RedLds &L) {
     mv = -INFINITY; mx = 9.0e15;
@@ -685,24 +764,34 @@ __device__ __forceinline__ void fold_argmax(const double *__restrict__ p, int64_
     group_argmax(mv, mx, L.a, L.b);
 }
 
-// all statistics from the (all-reduced) partial vector; every thread of the workgroup must call
+// all statistics from the (all-reduced) partial vector; every thread of the workgroup must call.  lognorm: the columns are
+// block-relative (block_partials): *ref_out receives M, the population's largest log-weight, the returned sum is sum exp(logw - M).
 __device__ __forceinline__ double fold_stats(const double *__restrict__ p, int64_t nblk, PfStatsDev *s, bool write,
                                              const float *__restrict__ pose, int64_t pose_base, int64_t pose_n, RedLds &L,
-                                             const PackedParticle *__restrict__ glob = nullptr) {
-    if (!write) return fold_sum(p, nblk, COL_SUM, L.a);
+                                             const PackedParticle *__restrict__ glob = nullptr, bool lognorm = false, double *ref_out = nullptr) {
+    double ml = 0.0, mli;
+    if (!write) {
+        if (!lognorm) return fold_sum(p, nblk, COL_SUM, L.a);
+        const int c1[1] = { COL_SUM };
+        double f1[1];
+        ml = fold_lognorm<1>(p, nblk, c1, f1, L);
+        if (ref_out) *ref_out = ml;
+        return f1[0];
+    }
     const int cols[5] = { COL_SUM, COL_NZ, COL_XW, COL_YW, COL_TW };
     double f[5];
-    fold_sums<5>(p, nblk, cols, f, L);
+    if (lognorm) { ml = fold_lognorm<5>(p, nblk, cols, f, L); if (ref_out) *ref_out = ml; }
+    else fold_sums<5>(p, nblk, cols, f, L);
     const double sum = f[0], nz = f[1], xw = f[2], yw = f[3], tw = f[4];
-    double mv, mx, ml, mli;
+    double mv, mx;
     fold_argmax(p, nblk, COL_MAX, COL_ARG, mv, mx, L);
-    fold_argmax(p, nblk, COL_MLW, -1, ml, mli, L);
+    if (!lognorm) fold_argmax(p, nblk, COL_MLW, -1, ml, mli, L);
     if (threadIdx.x == 0) {
         s->n_ambiguous = 0;
         s->weight_sum = sum;
-        s->max_w = mv;
+        s->max_w = lognorm ? exp(ml - lognorm_ref(ml)) : mv;            // (the largest rescaled weight is 1)
         s->strongest = mx < 8.0e15 ? (int32_t)mx : 0;
-        s->n_zero = (int32_t)nz;
+        if (!lognorm) s->n_zero = (int32_t)nz;                          // (log-normalising: counted where the weights are formed, normalize_pack_body)
         s->max_logw = ml;
         s->xs = xw; s->ys = yw; s->ts = tw;
         s->wpose[0] = (float)(xw / sum);                               // SLAM.java:176
@@ -750,9 +839,12 @@ k_fold_neff(const double *__restrict__ p2_all, int64_t nblk, PfStatsDev *__restr
 __device__ __forceinline__ void
 partials_body(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n,
               int64_t offset, int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part,
-              int32_t part_nseg, uint32_t bx, uint32_t by, const double *__restrict__ blockmax = nullptr) {
+              int32_t part_nseg, uint32_t bx, uint32_t by, PfStatsDev *__restrict__ lognorm_stats = nullptr) {
+    // lognorm_stats != nullptr: the log-normalising form (block_partials); the zero census of this pass is counted where the
+    // weights are formed (normalize_pack_body adds to it): cleared here, one launch ahead
     __shared__ RedLds L;
     const int32_t mi = (int32_t)by;
+    if (lognorm_stats && bx == 0 && threadIdx.x == 0) lognorm_stats[mi].n_zero = 0;
     const int64_t gb = bx;
     const int64_t lb = gb - offset / GMS_BLOCK;                       // block index inside the shard
     const int64_t nlb = ((int64_t)n + GMS_BLOCK - 1) / GMS_BLOCK;
@@ -764,7 +856,7 @@ partials_body(double *__restrict__ w, double *__restrict__ logw, const float *__
     double out[GMS_PARTIAL_STRIDE];
     const size_t o = (size_t)mi * n + lb * GMS_BLOCK;
     block_partials(w + o, logw + o, pose + 3 * o, block_count(n, lb), offset + lb * GMS_BLOCK, out, L, part, mi, n,
-                   part_nseg, lb * GMS_BLOCK, blockmax ? blockmax + (size_t)mi * nblk_global : nullptr, nblk_global);
+                   part_nseg, lb * GMS_BLOCK, lognorm_stats != nullptr);
     if (threadIdx.x == 0)
         for (int k = 0; k < GMS_PARTIAL_STRIDE; k++) p[k] = out[k];
 }
@@ -772,43 +864,10 @@ partials_body(double *__restrict__ w, double *__restrict__ logw, const float *__
 __global__ void __launch_bounds__(256)
 k_partials(double *__restrict__ w, double *__restrict__ logw, const float *__restrict__ pose, int32_t n,
            int64_t offset, int64_t nblk_global, double *__restrict__ partials, const double *__restrict__ part,
-           int32_t part_nseg, const double *__restrict__ blockmax) {
+           int32_t part_nseg, PfStatsDev *__restrict__ lognorm_stats) {
     GMS_STAMP(GMS_STAMP_ROW(1, blockIdx.x), 0);
-    partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y, blockmax);
+    partials_body(w, logw, pose, n, offset, nblk_global, partials, part, part_nseg, blockIdx.x, blockIdx.y, lognorm_stats);
     GMS_STAMP(GMS_STAMP_ROW(1, blockIdx.x), 1);
-}
-
-// Log-normalisation, first pass (gms_pf_set_log_normalize; stand-alone filters): the segment products are combined (weight and
-// log-weight stored, as k_score_combine does) and every reduction block leaves the largest log-weight of its 256 particles;
-// block_partials folds those maxima and rescales.  grid = (blocks, maps).
-__global__ void __launch_bounds__(256)
-k_logmax(double *__restrict__ w, double *__restrict__ logw, int32_t n, int64_t nblk, const double *__restrict__ part, int32_t part_nseg,
-         double *__restrict__ blockmax) {
-    __shared__ double s_m[4];
-    const int32_t mi = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * GMS_BLOCK + threadIdx.x;
-    double lw = -INFINITY;
-    if (i < n) {
-        const size_t o = (size_t)mi * n + i;
-        if (part) {
-            double wv;
-            combine_segments(part, mi, n, part_nseg, i, wv, lw);
-            w[o] = wv; logw[o] = lw;
-        } else {
-            lw = logw[o];
-        }
-        if (!(lw == lw)) lw = -INFINITY;                                // a NaN product does not set the scale
-    }
-#define GMS_STEP_(O) { const double v2 = wave_xor<O>(lw); if (v2 > lw) lw = v2; }
-    GMS_BUTTERFLY(GMS_STEP_)
-#undef GMS_STEP_
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = lw;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double mx = s_m[0];
-        for (int k = 1; k < 4; k++) if (s_m[k] > mx) mx = s_m[k];
-        blockmax[(size_t)mi * nblk + blockIdx.x] = mx;
-    }
 }
 
 // Level 0 of the cumulative weights: one wavefront = one 64-particle chunk, lane = particle, inclusive scan by
@@ -857,13 +916,23 @@ __device__ __forceinline__ void
 normalize_pack_body(const double *__restrict__ partials_all, int64_t nblk_global, double *__restrict__ w,
                     const float *__restrict__ pose, int32_t n, int64_t offset, PackedParticle *__restrict__ packed,
                     double *__restrict__ cum, double *__restrict__ chunk_tot, int64_t nchunks,
-                    double *__restrict__ p2_all, PfStatsDev *__restrict__ stats, uint32_t bx, uint32_t by) {
+                    double *__restrict__ p2_all, PfStatsDev *__restrict__ stats, uint32_t bx, uint32_t by,
+                    const double *__restrict__ logw_lognorm = nullptr) {
+    // logw_lognorm != nullptr (gms_pf_set_log_normalize): the partial vector is block-relative (block_partials) and the weights are
+    // formed here from the log-weights, exp(logw - M) / sum
     __shared__ RedLds L;
     const int32_t mi = (int32_t)by;
     const double *p = partials_all + (size_t)mi * nblk_global * GMS_PARTIAL_STRIDE;
-    const double sum = fold_stats(p, nblk_global, stats + mi, bx == 0, pose + (size_t)mi * n * 3, offset, n, L);
+    double M = 0.0;
+    const double sum = fold_stats(p, nblk_global, stats + mi, bx == 0, pose + (size_t)mi * n * 3, offset, n, L, nullptr, logw_lognorm != nullptr, &M);
     const int32_t i = (int32_t)bx * 256 + threadIdx.x;
     double wn = 0.0;
+    if (logw_lognorm) {                                                    // (uniform)
+        const double v = i < n ? exp(logw_lognorm[(size_t)mi * n + i] - lognorm_ref(M)) : 1.0;
+        const int32_t zeros = __popcll(__ballot(v == 0.0));
+        if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&stats[mi].n_zero, zeros);      // (cleared by the partials launch)
+        if (i < n) w[(size_t)mi * n + i] = v;
+    }
     if (i < n) {
         const size_t gi = (size_t)mi * n + i;
         wn = w[gi] / sum;
@@ -881,9 +950,9 @@ __global__ void __launch_bounds__(256)
 k_normalize_pack(const double *__restrict__ partials_all, int64_t nblk_global, double *__restrict__ w,
                  const float *__restrict__ pose, int32_t n, int64_t offset, PackedParticle *__restrict__ packed,
                  double *__restrict__ cum, double *__restrict__ chunk_tot, int64_t nchunks,
-                 double *__restrict__ p2_all, PfStatsDev *__restrict__ stats) {
+                 double *__restrict__ p2_all, PfStatsDev *__restrict__ stats, const double *__restrict__ logw_lognorm) {
     normalize_pack_body(partials_all, nblk_global, w, pose, n, offset, packed, cum, chunk_tot, nchunks, p2_all, stats, blockIdx.x,
-                        blockIdx.y);
+                        blockIdx.y, logw_lognorm);
 }
 
 // Level 0 as a kernel of its own (sharded filters after the all-gather; resample without normalise): the same
@@ -1551,27 +1620,18 @@ void gms_launch_pf_combine(gms_pf *pf) {
     pf->pending_nseg = 0;
 }
 
-// log-normalisation's first pass: combined weights / log-weights and the per-block maxima (no-op unless the option is on)
-const double *gms_launch_pf_logmax(gms_pf *pf) {
-    // only the weights of a scoring pass are rescaled: weights the caller set, or the copies a resampling left, are taken as they are
-    if (!pf->log_norm || !pf->score_fresh) return nullptr;
-    pf->score_fresh = 0;
-    gms_map *m = pf->map;
-    const int64_t nblk = nblk_global_of(pf);
-    hipLaunchKernelGGL(k_logmax, dim3((unsigned)nblk, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw, pf->n, nblk,
-                       pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg, pf->d_blockmax);
-    pf->pending_nseg = 0;
-    return pf->d_blockmax;
-}
+// whether the next partials / normalise pair takes the log-normalising form: the option is on and the weights are those of a scoring
+// pass nobody has consumed (weights the caller set, or the copies a resampling left, are taken as they are)
+bool gms_pf_lognorm_now(const gms_pf *pf) { return pf->log_norm && pf->score_fresh; }
 
 void gms_launch_pf_partials(gms_pf *pf, double *d_partials) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_REDUCE);
     const int64_t nblk = nblk_global_of(pf);
-    const double *blockmax = gms_launch_pf_logmax(pf);
     hipLaunchKernelGGL(k_partials, dim3((unsigned)nblk, pf->n_maps), dim3(256), 0, m->stream, pf->d_w, pf->d_logw,
                        pf->d_pose, pf->n, pf->offset, nblk, d_partials,
-                       pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg, blockmax);
+                       pf->pending_nseg ? (const double *)pf->d_part : (const double *)nullptr, pf->pending_nseg,
+                       gms_pf_lognorm_now(pf) ? pf->d_stats : (PfStatsDev *)nullptr);
     pf->pending_nseg = 0;                                             // k_partials stored the combined weights
 }
 
@@ -1583,7 +1643,9 @@ void gms_launch_pf_apply_partials(gms_pf *pf, const double *d_partials, PackedPa
     if (own) { pf->d_global = pf->d_global_own; pf->global_raw = 0; }
     hipLaunchKernelGGL(k_normalize_pack, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), 0, m->stream, d_partials, nblk,
                        pf->d_w, pf->d_pose, pf->n, pf->offset, d_packed_local, own ? pf->d_cum : (double *)nullptr,
-                       own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf), own ? pf->d_p2 : (double *)nullptr, pf->d_stats);
+                       own ? pf->d_chunk_tot : (double *)nullptr, nchunks_of(pf), own ? pf->d_p2 : (double *)nullptr, pf->d_stats,
+                       gms_pf_lognorm_now(pf) ? (const double *)pf->d_logw : (const double *)nullptr);
+    pf->score_fresh = 0;                                              // the scoring pass has been consumed
     pf->chunks_ready = own ? 1 : 0;
     pf->neff_folded = 0;
 }
