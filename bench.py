@@ -122,12 +122,22 @@ class Workload:
         cfg = dict(synth.CONFIGS[name])
         self.M = n_maps or cfg["n_maps"]
         self.batched = self.M > 1
+        # config 5 at N > 1: its 64 maps are split over the ranks, 64 / N independent maps per GPU, no collective on the
+        # data path: a FIXED job, strong scaling -- the one BASELINE configuration whose work divides without a replicated part
+        self.map_offset = 0
+        self.maps_total = self.M
+        if self.batched and world > 1 and n_maps is None:
+            if self.M % world:
+                raise SystemExit(f"bench.py: {self.M} maps do not split over {world} ranks")
+            self.M //= world
+            self.map_offset = rank * self.M
+            self.batched = True              # (one map per rank still runs as a batched handle's arithmetic would: the same kernels)
         self.sharded = sharded and not self.batched
         # C4 is BASELINE.json configs[3]: a FIXED population of 65 536 particles split over the ranks (strong scaling; --particles
         # overrides the population); every other configuration keeps the per-GPU work fixed as N grows (weak scaling; --particles
         # overrides the particles per GPU and per map)
-        self.strong = name == "C4"
-        if self.strong:
+        self.strong = name == "C4" or (self.M != self.maps_total)
+        if name == "C4":
             total = args.particles or cfg["particles"]
             parts = world if self.sharded else 1
             if total % parts or (parts > 1 and (total // parts) % 256):
@@ -169,16 +179,17 @@ class Workload:
             self.m = m = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M, device=local_rank, max_beams=max(2048, B))
             self.stream = torch.cuda.current_stream()
             m.set_stream(self.stream.cuda_stream)
+            mo = self.map_offset                 # this rank's maps are maps [mo, mo + M) of the job
             for t in range(T // 2):
-                m.update(np.stack([trs[i % nt].scans[t] for i in range(M)]), np.stack([trs[i % nt].poses[t] for i in range(M)]))
+                m.update(np.stack([trs[(mo + i) % nt].scans[t] for i in range(M)]), np.stack([trs[(mo + i) % nt].poses[t] for i in range(M)]))
             m.synchronize()
             self.log0 = None
-            self.scans_dev = [torch.from_numpy(np.stack([trs[i % nt].scans[t] for i in range(M)]).view(np.uint8).copy()).to(dev)
+            self.scans_dev = [torch.from_numpy(np.stack([trs[(mo + i) % nt].scans[t] for i in range(M)]).view(np.uint8).copy()).to(dev)
                               for t in range(T)]
             self.pose_sets = []
             for s in range(self.n_sets):
                 t = T // 2 + s
-                P = np.stack([synth.make_particles(trs[i % nt].poses[t], self.n_local, seed=7 + i + 64 * s) for i in range(M)])
+                P = np.stack([synth.make_particles(trs[(mo + i) % nt].poses[t], self.n_local, seed=7 + mo + i + 64 * s) for i in range(M)])
                 self.pose_sets.append(torch.from_numpy(P).to(dev))
             self.n_hit = int(trs[0].scans[T // 2]["hit"].sum())
             self.scan0 = trs[0].scans[T // 2]
@@ -621,9 +632,9 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
                         + (": every cell, likelihoodData written, as the reference does)" if a.full_rebuild else
                            "; the rebuild is dirty-tile / factor-table-only: bit-identical results, likelihoodData on demand -- the reference's own "
                            "every-cell rebuild is cpu_baseline.gpu_like_for_like_ms_per_step)"),
-            "particles_total": n_total, "particles_per_gpu": wl.n_local * wl.M, "beams": wl.B, "grid": [m.W, m.H], "resolution_m": wl.res, "maps": wl.M,
+            "particles_total": n_total, "particles_per_gpu": wl.n_local * wl.M, "beams": wl.B, "grid": [m.W, m.H], "resolution_m": wl.res, "maps": wl.M, "maps_total": wl.maps_total,
             "parallelism": ("single GPU" if wl.world == 1 else
-                            (f"{wl.M} independent maps per rank x{wl.world}, no collective" if wl.batched else
+                            (f"{wl.maps_total} independent maps split over {wl.world} ranks ({wl.M} per GPU), no collective" if wl.batched else
                              f"particles sharded x{wl.world}, map replicated")),
             "exchange": wl.exchange_text(),
             "likelihood_rebuild": "full" if a.full_rebuild else
@@ -1027,7 +1038,7 @@ def compact_line(full: dict, report_file: str | None) -> str:
     cfg = full.get("config") or {}
     line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                      "scaling", "vs_baseline", "dtype", "data")}
-    line["config"] = {k: cfg[k] for k in ("workload", "particles_total", "particles_per_gpu", "beams", "grid", "resolution_m", "maps",
+    line["config"] = {k: cfg[k] for k in ("workload", "particles_total", "particles_per_gpu", "beams", "grid", "resolution_m", "maps", "maps_total",
                                           "parallelism", "exchange", "inputs") if cfg.get(k) is not None}
     for k in ("timed_region_s", "map_update_ms_per_scan", "map_update_ms_per_scan_exploring", "beam_evals_per_s", "scans_per_s", "per_rank_ms_per_step", "exchange_latency_us",
               "sharded_equals_standalone", "rccl_ranks"):

@@ -52,7 +52,9 @@ struct PfStatsDev {
 };
 
 #define GMS_SCORE_MAXSEG 32
+#ifndef GMS_SCORE_SEGLEN
 #define GMS_SCORE_SEGLEN 45        // beams per segment product of the default scoring kernel, scans of more than GMS_SCORE_SHORT_SCAN beams
+#endif
 #define GMS_SCORE_SEGLEN_SHORT 12  // ... and of shorter scans (see gms_launch_pf_score)
 #define GMS_SCORE_SHORT_SCAN 384
 #define GMS_SCORE_SEGLEN_LONG 90   // ... and of scans of more than GMS_SCORE_LONG_SCAN beams

@@ -81,17 +81,18 @@ def test_bench_default_configuration_with_two_ranks_is_the_fixed_population_with
 
 
 def test_bench_config5_with_two_ranks_shards_by_map_without_a_collective(tmp_path):
-    """Config 5 (64 independent maps per handle) at N > 1: every rank runs its own 64 maps, nothing is exchanged on the data
-    path; the line must carry the aggregate over both ranks and each rank's own time."""
+    """Config 5 (64 independent maps) at N > 1: the job's 64 maps are SPLIT over the ranks -- 32 per rank here, 8 per GPU on an
+    8-GPU node -- nothing is exchanged on the data path, the job is fixed ("strong"); the line carries the aggregate
+    over both ranks and each rank's own time."""
     rep = str(tmp_path / "report.json")
     out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "C5", "--particles", "256", "--report", rep], 300)
     d, full = _line_and_report(out, rep)
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
-    assert d["config"]["maps"] == 64 and d["config"]["particles_total"] == 2 * 64 * 256
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["maps"] == 32 and d["config"]["maps_total"] == 64 and d["config"]["particles_total"] == 64 * 256
     assert "no collective" in d["config"]["parallelism"] and d["config"].get("exchange") is None and full["config"]["exchange"] is None
     assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
     # value = all ranks' particles x steps / the slowest rank's time
-    assert abs(d["value"] - 2 * 64 * 256 * 3 / (max(d["per_rank_ms_per_step"]) * 1e-3 * 3)) <= 1e-3 * d["value"]      # (per-rank times are printed to five decimals)
+    assert abs(d["value"] - 64 * 256 * 3 / (max(d["per_rank_ms_per_step"]) * 1e-3 * 3)) <= 1e-3 * d["value"]      # (per-rank times are printed to five decimals)
     assert d.get("sharded_equals_standalone") is None          # nothing is sharded: there is nothing to verify against
 
 

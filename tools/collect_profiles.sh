@@ -3,7 +3,7 @@
 # of bench.py (C3 default, C5) and of the dense-map likelihood rebuild; raw output under gpurun_out/prof/, the summaries
 # that are kept go to profiles/<round>/ afterwards (tools/kstats.py, tools/pmc_summary.py).
 # usage: collect_profiles.sh <round dir name, e.g. r02>
-R=${1:-r04}
+R=${1:-r05}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/prof_$R"
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -30,10 +30,17 @@ stats dense_likelihood $K
 pmc dense FETCH_SIZE $K
 pmc dense WRITE_SIZE $K
 stats c3_full_rebuild $B --full-rebuild --steps 100 --warmup 10
+# the reference's own filter shape (one GridMapData per particle): kernel trace at both sizes, fabric traffic at the size that leaves the caches
+PM="python3 $ROOT/bench.py --no-cpu-baseline"
+stats pm500 $PM --particle-maps 500,6,90 --steps 50 --report "$OUT/pm500_report.json"
+stats pm4096 $PM --particle-maps 4096,12.8,180 --steps 10 --report "$OUT/pm4096_report.json"
+pmc pm4096 FETCH_SIZE $PM --particle-maps 4096,12.8,180 --steps 6 --report "$OUT/pm4096_pmc_report.json"
+pmc pm4096 WRITE_SIZE $PM --particle-maps 4096,12.8,180 --steps 6 --report "$OUT/pm4096_pmc_report.json"
 stats trace_replay python3 $ROOT/bench.py --trace $ROOT/tests/golden/recording_360.bin --steps 300 --warmup 20
 cd "$ROOT"
 mkdir -p "$OUT/keep"
-for n in c3_bench c5_bench dense_likelihood c3_full_rebuild trace_replay; do
+python3 $ROOT/tools/pmc_kernels.py "$OUT/keep/per_particle_maps_kernels.json" k_slam "$OUT/pm4096_FETCH_SIZE" "$OUT/pm4096_WRITE_SIZE" "$OUT/pm4096" > "$OUT/keep/per_particle_maps_kernels.txt" 2>&1
+for n in c3_bench c5_bench dense_likelihood c3_full_rebuild trace_replay pm500 pm4096; do
   cp "$OUT/${n}_kernel_stats.csv" "$OUT/keep/" 2>/dev/null
   cp "$OUT/$n.stdout" "$OUT/keep/${n}_under_rocprof.json" 2>/dev/null
 done
@@ -57,6 +64,12 @@ python3 bench.py --host-inputs $Q --report "$OUT/keep/bench_host_inputs_report.j
 python3 bench.py --full-rebuild $Q --report "$OUT/keep/bench_full_rebuild_report.json" > "$OUT/keep/bench_full_rebuild.json" 2>> "$OUT/bench.stderr"
 python3 bench.py --config C5 --steps 50 --warmup 5 --report "$OUT/keep/bench_c5_report.json" > "$OUT/keep/bench_c5.json" 2>> "$OUT/bench.stderr"
 python3 bench.py --trace tests/golden/recording_360.bin --steps 300 --warmup 20 --report "$OUT/keep/bench_trace_replay_report.json" > "$OUT/keep/bench_trace_replay.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --particle-maps 500,6,90 --steps 50 --report "$OUT/keep/bench_particle_maps_500_report.json" > "$OUT/keep/bench_particle_maps_500.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --particle-maps 500,6,180 --steps 50 --no-cpu-baseline --report "$OUT/keep/bench_particle_maps_500_b180_report.json" > "$OUT/keep/bench_particle_maps_500_b180.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --particle-maps 4096,12.8,180 --steps 20 --no-cpu-baseline --report "$OUT/keep/bench_particle_maps_4096_report.json" > "$OUT/keep/bench_particle_maps_4096.json" 2>> "$OUT/bench.stderr"
+bash tools/pmc_likelihood.sh > "$OUT/keep/dense_likelihood_counters.txt" 2>&1
+cp gpurun_out/pmc_lik/summary.json "$OUT/keep/dense_likelihood_counters.json" 2>/dev/null
+bash tools/nseg_table.sh > "$OUT/keep/nseg_8_vs_16.txt" 2>&1
 # the per-GPU step of the fixed-population series (config 4) at 1 / 2 / 4 / 8 GPUs' shard sizes, on one GPU (no exchange): DESIGN.md section 7's curve
 for n in 65536 32768 16384 8192; do
   python3 bench.py --config C4 --particles $n $Q --steps 100 --warmup 10 --report "$OUT/keep/bench_c4_shard_${n}_report.json" > "$OUT/keep/bench_c4_shard_${n}.json" 2>> "$OUT/bench.stderr"
