@@ -1150,6 +1150,7 @@ def main() -> int:
                     help="C3 (default at 1 GPU: 16384 particles per GPU, weak scaling) | C4 (default at N > 1 GPUs: BASELINE's FIXED population of "
                          "65536 particles split over the ranks, strong scaling) | C2 | C5 (64 batched maps per rank)")
     ap.add_argument("--particles", type=int, default=0, help="override particles per GPU and per map (C4: the whole population)")
+    ap.add_argument("--maps", type=int, default=0, help="batched configurations: maps per handle instead of the configuration's (e.g. --config C5 --maps 8: one GPU's share of config 5 on an 8-GPU node)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C5 / C2 block of the default 1-GPU run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline's scan-step loop")
@@ -1237,7 +1238,7 @@ def main() -> int:
 
     def run_sharded_or_single(name, steps, warmup, comm=None, keep_log=False):
         """one configuration on this run's ranks: route, self-verification, measurement; rank 0 gets the report"""
-        w = Workload(name, args, torch, dist, rank, world, local_rank, sharded, keep_log=keep_log, comm=comm)
+        w = Workload(name, args, torch, dist, rank, world, local_rank, sharded, keep_log=keep_log, comm=comm, n_maps=(args.maps or None))
         ver = None
         if w.spf is not None:
             w.pick_route()

@@ -1559,7 +1559,9 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
     // quarter off the scoring kernel: it pays once the scoring launch is several rounds of workgroups deep (C5: 6144
     // workgroups, 328 -> 247 us), not at 256 workgroups (C3: -3 us for +5.5).  Results are the same either way.
     const int64_t wgs = nseg * (((int64_t)pf->n + 1023) / 1024) * pf->n_maps;
-    const bool ordered = pf->order_mode > 0 || (pf->order_mode < 0 && wgs >= 2048 && pf->n <= 32768);
+    // (batched handles order from one workgroup per CU on: 8 / 16 maps of config 5's shape, one GPU's share of it on an 8- / 4-GPU
+    // node: k_order 9 us, k_score_c 79 -> 54 / 110 -> 78 us: round 5, tools/c5_small_batch_tune.sh)
+    const bool ordered = pf->order_mode > 0 || (pf->order_mode < 0 && wgs >= (pf->n_maps > 1 ? (int64_t)m->n_cus : 2048) && pf->n <= 32768);
     if (motion && ordered) {
         // the locality order is built from the poses the particles score at: the sample gets a launch of its own in front of it
         gms_launch_pf_motion(pf, motion->d_center, motion->d_theta, motion->seed, motion->sequence);
@@ -1589,7 +1591,10 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
     int32_t threads = pf->n >= 1024 ? 1024 : ((pf->n + 63) / 64) * 64;
     if (pf->score_threads >= 64 && pf->score_threads <= 1024) threads = (pf->score_threads / 64) * 64;
     else {
-        while (threads > 256 && nseg * (((int64_t)pf->n + threads - 1) / threads) * pf->n_maps < m->n_cus) threads >>= 1;
+        // (batched, ordered launches want eight workgroups per CU before they stop halving: 8 maps 54 -> 44 -> 39 us at 1024 / 512 / 256
+        // lanes, 16 maps 78 -> 69 -> 68; 64 maps bring 2304 workgroups of 1024 lanes and keep them)
+        const int64_t want = ordered && pf->n_maps > 1 ? 8 * (int64_t)m->n_cus : (int64_t)m->n_cus;
+        while (threads > 256 && nseg * (((int64_t)pf->n + threads - 1) / threads) * pf->n_maps < want) threads >>= 1;
         threads = ((threads + 63) / 64) * 64;                     // whole wavefronts (700 particles: 704 -> 352 -> 384 lanes, not 352)
     }
     const int64_t groups = ((int64_t)pf->n + threads - 1) / threads;

@@ -606,6 +606,9 @@ struct orc_slam {
     double *lik_data;   /* [n][W*H] Particle.m.likelihoodData */
     double *scratch;    /* GridMap.probData + Util.tempArray */
     int32_t strongest;  /* index of strongestParticle (-1: null) */
+    /* the previous generation's arrays, kept for the next resample() to fill (a checker's economy: 4096 particles x 256^2 cells are
+     * 4.3 GB per generation, and fresh pages cost more than the copies) */
+    float *spare_pose; double *spare_weight, *spare_log, *spare_lik;
 };
 
 void orc_slam_reset(orc_slam *s) {                                   /* :65-77 */
@@ -637,6 +640,7 @@ orc_slam *orc_slam_new(const orc_grid *g, int32_t n) {               /* :56-62 *
 void orc_slam_free(orc_slam *s) {
     if (!s) return;
     free(s->pose); free(s->weight); free(s->log_data); free(s->lik_data); free(s->scratch);
+    free(s->spare_pose); free(s->spare_weight); free(s->spare_log); free(s->spare_lik);
     free(s);
 }
 
@@ -707,12 +711,13 @@ int32_t orc_slam_resample(orc_slam *s, double r01, int32_t *idx_out) {
     const size_t cells = (size_t)s->g.W * (size_t)s->g.H;
     const int32_t n = s->n;
     int32_t *idx = (int32_t *)malloc((size_t)n * sizeof(int32_t));
-    float *pose2 = (float *)malloc((size_t)n * 3 * sizeof(float));
-    double *w2 = (double *)malloc((size_t)n * sizeof(double));
-    double *log2 = (double *)malloc((size_t)n * cells * sizeof(double));
-    double *lik2 = (double *)malloc((size_t)n * cells * sizeof(double));
+    float *pose2 = s->spare_pose ? s->spare_pose : (float *)malloc((size_t)n * 3 * sizeof(float));
+    double *w2 = s->spare_weight ? s->spare_weight : (double *)malloc((size_t)n * sizeof(double));
+    double *log2 = s->spare_log ? s->spare_log : (double *)malloc((size_t)n * cells * sizeof(double));
+    double *lik2 = s->spare_lik ? s->spare_lik : (double *)malloc((size_t)n * cells * sizeof(double));
     const int32_t clamped = orc_resample_indices(s->weight, n, r01, idx);               /* :136-145 */
-    for (int32_t m = 0; m < n; m++) {                                                   /* :147 new Particle(particles.get(i)) */
+#pragma omp parallel for schedule(static)
+    for (int32_t m = 0; m < n; m++) {                                                   /* :147 new Particle(particles.get(i)) (copies are independent: any order) */
         const int32_t i = idx[m];
         w2[m] = s->weight[i];                                                           /* :42 */
         memcpy(pose2 + 3 * (size_t)m, s->pose + 3 * (size_t)i, 3 * sizeof(float));      /* :43 */
@@ -720,7 +725,8 @@ int32_t orc_slam_resample(orc_slam *s, double r01, int32_t *idx_out) {
         memcpy(lik2 + (size_t)m * cells, s->lik_data + (size_t)i * cells, cells * sizeof(double));   /* GridMap.java:121 */
     }
     if (idx_out) memcpy(idx_out, idx, (size_t)n * sizeof(int32_t));
-    free(s->pose); free(s->weight); free(s->log_data); free(s->lik_data); free(idx);
+    free(idx);
+    s->spare_pose = s->pose; s->spare_weight = s->weight; s->spare_log = s->log_data; s->spare_lik = s->lik_data;
     s->pose = pose2; s->weight = w2; s->log_data = log2; s->lik_data = lik2;            /* :152 */
     /* strongestParticle keeps pointing at an object of the OLD generation (GridMapApp.java:188-190 notes it): no index here */
     return clamped;

@@ -115,12 +115,14 @@ def test_the_reference_operating_point_500_particles_of_120x120_cells():
 
 
 def test_4096_particles_of_256x256_cells_on_the_committed_recording():
-    """tests/golden/recording_360.bin (the reference's DataRecorder format; synthetic: the reference ships no recording), every
-    other measurement of its 360 per revolution -- the reference's scans hold 90 to 180 (one per 2-4 degrees); at 360 the plain
-    product over a blank map, 0.1^360, is 0 for every particle and update() divides 0 by 0 -- and 4096 particles with
-    a 12.8 m map each: 4 GiB of GridMapData on the device."""
-    N = 4096
-    frames = read_trace(os.path.join(HERE, "golden", "recording_360.bin"))[:6]
+    """Thirty revolutions of tests/golden/recording_360.bin (the reference's DataRecorder format; synthetic: the reference ships no
+    recording), every other measurement of its 360 per revolution -- the reference's scans hold 90 to 180 (one per 2-4 degrees); at
+    360 the plain product over a blank map, 0.1^360, is 0 for every particle and update() divides 0 by 0 -- through
+    4096 particles with a 12.8 m map each (8.6 GB of GridMapData on the device, both generations), with the caller's resampling rule.
+    Poses, weights, Neff, strongest and weighted pose every frame; all 4096 maps (both arrays) at five of them and after the first
+    resampling copy."""
+    N, T = 4096, 30
+    frames = read_trace(os.path.join(HERE, "golden", "recording_360.bin"))[:T]
     for f in frames:
         f.angle, f.distance, f.hit = f.angle[::2].copy(), f.distance[::2].copy(), f.hit[::2].copy()
     scans = _frames_to_scans(frames)
@@ -130,21 +132,15 @@ def test_4096_particles_of_256x256_cells_on_the_committed_recording():
     assert (dev.W, dev.H) == (256, 256)
     g = orc.Grid(ext, ext, 0.05, -ext / 2, -ext / 2)
     o = orc.Slam(g, N)
-    rng = np.random.default_rng(3)
-    _run(dev, o, scans[:5], start, seed=7, rng=rng, check_maps_at={0, 4}, resample_rule=False, label="4096x256^2")
-    # resample() whatever Neff says (the GUI's button: GridMapApp.java:306), then one more revolution on the copies
+    resampled = _run(dev, o, scans, start, seed=7, rng=np.random.default_rng(3), check_maps_at={0, 9, 19, T - 1}, label="4096x256^2")
+    assert resampled >= 1 and dev.maps_copied() == resampled * N
+    # resample() whatever Neff says (the GUI's button: GridMapApp.java:306)
     r01 = 0.4242
     idx, amb = dev.resample(r01, want_indices=True)
     want, _ = o.resample(r01)
     assert_resample_indices(idx, want, amb)
     assert np.array_equal(idx, want)
-    _compare_maps(dev, o, "4096x256^2 after the resampling copy")
-    z, u = scans[5]
-    dev.update(z, u, seed=7, sequence=5)
-    o.set_poses(dev.get_particles()[0])
-    o.update(z, u, sample_motion=False, threads=THREADS)
-    _compare_weights(dev.get_particles()[1], o.weights, "4096x256^2 one revolution after the copy")
-    _compare_maps(dev, o, "4096x256^2 one revolution after the copy")
+    _compare_maps(dev, o, "4096x256^2 after the last resampling copy")
 
 
 def test_edge_scans_the_band_walk_and_the_skip_rule(monkeypatch):
