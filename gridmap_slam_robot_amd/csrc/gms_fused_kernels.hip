@@ -260,9 +260,9 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
     gms_map *m = pf->map;
     gms_launch_pf_chunk_sums(pf);                     // no-op when level 0 is already there
     ProfScope ps(m, GMS_K_LIKELIHOOD);
-    const int32_t k = m->gd.khalf;
+    const int32_t k = m->lik_kh;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
-    const size_t smem_l = gms_likelihood_lds_bytes(k);
+    const size_t smem_l = gms_likelihood_lds_bytes(m->gd.khalf, k != 0);
     int32_t blocks = tiles_x * tiles_y;
     const int32_t cap = gms_likelihood_blocks_cap(m, smem_l);
     if (blocks > cap) blocks = cap;

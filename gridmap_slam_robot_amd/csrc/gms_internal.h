@@ -118,6 +118,9 @@ struct gms_map {
     int32_t apply_pending;    // the last scan's counts are not in logData yet (deferred apply pass, gms_flush_apply)
     int32_t raycast_tile;     // batched ray casts accumulate in LDS tiles (k_raycast_tile; GMS_RAYCAST_TILE=0 turns it off)
     int32_t raycast_tile_min; // ... when the launch has more rays than this in all (default 4096; GMS_RAYCAST_TILE_MIN)
+    int32_t lik_kh;           // the likelihood kernels' compile-time half width (3 or 5), or 0 = the generic path: another kernel size, or taps
+                              // outside 2^-900 .. 2^900 (the fast path computes twice the horizontal sums and halves them: exact only
+                              // while nothing is subnormal; likelihood_body)
     int32_t lik_lazy;         // scan steps' dirty-tile rebuilds write the factor table only, likelihoodData on demand (GMS_LIK_LAZY=0 turns it off)
     int32_t lik_stale;        // likelihoodData is behind the factor table somewhere (gms_ensure_lik brings it up to date)
     int32_t fac_current;      // the factor table is the field of logData + the pending counts as of the last rebuild, and logData has not moved since except by those counts
@@ -233,7 +236,7 @@ void gms_launch_apply_ray(gms_map *m, RayIn ray);
 void gms_launch_apply_counts(gms_map *m);
 void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending = false, bool materialize = false);
 void gms_ensure_lik(gms_map *m);        // likelihoodData up to date everywhere (the scan steps' rebuilds write the factor table only)
-size_t gms_likelihood_lds_bytes(int32_t khalf);
+size_t gms_likelihood_lds_bytes(int32_t khalf, bool coded = true);   // coded: the byte-coded staging of the compile-time half widths (gms_map::lik_kh != 0)
 int32_t gms_likelihood_blocks_cap(const gms_map *m, size_t smem);
 void gms_launch_raycast_apply(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses, int32_t pose_stride);
 void gms_defer_apply(gms_map *m);       // host bookkeeping: the scan just cast keeps its counts until a later launch applies them

@@ -667,6 +667,12 @@ k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const 
 // dirty_only: tiles that cannot have changed (outside the touched box dilated by k) are skipped.
 // ---------------------------------------------------------------------------------------------
 #define LK_TW 64
+// registers: five workgroups of four wavefronts per CU = five wavefronts per SIMD = at most 96 vector registers (the variant that
+// also carries a scan's pending counts would spill at that: four)
+#ifndef GMS_LIK_WAVES_PER_EU
+#define GMS_LIK_WAVES_PER_EU 5
+#endif
+#define GMS_LIK_WAVES __attribute__((amdgpu_waves_per_eu(PENDING && KH == 5 ? 4 : GMS_LIK_WAVES_PER_EU)))
 #define LK_TH 32
 #define LK_STRIP 8
 
@@ -738,19 +744,45 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     // the map, so no load sits behind a branch: 13 dependent round trips otherwise), and the NEXT tile's loads are
     // issued as soon as this tile's values are in LDS, so they fly during the barriers and the two blur passes.
     constexpr int32_t CRW = LK_TW + 2 * (KH > 0 ? KH : 1), CRH = LK_TH + 2 * (KH > 0 ? KH : 1);
-    constexpr int32_t P1 = (CRW * CRH + 255) / 256;
+    // Which staged cells a thread takes.  Elements 0 .. QM-1: the rectangle's first 64 columns, lane = column, row = wavefront + 4 q:
+    // the row is the same for a whole wavefront, so its clamp, its bounds test and its base address are scalar work and a load is
+    // `row base (scalar) + column offset (one register for all rows)`: no vector instruction per load.  Elements QM .. P1-1: the
+    // SW = 2 KH columns on the right, (row, column) per lane, computed once per workgroup.  (Rounds 1-4 numbered the rectangle's
+    // cells row-major through the workgroup: a division, two clamps, a 64-bit multiply-add and four bounds tests under a branch per
+    // cell were 2300 of this kernel's 4800 vector instructions per tile: profiles/r05/dense_likelihood_counters.json.)
+    constexpr int32_t SW = CRW - LK_TW, QM = (CRH + 3) / 4, QS = (CRH * SW + 255) / 256;
+    constexpr int32_t P1 = QM + QS;
+    static_assert(LK_TW == 64, "lane = column of the staged rectangle's first 64");
+    const int32_t e_lane = (int32_t)(threadIdx.x & 63);
+    const int32_t e_wave = __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6));
+    int32_t s_r[QS], s_c[QS];
+    bool s_have[QS];
+#pragma unroll
+    for (int j = 0; j < QS; j++) {
+        const int32_t i2 = (int32_t)threadIdx.x + j * 256;
+        s_r[j] = i2 / SW; s_c[j] = LK_TW + (i2 - s_r[j] * SW);
+        s_have[j] = i2 < CRH * SW;
+        if (!s_have[j]) { s_r[j] = 0; s_c[j] = 0; }         // (loads a duplicate of the rectangle's first cell; not staged)
+    }
     double lv[P1];
     uint32_t cv[P1];
     auto issue_loads = [&](int32_t t) {
         const int32_t tile = tile_of(t);
         const int32_t ltx0 = (qx0 + tile % qnx) * LK_TW, lty0 = (qy0 + tile / qnx) * LK_TH;
+        // addresses clamped into the map (a cell outside it is given its code from the coordinates, below): no load behind a branch
+        const uint32_t gxm = (uint32_t)min(max(ltx0 - KH + e_lane, 0), g.W - 1);
 #pragma unroll
-        for (int q = 0; q < P1; q++) {
-            const int32_t idx = (int32_t)threadIdx.x + q * 256;
-            const int32_t r = idx / CRW, c = idx - r * CRW;
-            const int32_t gy = min(max(lty0 - KH + r, 0), g.H - 1), gx = min(max(ltx0 - KH + c, 0), g.W - 1);
-            lv[q] = mlog[(size_t)gy * g.W + gx];
-            cv[q] = mcnt ? mcnt[(size_t)gy * g.W + gx] : 0u;
+        for (int q = 0; q < QM; q++) {
+            const int32_t gy = min(max(lty0 - KH + e_wave + 4 * q, 0), g.H - 1);
+            const size_t row = (size_t)gy * (size_t)g.W;
+            lv[q] = (mlog + row)[gxm];
+            cv[q] = mcnt ? (mcnt + row)[gxm] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < QS; j++) {
+            const int32_t gy = min(max(lty0 - KH + s_r[j], 0), g.H - 1), gx = min(max(ltx0 - KH + s_c[j], 0), g.W - 1);
+            lv[QM + j] = mlog[(size_t)gy * g.W + gx];
+            cv[QM + j] = mcnt ? mcnt[(size_t)gy * g.W + gx] : 0u;
         }
     };
     if (KH > 0) {
@@ -772,8 +804,9 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
         const uint8_t tstate_old = tstate ? *reinterpret_cast<volatile uint8_t *>(tstate) : (uint8_t)0;
 
         // ---- phase 1
-        int32_t seen = 0;                                      // bit c: a cell of code c; bit 3: outside the map
-        uint32_t codes = 0;                                    // KH > 0: 2 bits per staged cell of this thread (3 = outside)
+        int32_t seen = 0;                                      // bit c: a cell of code c; bit 3: outside the map; bit 4: a code changes
+        uint32_t codes = 0;                                    // KH > 0: 2 bits per staged cell of this thread
+        bool a_chg = false;
         int32_t *smask = &s_mask[0];
         if (KH > 0) {
             // The codes come out of registers; LDS is written only if the tile turns out not to be uniform (most of a
@@ -784,24 +817,37 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 if (cv[q]) {
                     const double nv = lv[q] + ((double)(cv[q] & 0xffffu) * g.l_free + (double)(cv[q] >> 16) * g.l_occ);
                     // (a clamped duplicate of a border cell counts too: conservative)
-                    if (skip_unchanged && ((nv > 0.0) != (lv[q] > 0.0) || (nv < 0.0) != (lv[q] < 0.0))) seen |= 16;
+                    if (skip_unchanged && ((nv > 0.0) != (lv[q] > 0.0) || (nv < 0.0) != (lv[q] < 0.0))) a_chg = true;
                     lv[q] = nv;
                 }
+            // The class of every staged cell, two bits each in `codes` (3 = outside the map); which classes occur at all is read off
+            // the packed word afterwards -- a handful of instructions per thread instead of per cell -- and "does any lane of the
+            // wavefront hold one" is a scalar test of a comparison's lane mask: no butterfly.
+            auto classify = [&](int q, bool in) {
+                const double v = lv[q];
+                const uint32_t code = v > 0.0 ? 2u : (v < 0.0 ? 0u : 1u);               // GridMap.java:239-244
+                codes |= (in ? code : 3u) << (2 * q);
+            };
+            const bool x_in = (uint32_t)(tx0 - KH + e_lane) < (uint32_t)g.W;
+            uint32_t have_bits = 0;                                                     // bit 2q: element q is a cell of the rectangle
 #pragma unroll
-            for (int q = 0; q < P1; q++) {
-                const int32_t idx = (int32_t)threadIdx.x + q * 256;
-                const int32_t r = idx / CRW, c = idx - r * CRW;
-                const int32_t gy = ty0 - KH + r, gx = tx0 - KH + c;
-                if (idx < CRW * CRH) {
-                    int32_t code = 3;
-                    if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
-                        code = lv[q] > 0.0 ? 2 : (lv[q] < 0.0 ? 0 : 1);                    // GridMap.java:239-244
-                        seen |= 1 << code;
-                    } else {
-                        seen |= 8;
-                    }
-                    codes |= (uint32_t)code << (2 * q);
-                }
+            for (int q = 0; q < QM; q++) {
+                const int32_t r = e_wave + 4 * q;
+                classify(q, x_in && (uint32_t)(ty0 - KH + r) < (uint32_t)g.H);
+                if (r < CRH) have_bits |= 1u << (2 * q);
+            }
+#pragma unroll
+            for (int j = 0; j < QS; j++) {
+                classify(QM + j, (uint32_t)(tx0 - KH + s_c[j]) < (uint32_t)g.W && (uint32_t)(ty0 - KH + s_r[j]) < (uint32_t)g.H);
+                if (s_have[j]) have_bits |= 1u << (2 * (QM + j));
+            }
+            {
+                const uint32_t lo = codes, hi = codes >> 1;
+                const uint32_t is3 = lo & hi & have_bits, is2 = hi & ~lo & have_bits, is1 = lo & ~hi & have_bits, is0 = ~(lo | hi) & have_bits;
+                seen = (__builtin_amdgcn_ballot_w64(is0 != 0u) ? 1 : 0) | (__builtin_amdgcn_ballot_w64(is1 != 0u) ? 2 : 0) |
+                       (__builtin_amdgcn_ballot_w64(is2 != 0u) ? 4 : 0) | (__builtin_amdgcn_ballot_w64(is3 != 0u) ? 8 : 0) |
+                       (__builtin_amdgcn_ballot_w64(a_chg) ? 16 : 0);
+                codes &= ~(is3 | (is3 << 1));                                           // what LDS holds: outside the map 0
             }
         } else {
             __syncthreads();                                   // previous tile's LDS reads are done
@@ -825,9 +871,11 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 in_s[r * PIN + c] = val;
             }
         }
+        if (KH == 0) {
 #define GMS_STEP_(O) seen |= wave_xor<O>(seen);
-        GMS_BUTTERFLY(GMS_STEP_)
+            GMS_BUTTERFLY(GMS_STEP_)
 #undef GMS_STEP_
+        }
         if ((threadIdx.x & 63) == 0) atomicOr(smask, seen);
         __syncthreads();
         if (tile_iter == 0) GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 3);      // first tile: loads arrived, codes known
@@ -843,13 +891,13 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             if (!uniform && !unchanged) {
                 // stage {0, 0.5, 1} (outside the map: 0.0).  Every thread passed the barrier above, so the previous
                 // tile's reads of in_s and hs are over.
+                uint8_t *wb = in_b + e_wave * PINB + e_lane;
 #pragma unroll
-                for (int q = 0; q < P1; q++) {
-                    const int32_t idx = (int32_t)threadIdx.x + q * 256;
-                    const int32_t r = idx / CRW, c = idx - r * CRW;
-                    const uint32_t code = (codes >> (2 * q)) & 3u;
-                    if (idx < CRW * CRH) in_b[r * PINB + c] = (uint8_t)(code == 3u ? 0u : code);
-                }
+                for (int q = 0; q < QM; q++)
+                    if (e_wave + 4 * q < CRH) wb[q * 4 * PINB] = (uint8_t)((codes >> (2 * q)) & 3u);
+#pragma unroll
+                for (int j = 0; j < QS; j++)
+                    if (s_have[j]) in_b[s_r[j] * PINB + s_c[j]] = (uint8_t)((codes >> (2 * (QM + j))) & 3u);
             }
             if (t + (int32_t)gdx < ntiles) issue_loads(t + (int32_t)gdx);      // in flight during the rest of this tile
             if (unchanged) { ts_left++; continue; }                            // (one barrier, like a uniform tile)
@@ -883,7 +931,9 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
 
         if (KH > 0) {
             // ---- phase 2: strips of LK_STRIP outputs along x
-            for (int32_t sidx = threadIdx.x; sidx < RH * (LK_TW / LK_STRIP); sidx += blockDim.x) {
+            // (RH * 8 strips are 5.25 (KH = 5) wavefronts' worth: the wavefronts that take a second pass rotate from tile to tile,
+            // so that over the tiles a workgroup walks no SIMD carries more of them than another)
+            for (int32_t sidx = (int32_t)((threadIdx.x + 64u * (uint32_t)tile_iter) & 255u); sidx < RH * (LK_TW / LK_STRIP); sidx += 256) {
                 const int32_t r = sidx / (LK_TW / LK_STRIP), c0 = (sidx - r * (LK_TW / LK_STRIP)) * LK_STRIP;
                 double v[LK_STRIP + 2 * (KH > 0 ? KH : 1)];
                 // c0 and PINB are multiples of 8: the strip's LK_STRIP + 2 KH codes come as 8-byte words
@@ -893,13 +943,17 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
 #pragma unroll
                 for (int j = 0; j < NQ; j++) q[j] = row[j];
 #pragma unroll
-                for (int j = 0; j < LK_STRIP + 2 * KH; j++) v[j] = 0.5 * (double)(uint32_t)((q[j >> 3] >> (8 * (j & 7))) & 0xffu);   // exact: {0, 0.5, 1}
+                // Twice the sums: the codes themselves (0, 1, 2) stand in for the cells' {0, 0.5, 1}.  Doubling every term of an
+                // in-order sum of products doubles every intermediate exactly (scaling by a power of two commutes with rounding while
+                // nothing is subnormal: the launchers check the taps, gms_map::lik_kh), so 0.5 * total below IS Util.java:393-401's
+                // total, bit for bit -- and a conversion is one instruction less per staged value.
+                for (int j = 0; j < LK_STRIP + 2 * KH; j++) v[j] = (double)(uint32_t)((q[j >> 3] >> (8 * (j & 7))) & 0xffu);
 #pragma unroll
                 for (int o = 0; o < LK_STRIP; o++) {
                     double total = 0.0;
 #pragma unroll
                     for (int i = 0; i < 2 * KH + 1; i++) total += taps_g[i] * v[o + i];
-                    hs[r * PHS + c0 + o] = total;
+                    hs[r * PHS + c0 + o] = 0.5 * total;         // see "twice the sums" above
                 }
             }
             __syncthreads();
@@ -954,7 +1008,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
 }
 
 template <int KH, bool PENDING>      // PENDING = false: no count grid is read (the code for it is not generated: 1.3 us of a 21 us full rebuild)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) GMS_LIK_WAVES
 k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
              int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
              int32_t tiles_x, int32_t tiles_y, uint8_t *__restrict__ tile_state, const uint32_t *__restrict__ cnt_pending,
@@ -1207,9 +1261,9 @@ void gms_launch_apply_counts(gms_map *m) {
 }
 
 // dynamic LDS of a likelihood workgroup (likelihood_body's layout) and how many of them to launch per map
-size_t gms_likelihood_lds_bytes(int32_t k) {
+size_t gms_likelihood_lds_bytes(int32_t k, bool coded) {
     const size_t RH = LK_TH + 2 * k, RW = LK_TW + 2 * k;
-    if (k == 3 || k == 5) return ((RH * ((RW + 7) & ~(size_t)7) + 15) & ~(size_t)15) + RH * (LK_TW + 1) * sizeof(double);
+    if (coded && (k == 3 || k == 5)) return ((RH * ((RW + 7) & ~(size_t)7) + 15) & ~(size_t)15) + RH * (LK_TW + 1) * sizeof(double);
     return (RH * (RW + 1) + RH * (LK_TW + 1) + (2 * (size_t)k + 1)) * sizeof(double);
 }
 int32_t gms_likelihood_blocks_cap(const gms_map *m, size_t smem) {
@@ -1251,9 +1305,9 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending, 
         m->fac_current = 1;                                   // after this launch the factor table is the field of logData + pending counts
     }
     ProfScope ps(m, GMS_K_LIKELIHOOD);
-    const int32_t k = m->gd.khalf;
+    const int32_t k = m->lik_kh;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
-    const size_t smem = gms_likelihood_lds_bytes(k);
+    const size_t smem = gms_likelihood_lds_bytes(m->gd.khalf, k != 0);
     // persistent workgroups, each walks tiles blockIdx.x, += gridDim.x
     int32_t blocks = tiles_x * tiles_y;
     const int32_t cap = gms_likelihood_blocks_cap(m, smem);

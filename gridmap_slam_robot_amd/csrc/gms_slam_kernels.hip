@@ -310,9 +310,9 @@ k_slam_gather_maps(const double *__restrict__ src_log, const double *__restrict_
 // ---------------------------------------------------------------------------------------------
 void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, int32_t n) {
     ProfScope ps(m, GMS_K_LIKELIHOOD);
-    const int32_t k = m->gd.khalf;
+    const int32_t k = m->lik_kh;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
-    const size_t smem = gms_likelihood_lds_bytes(k);
+    const size_t smem = gms_likelihood_lds_bytes(m->gd.khalf, k != 0);
     // a workgroup per tile while that stays a few rounds of the chip; beyond it persistent workgroups walk a map's tiles
     int32_t blocks = tiles_x * tiles_y;
     int32_t per_cu = (int32_t)((size_t)m->lds_per_cu / (smem + 256));
