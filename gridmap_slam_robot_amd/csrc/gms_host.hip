@@ -329,8 +329,8 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     g.ktaps = p->ktaps; g.khalf = (p->ktaps - 1) / 2;                // Util.java:384
     m->lik_kh = (g.khalf == 3 || g.khalf == 5) ? g.khalf : 0;
     for (int32_t i = 0; i < p->ktaps; i++) {
-        const double a = fabs(p->kernel[i]);
-        if (a != 0.0 && !(a >= 0x1p-900 && a <= 0x1p900)) m->lik_kh = 0;
+        const double a = p->kernel[i];
+        if (std::signbit(a) || (a != 0.0 && !(a >= 0x1p-900 && a <= 0x1p900))) m->lik_kh = 0;
     }
 
     const size_t cells = (size_t)g.cells * m->n_maps;

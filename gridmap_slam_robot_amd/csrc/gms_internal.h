@@ -118,9 +118,10 @@ struct gms_map {
     int32_t apply_pending;    // the last scan's counts are not in logData yet (deferred apply pass, gms_flush_apply)
     int32_t raycast_tile;     // batched ray casts accumulate in LDS tiles (k_raycast_tile; GMS_RAYCAST_TILE=0 turns it off)
     int32_t raycast_tile_min; // ... when the launch has more rays than this in all (default 4096; GMS_RAYCAST_TILE_MIN)
-    int32_t lik_kh;           // the likelihood kernels' compile-time half width (3 or 5), or 0 = the generic path: another kernel size, or taps
-                              // outside 2^-900 .. 2^900 (the fast path computes twice the horizontal sums and halves them: exact only
-                              // while nothing is subnormal; likelihood_body)
+    int32_t lik_kh;           // the likelihood kernels' compile-time half width (3 or 5), or 0 = the generic path: another kernel size, or a tap
+                              // that is negative or outside 2^-900 .. 2^900 (the fast path computes twice the horizontal sums and halves them --
+                              // exact only while nothing is subnormal -- and starts a sum with its first product instead of 0.0 + it -- the
+                              // same bits only while that product is not -0.0; likelihood_body)
     int32_t lik_lazy;         // scan steps' dirty-tile rebuilds write the factor table only, likelihoodData on demand (GMS_LIK_LAZY=0 turns it off)
     int32_t lik_stale;        // likelihoodData is behind the factor table somewhere (gms_ensure_lik brings it up to date)
     int32_t fac_current;      // the factor table is the field of logData + the pending counts as of the last rebuild, and logData has not moved since except by those counts

@@ -679,6 +679,13 @@ k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const 
 // the factor table's stores go through to memory at once: nobody in the launch reads them again, and dirty lines would be written
 // back at the kernel's end, in front of the next scan's scoring launch (C3 step -0.4 us, C5 -5 us)
 #define FAC_STORE(p, v) store_through((p), (v))
+// ... and so do likelihoodData's: a full rebuild of a 2048 x 2048 map leaves 33 MB of it, more than the L2s hold, and what is still dirty
+// at the kernel's end is written back there with nothing to hide behind (dense map: 24.6 -> 21.8 us per rebuild, bracketed)
+#ifndef GMS_LIK_STORE_PLAIN
+#define LIK_STORE(p, v) store_through((p), (v))
+#else
+#define LIK_STORE(p, v) (*(p) = (v))
+#endif
 template <int KH>   // KH > 0: compile-time half width; KH == 0: runtime g.khalf (generic, slower)
 __device__ __forceinline__ void
 likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
@@ -919,7 +926,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             for (int32_t idx = threadIdx.x; idx < LK_TH * LK_TW; idx += blockDim.x) {
                 const int32_t r = idx / LK_TW, c = idx - r * LK_TW;
                 const size_t o = (size_t)(ty0 + r) * g.W + tx0 + c;               // tile is inside the map (bit 3 clear)
-                if (wr_lik) mlik[o] = vc;
+                if (wr_lik) LIK_STORE(&mlik[o], vc);
                 if (wr_fac) FAC_STORE(&mfac[(size_t)(ty0 + r) * g.fpitch + tx0 + c], fc);
             }
             if (wr_fac && tstate && threadIdx.x == 0) *tstate = want;
@@ -928,6 +935,9 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
         }
         if (wr_fac && tstate && threadIdx.x == 0) *tstate = 0;
         ts_blurred++;
+#if defined(GMS_LIK_EXP) && GMS_LIK_EXP == 1       // experiment: the staging alone (tools/lik_phases.sh)
+        continue;
+#endif
 
         if (KH > 0) {
             // ---- phase 2: strips of LK_STRIP outputs along x
@@ -950,30 +960,42 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 for (int j = 0; j < LK_STRIP + 2 * KH; j++) v[j] = (double)(uint32_t)((q[j >> 3] >> (8 * (j & 7))) & 0xffu);
 #pragma unroll
                 for (int o = 0; o < LK_STRIP; o++) {
-                    double total = 0.0;
+                    double total = taps_g[0] * v[o];            // (== 0.0 + the product: no tap is negative, gms_map::lik_kh)
 #pragma unroll
-                    for (int i = 0; i < 2 * KH + 1; i++) total += taps_g[i] * v[o + i];
+                    for (int i = 1; i < 2 * KH + 1; i++) total += taps_g[i] * v[o + i];
                     hs[r * PHS + c0 + o] = 0.5 * total;         // see "twice the sums" above
                 }
             }
             __syncthreads();
             if (tile_iter == 1) GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 4);  // first tile (non-uniform): horizontal sums done
             // ---- phase 3: strips of LK_STRIP outputs along y
+#if defined(GMS_LIK_EXP) && GMS_LIK_EXP == 2       // experiment: staging and horizontal sums
+            if (hs[threadIdx.x] == 123.0) mlik[0] = 1.0;
+            continue;
+#endif
             {
-                const int32_t c = threadIdx.x & (LK_TW - 1), r0 = (threadIdx.x >> 6) * LK_STRIP;
+                // lane = column, wavefront = eight rows: the rows' bounds tests and base addresses are scalar, a store is
+                // `row base (scalar) + column offset (one register)`
+                const int32_t c = e_lane, r0 = e_wave * LK_STRIP;
                 double v[LK_STRIP + 2 * (KH > 0 ? KH : 1)];
+                const double *hcol = hs + r0 * PHS + c;
 #pragma unroll
-                for (int j = 0; j < LK_STRIP + 2 * KH; j++) v[j] = hs[(r0 + j) * PHS + c];
-                const int32_t gx = tx0 + c;
+                for (int j = 0; j < LK_STRIP + 2 * KH; j++) v[j] = hcol[j * PHS];
+                const uint32_t gx = (uint32_t)(tx0 + c);
+                const bool x_ok = gx < (uint32_t)g.W;
 #pragma unroll
                 for (int o = 0; o < LK_STRIP; o++) {
-                    double total = 0.0;
+                    double total = taps_g[0] * v[o];
 #pragma unroll
-                    for (int i = 0; i < 2 * KH + 1; i++) total += taps_g[i] * v[o + i];
+                    for (int i = 1; i < 2 * KH + 1; i++) total += taps_g[i] * v[o + i];
                     const int32_t gy = ty0 + r0 + o;
-                    if (gx < g.W && gy < g.H) {
-                        if (wr_lik) mlik[(size_t)gy * g.W + gx] = total;
-                        if (wr_fac) FAC_STORE(&mfac[(size_t)gy * g.fpitch + gx], lik_factor(g, total));
+#if defined(GMS_LIK_EXP) && GMS_LIK_EXP == 3       // experiment: everything but the stores
+                    if (total == 123.0) mlik[0] = total;
+                    continue;
+#endif
+                    if (gy < g.H && x_ok) {
+                        if (wr_lik) LIK_STORE(mlik + (size_t)gy * (size_t)g.W + gx, total);
+                        if (wr_fac) FAC_STORE(mfac + (size_t)gy * (size_t)g.fpitch + gx, lik_factor(g, total));
                     }
                 }
             }

@@ -160,6 +160,26 @@ def test_likelihood_custom_kernels():
         assert np.array_equal(m.download_likelihood().reshape(-1), g.build_likelihood(log))
 
 
+def test_likelihood_kernels_outside_the_fast_paths_domain():
+    """The 7- and 11-tap kernels (half width 3, 5) compute twice the horizontal sums and start a sum with its first product; that is
+    the reference's arithmetic bit for bit only for non-negative taps of ordinary magnitude (gms_map::lik_kh).  A negative tap, a -0.0
+    and taps near the subnormal range take the generic kernel instead: the same bits as the oracle, zeros' signs included."""
+    gauss11 = orc.gaussian_kernel(1.0, 5)
+    gauss7 = orc.gaussian_kernel(0.5, 3)
+    neg = gauss11.copy(); neg[2] = -neg[2]
+    mzero = gauss7.copy(); mzero[0] = -0.0
+    tiny = gauss11 * 2.0 ** -1015
+    for taps in (neg, mzero, tiny, gauss11 * 2.0 ** 950):
+        m = GridMap(6.4, 3.2, 0.05, (-3.2, -1.6), kernel=list(taps))
+        g = orc.Grid(6.4, 3.2, 0.05, -3.2, -1.6)
+        g.set_kernel(list(taps))
+        log = np.random.default_rng(len(taps)).choice([-1.5, 0.0, 0.0, 2.0], size=g.W * g.H)
+        m.upload_log(log)
+        m.compute_likelihood_map()
+        got, want = m.download_likelihood().reshape(-1), g.build_likelihood(log)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
 def test_widest_blur_kernels():
     """65 taps (half width 32) is what the likelihood pass's LDS tile holds on this GPU: bit-identical to the oracle; the
     structure's 129 taps are refused when the map is created, with the byte counts in the message (before: a launch failure
