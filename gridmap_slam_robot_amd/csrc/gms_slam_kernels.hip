@@ -47,6 +47,9 @@ __device__ __forceinline__ RayIn ps_make_ray(const GridDev &g, const XformDev &t
     return r;
 }
 
+#ifndef PS_APPLY
+#define PS_APPLY 12                     // cells per thread and pass of k_slam_particle's read-modify-write of logData
+#endif
 #define PS_WORDS 8                      // decision words per ray and round of k_slam_particle (256 steps of the walk)
 struct PsRay {                          // what a consumer needs of a ray
     int32_t x0, y0, x_inc, y_inc, n_eff, hit;
@@ -87,7 +90,7 @@ __device__ __forceinline__ void ps_phase_b(const GridDev &g, const PsRay &mt, co
 // per step on one or two wavefronts per SIMD, which issue one instruction per ~4.6 clocks: 29 us of walking for 90 rays against 17 for
 // this split form, whose cell work spreads over every wavefront of the workgroup.)
 template <int NT, int NP>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4)))       // (2 x 512 or 1024 lanes per CU: 128 registers)
 k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, double *__restrict__ log_all,
                 const double *__restrict__ lik_all, float *__restrict__ pose, float *__restrict__ cs, double *__restrict__ w,
                 double *__restrict__ logw, MotionArgs mo, int32_t integrate, int32_t tile_cap) {
@@ -134,6 +137,11 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     const double *lik = lik_all + (size_t)p * (size_t)g.cells;
     double lsum = 0.0;
     int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
+    // the ray of beam threadIdx.x, kept: the producer lane of that beam in the first group of rays below is this very thread
+    RayDev r_first;
+    RayMeta mt_first;
+    r_first.dx = r_first.dy = r_first.error = 0.0f; r_first.x = r_first.y = r_first.x_inc = r_first.y_inc = r_first.n = 0;
+    mt_first = RayMeta{};
     for (int32_t b = (int32_t)threadIdx.x; b < B; b += NT) {
         const gms_beam bm = beams[b];
         double f = 1.0;                                                        // a beam that is skipped leaves the product as it is: x * 1.0 == x
@@ -148,6 +156,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
         if (integrate) {
             RayDev r;
             const RayMeta mt = ray_meta(g, ps_make_ray(g, t, bm), r);
+            if (b == (int32_t)threadIdx.x) { r_first = r; mt_first = mt; }
             if (mt.n_eff > 0) {
                 bx0 = min(bx0, min(mt.x0, mt.hx)); bx1 = max(bx1, max(mt.x0, mt.hx));
                 by0 = min(by0, min(mt.y0, mt.hy)); by1 = max(by1, max(mt.y0, mt.hy));
@@ -196,7 +205,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
         const int32_t th = min(band_rows, Y1 - ty0 + 1);
         for (int32_t i = threadIdx.x; i < tw * th; i += NT) s_tile[i] = 0u;
         for (int32_t g0 = 0; g0 < B; g0 += GR) {
-            // this group's rays: a producer lane per ray (the same arithmetic as the box pass above: same values)
+            // this group's rays: a producer lane per ray
             RayDev r;
             r.dx = r.dy = r.error = 0.0f; r.x = r.y = r.x_inc = r.y_inc = r.n = 0;
             int32_t my_nwords = 0;
@@ -205,7 +214,9 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                 PsRay pr;
                 pr.n_eff = 0; pr.x0 = pr.y0 = pr.x_inc = pr.y_inc = pr.hit = 0; pr.sx = pr.sy = pr.s_free = pr.s_prior = 0.0f;
                 if (ri < B) {
-                    const RayMeta mt = ray_meta(g, ps_make_ray(g, t, beams[ri]), r);
+                    RayMeta mt;
+                    if (g0 == 0) { mt = mt_first; r = r_first; }               // (ri == threadIdx.x)
+                    else mt = ray_meta(g, ps_make_ray(g, t, beams[ri]), r);    // the same arithmetic as the box pass above: same values
                     // a ray that never enters this band's rows is not walked for it (its box says so)
                     const bool in_band = mt.n_eff > 0 && !(max(mt.y0, mt.hy) < ty0 || min(mt.y0, mt.hy) >= ty0 + th);
                     const RayThr thr = ray_thresholds(mt.measured, mt.hit, g.half_tol);
@@ -245,27 +256,42 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
             }
             if (nwords_max == 0) __syncthreads();                              // (s_ray / s_grp_words are rewritten by the next group)
         }
-        // logData[c] += n_free * logOdds(P_FREE) + n_occ * logOdds(P_OCC): the expression of apply_body (GridMap.java:223).  Eight
-        // cells per thread and pass, every load issued before the first store: a read-modify-write per iteration is one memory round
-        // trip each (the first form of this loop: 14 of them in a row on a 100 x 100 box)
+        // logData[c] += n_free * logOdds(P_FREE) + n_occ * logOdds(P_OCC): the expression of apply_body (GridMap.java:223).  PS_APPLY
+        // cells per thread and pass (cell i = base + u NT + thread, row-major through the box), every load of a pass issued before its
+        // first store, so a pass is one memory round trip; the cell's row and column advance by a recurrence (no division per cell).
+        // (A read-modify-write per loop iteration was 14 round trips in a row on a 100 x 100 box.  Beyond 8 cells per pass the width
+        // does not matter -- 8 / 12 / 16: 70.8 / 71.8 / 71.1 us per update at 500 x 120 x 120, 2.08 / 2.05 / 2.09 ms at 4096 x 256 x 256;
+        // 24 spills: 83 us -- the pass is bound by the touched lines' read-modify-write, not by its round trips.  Loading the box BEFORE
+        // the counting, to fly during it, was measured too: the registers it holds through the counting spill there, 73 -> 82 us.)
         const int32_t ncell = tw * th;
+        const int32_t pq = NT / tw, pr = NT - pq * tw;                         // cell i + NT is pq rows and pr columns further on
         if (ty0 == Y0) GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 6);
-        for (int32_t base = 0; base < ncell; base += NT * 8) {
-            uint32_t c[8];
-            size_t o[8];
-            double v[8];
+        for (int32_t base = 0; base < ncell; base += NT * PS_APPLY) {
+            const int32_t i0 = base + (int32_t)threadIdx.x;
+            const int32_t y0 = i0 / tw, x0 = i0 - y0 * tw;
+            uint32_t c[PS_APPLY];
+            double v[PS_APPLY];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int32_t i = base + u * NT + (int32_t)threadIdx.x;
-                c[u] = i < ncell ? s_tile[i] : 0u;
-                const int32_t ry = i / tw, rx = i - ry * tw;
-                o[u] = (size_t)(ty0 + ry) * g.W + X0 + rx;
+            for (int u = 0; u < PS_APPLY; u++) c[u] = i0 + u * NT < ncell ? s_tile[i0 + u * NT] : 0u;
+            {
+                int32_t y = y0, x = x0;
+#pragma unroll
+                for (int u = 0; u < PS_APPLY; u++) {
+                    v[u] = c[u] ? mlog[(size_t)(ty0 + y) * g.W + X0 + x] : 0.0;
+                    x += pr; y += pq;
+                    if (x >= tw) { x -= tw; y++; }
+                }
             }
+            {
+                int32_t y = y0, x = x0;
+                asm volatile("" : "+v"(y), "+v"(x));           // (the addresses are formed again, not kept in 2 PS_APPLY registers)
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = c[u] ? mlog[o[u]] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (c[u]) mlog[o[u]] = v[u] + ((double)(c[u] & 0xffffu) * g.l_free + (double)(c[u] >> 16) * g.l_occ);
+                for (int u = 0; u < PS_APPLY; u++) {
+                    if (c[u]) mlog[(size_t)(ty0 + y) * g.W + X0 + x] = v[u] + ((double)(c[u] & 0xffffu) * g.l_free + (double)(c[u] >> 16) * g.l_occ);
+                    x += pr; y += pq;
+                    if (x >= tw) { x -= tw; y++; }
+                }
+            }
         }
         __syncthreads();
         if (ty0 == Y0) GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 7);
