@@ -82,5 +82,16 @@ if [ -f gridmap_slam_robot_amd/lib/exp_stamps.so ]; then
   GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/stamps.py > "$OUT/keep/c3_step_timeline.txt" 2>> "$OUT/bench.stderr"
   GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/stamps.py --config C2 2>> "$OUT/bench.stderr" | head -24 > "$OUT/keep/c2_step_timeline.txt"
 fi
+if [ -f gridmap_slam_robot_amd/lib/exp_stamps.so ]; then
+  GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/pm_stamps.py 500 6 90 > "$OUT/keep/pm500_timeline.txt" 2>> "$OUT/bench.stderr"
+  GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/pm_stamps.py 1024 12.8 180 > "$OUT/keep/pm1024x256_timeline.txt" 2>> "$OUT/bench.stderr"
+fi
+# where the dense rebuild's time goes (lib/lik_exp{1,2,3}.so, when shipped along) and the log-normalising loop beside the plain one
+bash tools/lik_phases.sh > "$OUT/keep/dense_likelihood_phases.txt" 2>> "$OUT/bench.stderr"
+python3 tools/lognorm_probe.py > "$OUT/keep/lognorm_probe.txt" 2>> "$OUT/bench.stderr"
+# config 5 split by map: one GPU's share at 1 / 2 / 4 / 8 GPUs
+for mm in 64 32 16 8; do
+  python3 bench.py --config C5 --maps $mm --steps 30 --warmup 4 $Q --report "$OUT/keep/bench_c5_maps_${mm}_report.json" > "$OUT/keep/bench_c5_maps_${mm}.json" 2>> "$OUT/bench.stderr"
+done
 ls -la "$OUT/keep"
 for f in "$OUT"/keep/*_kernel_stats.csv; do echo "== $f"; python3 tools/kstats.py "$f" | head -8; done

@@ -46,6 +46,10 @@ def main():
     s[s == 0] = np.nan
     t0 = np.nanmin(s[0, :, 0])
     s[np.abs(s - t0) > 1e5] = np.nan          # (a slot left over from an earlier launch of another shape: more than a millisecond away)
+    # a stage a workgroup did not reach in THIS step keeps an earlier step's stamp: older than the workgroup's own entry
+    for kid in range(4):
+        stale = s[kid] < s[kid][:, 0:1]
+        s[kid][stale] = np.nan
     print(f"{a.config}: stage stamps of the last of {a.steps} steps, microseconds after the first scoring workgroup entered")
     for kid, (name, slots) in STAGES.items():
         for slot, what in slots.items():
