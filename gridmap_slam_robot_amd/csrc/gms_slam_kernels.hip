@@ -105,6 +105,8 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     __shared__ int32_t s_box[4];                                               // the scan's box x0, y0, x1, y1 (inclusive)
     __shared__ int32_t s_grp_words[NP];
     __shared__ double s_red[NW];
+    __shared__ uint16_t s_work[(PS_WORDS / 2) * GR];                           // a round's cell work: slot | block << 8, block-major
+    __shared__ int32_t s_nwork, s_next;
     const int32_t p = blockIdx.x;
     const int32_t lane = threadIdx.x & 63;
     const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6));
@@ -239,18 +241,50 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
             RayWalk wk = ray_walk_begin(r);
             for (int32_t wb = 0; wb < nwords_max; wb += PS_WORDS) {            // one round = up to 256 steps of every ray of the group
                 for (int32_t i = threadIdx.x; i < PS_WORDS * GR; i += NT) s_slots[i] = 0ull;
+                // The round's cell work as a list of (ray, 64-cell block) pairs that exist, block-major (the order in which the
+                // producers publish their words), built by the last wavefront while the others clear the slots.  (Walking all
+                // PS_WORDS / 2 x GR pairs and skipping the empty ones -- rays shorter than the round, slots beyond the scan's beams --
+                // cost an LDS round trip per skipped pair: 2.4 of the counting's 10.7 us at 90 beams.)
+                const int32_t blk0 = wb >> 1, nblk = min(PS_WORDS / 2, (nwords_max - wb + 1) >> 1);
+                if (wave == NW - 1) {
+                    int32_t cnt = 0;
+                    for (int32_t b = 0; b < nblk; b++)
+#pragma unroll
+                        for (int h = 0; h < NP; h++) {
+                            const int32_t slot = h * 64 + lane;
+                            const bool on = (blk0 + b) * 64 < s_ray[slot].n_eff;
+                            const uint64_t mask = __ballot(on);
+                            if (on) s_work[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)(slot | (blk0 + b) << 8);
+                            cnt += __popcll(mask);
+                        }
+                    if (lane == 0) { s_nwork = cnt; s_next = 0; }
+                }
                 __syncthreads();                                               // (also: the tile is cleared, the previous round consumed)
                 if (wave < NP) {
                     if (wb < my_nwords) ray_phase_a(wk, wb, min(my_nwords, wb + PS_WORDS), s_slots, GR, wave * 64 + lane);
                     if (g0 == 0 && ty0 == Y0 && wb == 0) GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 5);
                 }
-                // the cell work: every wavefront, the producers once their words are out (block-major: the order of publication)
-                const int32_t blk0 = wb >> 1, nblk = min(PS_WORDS / 2, (nwords_max - wb + 1) >> 1);
-                for (int32_t q = wave; q < nblk * GR; q += NW) {
-                    const int32_t blk = blk0 + q / GR, slot = q % GR;
-                    const int32_t n_eff = s_ray[slot].n_eff;
-                    if (blk * 64 >= n_eff) continue;
-                    ps_phase_b(g, s_ray[slot], s_slots, GR, slot, blk, lane, s_tile, X0, ty0, tw, th, wb);
+                // the cell work: every wavefront takes the next pair off the list (the producers once their words are out), and has
+                // the pair after it and that pair's ray record on the way while it works
+                const int32_t nwork = s_nwork;
+                auto grab = [&]() -> int32_t {
+                    int32_t w = 0;
+                    if (lane == 0) w = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return __builtin_amdgcn_readfirstlane(w);
+                };
+                if (g0 == 0 && ty0 == Y0 && wb == 0) { GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(0, blockIdx.x), 8); GMS_STAMP_T(64 * NP, GMS_STAMP_ROW(0, blockIdx.x), 12); }
+                int32_t w = grab();
+                int32_t item = w < nwork ? (int32_t)s_work[w] : 0;
+                PsRay ray = s_ray[item & 255];
+                while (w < nwork) {
+                    const int32_t w2 = grab();
+                    const int32_t item2 = w2 < nwork ? (int32_t)s_work[w2] : 0;
+                    const PsRay ray2 = s_ray[item2 & 255];
+                    ps_phase_b(g, ray, s_slots, GR, item & 255, item >> 8, lane, s_tile, X0, ty0, tw, th, wb);
+                    w = w2; item = item2; ray = ray2;
+                }
+                if (g0 == 0 && ty0 == Y0 && wb == 0) {      // the last wavefront's, the first consumer-only wavefront's and a producer's end of the cell work
+                    GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(0, blockIdx.x), 9); GMS_STAMP_T(64 * NP, GMS_STAMP_ROW(0, blockIdx.x), 10); GMS_STAMP_T(0, GMS_STAMP_ROW(0, blockIdx.x), 11);
                 }
                 __syncthreads();
             }
@@ -381,7 +415,7 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, do
     const size_t fixed = slam_particle_fixed_lds(Bpad, NP);
     // the count tile: the whole map when two workgroups then still share a CU's LDS, else whatever one workgroup can have (the kernel
     // walks the scan's box in bands of rows when it is larger)
-    const size_t lds_wg = (size_t)m->lds_per_cu - 2048;                         // (static LDS of the kernel, allocation granularity)
+    const size_t lds_wg = (size_t)m->lds_per_cu - 4096;                         // (static LDS of the kernel -- 1.2 KiB per workgroup --, allocation granularity)
     size_t cells = (size_t)m->gd.cells;
     size_t tile = cells;
     if (fixed + tile * 4 > lds_wg / 2) {

@@ -29,11 +29,12 @@ st = buf.cpu().numpy().reshape(4, 1024, 16).astype(np.float64)[0]
 st[st == 0] = np.nan
 t0 = np.nanmin(st[:, 0])
 names = {0: "entered", 1: "pose ready", 2: "factors + boxes ready", 3: "product chain done (its lane)", 4: "first group's rays set up", 5: "first round walked (producer)",
-         6: "all rays counted", 7: "cells applied"}
+         8: "cell work begins (last wavefront: after the list)", 12: "cell work begins (first consumer wavefront)", 11: "cell work done (producer wavefront 0)",
+         10: "cell work done (first consumer wavefront)", 9: "cell work done (last wavefront)", 6: "all rays counted", 7: "cells applied"}
 print(f"k_slam_particle, {N} particles x {int(ext/0.05)}^2, {B} beams: microseconds after the first workgroup entered (workgroups 0..{min(N,1024)-1})")
 for k, nm in names.items():
     v = (st[:min(N, 1024), k] - t0) * 0.01
     v = v[~np.isnan(v)]
     if v.size: print(f"  {nm:34s} n={v.size:4d} first {v.min():7.2f} median {np.median(v):7.2f} last {v.max():7.2f}")
 d = (st[:min(N, 1024)] - st[:min(N, 1024), 0:1]) * 0.01
-print("  per workgroup, microseconds after ITS OWN entry (median):", " | ".join(f"{names[k].split(' ')[0]} {np.nanmedian(d[:, k]):.2f}" for k in range(1, 8)))
+print("  per workgroup, microseconds after ITS OWN entry (median):", " | ".join(f"{names[k].split(' ')[0]} {np.nanmedian(d[:, k]):.2f}" for k in (1, 2, 3, 4, 5, 6, 7)))
