@@ -183,6 +183,36 @@ def test_edge_scans_the_band_walk_and_the_skip_rule(monkeypatch):
         dev.close()
 
 
+@pytest.mark.parametrize("case", ["2cm_11_taps", "ragged_map", "one_particle", "three_ray_groups"])
+def test_other_geometries(case):
+    """what the two sizes above do not reach: the 11-tap kernel of a 2 cm map (k_slam_likelihood<5>), a map that is no multiple of the
+    64 x 32 likelihood tiles and narrower than one, a filter of one particle, a scan of more beams than one group of producer lanes
+    holds (128): several groups of rays per band."""
+    W, H, res, B, N, T = {"2cm_11_taps": (3.2, 3.2, 0.02, 72, 12, 5), "ragged_map": (2.6, 4.45, 0.05, 64, 10, 5),
+                          "one_particle": (4.0, 4.0, 0.05, 90, 1, 5), "three_ray_groups": (4.0, 4.0, 0.05, 300, 6, 4)}[case]
+    ext = min(W, H)
+    tr = synth.make_trace(ext, res, B, T=T, seed=31)
+    g = orc.Grid(W, H, res, -W / 2, -H / 2)
+    dev = SLAMParticleMaps(W, H, res, (-W / 2, -H / 2), num_particles=N, max_beams=max(128, B))
+    o = orc.Slam(g, N)
+    assert (dev.W, dev.H) == (g.W, g.H)
+    P = synth.make_particles(tr.poses[0], N, seed=4, sigma_xy=0.03, sigma_theta_deg=2.0)
+    dev.set_poses(P); o.set_poses(P)
+    rng = np.random.default_rng(2)
+    for k in range(T):
+        z = tr.scans[k]
+        dev.update(z, None); o.update(z, None, threads=THREADS)
+        _compare_weights(dev.get_particles()[1], o.weights, f"{case} frame {k}")
+        _compare_maps(dev, o, f"{case} frame {k}")
+        if N > 1 and k == T - 2:
+            r01 = float(rng.random())
+            idx, amb = dev.resample(r01, want_indices=True)
+            want, _ = o.resample(r01)
+            assert_resample_indices(idx, want, amb)
+            assert np.array_equal(idx, want)
+    dev.close()
+
+
 def test_squared_thresholds_classify_like_the_square_root():
     """inverseSensorModel compares (float) Math.sqrt(s) with measured -+ 1 (GridMap.java:217, SensorModel.java:31-41); the per-particle
     ray cast compares s with two thresholds per ray instead (gms_device.h: sq_lower / sq_upper).  For thousands of thresholds t --
