@@ -105,7 +105,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     __shared__ int32_t s_box[4];                                               // the scan's box x0, y0, x1, y1 (inclusive)
     __shared__ int32_t s_grp_words[NP];
     __shared__ double s_red[NW];
-    __shared__ uint16_t s_work[(PS_WORDS / 2) * GR];                           // a round's cell work: slot | block << 8, block-major
+    __shared__ uint16_t s_work[GR];                                            // a round's cell work: the rays that have cells in it
     __shared__ int32_t s_nwork, s_next;
     const int32_t p = blockIdx.x;
     const int32_t lane = threadIdx.x & 63;
@@ -241,22 +241,22 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
             RayWalk wk = ray_walk_begin(r);
             for (int32_t wb = 0; wb < nwords_max; wb += PS_WORDS) {            // one round = up to 256 steps of every ray of the group
                 for (int32_t i = threadIdx.x; i < PS_WORDS * GR; i += NT) s_slots[i] = 0ull;
-                // The round's cell work as a list of (ray, 64-cell block) pairs that exist, block-major (the order in which the
-                // producers publish their words), built by the last wavefront while the others clear the slots.  (Walking all
-                // PS_WORDS / 2 x GR pairs and skipping the empty ones -- rays shorter than the round, slots beyond the scan's beams --
-                // cost an LDS round trip per skipped pair: 2.4 of the counting's 10.7 us at 90 beams.)
+                // The round's cell work as a list of the rays that have cells in it, built by the last wavefront while the others clear
+                // the slots; a wavefront takes a ray off the list and counts its 64-cell blocks of this round one after the other --
+                // the ray's record, the list entry and the ticket are fetched once per ray, not once per block.  (Walking all
+                // PS_WORDS / 2 x GR (block, ray) pairs and skipping the empty ones -- rays shorter than the round, slots beyond the
+                // scan's beams -- cost an LDS round trip per skipped pair.)
                 const int32_t blk0 = wb >> 1, nblk = min(PS_WORDS / 2, (nwords_max - wb + 1) >> 1);
                 if (wave == NW - 1) {
                     int32_t cnt = 0;
-                    for (int32_t b = 0; b < nblk; b++)
 #pragma unroll
-                        for (int h = 0; h < NP; h++) {
-                            const int32_t slot = h * 64 + lane;
-                            const bool on = (blk0 + b) * 64 < s_ray[slot].n_eff;
-                            const uint64_t mask = __ballot(on);
-                            if (on) s_work[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)(slot | (blk0 + b) << 8);
-                            cnt += __popcll(mask);
-                        }
+                    for (int h = 0; h < NP; h++) {
+                        const int32_t slot = h * 64 + lane;
+                        const bool on = blk0 * 64 < s_ray[slot].n_eff;
+                        const uint64_t mask = __ballot(on);
+                        if (on) s_work[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)slot;
+                        cnt += __popcll(mask);
+                    }
                     if (lane == 0) { s_nwork = cnt; s_next = 0; }
                 }
                 __syncthreads();                                               // (also: the tile is cleared, the previous round consumed)
@@ -264,8 +264,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                     if (wb < my_nwords) ray_phase_a(wk, wb, min(my_nwords, wb + PS_WORDS), s_slots, GR, wave * 64 + lane);
                     if (g0 == 0 && ty0 == Y0 && wb == 0) GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 5);
                 }
-                // the cell work: every wavefront takes the next pair off the list (the producers once their words are out), and has
-                // the pair after it and that pair's ray record on the way while it works
+                // the cell work: every wavefront (the producers once their words are out), with the next ray's record on the way
                 const int32_t nwork = s_nwork;
                 auto grab = [&]() -> int32_t {
                     int32_t w = 0;
@@ -274,14 +273,15 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                 };
                 if (g0 == 0 && ty0 == Y0 && wb == 0) { GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(0, blockIdx.x), 8); GMS_STAMP_T(64 * NP, GMS_STAMP_ROW(0, blockIdx.x), 12); }
                 int32_t w = grab();
-                int32_t item = w < nwork ? (int32_t)s_work[w] : 0;
-                PsRay ray = s_ray[item & 255];
+                int32_t slot = w < nwork ? (int32_t)s_work[w] : 0;
+                PsRay ray = s_ray[slot];
                 while (w < nwork) {
                     const int32_t w2 = grab();
-                    const int32_t item2 = w2 < nwork ? (int32_t)s_work[w2] : 0;
-                    const PsRay ray2 = s_ray[item2 & 255];
-                    ps_phase_b(g, ray, s_slots, GR, item & 255, item >> 8, lane, s_tile, X0, ty0, tw, th, wb);
-                    w = w2; item = item2; ray = ray2;
+                    const int32_t slot2 = w2 < nwork ? (int32_t)s_work[w2] : 0;
+                    const PsRay ray2 = s_ray[slot2];
+                    const int32_t nb = min(nblk, ((ray.n_eff + 63) >> 6) - blk0);
+                    for (int32_t b = 0; b < nb; b++) ps_phase_b(g, ray, s_slots, GR, slot, blk0 + b, lane, s_tile, X0, ty0, tw, th, wb);
+                    w = w2; slot = slot2; ray = ray2;
                 }
                 if (g0 == 0 && ty0 == Y0 && wb == 0) {      // the last wavefront's, the first consumer-only wavefront's and a producer's end of the cell work
                     GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(0, blockIdx.x), 9); GMS_STAMP_T(64 * NP, GMS_STAMP_ROW(0, blockIdx.x), 10); GMS_STAMP_T(0, GMS_STAMP_ROW(0, blockIdx.x), 11);
