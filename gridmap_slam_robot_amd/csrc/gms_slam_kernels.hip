@@ -58,19 +58,9 @@ struct PsRay {                          // what a consumer needs of a ray
 
 // phase B of the ray cast (ray_phase_b) for an LDS tile of 32-bit cells n_free | n_occ << 16 -- a whole scan's visits of one cell fit
 // (gms_map_create: (1 + extra) * beams < 65536) -- covering [tx0, tx0 + tw) x [ty0, ty0 + th); cells outside it belong to another band
-__device__ __forceinline__ void ps_phase_b(const GridDev &g, const PsRay &mt, const uint64_t *__restrict__ slots, int32_t stride, int32_t slot,
-                                           int32_t blk, int32_t lane, uint32_t *__restrict__ tile, int32_t tx0, int32_t ty0, int32_t tw,
-                                           int32_t th, int32_t w_base) {
-    const int32_t nwords = (mt.n_eff + 31) >> 5;
-    const int32_t w0 = 2 * blk - w_base, w1 = min(2 * blk + 1, nwords - 1) - w_base;
-    uint64_t a, c;
-    for (;;) {                                         // wave-uniform: every lane reads the same two slots
-        lds_poll_2xu64(&slots[w0 * stride + slot], &slots[w1 * stride + slot], a, c);
-        if (((a & c) >> 63) != 0u) break;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    const int32_t k = blk * 64 + lane;
-    const uint64_t sl = lane < 32 ? a : c;
+// one lane's cell of a ray: step k of the walk, from the decision word `sl` that covers it (its y steps before the word in the high half)
+__device__ __forceinline__ void ps_count_cell(const GridDev &g, const PsRay &mt, uint64_t sl, int32_t k, int32_t lane, uint32_t *__restrict__ tile,
+                                              int32_t tx0, int32_t ty0, int32_t tw, int32_t th) {
     const int32_t ny = (int32_t)(((uint32_t)(sl >> 32) & ~RC_VALID) + __popc((uint32_t)sl & ((1u << (lane & 31)) - 1u)));
     const int32_t nx = k - ny;
     const int32_t cx = mt.x0 + __mul24(mt.x_inc, nx), cy = mt.y0 + __mul24(mt.y_inc, ny);     // (|n| <= W + H + 1 < 2^23: gms_map_create)
@@ -81,6 +71,32 @@ __device__ __forceinline__ void ps_phase_b(const GridDev &g, const PsRay &mt, co
     if (k < mt.n_eff && (uint32_t)cx < (uint32_t)g.W && (uint32_t)cy < (uint32_t)g.H && ux < (uint32_t)tw && uy < (uint32_t)th && cls != 1)
         __hip_atomic_fetch_add((gms_lds_u32 *)(tile) + (__umul24(uy, (uint32_t)tw) + ux), cls == 0 ? 1u : 0x10000u, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void ps_wait_words(const uint64_t *__restrict__ slots, int32_t o0, int32_t o1, uint64_t &a, uint64_t &c) {
+    for (;;) {                                         // wave-uniform: every lane reads the same two slots
+        lds_poll_2xu64(&slots[o0], &slots[o1], a, c);
+        if (((a & c) >> 63) != 0u) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// phase B of the ray cast (ray_phase_b) for an LDS tile of 32-bit cells n_free | n_occ << 16 -- a whole scan's visits of one cell fit
+// (gms_map_create: (1 + extra) * beams < 65536) -- covering [tx0, tx0 + tw) x [ty0, ty0 + th); cells outside it belong to another band.
+// NB = 1: the 64 cells of block blk; NB = 2: blocks blk and blk + 1, two cells per lane (the second block exists: the caller checks).
+template <int NB>
+__device__ __forceinline__ void ps_phase_b(const GridDev &g, const PsRay &mt, const uint64_t *__restrict__ slots, int32_t stride, int32_t slot,
+                                           int32_t blk, int32_t lane, uint32_t *__restrict__ tile, int32_t tx0, int32_t ty0, int32_t tw,
+                                           int32_t th, int32_t w_base) {
+    const int32_t nwords = (mt.n_eff + 31) >> 5;
+    uint64_t a[NB], c[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const int32_t w0 = 2 * (blk + j) - w_base, w1 = min(2 * (blk + j) + 1, nwords - 1) - w_base;
+        ps_wait_words(slots, w0 * stride + slot, w1 * stride + slot, a[j], c[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; j++)
+        ps_count_cell(g, mt, lane < 32 ? a[j] : c[j], (blk + j) * 64 + lane, lane, tile, tx0, ty0, tw, th);
 }
 
 // One workgroup per particle.  NT threads; wavefronts 0 .. NP-1 walk 64 rays each (RayIterator's float recurrence, ray_phase_a), then
@@ -280,7 +296,9 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                     const int32_t slot2 = w2 < nwork ? (int32_t)s_work[w2] : 0;
                     const PsRay ray2 = s_ray[slot2];
                     const int32_t nb = min(nblk, ((ray.n_eff + 63) >> 6) - blk0);
-                    for (int32_t b = 0; b < nb; b++) ps_phase_b(g, ray, s_slots, GR, slot, blk0 + b, lane, s_tile, X0, ty0, tw, th, wb);
+                    int32_t b = 0;
+                    for (; b + 2 <= nb; b += 2) ps_phase_b<2>(g, ray, s_slots, GR, slot, blk0 + b, lane, s_tile, X0, ty0, tw, th, wb);
+                    if (b < nb) ps_phase_b<1>(g, ray, s_slots, GR, slot, blk0 + b, lane, s_tile, X0, ty0, tw, th, wb);
                     w = w2; slot = slot2; ray = ray2;
                 }
                 if (g0 == 0 && ty0 == Y0 && wb == 0) {      // the last wavefront's, the first consumer-only wavefront's and a producer's end of the cell work
