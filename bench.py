@@ -1218,6 +1218,13 @@ def main() -> int:
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": pm["update_ms"], "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": pm["workload"]},
                "per_particle_maps": pm, "roofline": None, "cpu_baseline": pm.get("cpu_baseline")}
+        lk = pm["kernels"].get("likelihood")
+        if lk and "achieved_TBps" in lk:
+            # this mode's streaming kernel (the particle kernel is bound by vector issue and by the touched lines' read-modify-write, not by
+            # a byte model); duration from the HIP-event brackets (an upper bound: ~2 us of markers), traffic: profiles/r05/per_particle_maps_kernels.json
+            out["roofline"] = {"kernel": "likelihood", "kernel_symbol": "k_slam_likelihood", "bound": "hbm", "achieved": lk["achieved_TBps"] * 1e3,
+                               "peak": 8000.0, "unit": "GB/s", "frac": lk["hbm_frac"], "traffic": None,
+                               "algorithmic_bytes_per_launch": lk["algorithmic_bytes_per_launch"], "avg_launch_us": lk["avg_launch_us"]}
         emit(out, result_fd, args.report)
         return 0
 

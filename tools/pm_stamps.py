@@ -38,3 +38,15 @@ for k, nm in names.items():
     if v.size: print(f"  {nm:34s} n={v.size:4d} first {v.min():7.2f} median {np.median(v):7.2f} last {v.max():7.2f}")
 d = (st[:min(N, 1024)] - st[:min(N, 1024), 0:1]) * 0.01
 print("  per workgroup, microseconds after ITS OWN entry (median):", " | ".join(f"{names[k].split(' ')[0]} {np.nanmedian(d[:, k]):.2f}" for k in (1, 2, 3, 4, 5, 6, 7)))
+# the slowest workgroups: which stage they lose their time in (microseconds spent per stage)
+n = min(N, 1024)
+tot = d[:n, 7]
+order = np.argsort(-np.nan_to_num(tot))[:8]
+print("  slowest workgroups (id: rays set up | walked | counted | applied, each after the previous stage):")
+for i in order:
+    print(f"    {i:4d}: {d[i, 4]:.1f} | {d[i, 5] - d[i, 4]:.1f} | {d[i, 6] - d[i, 5]:.1f} | {d[i, 7] - d[i, 6]:.1f}   total {tot[i]:.1f}")
+med = np.nanmedian(d[:n], axis=0)
+print(f"    median: {med[4]:.1f} | {med[5] - med[4]:.1f} | {med[6] - med[5]:.1f} | {med[7] - med[6]:.1f}   total {med[7]:.1f}")
+print("  median total by XCD (id & 7):", " ".join(f"{np.nanmedian(tot[x::8]):.1f}" for x in range(8)), "| ids < 256:", f"{np.nanmedian(tot[:256]):.1f}", "ids >= 256:", f"{np.nanmedian(tot[256:n]):.1f}")
+print("  max total by XCD:            ", " ".join(f"{np.nanmax(tot[x::8]):.1f}" for x in range(8)))
+print("  workgroups slower than median + 3 us:", int((tot > med[7] + 3).sum()), "of", n, "; their ids mod 32:", sorted(set(int(i) % 32 for i in np.where(tot > med[7] + 3)[0])))
