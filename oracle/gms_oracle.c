@@ -704,6 +704,19 @@ double orc_slam_update(orc_slam *s, const orc_beam *z, int32_t B, int32_t sample
     return orc_slam_update_mt(s, z, B, sample_motion, d_center, d_theta, seed, sequence, refine, 1);
 }
 
+/* how many OpenMP threads the parallel loops of this file use from now on (0: the runtime's default); returns what was in force.
+ * bench.py times orc_slam_resample's copies with one thread for its single-thread baseline; tests leave the default. */
+int32_t orc_set_threads(int32_t n) {
+#ifdef _OPENMP
+    const int32_t before = omp_get_max_threads();
+    if (n > 0) omp_set_num_threads(n);
+    return before;
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 /* SLAM.resample() :133-153 with Math.random() = r01: every slot receives a deep copy of a particle (pose, weight, both map
  * arrays).  idx_out (may be NULL) receives the source of every slot.  Returns the number of slots where Java would have run off
  * the list (clamped to the last particle, as orc_resample_indices). */

@@ -140,6 +140,8 @@ def lib() -> C.CDLL:
         L.orc_slam_update.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int32]
         L.orc_slam_update_mt.restype = C.c_double
         L.orc_slam_update_mt.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]
+        L.orc_set_threads.restype = C.c_int32
+        L.orc_set_threads.argtypes = [C.c_int32]
         L.orc_slam_resample.restype = C.c_int32
         L.orc_slam_resample.argtypes = [vp, C.c_double, ip]
         L.orc_slam_neff.restype = C.c_double
@@ -330,6 +332,11 @@ def count_sqrt_mismatches(a: np.ndarray, got: np.ndarray, threads: int = 1):
     first = C.c_int64(-1)
     n = lib().orc_count_sqrt_mismatches(_fp(a), _fp(got), len(a), threads, C.byref(first))
     return int(n), int(first.value)
+
+
+def set_threads(n: int) -> int:
+    """OpenMP threads of the oracle's parallel loops from now on (orc_set_threads); returns the previous maximum"""
+    return int(lib().orc_set_threads(int(n)))
 
 
 def gaussian_kernel(sigma: float, size: int) -> np.ndarray:
