@@ -213,6 +213,45 @@ def test_other_geometries(case):
     dev.close()
 
 
+def test_properties_that_need_no_oracle_at_1024_particles_of_256x256_cells():
+    """size-independent properties of the per-particle-map path on 2 GB of GridMapData: (1) with equal weights and r = 0.5 the systematic
+    draw is the identity, so resample()'s deep copies must reproduce every map bit for bit in the other generation; (2) an update with
+    an empty scan integrates nothing and rebuilds every likelihood field from unchanged log-odds: both arrays stay as they are
+    (computeLikelihoodMap is idempotent); (3) the same scan integrated into two filters whose particles are permutations of each other
+    gives permuted maps (no cross-talk between workgroups sharing a CU)."""
+    N, ext, res, B = 1024, 12.8, 0.05, 120
+    tr = synth.make_trace(ext, res, B, T=4, seed=77)
+    dev = SLAMParticleMaps(ext, ext, res, (-ext / 2, -ext / 2), num_particles=N, max_beams=128)
+    P = synth.make_particles(tr.poses[0], N, seed=3, sigma_xy=0.2, sigma_theta_deg=8.0)
+    dev.set_poses(P)
+    for k in range(3):
+        dev.update(tr.scans[k], None)
+    logs = dev.maps().copy()
+    assert (logs != 0).any(axis=(1, 2)).all()
+    # (2) empty scans: the first brings likelihoodData up to the log-odds of the third scan (the field in memory was computed in front
+    # of its integration, SLAM.java:93 before :105), the second finds nothing to change
+    dev.update(tr.scans[0][:0], None)
+    liks = dev.maps(likelihood=True).copy()
+    dev.update(tr.scans[0][:0], None)
+    assert np.array_equal(dev.maps(), logs) and np.array_equal(dev.maps(likelihood=True), liks)
+    # (1) identity resampling: equal weights (an empty scan leaves every product at 1), r = 0.5
+    w = dev.get_particles()[1]
+    assert np.array_equal(w, np.full(N, 1.0 / N))
+    before = dev.maps_copied()
+    idx, amb = dev.resample(0.5, want_indices=True)
+    assert np.array_equal(idx, np.arange(N)) and dev.maps_copied() == before + N
+    assert np.array_equal(dev.maps(), logs) and np.array_equal(dev.maps(likelihood=True), liks)
+    # (3) a permuted filter
+    perm = np.random.default_rng(5).permutation(N)
+    dev2 = SLAMParticleMaps(ext, ext, res, (-ext / 2, -ext / 2), num_particles=N, max_beams=128)
+    dev2.set_poses(P[perm])
+    for k in range(3):
+        dev2.update(tr.scans[k], None)
+    dev2.update(tr.scans[0][:0], None)
+    assert np.array_equal(dev2.maps(), logs[perm]) and np.array_equal(dev2.maps(likelihood=True), liks[perm])
+    dev.close(); dev2.close()
+
+
 def test_squared_thresholds_classify_like_the_square_root():
     """inverseSensorModel compares (float) Math.sqrt(s) with measured -+ 1 (GridMap.java:217, SensorModel.java:31-41); the per-particle
     ray cast compares s with two thresholds per ray instead (gms_device.h: sq_lower / sq_upper).  For thousands of thresholds t --
