@@ -47,6 +47,8 @@ __device__ __forceinline__ RayIn ps_make_ray(const GridDev &g, const XformDev &t
     return r;
 }
 
+#include <type_traits>
+
 #ifndef PS_APPLY
 #define PS_APPLY 12                     // cells per thread and pass of k_slam_particle's read-modify-write of logData
 #endif
@@ -57,8 +59,9 @@ struct PsRay {                          // what a consumer needs of a ray
 };
 
 // phase B of the ray cast (ray_phase_b) for an LDS tile of 32-bit cells n_free | n_occ << 16 -- a whole scan's visits of one cell fit
-// (gms_map_create: (1 + extra) * beams < 65536) -- covering [tx0, tx0 + tw) x [ty0, ty0 + th); cells outside it belong to another band
+// (gms_map_create: (1 + extra) * beams < 65536) -- or, NARROW, of 16-bit cells n_free | n_occ << 8, covering [tx0, tx0 + tw) x [ty0, ty0 + th); cells outside it belong to another band
 // one lane's cell of a ray: step k of the walk, from the decision word `sl` that covers it (its y steps before the word in the high half)
+template <bool NARROW>
 __device__ __forceinline__ void ps_count_cell(const GridDev &g, const PsRay &mt, uint64_t sl, int32_t k, int32_t lane, uint32_t *__restrict__ tile,
                                               int32_t tx0, int32_t ty0, int32_t tw, int32_t th) {
     const int32_t ny = (int32_t)(((uint32_t)(sl >> 32) & ~RC_VALID) + __popc((uint32_t)sl & ((1u << (lane & 31)) - 1u)));
@@ -68,9 +71,14 @@ __device__ __forceinline__ void ps_count_cell(const GridDev &g, const PsRay &mt,
     const int32_t cls = sensor_class_sq(dX * dX + dY * dY, RayThr{mt.s_free, mt.s_prior}, mt.hit);   // :217, :223
     const uint32_t ux = (uint32_t)(cx - tx0), uy = (uint32_t)(cy - ty0);
     // inside the map (RayIterator.java:108; the tile lies inside it), of this band, and not `+= logOdds(0.5)` = 0.0
-    if (k < mt.n_eff && (uint32_t)cx < (uint32_t)g.W && (uint32_t)cy < (uint32_t)g.H && ux < (uint32_t)tw && uy < (uint32_t)th && cls != 1)
-        __hip_atomic_fetch_add((gms_lds_u32 *)(tile) + (__umul24(uy, (uint32_t)tw) + ux), cls == 0 ? 1u : 0x10000u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k < mt.n_eff && (uint32_t)cx < (uint32_t)g.W && (uint32_t)cy < (uint32_t)g.H && ux < (uint32_t)tw && uy < (uint32_t)th && cls != 1) {
+        const uint32_t cell = __umul24(uy, (uint32_t)tw) + ux;
+        if (NARROW)     // 16-bit cells n_free | n_occ << 8, two to a word (k_slam_particle decides: no field of this scan can pass 255)
+            __hip_atomic_fetch_add((gms_lds_u32 *)(tile) + (cell >> 1), (cls == 0 ? 1u : 0x100u) << ((cell & 1u) << 4), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+            __hip_atomic_fetch_add((gms_lds_u32 *)(tile) + cell, cls == 0 ? 1u : 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 }
 __device__ __forceinline__ void ps_wait_words(const uint64_t *__restrict__ slots, int32_t o0, int32_t o1, uint64_t &a, uint64_t &c) {
     for (;;) {                                         // wave-uniform: every lane reads the same two slots
@@ -81,9 +89,9 @@ __device__ __forceinline__ void ps_wait_words(const uint64_t *__restrict__ slots
 }
 
 // phase B of the ray cast (ray_phase_b) for an LDS tile of 32-bit cells n_free | n_occ << 16 -- a whole scan's visits of one cell fit
-// (gms_map_create: (1 + extra) * beams < 65536) -- covering [tx0, tx0 + tw) x [ty0, ty0 + th); cells outside it belong to another band.
+// (gms_map_create: (1 + extra) * beams < 65536) -- or, NARROW, of 16-bit cells n_free | n_occ << 8, covering [tx0, tx0 + tw) x [ty0, ty0 + th); cells outside it belong to another band.
 // NB = 1: the 64 cells of block blk; NB = 2: blocks blk and blk + 1, two cells per lane (the second block exists: the caller checks).
-template <int NB>
+template <int NB, bool NARROW>
 __device__ __forceinline__ void ps_phase_b(const GridDev &g, const PsRay &mt, const uint64_t *__restrict__ slots, int32_t stride, int32_t slot,
                                            int32_t blk, int32_t lane, uint32_t *__restrict__ tile, int32_t tx0, int32_t ty0, int32_t tw,
                                            int32_t th, int32_t w_base) {
@@ -96,33 +104,34 @@ __device__ __forceinline__ void ps_phase_b(const GridDev &g, const PsRay &mt, co
     }
 #pragma unroll
     for (int j = 0; j < NB; j++)
-        ps_count_cell(g, mt, lane < 32 ? a[j] : c[j], (blk + j) * 64 + lane, lane, tile, tx0, ty0, tw, th);
+        ps_count_cell<NARROW>(g, mt, lane < 32 ? a[j] : c[j], (blk + j) * 64 + lane, lane, tile, tx0, ty0, tw, th);
 }
 
 // One workgroup per particle.  NT threads; wavefronts 0 .. NP-1 walk 64 rays each (RayIterator's float recurrence, ray_phase_a), then
 // join the others in the cell work.  Dynamic LDS: factors [Bpad] f64 | decision slots [PS_WORDS][64 NP] u64 | ray records [64 NP] |
-// count tile [tile_cap] u32.
+// count tile [tile_bytes].
 // (A lane per ray running the reference's loop as it stands -- walk, distance, class, count -- was built and measured: 80 instructions
 // per step on one or two wavefronts per SIMD, which issue one instruction per ~4.6 clocks: 29 us of walking for 90 rays against 17 for
 // this split form, whose cell work spreads over every wavefront of the workgroup.)
-template <int NT, int NP>
+template <int NT, int NP, bool NA>      // NA: 16-bit count cells are on offer (the map does not fit as 32-bit cells)
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4)))       // (2 x 512 or 1024 lanes per CU: 128 registers)
 k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, double *__restrict__ log_all,
                 const double *__restrict__ lik_all, float *__restrict__ pose, float *__restrict__ cs, double *__restrict__ w,
-                double *__restrict__ logw, MotionArgs mo, int32_t integrate, int32_t tile_cap) {
+                double *__restrict__ logw, MotionArgs mo, int32_t integrate, int32_t tile_bytes) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NW = NT / 64, GR = 64 * NP;
     static_assert(NW > NP, "at least one wavefront that only consumes");
     double *s_fac = reinterpret_cast<double *>(smem);                          // [Bpad]
     uint64_t *s_slots = reinterpret_cast<uint64_t *>(s_fac + Bpad);            // [PS_WORDS][GR]
     PsRay *s_ray = reinterpret_cast<PsRay *>(s_slots + PS_WORDS * GR);         // [GR]
-    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_ray + GR);               // [tile_cap]
+    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_ray + GR);               // [tile_bytes / 4] words: 32-bit cells, or 16-bit cells two to a word
     __shared__ float s_pose[5];                                                // x, y, theta, (float)cos, (float)sin
     __shared__ int32_t s_box[4];                                               // the scan's box x0, y0, x1, y1 (inclusive)
     __shared__ int32_t s_grp_words[NP];
     __shared__ double s_red[NW];
     __shared__ uint16_t s_work[GR];                                            // a round's cell work: the rays that have cells in it
     __shared__ int32_t s_nwork, s_next;
+    __shared__ int32_t s_nzero;                                                // rays of zero length: the only ones that visit a cell more than once
     const int32_t p = blockIdx.x;
     const int32_t lane = threadIdx.x & 63;
     const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6));
@@ -145,6 +154,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
         }
     }
     if (threadIdx.x >= 64 && threadIdx.x < 68) s_box[threadIdx.x - 64] = threadIdx.x < 66 ? INT32_MAX : INT32_MIN;
+    if (threadIdx.x == 68) s_nzero = 0;
     __syncthreads();
     GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 1);
     XformDev t;
@@ -154,7 +164,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     //      beside it every beam's ray box (GridMap.java:175-188 + ray_meta) for the count tile
     const double *lik = lik_all + (size_t)p * (size_t)g.cells;
     double lsum = 0.0;
-    int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN;
+    int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN, nzero = 0;
     // the ray of beam threadIdx.x, kept: the producer lane of that beam in the first group of rays below is this very thread
     RayDev r_first;
     RayMeta mt_first;
@@ -176,6 +186,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
             const RayMeta mt = ray_meta(g, ps_make_ray(g, t, bm), r);
             if (b == (int32_t)threadIdx.x) { r_first = r; mt_first = mt; }
             if (mt.n_eff > 0) {
+                nzero += (mt.x_inc == 0 && mt.y_inc == 0) ? 1 : 0;
                 bx0 = min(bx0, min(mt.x0, mt.hx)); bx1 = max(bx1, max(mt.x0, mt.hx));
                 by0 = min(by0, min(mt.y0, mt.hy)); by1 = max(by1, max(mt.y0, mt.hy));
             }
@@ -184,11 +195,12 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     lsum = wave_sum_f64(lsum);
     if (lane == 0) s_red[wave] = lsum;
     if (integrate) {
-#define GMS_STEP_(O) { bx0 = min(bx0, wave_xor<O>(bx0)); by0 = min(by0, wave_xor<O>(by0)); bx1 = max(bx1, wave_xor<O>(bx1)); by1 = max(by1, wave_xor<O>(by1)); }
+#define GMS_STEP_(O) { bx0 = min(bx0, wave_xor<O>(bx0)); by0 = min(by0, wave_xor<O>(by0)); bx1 = max(bx1, wave_xor<O>(bx1)); by1 = max(by1, wave_xor<O>(by1)); nzero += wave_xor<O>(nzero); }
         GMS_BUTTERFLY(GMS_STEP_)
 #undef GMS_STEP_
         if (lane == 0 && bx1 >= bx0) {
             atomicMin(&s_box[0], bx0); atomicMin(&s_box[1], by0); atomicMax(&s_box[2], bx1); atomicMax(&s_box[3], by1);
+            if (nzero) atomicAdd(&s_nzero, nzero);
         }
     }
     __syncthreads();
@@ -217,11 +229,16 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     const int32_t X0 = s_box[0], Y0 = s_box[1], X1 = s_box[2], Y1 = s_box[3];
     if (X1 < X0) return;                                                       // no ray touches the map
     const int32_t tw = X1 - X0 + 1, th_all = Y1 - Y0 + 1;
-    const int32_t band_rows = max(1, min(th_all, tile_cap / tw));              // (the launcher guarantees tile_cap >= W)
+    // 16-bit cells -- twice the box per band, and a band is a walk of every ray that crosses it -- where the launcher allows them (the map
+    // does not fit as 32-bit cells) and no count of this scan can pass 255: a ray visits a cell once, except a ray of zero length,
+    // which emits its one cell 1 + extra times (RayIterator.java:75)
+    const bool narrow = NA && B + g.extra * s_nzero <= 255;
+    const int32_t tile_cap = narrow ? tile_bytes / 2 : tile_bytes / 4;
+    const int32_t band_rows = max(1, min(th_all, tile_cap / tw));              // (the launcher guarantees a row at least)
     double *mlog = log_all + (size_t)p * (size_t)g.cells;
     for (int32_t ty0 = Y0; ty0 <= Y1; ty0 += band_rows) {
         const int32_t th = min(band_rows, Y1 - ty0 + 1);
-        for (int32_t i = threadIdx.x; i < tw * th; i += NT) s_tile[i] = 0u;
+        for (int32_t i = threadIdx.x; i < (narrow ? (tw * th + 1) >> 1 : tw * th); i += NT) s_tile[i] = 0u;
         for (int32_t g0 = 0; g0 < B; g0 += GR) {
             // this group's rays: a producer lane per ray
             RayDev r;
@@ -288,19 +305,23 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                     return __builtin_amdgcn_readfirstlane(w);
                 };
                 if (g0 == 0 && ty0 == Y0 && wb == 0) { GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(0, blockIdx.x), 8); GMS_STAMP_T(64 * NP, GMS_STAMP_ROW(0, blockIdx.x), 12); }
-                int32_t w = grab();
-                int32_t slot = w < nwork ? (int32_t)s_work[w] : 0;
-                PsRay ray = s_ray[slot];
-                while (w < nwork) {
-                    const int32_t w2 = grab();
-                    const int32_t slot2 = w2 < nwork ? (int32_t)s_work[w2] : 0;
-                    const PsRay ray2 = s_ray[slot2];
-                    const int32_t nb = min(nblk, ((ray.n_eff + 63) >> 6) - blk0);
-                    int32_t b = 0;
-                    for (; b + 2 <= nb; b += 2) ps_phase_b<2>(g, ray, s_slots, GR, slot, blk0 + b, lane, s_tile, X0, ty0, tw, th, wb);
-                    if (b < nb) ps_phase_b<1>(g, ray, s_slots, GR, slot, blk0 + b, lane, s_tile, X0, ty0, tw, th, wb);
-                    w = w2; slot = slot2; ray = ray2;
-                }
+                auto consume = [&](auto narrow_c) {
+                    constexpr bool NR = decltype(narrow_c)::value;
+                    int32_t w = grab();
+                    int32_t slot = w < nwork ? (int32_t)s_work[w] : 0;
+                    PsRay ray = s_ray[slot];
+                    while (w < nwork) {
+                        const int32_t w2 = grab();
+                        const int32_t slot2 = w2 < nwork ? (int32_t)s_work[w2] : 0;
+                        const PsRay ray2 = s_ray[slot2];
+                        const int32_t nb = min(nblk, ((ray.n_eff + 63) >> 6) - blk0);
+                        int32_t b = 0;
+                        for (; b + 2 <= nb; b += 2) ps_phase_b<2, NR>(g, ray, s_slots, GR, slot, blk0 + b, lane, s_tile, X0, ty0, tw, th, wb);
+                        if (b < nb) ps_phase_b<1, NR>(g, ray, s_slots, GR, slot, blk0 + b, lane, s_tile, X0, ty0, tw, th, wb);
+                        w = w2; slot = slot2; ray = ray2;
+                    }
+                };
+                if (narrow) consume(std::true_type{}); else consume(std::false_type{});
                 if (g0 == 0 && ty0 == Y0 && wb == 0) {      // the last wavefront's, the first consumer-only wavefront's and a producer's end of the cell work
                     GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(0, blockIdx.x), 9); GMS_STAMP_T(64 * NP, GMS_STAMP_ROW(0, blockIdx.x), 10); GMS_STAMP_T(0, GMS_STAMP_ROW(0, blockIdx.x), 11);
                 }
@@ -324,7 +345,15 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
             uint32_t c[PS_APPLY];
             double v[PS_APPLY];
 #pragma unroll
-            for (int u = 0; u < PS_APPLY; u++) c[u] = i0 + u * NT < ncell ? s_tile[i0 + u * NT] : 0u;
+            for (int u = 0; u < PS_APPLY; u++) {
+                const int32_t i = i0 + u * NT;
+                if (narrow) {                                  // (uniform) n_free | n_occ << 8 -> n_free | n_occ << 16
+                    const uint32_t h = i < ncell ? (s_tile[i >> 1] >> ((i & 1) << 4)) & 0xffffu : 0u;
+                    c[u] = (h & 0xffu) | ((h >> 8) << 16);
+                } else {
+                    c[u] = i < ncell ? s_tile[i] : 0u;
+                }
+            }
             {
                 int32_t y = y0, x = x0;
 #pragma unroll
@@ -443,18 +472,21 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, do
     }
     if (m->slam_tile_cells > 0 && tile > (size_t)m->slam_tile_cells) tile = (size_t)m->slam_tile_cells;
     if (tile < (size_t)m->gd.W) tile = (size_t)m->gd.W;                         // one row at least (refused at creation if even that cannot fit)
+    // a map that does not fit as 32-bit cells: 16-bit cells where a workgroup finds that its scan allows them (k_slam_particle)
+    const int32_t narrow_allowed = tile < cells && B <= 255 ? 1 : 0;
     const size_t smem = fixed + tile * 4;
     // Workgroup shape: 512 lanes when two workgroups then share a CU (their latency chains -- pose, factors, the product, the walks,
     // the read-modify-write of the touched cells -- overlap), 1024 when the tile leaves room for one only.  GMS_SLAM_THREADS forces one.
     int32_t threads = smem <= lds_wg / 2 ? 512 : 1024;
     if (m->slam_threads == 512 || m->slam_threads == 1024) threads = m->slam_threads;
-#define PS_LAUNCH(NT)                                                                                                                   \
+#define PS_LAUNCH(NT, NA)                                                                                                               \
     do {                                                                                                                                \
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_particle<NT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((k_slam_particle<NT, NP>), dim3((unsigned)pf->n), dim3(NT), smem, m->stream, m->gd, d_beams, B, Bpad, d_log, d_lik, \
-                           pf->d_pose, pf->d_cs, pf->d_w, pf->d_logw, mo, integrate, (int32_t)tile);                                   \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_particle<NT, NP, NA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((k_slam_particle<NT, NP, NA>), dim3((unsigned)pf->n), dim3(NT), smem, m->stream, m->gd, d_beams, B, Bpad, d_log, d_lik, \
+                           pf->d_pose, pf->d_cs, pf->d_w, pf->d_logw, mo, integrate, (int32_t)(tile * 4));                             \
     } while (0)
-    if (threads == 512) PS_LAUNCH(512); else PS_LAUNCH(1024);
+    if (threads == 512) { if (narrow_allowed) PS_LAUNCH(512, true); else PS_LAUNCH(512, false); }
+    else { if (narrow_allowed) PS_LAUNCH(1024, true); else PS_LAUNCH(1024, false); }
 #undef PS_LAUNCH
     pf->pending_nseg = 0;
     pf->score_fresh = 1;

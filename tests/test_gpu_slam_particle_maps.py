@@ -213,6 +213,31 @@ def test_other_geometries(case):
     dev.close()
 
 
+def test_sixteen_bit_count_tiles_and_their_fallback(monkeypatch):
+    """A map whose scan box does not fit a workgroup's LDS as 32-bit count cells is counted in 16-bit cells (n_free | n_occ << 8) when
+    no count of the scan can pass 255: every ray visits a cell once, except a ray of zero length, which emits its one cell
+    1 + additionalSteps times (RayIterator.java:75) -- beams + 2 x (zero-length beams) <= 255.  Both sides of that rule against the
+    oracle, with the tile forced small (so that the 16-bit form is on offer and the box is walked in bands): 128 beams of which 10
+    have no length (148: narrow; the robot's own cell collects 148 visits), and of which 70 have none (268: the 32-bit form)."""
+    ext, res, B, N = 6.4, 0.05, 128, 16
+    monkeypatch.setenv("GMS_SLAM_TILE_CELLS", "3000")
+    tr = synth.make_trace(ext, res, B, T=3, seed=41)
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    for n_zero in (10, 70):
+        dev = SLAMParticleMaps(ext, ext, res, (-ext / 2, -ext / 2), num_particles=N, max_beams=128)
+        o = orc.Slam(g, N)
+        P = synth.make_particles(tr.poses[0], N, seed=6, sigma_xy=0.04, sigma_theta_deg=2.0)
+        dev.set_poses(P); o.set_poses(P)
+        for k in range(3):
+            z = tr.scans[k].copy()
+            z["local_x"][:n_zero] = 0.0; z["local_y"][:n_zero] = 0.0; z["distance"][:n_zero] = 0.0; z["hit"][:n_zero] = 1
+            dev.update(z, None); o.update(z, None, threads=THREADS)
+            _compare_maps(dev, o, f"{n_zero} zero-length beams, scan {k}")
+            _compare_weights(dev.get_particles()[1], o.weights, f"{n_zero} zero-length beams, scan {k}")
+        # the robot's own cell: every ray's first step and all three steps of the zero-length ones, as free visits
+        dev.close()
+
+
 def test_properties_that_need_no_oracle_at_1024_particles_of_256x256_cells():
     """size-independent properties of the per-particle-map path on 2 GB of GridMapData: (1) with equal weights and r = 0.5 the systematic
     draw is the identity, so resample()'s deep copies must reproduce every map bit for bit in the other generation; (2) an update with
