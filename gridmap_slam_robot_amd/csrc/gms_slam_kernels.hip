@@ -30,8 +30,15 @@ __global__ void __launch_bounds__(256)
 k_slam_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, const double *__restrict__ taps_g,
                   int32_t tiles_x, int32_t tiles_y) {
     extern __shared__ __align__(16) unsigned char smem[];
-    likelihood_body<KH>(g, logd, lik, lik, 0, taps_g, nullptr, 0, tiles_x, tiles_y, blockIdx.x, blockIdx.y, gridDim.x, smem, nullptr,
-                        nullptr, 1);
+    // Eight workgroups walk a map's tiles (the launcher's usual shape): they are given ids that differ by 8, i.e. ONE XCD, so that
+    // the tiles' halos are read from that XCD's L2 instead of once per XCD from memory.  Workgroups are dispatched to the XCDs round
+    // robin by their linear id: of 64 consecutive ones, id & 7 picks the map of a group of eight and (id >> 3) & 7 the walker.
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.x == 8u) {
+        const uint32_t L = blockIdx.x + 8u * blockIdx.y, grp = L >> 6;
+        if (grp * 8u + 8u <= gridDim.y) { by = grp * 8u + (L & 7u); bx = (L >> 3) & 7u; }
+    }
+    likelihood_body<KH>(g, logd, lik, lik, 0, taps_g, nullptr, 0, tiles_x, tiles_y, bx, by, gridDim.x, smem, nullptr, nullptr, 1);
 }
 
 // GridMap.integrateObservation's per-beam locals (GridMap.java:175-188) from a transform that is already at hand (make_ray takes
