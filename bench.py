@@ -841,8 +841,8 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
     """The reference's own filter shape (SLAM.java: one GridMapData per particle; gms_slam_*): `particles` particles with a map of
     extent x extent metres each, scans of `beams` measurements of a synthetic drive through a room that fits the map.  Timed, inputs
     resident in HBM, nothing read back: `steps` SLAM.update calls (motion model inside, no resampling: the maps keep growing), then
-    SLAM.resample's deep copies (`steps` draws back to back); then the same with HIP-event brackets around every launch for the
-    per-kernel table.  Rooflines by algorithmic bytes: computeLikelihoodMap 16 B per cell and particle; the resampling copy 32 B per
+    update / resample pairs (SLAM.resample as the filter runs it) and `steps` draws back to back (both arrays moved per call); then
+    the pairs with HIP-event brackets around every launch for the per-kernel table.  Rooflines by algorithmic bytes: computeLikelihoodMap 16 B per cell and particle; the resampling copy 32 B per
     cell and particle (both arrays read and written, GridMap.java:118-121)."""
     from gridmap_slam_robot_amd import SLAMParticleMaps, synth
     from gridmap_slam_robot_amd._lib import BEAM_DTYPE
@@ -876,36 +876,56 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
     torch.cuda.synchronize()
     upd = (time.perf_counter() - t0) / steps
     st = s.pf.stats()
+    # SLAM.resample as the filter runs it: update, resample, update, ... (the pair's time less the update's).  The library copies
+    # logData at once and likelihoodData only if somebody reads it before the next update's computeLikelihoodMap has overwritten every
+    # cell of it (gms_slam::lazy_lik; GMS_SLAM_LAZY_LIK_COPY=0: both at once) ...
+    lazy = os.environ.get("GMS_SLAM_LAZY_LIK_COPY", "1") != "0"
     t0 = time.perf_counter()
     for i in range(steps):
+        step(warm_frames + steps + i)
         s.resample(float(r01[(17 + i) % 4096]))
     torch.cuda.synchronize()
-    rsm = (time.perf_counter() - t0) / steps
+    pair = (time.perf_counter() - t0) / steps
+    rsm = max(pair - upd, 0.0)
+    # ... and `steps` draws back to back: every call first brings likelihoodData up to date, so both arrays move per call
+    t0 = time.perf_counter()
+    for i in range(steps):
+        s.resample(float(r01[(517 + i) % 4096]))
+    torch.cuda.synchronize()
+    rsm_both = (time.perf_counter() - t0) / steps
     # per kernel: event brackets (they cost ~2 us each on the stream: these durations are upper bounds of the un-bracketed ones)
     s.grid_map.profile(True)
     s.grid_map.profile_reset()
     for i in range(steps):
-        step(warm_frames + steps + i)
+        step(warm_frames + 2 * steps + i)
         s.resample(float(r01[(99 + i) % 4096]))
     torch.cuda.synchronize()
     prof = s.grid_map.profile_get()
     s.grid_map.profile(False)
     kern = {name: {"avg_launch_us": ms / n * 1e3, "launches": n} for name, (ms, n) in prof.items() if n}
     lik_b, copy_b = 16.0 * cells * particles, 32.0 * cells * particles
+    moved_b = copy_b / 2 if lazy else copy_b           # per launch of the copy kernel in the loop above
     if "likelihood" in kern:
         kern["likelihood"].update(algorithmic_bytes_per_launch=lik_b, achieved_TBps=lik_b / (kern["likelihood"]["avg_launch_us"] * 1e-6) / 1e12,
                                   hbm_frac=lik_b / (kern["likelihood"]["avg_launch_us"] * 1e-6) / 8e12, what="computeLikelihoodMap of every particle's map (GridMap.java:233-250): 16 B per cell",
                                   us_per_map=kern["likelihood"]["avg_launch_us"] / particles)
     if "mapcopy" in kern:
-        kern["mapcopy"].update(algorithmic_bytes_per_launch=copy_b, achieved_TBps=copy_b / (kern["mapcopy"]["avg_launch_us"] * 1e-6) / 1e12,
-                               hbm_frac=copy_b / (kern["mapcopy"]["avg_launch_us"] * 1e-6) / 8e12, what="resample()'s deep copies, map[m] <- map[idx[m]] for both arrays (SLAM.java:41-45, GridMap.java:118-121): 32 B per cell")
+        kern["mapcopy"].update(algorithmic_bytes_per_launch=moved_b, achieved_TBps=moved_b / (kern["mapcopy"]["avg_launch_us"] * 1e-6) / 1e12,
+                               hbm_frac=moved_b / (kern["mapcopy"]["avg_launch_us"] * 1e-6) / 8e12,
+                               what=("resample()'s deep copy of logData, map[m] <- map[idx[m]] (SLAM.java:41-45, GridMap.java:120): 16 B per cell moved; likelihoodData's "
+                                     "(:121) is deferred and never needed on the path" if lazy else
+                                     "resample()'s deep copies, map[m] <- map[idx[m]] for both arrays (SLAM.java:41-45, GridMap.java:118-121): 32 B per cell"))
     if "score" in kern:
         kern["score"]["what"] = "k_slam_particle: motion sample, probabilityOf against the particle's own field (one lane's product in beam order), integrateObservation into the particle's own map through an LDS count tile"
     out = {"workload": f"SLAM.java's own shape: {particles} particles x one {s.W}x{s.H} map each @ {res} m, {beams} beams per scan; SLAM.update per particle "
-                       "(motion model, computeLikelihoodMap, probabilityOf, integrateObservation), SLAM.resample with deep copies of both map arrays",
+                       "(motion model, computeLikelihoodMap, probabilityOf, integrateObservation), SLAM.resample with its deep copies of the maps ("
+                       + ("logData at once, likelihoodData when it is read: the next update overwrites it first" if lazy else "both arrays at once") + ")",
            "particles": particles, "grid": [s.W, s.H], "beams": beams, "steps": steps,
            "update_ms": upd * 1e3, "updates_per_s": 1.0 / upd, "particle_scan_evals_per_s": particles / upd,
-           "resample_ms": rsm * 1e3, "resample_copy_TBps_algorithmic": copy_b / rsm / 1e12, "resample_copy_hbm_frac": copy_b / rsm / 8e12,
+           "resample_ms": rsm * 1e3, "resample_what": ("in the update / resample loop; logData copied, likelihoodData's copy deferred (overwritten by the next "
+                                                       "update's computeLikelihoodMap before anything reads it; materialised on demand)" if lazy else
+                                                       "in the update / resample loop; both arrays copied at once"),
+           "resample_both_arrays_ms": rsm_both * 1e3, "resample_copy_TBps_algorithmic": copy_b / rsm_both / 1e12, "resample_copy_hbm_frac": copy_b / rsm_both / 8e12,
            "gridmapdata_bytes_on_device": 4.0 * 8 * cells * particles, "neff_last": st["neff"], "n_zero_weights": st["n_zero"],
            "kernels": kern}
     if cpu_seconds > 0:

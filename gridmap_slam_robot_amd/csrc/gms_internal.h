@@ -215,6 +215,10 @@ struct gms_slam {
     int32_t n;
     double *d_log[2], *d_lik[2];    // [n][H][W] every particle's GridMapData, double-buffered for resample()'s deep copies
     int32_t cur;                    // the buffer that holds the current generation
+    int32_t lazy_lik;               // resample() copies logData at once and likelihoodData when somebody asks for it: the next update's
+                                    // computeLikelihoodMap overwrites every cell of it before anything on the path reads one (GMS_SLAM_LAZY_LIK_COPY=0: both at once)
+    int32_t lik_behind;             // d_lik[cur] does not hold the last resample()'s copies yet: slot m's field is d_lik[1 - cur][d_idx_lik[m]]
+    int32_t *d_idx_lik;             // [n] the source indices of that resample()
     int32_t reference_order;        // gms_slam_set_reference_order: weightSum / the cumulative weights as ONE sequential chain (SLAM.java:100,137-144)
     int64_t copies;                 // maps copied by resampling steps so far (measurement)
 };
@@ -293,6 +297,7 @@ void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, 
 void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, double *d_log, const double *d_lik, const MotionModel *motion,
                               int32_t integrate);
 void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik);
+void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx);     // one array: dst[m] <- src[d_idx[m]]
 void gms_launch_slam_combine(gms_map *dst, const double *d_logs, int32_t n);
 
 // profiling brackets

@@ -1,6 +1,7 @@
 // gms_slam_host.hip -- C-ABI of the reference's own filter shape: SLAM (J/slam/SLAM.java), every particle with its own GridMapData.
 // Handle lifetime and the launch sequences of SLAM.update / SLAM.resample; the kernels are in gms_slam_kernels.hip.  No CPU path.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -23,6 +24,7 @@ int gms_slam_destroy(gms_slam *s) {
     if (!s) return GMS_OK;
     if (s->map) { hipSetDevice(s->map->device); hipStreamSynchronize(s->map->stream); }
     for (int k = 0; k < 2; k++) { hipFree(s->d_log[k]); hipFree(s->d_lik[k]); }
+    hipFree(s->d_idx_lik);
     if (s->pf) gms_pf_destroy(s->pf);
     if (s->map) gms_map_destroy(s->map);
     delete s;
@@ -47,9 +49,12 @@ int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out) { 
         return gms_fail(GMS_ERR_INVALID, "gms_slam_create: %d beams and rows of %d cells do not fit a workgroup's LDS", m->max_beams, m->gd.W);
     }
     const size_t bytes = (size_t)n_particles * (size_t)m->gd.cells * sizeof(double);
+    const char *lazy_env = getenv("GMS_SLAM_LAZY_LIK_COPY");
+    s->lazy_lik = !(lazy_env && lazy_env[0] == '0');
     bool ok = true;
     for (int k = 0; k < 2; k++)
         ok = ok && hipMalloc(&s->d_log[k], bytes) == hipSuccess && hipMalloc(&s->d_lik[k], bytes) == hipSuccess;
+    ok = ok && hipMalloc(&s->d_idx_lik, (size_t)n_particles * sizeof(int32_t)) == hipSuccess;
     if (!ok) {
         gms_slam_destroy(s);
         return gms_fail(GMS_ERR_NOMEM, "gms_slam_create: device allocation failed (%d particles x %lld cells x 32 bytes)", n_particles, (long long)m->gd.cells);
@@ -66,6 +71,7 @@ int gms_slam_reset(gms_slam *s) {                                               
     // createMapData(null) per particle (GridMap.java:106-117): logData = logOdds(0.5) = 0.0, likelihoodData a fresh double[] = 0.0
     HIPCHK(hipMemsetAsync(s->d_log[s->cur], 0, bytes, m->stream));
     HIPCHK(hipMemsetAsync(s->d_lik[s->cur], 0, bytes, m->stream));
+    s->lik_behind = 0;
     gms_launch_pf_init(s->pf);                                                               // Pose(0, 0, 0), weight 1 / numParticles (:68-71)
     s->pf->pending_nseg = 0; s->pf->have_global = 0; s->pf->stats_current = 0; s->pf->score_fresh = 0;
     HIPCHK(hipGetLastError());
@@ -99,6 +105,7 @@ int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int
     MotionModel mo;
     mo.d_center = d_center; mo.d_theta = d_theta; mo.seed = seed; mo.sequence = sequence;
     gms_launch_slam_likelihood(m, s->d_log[s->cur], s->d_lik[s->cur], s->n);                                // :93 for every particle
+    s->lik_behind = 0;                                                                                     // (every cell of every field has just been written)
     gms_launch_slam_particle(pf, dev_beams, B, s->d_log[s->cur], s->d_lik[s->cur], sample_motion ? &mo : nullptr, skip_update ? 0 : 1);   // :90, :99, :102-107
     pf->have_global = 0;
     pf->stats_current = 0;
@@ -114,14 +121,32 @@ int gms_slam_update_per_particle(gms_slam *s, const gms_beam *beams, int32_t B, 
     return gms_slam_update_per_particle_dev(s, s->map->d_beams, B, sample_motion, d_center, d_theta, seed, sequence, stats);
 }
 
+// likelihoodData as the last resample() left it, for whoever reads it before the next update (downloads; a second resample())
+static int slam_lik_current(gms_slam *s) {
+    if (!s->lik_behind) return GMS_OK;
+    gms_launch_slam_gather_one(s->pf, s->d_lik[1 - s->cur], s->d_lik[s->cur], s->d_idx_lik);               // GridMap.java:121, late
+    s->lik_behind = 0;
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
 // SLAM.resample() (SLAM.java:133-153): the systematic draw over the particles' weights, then every slot's deep copy
 int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n_ambiguous) {
     REQUIRE(s, "null handle");
     gms_map *m = s->map;
     HIPCHK(hipSetDevice(m->device));
-    int rc = gms_pf_resample(s->pf, &r01, indices, n_ambiguous);                                           // :136-145 + pose, weight (:42-43)
+    int rc = slam_lik_current(s);                                                                          // (two resample() calls in a row)
+    if (!rc) rc = gms_pf_resample(s->pf, &r01, indices, n_ambiguous);                                      // :136-145 + pose, weight (:42-43)
     if (rc) return rc;
-    gms_launch_slam_gather_maps(s->pf, s->d_log[s->cur], s->d_lik[s->cur], s->d_log[1 - s->cur], s->d_lik[1 - s->cur]);   // :44
+    if (s->lazy_lik) {
+        // logData now (GridMap.java:120); likelihoodData (:121) when it is asked for: SLAM.update starts with computeLikelihoodMap of
+        // every particle (:93), which overwrites every cell of it -- nothing on the path ever reads the copies
+        gms_launch_slam_gather_one(s->pf, s->d_log[s->cur], s->d_log[1 - s->cur], s->pf->d_idx);
+        HIPCHK(hipMemcpyAsync(s->d_idx_lik, s->pf->d_idx, (size_t)s->n * sizeof(int32_t), hipMemcpyDeviceToDevice, m->stream));
+        s->lik_behind = 1;
+    } else {
+        gms_launch_slam_gather_maps(s->pf, s->d_log[s->cur], s->d_lik[s->cur], s->d_log[1 - s->cur], s->d_lik[1 - s->cur]);   // :44
+    }
     s->cur = 1 - s->cur;                                                                                   // :152
     s->copies += s->n;
     HIPCHK(hipGetLastError());
@@ -141,8 +166,8 @@ static int slam_map_xfer(gms_slam *s, int32_t i, int32_t count, double *dev_base
 int gms_slam_download_map(gms_slam *s, int32_t i, double *log_data, double *lik) {          // Particle.m (SLAM.java:33)
     REQUIRE(s && i >= 0 && i < s->n, "gms_slam_download_map: particle index out of range");
     HIPCHK(hipSetDevice(s->map->device));
-    int rc = GMS_OK;
-    if (log_data) rc = slam_map_xfer(s, i, 1, s->d_log[s->cur], log_data, false);
+    int rc = lik ? slam_lik_current(s) : GMS_OK;
+    if (!rc && log_data) rc = slam_map_xfer(s, i, 1, s->d_log[s->cur], log_data, false);
     if (!rc && lik) rc = slam_map_xfer(s, i, 1, s->d_lik[s->cur], lik, false);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->map->stream));
@@ -152,8 +177,8 @@ int gms_slam_download_map(gms_slam *s, int32_t i, double *log_data, double *lik)
 int gms_slam_download_maps(gms_slam *s, double *log_all, double *lik_all) {
     REQUIRE(s, "null handle");
     HIPCHK(hipSetDevice(s->map->device));
-    int rc = GMS_OK;
-    if (log_all) rc = slam_map_xfer(s, 0, s->n, s->d_log[s->cur], log_all, false);
+    int rc = lik_all ? slam_lik_current(s) : GMS_OK;
+    if (!rc && log_all) rc = slam_map_xfer(s, 0, s->n, s->d_log[s->cur], log_all, false);
     if (!rc && lik_all) rc = slam_map_xfer(s, 0, s->n, s->d_lik[s->cur], lik_all, false);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->map->stream));
@@ -163,8 +188,8 @@ int gms_slam_download_maps(gms_slam *s, double *log_all, double *lik_all) {
 int gms_slam_upload_map(gms_slam *s, int32_t i, const double *log_data, const double *lik) {
     REQUIRE(s && i >= 0 && i < s->n, "gms_slam_upload_map: particle index out of range");
     HIPCHK(hipSetDevice(s->map->device));
-    int rc = GMS_OK;
-    if (log_data) rc = slam_map_xfer(s, i, 1, s->d_log[s->cur], const_cast<double *>(log_data), true);
+    int rc = lik ? slam_lik_current(s) : GMS_OK;                  // (the other slots' fields first, then this one's over its copy)
+    if (!rc && log_data) rc = slam_map_xfer(s, i, 1, s->d_log[s->cur], const_cast<double *>(log_data), true);
     if (!rc && lik) rc = slam_map_xfer(s, i, 1, s->d_lik[s->cur], const_cast<double *>(lik), true);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->map->stream));

@@ -416,6 +416,36 @@ k_slam_gather_maps(const double *__restrict__ src_log, const double *__restrict_
     }
 }
 
+// ... and one array only: resample() with likelihoodData's copies deferred (gms_slam::lik_behind) moves logData at once and
+// likelihoodData if and when somebody reads it before the next update's computeLikelihoodMap has overwritten it
+#ifndef GATHER_U
+#define GATHER_U 8
+#endif
+__global__ void __launch_bounds__(256)
+k_slam_gather_one(const double *__restrict__ src, double *__restrict__ dst, const int32_t *__restrict__ idx, int64_t cells) {
+    const int32_t m = blockIdx.y;
+    const int32_t i = idx[m];
+    const size_t so = (size_t)i * (size_t)cells, dof = (size_t)m * (size_t)cells;
+    if ((cells & 1) == 0) {
+        const int64_t n2 = cells >> 1;
+        const double2 *sp = reinterpret_cast<const double2 *>(src + so);
+        double2 *dp = reinterpret_cast<double2 *>(dst + dof);
+        const int64_t stride = (int64_t)gridDim.x * 256;
+        // GATHER_U 16-byte loads in flight per lane: at 500 x 120 x 120 the copy is bound by its workgroups' round trips (the source
+        // index, then the data), not by bytes -- the maps sit in the Infinity Cache --, so a workgroup moves 32 KiB and the whole
+        // copy is one residency of workgroups
+        for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < n2; e0 += GATHER_U * stride) {
+            double2 v[GATHER_U];
+#pragma unroll
+            for (int u = 0; u < GATHER_U; u++) v[u] = sp[min(e0 + u * stride, n2 - 1)];              // (clamped: no load behind a branch)
+#pragma unroll
+            for (int u = 0; u < GATHER_U; u++) if (e0 + u * stride < n2) dp[e0 + u * stride] = v[u];
+        }
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < cells; e += (int64_t)gridDim.x * 256) dst[dof + e] = src[so + e];
+    }
+}
+
 // createMapData(null) for every particle (SLAM.reset, SLAM.java:65-77): logData = logOdds(0.5) = 0.0, likelihoodData = 0.0
 // (hipMemsetAsync does it: both are all-zero bit patterns)
 
@@ -497,6 +527,21 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, do
 #undef PS_LAUNCH
     pf->pending_nseg = 0;
     pf->score_fresh = 1;
+}
+
+void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx) {
+    gms_map *m = pf->map;
+    ProfScope ps(m, GMS_K_MAPCOPY);
+    const int64_t cells = m->gd.cells;
+    // 256 lanes x 16 bytes x GATHER_U in flight = 32 KiB of the array per workgroup pass
+    // ... while that is a residency or two of workgroups (500 maps of 120 x 120: 2000); a copy that streams from memory does better with
+    // a quarter of that per workgroup and pass (4096 x 256 x 256: 443 us at 32 KiB, 409 at 16, 367 at 8, 496 at 4; 1024 x 256 x 256: 147 / 122)
+    int64_t per = 256 * GATHER_U;
+    if (((cells / 2 + per - 1) / per) * pf->n > 4096) per = 512;
+    int64_t chunks = (cells / 2 + per - 1) / per;
+    if (chunks < 1) chunks = 1;
+    while (chunks > 1 && chunks * pf->n > 262144) chunks = (chunks + 1) / 2;
+    hipLaunchKernelGGL(k_slam_gather_one, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, src, dst, d_idx, cells);
 }
 
 void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik) {

@@ -299,7 +299,10 @@ int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int
                                      uint64_t seed, uint64_t sequence, gms_pf_stats *stats);
 /* SLAM.resample() (SLAM.java:133-153) with Math.random() = r01: the systematic draw over the particles' weights, then every slot's
  * deep copy -- pose, weight (:42-43) and both arrays of the map (:44, GridMap.java:118-121): map[m] <- map[idx[m]], double-buffered,
- * a pure HBM stream of 32 bytes per cell.  indices [n] / n_ambiguous as gms_pf_resample (either may be NULL). */
+ * a pure HBM stream.  logData moves at once (16 bytes per cell); likelihoodData's copy is made when something reads it -- a download,
+ * an upload into a slot, another resample -- because the next update's computeLikelihoodMap overwrites every cell of it before
+ * anything on the path does (what a caller can see is the deep copy either way; GMS_SLAM_LAZY_LIK_COPY=0 moves both at once).
+ * indices [n] / n_ambiguous as gms_pf_resample (either may be NULL). */
 int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n_ambiguous);
 /* Particle i's GridMapData (SLAM.java:33; GridMap.java:72-74): W * H doubles each, either pointer may be NULL. */
 int gms_slam_download_map(gms_slam *s, int32_t i, double *log_data, double *lik);

@@ -238,6 +238,41 @@ def test_sixteen_bit_count_tiles_and_their_fallback(monkeypatch):
         dev.close()
 
 
+@pytest.mark.parametrize("lazy", ["1", "0"])
+def test_resample_copies_likelihood_data_late_or_at_once(lazy, monkeypatch):
+    """resample() copies logData at once and likelihoodData when it is asked for (the next update's computeLikelihoodMap overwrites
+    every cell of it first; GMS_SLAM_LAZY_LIK_COPY=0: both at once).  What a caller can see is the reference's deep copy either way:
+    after one resample(), after two in a row (the second must move the first one's fields), after an upload into one slot while the
+    copies are still owed, and across an update that makes them moot."""
+    monkeypatch.setenv("GMS_SLAM_LAZY_LIK_COPY", lazy)
+    ext, res, B, N = 4.0, 0.05, 60, 32
+    tr = synth.make_trace(ext, res, B, T=6, seed=13)
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    dev = SLAMParticleMaps(ext, ext, res, (-ext / 2, -ext / 2), num_particles=N, max_beams=128)
+    o = orc.Slam(g, N)
+    P = synth.make_particles(tr.poses[0], N, seed=9, sigma_xy=0.05, sigma_theta_deg=3.0)
+    dev.set_poses(P); o.set_poses(P)
+    for k in range(2):
+        dev.update(tr.scans[k], None); o.update(tr.scans[k], None, threads=THREADS)
+    for r01 in (0.31, 0.77):                                                   # two in a row
+        idx, _ = dev.resample(r01, want_indices=True)
+        want, _ = o.resample(r01)
+        assert np.array_equal(idx, want)
+    _compare_maps(dev, o, "two resamples in a row")
+    dev.update(tr.scans[2], None); o.update(tr.scans[2], None, threads=THREADS)
+    idx, _ = dev.resample(0.5, want_indices=True)
+    want, _ = o.resample(0.5)
+    assert np.array_equal(idx, want)
+    field = np.full((dev.H, dev.W), 0.25)
+    dev.set_map(3, lik=field)                                                  # an upload while the copies are owed
+    liks = dev.maps(likelihood=True)
+    for i in range(N):
+        assert np.array_equal(liks[i].reshape(-1), field.reshape(-1) if i == 3 else o.lik(i)), f"slot {i}"
+    dev.update(tr.scans[3], None); o.update(tr.scans[3], None, threads=THREADS)      # ... and an update makes every field current
+    _compare_maps(dev, o, "update after the resample")
+    dev.close()
+
+
 def test_properties_that_need_no_oracle_at_1024_particles_of_256x256_cells():
     """size-independent properties of the per-particle-map path on 2 GB of GridMapData: (1) with equal weights and r = 0.5 the systematic
     draw is the identity, so resample()'s deep copies must reproduce every map bit for bit in the other generation; (2) an update with
