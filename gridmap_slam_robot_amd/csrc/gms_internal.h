@@ -297,7 +297,7 @@ void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, 
 void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, double *d_log, const double *d_lik, const MotionModel *motion,
                               int32_t integrate);
 void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik);
-void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx);     // one array: dst[m] <- src[d_idx[m]]
+void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx, int32_t *d_idx_keep);   // one array: dst[m] <- src[d_idx[m]]; d_idx_keep (may be NULL) receives d_idx
 void gms_launch_slam_combine(gms_map *dst, const double *d_logs, int32_t n);
 
 // profiling brackets

@@ -124,7 +124,7 @@ int gms_slam_update_per_particle(gms_slam *s, const gms_beam *beams, int32_t B, 
 // likelihoodData as the last resample() left it, for whoever reads it before the next update (downloads; a second resample())
 static int slam_lik_current(gms_slam *s) {
     if (!s->lik_behind) return GMS_OK;
-    gms_launch_slam_gather_one(s->pf, s->d_lik[1 - s->cur], s->d_lik[s->cur], s->d_idx_lik);               // GridMap.java:121, late
+    gms_launch_slam_gather_one(s->pf, s->d_lik[1 - s->cur], s->d_lik[s->cur], s->d_idx_lik, nullptr);      // GridMap.java:121, late
     s->lik_behind = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
@@ -141,8 +141,7 @@ int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n
     if (s->lazy_lik) {
         // logData now (GridMap.java:120); likelihoodData (:121) when it is asked for: SLAM.update starts with computeLikelihoodMap of
         // every particle (:93), which overwrites every cell of it -- nothing on the path ever reads the copies
-        gms_launch_slam_gather_one(s->pf, s->d_log[s->cur], s->d_log[1 - s->cur], s->pf->d_idx);
-        HIPCHK(hipMemcpyAsync(s->d_idx_lik, s->pf->d_idx, (size_t)s->n * sizeof(int32_t), hipMemcpyDeviceToDevice, m->stream));
+        gms_launch_slam_gather_one(s->pf, s->d_log[s->cur], s->d_log[1 - s->cur], s->pf->d_idx, s->d_idx_lik);      // (keeps the indices for that)
         s->lik_behind = 1;
     } else {
         gms_launch_slam_gather_maps(s->pf, s->d_log[s->cur], s->d_lik[s->cur], s->d_log[1 - s->cur], s->d_lik[1 - s->cur]);   // :44

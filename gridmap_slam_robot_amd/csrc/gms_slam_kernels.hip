@@ -422,9 +422,11 @@ k_slam_gather_maps(const double *__restrict__ src_log, const double *__restrict_
 #define GATHER_U 8
 #endif
 __global__ void __launch_bounds__(256)
-k_slam_gather_one(const double *__restrict__ src, double *__restrict__ dst, const int32_t *__restrict__ idx, int64_t cells) {
+k_slam_gather_one(const double *__restrict__ src, double *__restrict__ dst, const int32_t *__restrict__ idx, int64_t cells,
+                  int32_t *__restrict__ idx_keep) {
     const int32_t m = blockIdx.y;
     const int32_t i = idx[m];
+    if (idx_keep && blockIdx.x == 0 && threadIdx.x == 0) idx_keep[m] = i;      // for the copy that is still owed (gms_slam::d_idx_lik)
     const size_t so = (size_t)i * (size_t)cells, dof = (size_t)m * (size_t)cells;
     if ((cells & 1) == 0) {
         const int64_t n2 = cells >> 1;
@@ -529,7 +531,7 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, do
     pf->score_fresh = 1;
 }
 
-void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx) {
+void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx, int32_t *d_idx_keep) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_MAPCOPY);
     const int64_t cells = m->gd.cells;
@@ -541,7 +543,7 @@ void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, cons
     int64_t chunks = (cells / 2 + per - 1) / per;
     if (chunks < 1) chunks = 1;
     while (chunks > 1 && chunks * pf->n > 262144) chunks = (chunks + 1) / 2;
-    hipLaunchKernelGGL(k_slam_gather_one, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, src, dst, d_idx, cells);
+    hipLaunchKernelGGL(k_slam_gather_one, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, src, dst, d_idx, cells, d_idx_keep);
 }
 
 void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik) {
