@@ -946,7 +946,8 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
         o.resample(0.61)
         rs = time.perf_counter() - t1
         orc.set_threads(before)
-        out["cpu_baseline"] = {"kind": "port", "cores": 1, "update_ms": el / n * 1e3, "resample_ms": rs * 1e3,
+        out["cpu_baseline"] = {"value": particles / (el / n), "unit": "particle-scan evals/s", "kind": "port", "cores": 1, "seconds": el,
+                               "update_ms": el / n * 1e3, "resample_ms": rs * 1e3,
                                "sample": f"{n} SLAM.update calls of the same recording (oracle/gms_oracle.c::orc_slam_update), one orc_slam_resample with its copies on one thread"}
     s.close()
     return out
