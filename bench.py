@@ -881,11 +881,13 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
         s.update_dev(scans[k].data_ptr(), beams, odo[k], seed=11, sequence=seq)
         k = (k + 1) % T
     r01 = np.random.default_rng(5).random(4096)
-    for i in range(warm_frames):                       # the maps are partly explored when the timed region starts
+    pre = (preroll_steps() * 2) // 3                   # untimed, as in measure(): the clocks ramp over the first tens of milliseconds
+    for i in range(pre + warm_frames):                 # the maps are explored (the drive has gone round) when the timed region starts
         step(i)
         if i % 4 == 3:
-            s.resample(float(r01[i]))
+            s.resample(float(r01[i % 4096]))
     torch.cuda.synchronize()
+    warm_frames += pre                                  # (sequence numbers go on from here)
     t0 = time.perf_counter()
     for i in range(steps):
         step(warm_frames + i)
