@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--particles", type=int, default=0)
     ap.add_argument("--sigma", type=float, default=0.10)
     ap.add_argument("--beams", type=int, default=0, help="override beams per scan")
+    ap.add_argument("--preroll", type=int, default=0, help="untimed calls in front of every measured loop (5 at least)")
     ap.add_argument("--dense", action="store_true", help="likelihood mode only: replace the map by the dense worst case (every 64x32 tile non-uniform) first")
     ap.add_argument("--sort", default="", help="order the particles on the host first: theta | cluster:<deg>:<m> (locality experiment)")
     args = ap.parse_args()
@@ -78,7 +79,7 @@ def main():
     def want(k): return only is None or k in only
     out = {}
     def run(name, fn, iters=args.iters):
-        for _ in range(5): fn()
+        for _ in range(max(5, args.preroll)): fn()          # untimed: the clocks ramp over the first tens of milliseconds of a process
         torch.cuda.synchronize()
         m.profile_reset(); m.profile(True)
         t0 = time.perf_counter()
