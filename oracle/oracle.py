@@ -434,6 +434,9 @@ class Slam:
     def set_log(self, i: int, log):
         np.ctypeslib.as_array(lib().orc_slam_log(self._h, int(i)), shape=(self.cells,))[:] = np.asarray(log, dtype=np.float64).reshape(-1)
 
+    def set_lik(self, i: int, lik):
+        np.ctypeslib.as_array(lib().orc_slam_lik(self._h, int(i)), shape=(self.cells,))[:] = np.asarray(lik, dtype=np.float64).reshape(-1)
+
     def logs(self) -> np.ndarray:
         return np.stack([self.log(i) for i in range(self.n)])
 

@@ -273,6 +273,66 @@ def test_resample_copies_likelihood_data_late_or_at_once(lazy, monkeypatch):
     dev.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_call_sequences_against_the_oracle(seed):
+    """forty calls drawn at random -- update (with and without the motion sample, sometimes with a turn that skips the integration),
+    resample, download of one or of all maps, upload of a log or of a field into a slot, reset, the combined map -- on the device
+    and on the oracle: the handle's state machine (which generation is current, which copies are owed) against the plain loop."""
+    rng = np.random.default_rng(seed)
+    ext, res, B, N = 3.2, 0.05, 48, 12
+    tr = synth.make_trace(ext, res, B, T=8, seed=50 + seed)
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    dev = SLAMParticleMaps(ext, ext, res, (-ext / 2, -ext / 2), num_particles=N, max_beams=64)
+    o = orc.Slam(g, N)
+    P = synth.make_particles(tr.poses[0], N, seed=seed, sigma_xy=0.04, sigma_theta_deg=2.0)
+    dev.set_poses(P); o.set_poses(P)
+    normalised = False
+    for step in range(40):
+        op = rng.choice(["update", "update", "update", "resample", "get_one", "get_all", "put_log", "put_lik", "reset", "combined"])
+        where = f"seed {seed} call {step} ({op})"
+        if op == "update":
+            z = tr.scans[int(rng.integers(0, 8))]
+            u = None if rng.random() < 0.5 else (0.01, float(np.radians(rng.choice([1.0, 40.0]))))
+            dev.update(z, u, seed=seed, sequence=step)
+            o.set_poses(dev.get_particles()[0])
+            o.update(z, u, sample_motion=False, threads=THREADS)
+            _compare_weights(dev.get_particles()[1], o.weights, where)
+            normalised = True
+        elif op == "resample" and normalised:
+            r01 = float(rng.random())
+            idx, amb = dev.resample(r01, want_indices=True)
+            want, _ = o.resample(r01)
+            assert_resample_indices(idx, want, amb)
+            if not np.array_equal(idx, want):                                  # (a draw on a rounding boundary: follow the device)
+                pytest.skip(f"{where}: the draw sits on a rounding boundary")
+        elif op == "get_one":
+            i = int(rng.integers(0, N))
+            assert np.array_equal(dev.map_of(i, likelihood=True).reshape(-1), o.lik(i)), where
+            assert np.max(np.abs(dev.map_of(i).reshape(-1) - o.log(i))) <= 1e-12, where
+        elif op == "get_all":
+            _compare_maps(dev, o, where)
+        elif op == "put_log":
+            i = int(rng.integers(0, N))
+            lg = rng.choice([-1.7, 0.0, 0.0, 2.2], size=g.W * g.H)
+            dev.set_map(i, log=lg.reshape(g.H, g.W)); o.set_log(i, lg)
+        elif op == "put_lik":
+            i = int(rng.integers(0, N))
+            lk = rng.random(g.W * g.H)
+            dev.set_map(i, lik=lk.reshape(g.H, g.W)); o.set_lik(i, lk)
+        elif op == "reset":
+            dev.reset(); o.reset()
+            dev.set_poses(P); o.set_poses(P)
+            normalised = False
+        elif op == "combined":
+            want = orc.combine_maps(o.logs())                                  # GridMapApp.calculateCombined (GridMapApp.java:439-458)
+            got = dev.calculate_combined().reshape(-1)
+            fin = np.isfinite(want)
+            assert np.array_equal(np.isfinite(got), fin), where
+            assert not fin.any() or np.max(np.abs(got[fin] - want[fin])) <= 1e-9 * max(1.0, np.abs(want[fin]).max()), where
+    _compare_maps(dev, o, f"seed {seed}: at the end")
+    dev.close()
+
+
 def test_properties_that_need_no_oracle_at_1024_particles_of_256x256_cells():
     """size-independent properties of the per-particle-map path on 2 GB of GridMapData: (1) with equal weights and r = 0.5 the systematic
     draw is the identity, so resample()'s deep copies must reproduce every map bit for bit in the other generation; (2) an update with
