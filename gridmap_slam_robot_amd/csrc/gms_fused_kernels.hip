@@ -152,7 +152,7 @@ k_raycast_norm_chunks(GridDev g, const gms_beam *__restrict__ beams, int32_t B, 
 }
 
 // ---- C: likelihood rebuild (dirty tiles)  |  resample ---------------------------------------------------------
-template <int KH>
+template <int KH, int SPLIT>
 __global__ void __launch_bounds__(256)
 k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac, int64_t fac_stride,
                const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t tiles_x, int32_t tiles_y,
@@ -172,8 +172,8 @@ k_lik_resample(GridDev g, const double *__restrict__ logd, double *__restrict__ 
         resample_body(glob, n_global, nchunks, cum, chunk_off, r01_maps, r01, fraction, n, offset, pose2, cs2, w2, idx_out, p2,
                       nblk_global, stats, blockIdx.x, blockIdx.y, smem, raw_weights != 0);
     else
-        likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, 1, tiles_x, tiles_y, blockIdx.x - n_res_blocks,
-                            blockIdx.y, gridDim.x - n_res_blocks, smem, cnt_pending, tile_state, lik_mode);
+        likelihood_body<KH, SPLIT>(g, logd, lik, fac, fac_stride, taps_g, bbox, 1, tiles_x, tiles_y, blockIdx.x - n_res_blocks,
+                                   blockIdx.y, gridDim.x - n_res_blocks, smem, cnt_pending, tile_state, lik_mode);
     GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), blockIdx.x < n_res_blocks ? 1 : 2);
 }
 
@@ -277,20 +277,21 @@ void gms_launch_lik_resample(gms_pf *pf, double fraction) {
     if (m->lik_lazy) m->lik_stale = 1;
     if (m->fac_current && m->lik_skip) lik_mode |= 4;         // tiles whose codes this scan does not change are left alone (likelihood_body)
     m->fac_current = 1;
-#define LR_LAUNCH(KH)                                                                                                     \
+    const bool split = k != 0 && gms_likelihood_split(m, blocks);              // (likelihood_body, "split")
+#define LR_LAUNCH(KH, SP)                                                                                                 \
     do {                                                                                                                  \
         if (smem > 48 * 1024)                                                                                             \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lik_resample<KH>),                                     \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lik_resample<KH, SP>),                                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
-        hipLaunchKernelGGL(k_lik_resample<KH>, dim3((uint32_t)blocks + n_res, pf->n_maps), dim3(256), smem, m->stream, m->gd, m->d_log, \
+        hipLaunchKernelGGL((k_lik_resample<KH, SP>), dim3((uint32_t)blocks + n_res, pf->n_maps), dim3(256), smem, m->stream, m->gd, m->d_log, \
                            m->d_lik, m->d_fac, m->fac_stride, m->d_taps, bb, tiles_x, tiles_y, m->d_cnt, m->d_tile_state, n_res, pf->d_global, \
                            pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, r01_maps, pf->r01_scalar, fraction, pf->n, pf->offset, \
                            pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats,       \
                            pf->global_raw, m->d_bbox + (size_t)(1 - m->bbox_cur) * m->n_maps * 4, lik_mode);             \
     } while (0)
-    if (k == 3) LR_LAUNCH(3);
-    else if (k == 5) LR_LAUNCH(5);
-    else LR_LAUNCH(0);
+    if (k == 3) { if (split) LR_LAUNCH(3, 2); else LR_LAUNCH(3, 1); }
+    else if (k == 5) { if (split) LR_LAUNCH(5, 2); else LR_LAUNCH(5, 1); }
+    else LR_LAUNCH(0, 1);
 #undef LR_LAUNCH
     pf->neff_folded = 1;
 }

@@ -348,7 +348,7 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     ok = ok && hipMalloc(&m->d_cnt, cells * sizeof(uint32_t)) == hipSuccess && hipMalloc(&m->d_cnt_pend, cells * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_bbox, (size_t)m->n_maps * 8 * sizeof(int32_t)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_taps, GMS_MAX_TAPS * sizeof(double)) == hipSuccess;
-    ok = ok && hipMalloc(&m->d_tile_state, (size_t)((g.W + 63) / 64) * ((g.H + 31) / 32) * m->n_maps) == hipSuccess;
+    ok = ok && hipMalloc(&m->d_tile_state, 2 * (size_t)((g.W + 63) / 64) * ((g.H + 31) / 32) * m->n_maps) == hipSuccess;
     ok = ok && hipMalloc(&m->d_tile_stats, 64 * 4 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_beams, (size_t)m->n_maps * m->max_beams * sizeof(gms_beam)) == hipSuccess;
     ok = ok && hipMalloc(&m->d_poses, (size_t)m->n_maps * 3 * sizeof(float) + 16) == hipSuccess;   // (+16: copied in 16-byte units)
@@ -386,6 +386,8 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     m->fac_current = 0;
     if (const char *v = getenv("GMS_PAIR_LAUNCHES")) m->pair_launches = atoi(v) != 0;
     if (const char *v = getenv("GMS_SLAM_TILE_CELLS")) m->slam_tile_cells = atoi(v);
+    m->lik_split = 1;
+    if (const char *v = getenv("GMS_LIK_SPLIT")) m->lik_split = atoi(v) != 0;
     if (const char *v = getenv("GMS_SLAM_THREADS")) m->slam_threads = atoi(v);
     *out = m;
     return GMS_OK;

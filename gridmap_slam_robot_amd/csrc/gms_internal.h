@@ -109,7 +109,7 @@ struct gms_map {
     int32_t bbox_cur;     // half in use
     int32_t bbox_dirty;   // an integrate ran since the last likelihood build
     double *d_taps;       // [ktaps]
-    uint8_t *d_tile_state;  // [n_maps][likelihood tiles]: 0 unknown, 1..3 the tile of d_lik/d_fac holds the constants of a uniform tile of code 0 / 0.5 / 1
+    uint8_t *d_tile_state;  // [n_maps][likelihood tiles][2 halves of a tile's rows]: 0 unknown, 1..3 the tile of d_lik/d_fac holds the constants of a uniform tile of code 0 / 0.5 / 1
     uint32_t *d_tile_stats; // [64][4] counters behind gd.tile_stats (always allocated; gd.tile_stats points at them while the census is on)
     gms_beam *d_beams;    // [n_maps][max_beams] staging
     float *d_poses;       // [n_maps][3] staging
@@ -122,6 +122,7 @@ struct gms_map {
                               // that is negative or outside 2^-900 .. 2^900 (the fast path computes twice the horizontal sums and halves them --
                               // exact only while nothing is subnormal -- and starts a sum with its first product instead of 0.0 + it -- the
                               // same bits only while that product is not -0.0; likelihood_body)
+    int32_t lik_split;        // dirty-tile rebuilds of a single map give every tile two workgroups when the chip has them to spare (GMS_LIK_SPLIT=0: one)
     int32_t lik_lazy;         // scan steps' dirty-tile rebuilds write the factor table only, likelihoodData on demand (GMS_LIK_LAZY=0 turns it off)
     int32_t lik_stale;        // likelihoodData is behind the factor table somewhere (gms_ensure_lik brings it up to date)
     int32_t fac_current;      // the factor table is the field of logData + the pending counts as of the last rebuild, and logData has not moved since except by those counts
@@ -241,6 +242,7 @@ void gms_launch_apply_ray(gms_map *m, RayIn ray);
 void gms_launch_apply_counts(gms_map *m);
 void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending = false, bool materialize = false);
 void gms_ensure_lik(gms_map *m);        // likelihoodData up to date everywhere (the scan steps' rebuilds write the factor table only)
+bool gms_likelihood_split(const gms_map *m, int32_t blocks);      // likelihood_body's SPLIT = 2 for a dirty-tile rebuild launched with `blocks` workgroups?
 size_t gms_likelihood_lds_bytes(int32_t khalf, bool coded = true);   // coded: the byte-coded staging of the compile-time half widths (gms_map::lik_kh != 0)
 int32_t gms_likelihood_blocks_cap(const gms_map *m, size_t smem);
 void gms_launch_raycast_apply(gms_map *m, const gms_beam *d_beams, int32_t B, int32_t beam_stride, const float *d_poses, int32_t pose_stride);

@@ -686,7 +686,8 @@ k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const 
 #else
 #define LIK_STORE(p, v) (*(p) = (v))
 #endif
-template <int KH>   // KH > 0: compile-time half width; KH == 0: runtime g.khalf (generic, slower)
+template <int KH, int SPLIT = 1>   // KH > 0: compile-time half width; KH == 0: runtime g.khalf (generic, slower).  SPLIT = 2 (KH > 0, dirty
+                                  // tiles only): a tile's horizontal and vertical sums are shared by TWO workgroups, see "split" below
 __device__ __forceinline__ void
 likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
                 int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
@@ -792,23 +793,46 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             cv[QM + j] = mcnt ? mcnt[(size_t)gy * g.W + gx] : 0u;
         }
     };
+    // work items (see "split" at the tile loop): item w -> tile item_tile(w), part (w >> 3) & 1
+    const int32_t nitems = SPLIT == 1 ? ntiles : ((ntiles + 7) >> 3) << 4;
+    auto item_tile = [&](int32_t w) { return SPLIT == 1 ? w : ((w >> 4) << 3) + (w & 7); };
+    auto next_item = [&](int32_t w) {                     // the next item from w on that names a tile (the last group of eight may not be full)
+        if (SPLIT != 1)
+            while (w < nitems && item_tile(w) >= ntiles) w += (int32_t)gdx;
+        return w;
+    };
+    const int32_t first_w = next_item((int32_t)bx);
     if (KH > 0) {
         if (threadIdx.x < 3) s_mask[threadIdx.x] = 0;
         __syncthreads();
-        if ((int32_t)bx < ntiles) issue_loads((int32_t)bx);
+        if (first_w < nitems) issue_loads(item_tile(first_w));
     }
 
-    for (int32_t t = (int32_t)bx; t < ntiles; t += (int32_t)gdx) {
+    // split (SPLIT = 2): a scan step's dirty box is a few hundred tiles of which a few dozen are blurred, on a chip that holds 1280
+    // workgroups: the blurred ones decide when the launch ends (8.7 us each at C3: 4.7 staging, 2.2 + 1.7 for the two passes).  Work item
+    // w = (tile, part): both parts stage and classify the whole rectangle (the same decision, the same tile state), part p then takes the
+    // horizontal sums of rows [16 p, 16 p + 16 + 2 KH) and the vertical sums and stores of rows [16 p, 16 p + 16).  Of sixteen consecutive
+    // items the first eight are part 0 of eight tiles and the last eight part 1 of the same: a tile's two workgroups share an XCD.
+    static_assert(SPLIT == 1 || (SPLIT == 2 && KH > 0), "split tiles: compile-time half widths only");
+    int32_t w_next = nitems;
+    for (int32_t w = first_w; w < nitems; w = w_next) {
+        w_next = next_item(w + (int32_t)gdx);
+        const int32_t t = item_tile(w);
+        const int32_t part = SPLIT == 1 ? 0 : (w >> 3) & 1;
         const int32_t tile = tile_of(t);
         const int32_t tx0 = (qx0 + tile % qnx) * LK_TW, ty0 = (qy0 + tile / qnx) * LK_TH;
         // what this tile of likelihoodData / the factor table holds: 0 unknown, 1..3 the constants of a uniform tile
-        uint8_t *tstate = tile_state ? tile_state + (size_t)mi * tiles_x * tiles_y + (size_t)(qy0 + tile / qnx) * tiles_x + (qx0 + tile % qnx)
+        // (two entries per tile, one per half of its rows: a split tile's two workgroups each keep their own -- one of them must not find
+        // the other's fresh entry and skip its own half's stores --, an unsplit tile's workgroup keeps both alike)
+        uint8_t *tstate = tile_state ? tile_state + 2 * ((size_t)mi * tiles_x * tiles_y + (size_t)(qy0 + tile / qnx) * tiles_x + (qx0 + tile % qnx)) +
+                                           (SPLIT == 1 ? 0 : part)
                                      : nullptr;
         // Read by EVERY thread here, before this tile's first barrier: thread 0 rewrites the state after that barrier, and a
         // wavefront that read it later could see the new value and skip its share of a uniform tile's stores (round 1 read
         // it at the point of use: one wavefront's 8 rows of a far-away tile were left stale about once in forty full-size
         // multi-map runs; found by tests/test_gpu_configs.py).
-        const uint8_t tstate_old = tstate ? *reinterpret_cast<volatile uint8_t *>(tstate) : (uint8_t)0;
+        uint8_t tstate_old = tstate ? *reinterpret_cast<volatile uint8_t *>(tstate) : (uint8_t)0;
+        if (SPLIT == 1 && tstate && *reinterpret_cast<volatile uint8_t *>(tstate + 1) != tstate_old) tstate_old = 0;
 
         // ---- phase 1
         int32_t seen = 0;                                      // bit c: a cell of code c; bit 3: outside the map; bit 4: a code changes
@@ -906,8 +930,8 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 for (int j = 0; j < QS; j++)
                     if (s_have[j]) in_b[s_r[j] * PINB + s_c[j]] = (uint8_t)((codes >> (2 * (QM + j))) & 3u);
             }
-            if (t + (int32_t)gdx < ntiles) issue_loads(t + (int32_t)gdx);      // in flight during the rest of this tile
-            if (unchanged) { ts_left++; continue; }                            // (one barrier, like a uniform tile)
+            if (w_next < nitems) issue_loads(item_tile(w_next));               // in flight during the rest of this tile
+            if (unchanged) { if (part == 0) ts_left++; continue; }             // (one barrier, like a uniform tile)
             if (!uniform) __syncthreads();
         }
 
@@ -915,7 +939,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
         if (mk == 1 || mk == 2 || mk == 4) {
             // ---- uniform tile: every in-order sum sees the same inputs
             const uint8_t want = mk == 1 ? 1 : (mk == 2 ? 2 : 3);
-            if (wr_fac && tstate && tstate_old == want) { ts_const_kept++; continue; }    // the tile already holds exactly these constants: no store (mode 3: both
+            if (wr_fac && tstate && tstate_old == want) { if (part == 0) ts_const_kept++; continue; }    // the tile already holds exactly these constants: no store (mode 3: both
                                                                     // arrays do -- a full rebuild invalidates the states first when likelihoodData is behind)
             const double cval = mk == 1 ? 0.0 : (mk == 2 ? 0.5 : 1.0);
             double hc = 0.0;
@@ -923,18 +947,18 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             double vc = 0.0;
             for (int32_t i = 0; i < ntaps; i++) vc += taps_g[i] * hc;             // Util.java:415-422
             const double fc = lik_factor(g, vc);
-            for (int32_t idx = threadIdx.x; idx < LK_TH * LK_TW; idx += blockDim.x) {
-                const int32_t r = idx / LK_TW, c = idx - r * LK_TW;
+            for (int32_t idx = threadIdx.x; idx < (LK_TH / SPLIT) * LK_TW; idx += blockDim.x) {
+                const int32_t r = part * (LK_TH / SPLIT) + idx / LK_TW, c = idx % LK_TW;
                 const size_t o = (size_t)(ty0 + r) * g.W + tx0 + c;               // tile is inside the map (bit 3 clear)
                 if (wr_lik) LIK_STORE(&mlik[o], vc);
                 if (wr_fac) FAC_STORE(&mfac[(size_t)(ty0 + r) * g.fpitch + tx0 + c], fc);
             }
-            if (wr_fac && tstate && threadIdx.x == 0) *tstate = want;
-            ts_const_written++;
+            if (wr_fac && tstate && threadIdx.x == 0) { *tstate = want; if (SPLIT == 1) tstate[1] = want; }
+            if (part == 0) ts_const_written++;
             continue;
         }
-        if (wr_fac && tstate && threadIdx.x == 0) *tstate = 0;
-        ts_blurred++;
+        if (wr_fac && tstate && threadIdx.x == 0) { *tstate = 0; if (SPLIT == 1) tstate[1] = 0; }
+        if (part == 0) ts_blurred++;
 #if defined(GMS_LIK_EXP) && GMS_LIK_EXP == 1       // experiment: the staging alone (tools/lik_phases.sh)
         continue;
 #endif
@@ -943,8 +967,10 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             // ---- phase 2: strips of LK_STRIP outputs along x
             // (RH * 8 strips are 5.25 (KH = 5) wavefronts' worth: the wavefronts that take a second pass rotate from tile to tile,
             // so that over the tiles a workgroup walks no SIMD carries more of them than another)
-            for (int32_t sidx = (int32_t)((threadIdx.x + 64u * (uint32_t)tile_iter) & 255u); sidx < RH * (LK_TW / LK_STRIP); sidx += 256) {
-                const int32_t r = sidx / (LK_TW / LK_STRIP), c0 = (sidx - r * (LK_TW / LK_STRIP)) * LK_STRIP;
+            constexpr int32_t RHP = LK_TH / SPLIT + 2 * (KH > 0 ? KH : 1);      // rows of horizontal sums this workgroup needs: all RH, or its part's
+            const int32_t R0 = part * (LK_TH / SPLIT);
+            for (int32_t sidx = (int32_t)((threadIdx.x + 64u * (uint32_t)tile_iter) & 255u); sidx < RHP * (LK_TW / LK_STRIP); sidx += 256) {
+                const int32_t r = R0 + sidx / (LK_TW / LK_STRIP), c0 = (sidx % (LK_TW / LK_STRIP)) * LK_STRIP;
                 double v[LK_STRIP + 2 * (KH > 0 ? KH : 1)];
                 // c0 and PINB are multiples of 8: the strip's LK_STRIP + 2 KH codes come as 8-byte words
                 const uint64_t *row = reinterpret_cast<const uint64_t *>(in_b + r * PINB + c0);
@@ -976,15 +1002,16 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             {
                 // lane = column, wavefront = eight rows: the rows' bounds tests and base addresses are scalar, a store is
                 // `row base (scalar) + column offset (one register)`
-                const int32_t c = e_lane, r0 = e_wave * LK_STRIP;
-                double v[LK_STRIP + 2 * (KH > 0 ? KH : 1)];
+                constexpr int VS = LK_STRIP / SPLIT;                               // outputs per lane: four wavefronts x VS rows = this workgroup's rows
+                const int32_t c = e_lane, r0 = R0 + e_wave * VS;
+                double v[VS + 2 * (KH > 0 ? KH : 1)];
                 const double *hcol = hs + r0 * PHS + c;
 #pragma unroll
-                for (int j = 0; j < LK_STRIP + 2 * KH; j++) v[j] = hcol[j * PHS];
+                for (int j = 0; j < VS + 2 * KH; j++) v[j] = hcol[j * PHS];
                 const uint32_t gx = (uint32_t)(tx0 + c);
                 const bool x_ok = gx < (uint32_t)g.W;
 #pragma unroll
-                for (int o = 0; o < LK_STRIP; o++) {
+                for (int o = 0; o < VS; o++) {
                     double total = taps_g[0] * v[o];
 #pragma unroll
                     for (int i = 1; i < 2 * KH + 1; i++) total += taps_g[i] * v[o + i];
@@ -1029,7 +1056,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     }
 }
 
-template <int KH, bool PENDING>      // PENDING = false: no count grid is read (the code for it is not generated: 1.3 us of a 21 us full rebuild)
+template <int KH, bool PENDING, int SPLIT = 1>      // PENDING = false: no count grid is read (the code for it is not generated: 1.3 us of a 21 us full rebuild)
 __global__ void __launch_bounds__(256) GMS_LIK_WAVES
 k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
              int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
@@ -1039,8 +1066,8 @@ k_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ li
     // bbox_clear: the box half the NEXT ray cast will raise (it shares its launch with this scan's deferred apply pass,
     // which therefore cannot clear it: k_raycast_apply); nobody reads it during this launch
     if (bbox_clear && blockIdx.x == 0 && threadIdx.x < 4) bbox_clear[4 * blockIdx.y + threadIdx.x] = 0;
-    likelihood_body<KH>(g, logd, lik, fac, fac_stride, taps_g, bbox, dirty_only, tiles_x, tiles_y, blockIdx.x, blockIdx.y,
-                        gridDim.x, smem, PENDING ? cnt_pending : (const uint32_t *)nullptr, tile_state, mode);
+    likelihood_body<KH, SPLIT>(g, logd, lik, fac, fac_stride, taps_g, bbox, dirty_only, tiles_x, tiles_y, blockIdx.x, blockIdx.y,
+                               gridDim.x, smem, PENDING ? cnt_pending : (const uint32_t *)nullptr, tile_state, mode);
 }
 
 // The stand-alone map update (GridMap.integrateObservation + computeLikelihoodMap as an entry point of its own) in two
@@ -1309,6 +1336,17 @@ int32_t gms_likelihood_blocks_cap(const gms_map *m, size_t smem) {
     return per_map;
 }
 
+// Whether a dirty-tile rebuild launched with `blocks` workgroups per map may split its tiles in two: one map, and twice the tiles of the
+// largest box a scan can touch (both ends of a ray of maximal range, its walk's margin, the blur's reach) are not more than `blocks`
+bool gms_likelihood_split(const gms_map *m, int32_t blocks) {
+    if (m->n_maps != 1 || m->lik_kh == 0 || m->lik_split == 0) return false;
+    const double side = 2.0 / (m->gd.inv_max * m->gd.res) + 2.0 * m->gd.khalf + 2.0 * RC_BOX_MARGIN + 8.0;       // cells
+    const int64_t tx = (int64_t)(side / LK_TW) + 2, ty = (int64_t)(side / LK_TH) + 2;
+    const int64_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
+    const int64_t most = (tx < tiles_x ? tx : tiles_x) * (ty < tiles_y ? ty : tiles_y);
+    return 2 * (((most + 7) >> 3) << 3) <= blocks;
+}
+
 void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending, bool materialize) {
     // counts_pending: the scan just cast is not in logData yet; its counts (m->d_cnt) are added on the fly and its apply pass
     // is deferred by the caller (gms_defer_apply); the other box half is cleared for the next ray cast
@@ -1345,21 +1383,24 @@ void gms_launch_likelihood(gms_map *m, int32_t dirty_only, bool counts_pending, 
         counts_pending = m->apply_pending != 0;
         pend = counts_pending ? m->d_cnt_pend : (const uint32_t *)nullptr;       // (gms_defer_apply has swapped the grids)
     }
+    // a dirty-tile rebuild of a single map splits its tiles over two workgroups each when the largest box a scan can touch still leaves
+    // every (tile, part) a workgroup of its own (likelihood_body, "split")
+    const bool split = k != 0 && dirty_only && counts_pending && gms_likelihood_split(m, blocks);
 #define LK_LAUNCH(KH)                                                                                         \
     do {                                                                                                      \
-        if (counts_pending) LK_LAUNCH2(KH, true); else LK_LAUNCH2(KH, false);                                 \
+        if (split) LK_LAUNCH2(KH, true, 2); else if (counts_pending) LK_LAUNCH2(KH, true, 1); else LK_LAUNCH2(KH, false, 1); \
     } while (0)
-#define LK_LAUNCH2(KH, PEND)                                                                                  \
+#define LK_LAUNCH2(KH, PEND, SP)                                                                              \
     do {                                                                                                      \
         if (smem > 48 * 1024)                                                                                 \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_likelihood<KH, PEND>),                     \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_likelihood<KH, PEND, SP>),                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                       \
-        hipLaunchKernelGGL((k_likelihood<KH, PEND>), grid, dim3(256), smem, m->stream, m->gd, m->d_log, m->d_lik,     \
+        hipLaunchKernelGGL((k_likelihood<KH, PEND, SP>), grid, dim3(256), smem, m->stream, m->gd, m->d_log, m->d_lik, \
                            m->d_fac, m->fac_stride, m->d_taps, bb, dirty_only, tiles_x, tiles_y, tstate, pend, bb_clear, mode);                         \
     } while (0)
     if (k == 3) LK_LAUNCH(3);
     else if (k == 5) LK_LAUNCH(5);
-    else LK_LAUNCH(0);
+    else { if (counts_pending) LK_LAUNCH2(0, true, 1); else LK_LAUNCH2(0, false, 1); }
 #undef LK_LAUNCH
 #undef LK_LAUNCH2
 }
@@ -1410,7 +1451,7 @@ void gms_launch_noop(gms_map *m) { hipLaunchKernelGGL(k_noop, dim3(1), dim3(64),
 // about their tiles any more
 void gms_invalidate_tile_state(gms_map *m) {
     const size_t tiles = (size_t)((m->gd.W + LK_TW - 1) / LK_TW) * ((m->gd.H + LK_TH - 1) / LK_TH);
-    hipMemsetAsync(m->d_tile_state, 0, tiles * m->n_maps, m->stream);
+    hipMemsetAsync(m->d_tile_state, 0, 2 * tiles * m->n_maps, m->stream);     // (two entries per tile: likelihood_body)
 }
 
 void gms_launch_factors(gms_map *m) {
