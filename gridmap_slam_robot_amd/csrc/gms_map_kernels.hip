@@ -758,7 +758,10 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     // SW = 2 KH columns on the right, (row, column) per lane, computed once per workgroup.  (Rounds 1-4 numbered the rectangle's
     // cells row-major through the workgroup: a division, two clamps, a 64-bit multiply-add and four bounds tests under a branch per
     // cell were 2300 of this kernel's 4800 vector instructions per tile: profiles/r05/dense_likelihood_counters.json.)
-    constexpr int32_t SW = CRW - LK_TW, QM = (CRH + 3) / 4, QS = (CRH * SW + 255) / 256;
+    // (SPLIT = 2: an item is half a tile's rows and stages the CRS = LK_TH / 2 + 2 KH rows its own sums need, from row R0 = 16 part of
+    // the tile's rectangle on: a 64 x 16 tile with its own class decision and its own tile state)
+    constexpr int32_t CRS = LK_TH / SPLIT + 2 * (KH > 0 ? KH : 1);
+    constexpr int32_t SW = CRW - LK_TW, QM = (CRS + 3) / 4, QS = (CRS * SW + 255) / 256;
     constexpr int32_t P1 = QM + QS;
     static_assert(LK_TW == 64, "lane = column of the staged rectangle's first 64");
     const int32_t e_lane = (int32_t)(threadIdx.x & 63);
@@ -769,14 +772,14 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     for (int j = 0; j < QS; j++) {
         const int32_t i2 = (int32_t)threadIdx.x + j * 256;
         s_r[j] = i2 / SW; s_c[j] = LK_TW + (i2 - s_r[j] * SW);
-        s_have[j] = i2 < CRH * SW;
+        s_have[j] = i2 < CRS * SW;
         if (!s_have[j]) { s_r[j] = 0; s_c[j] = 0; }         // (loads a duplicate of the rectangle's first cell; not staged)
     }
     double lv[P1];
     uint32_t cv[P1];
-    auto issue_loads = [&](int32_t t) {
+    auto issue_loads = [&](int32_t t, int32_t lr0) {          // tile index, first staged row of the tile's rectangle (0, or 16 part)
         const int32_t tile = tile_of(t);
-        const int32_t ltx0 = (qx0 + tile % qnx) * LK_TW, lty0 = (qy0 + tile / qnx) * LK_TH;
+        const int32_t ltx0 = (qx0 + tile % qnx) * LK_TW, lty0 = (qy0 + tile / qnx) * LK_TH + lr0;
         // addresses clamped into the map (a cell outside it is given its code from the coordinates, below): no load behind a branch
         const uint32_t gxm = (uint32_t)min(max(ltx0 - KH + e_lane, 0), g.W - 1);
 #pragma unroll
@@ -796,6 +799,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     // work items (see "split" at the tile loop): item w -> tile item_tile(w), part (w >> 3) & 1
     const int32_t nitems = SPLIT == 1 ? ntiles : ((ntiles + 7) >> 3) << 4;
     auto item_tile = [&](int32_t w) { return SPLIT == 1 ? w : ((w >> 4) << 3) + (w & 7); };
+    auto item_row0 = [&](int32_t w) { return SPLIT == 1 ? 0 : ((w >> 3) & 1) * (LK_TH / SPLIT); };
     auto next_item = [&](int32_t w) {                     // the next item from w on that names a tile (the last group of eight may not be full)
         if (SPLIT != 1)
             while (w < nitems && item_tile(w) >= ntiles) w += (int32_t)gdx;
@@ -805,20 +809,21 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     if (KH > 0) {
         if (threadIdx.x < 3) s_mask[threadIdx.x] = 0;
         __syncthreads();
-        if (first_w < nitems) issue_loads(item_tile(first_w));
+        if (first_w < nitems) issue_loads(item_tile(first_w), item_row0(first_w));
     }
 
     // split (SPLIT = 2): a scan step's dirty box is a few hundred tiles of which a few dozen are blurred, on a chip that holds 1280
     // workgroups: the blurred ones decide when the launch ends (8.7 us each at C3: 4.7 staging, 2.2 + 1.7 for the two passes).  Work item
-    // w = (tile, part): both parts stage and classify the whole rectangle (the same decision, the same tile state), part p then takes the
-    // horizontal sums of rows [16 p, 16 p + 16 + 2 KH) and the vertical sums and stores of rows [16 p, 16 p + 16).  Of sixteen consecutive
-    // items the first eight are part 0 of eight tiles and the last eight part 1 of the same: a tile's two workgroups share an XCD.
+    // w = (tile, part) is a 64 x 16 tile of its own: it stages and classifies the 16 + 2 KH rows of the tile's rectangle from row 16 part on
+    // (its own uniform / unchanged / blur decision, its own tile state), takes their horizontal sums and the vertical sums and stores of its
+    // 16 rows.  Of sixteen consecutive items the first eight are part 0 of eight tiles and the last eight part 1 of the same: one XCD.
     static_assert(SPLIT == 1 || (SPLIT == 2 && KH > 0), "split tiles: compile-time half widths only");
     int32_t w_next = nitems;
     for (int32_t w = first_w; w < nitems; w = w_next) {
         w_next = next_item(w + (int32_t)gdx);
         const int32_t t = item_tile(w);
         const int32_t part = SPLIT == 1 ? 0 : (w >> 3) & 1;
+        const int32_t R0 = part * (LK_TH / SPLIT);                                      // the item's first row of the tile (and of its rectangle)
         const int32_t tile = tile_of(t);
         const int32_t tx0 = (qx0 + tile % qnx) * LK_TW, ty0 = (qy0 + tile / qnx) * LK_TH;
         // what this tile of likelihoodData / the factor table holds: 0 unknown, 1..3 the constants of a uniform tile
@@ -863,13 +868,13 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             uint32_t have_bits = 0;                                                     // bit 2q: element q is a cell of the rectangle
 #pragma unroll
             for (int q = 0; q < QM; q++) {
-                const int32_t r = e_wave + 4 * q;
-                classify(q, x_in && (uint32_t)(ty0 - KH + r) < (uint32_t)g.H);
-                if (r < CRH) have_bits |= 1u << (2 * q);
+                const int32_t r = e_wave + 4 * q;                                       // (a row of the item's CRS staged rows)
+                classify(q, x_in && (uint32_t)(ty0 + R0 - KH + r) < (uint32_t)g.H);
+                if (r < CRS) have_bits |= 1u << (2 * q);
             }
 #pragma unroll
             for (int j = 0; j < QS; j++) {
-                classify(QM + j, (uint32_t)(tx0 - KH + s_c[j]) < (uint32_t)g.W && (uint32_t)(ty0 - KH + s_r[j]) < (uint32_t)g.H);
+                classify(QM + j, (uint32_t)(tx0 - KH + s_c[j]) < (uint32_t)g.W && (uint32_t)(ty0 + R0 - KH + s_r[j]) < (uint32_t)g.H);
                 if (s_have[j]) have_bits |= 1u << (2 * (QM + j));
             }
             {
@@ -922,15 +927,15 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             if (!uniform && !unchanged) {
                 // stage {0, 0.5, 1} (outside the map: 0.0).  Every thread passed the barrier above, so the previous
                 // tile's reads of in_s and hs are over.
-                uint8_t *wb = in_b + e_wave * PINB + e_lane;
+                uint8_t *wb = in_b + (R0 + e_wave) * PINB + e_lane;
 #pragma unroll
                 for (int q = 0; q < QM; q++)
-                    if (e_wave + 4 * q < CRH) wb[q * 4 * PINB] = (uint8_t)((codes >> (2 * q)) & 3u);
+                    if (e_wave + 4 * q < CRS) wb[q * 4 * PINB] = (uint8_t)((codes >> (2 * q)) & 3u);
 #pragma unroll
                 for (int j = 0; j < QS; j++)
-                    if (s_have[j]) in_b[s_r[j] * PINB + s_c[j]] = (uint8_t)((codes >> (2 * (QM + j))) & 3u);
+                    if (s_have[j]) in_b[(R0 + s_r[j]) * PINB + s_c[j]] = (uint8_t)((codes >> (2 * (QM + j))) & 3u);
             }
-            if (w_next < nitems) issue_loads(item_tile(w_next));               // in flight during the rest of this tile
+            if (w_next < nitems) issue_loads(item_tile(w_next), item_row0(w_next));      // in flight during the rest of this tile
             if (unchanged) { if (part == 0) ts_left++; continue; }             // (one barrier, like a uniform tile)
             if (!uniform) __syncthreads();
         }
@@ -967,8 +972,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
             // ---- phase 2: strips of LK_STRIP outputs along x
             // (RH * 8 strips are 5.25 (KH = 5) wavefronts' worth: the wavefronts that take a second pass rotate from tile to tile,
             // so that over the tiles a workgroup walks no SIMD carries more of them than another)
-            constexpr int32_t RHP = LK_TH / SPLIT + 2 * (KH > 0 ? KH : 1);      // rows of horizontal sums this workgroup needs: all RH, or its part's
-            const int32_t R0 = part * (LK_TH / SPLIT);
+            constexpr int32_t RHP = CRS;                                        // rows of horizontal sums this workgroup needs: the rows it staged
             for (int32_t sidx = (int32_t)((threadIdx.x + 64u * (uint32_t)tile_iter) & 255u); sidx < RHP * (LK_TW / LK_STRIP); sidx += 256) {
                 const int32_t r = R0 + sidx / (LK_TW / LK_STRIP), c0 = (sidx % (LK_TW / LK_STRIP)) * LK_STRIP;
                 double v[LK_STRIP + 2 * (KH > 0 ? KH : 1)];
