@@ -1088,6 +1088,7 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
     double norm_sum, sq_sum;
     fold_neff(p2_all + (size_t)mi * nblk_global * 2, nblk_global, norm_sum, sq_sum, L.a);   // calculateNeff (SLAM.java:180-190)
     if (bx == 0 && threadIdx.x == 0) { stats[mi].norm_sum = norm_sum; stats[mi].sq_sum = sq_sum; }
+    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 5);                                              // (development builds) Neff folded
     const bool go = fraction < 0.0 || (1.0 / sq_sum) < fraction * (double)n_global;         // GridMapApp.java:185
     const int64_t nsuper = (nchunks + 63) / 64;
     double *sup = off + nchunks + 1;                                   // [nsuper + 1]
@@ -1141,6 +1142,7 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
         for (int64_t c = 64 + threadIdx.x; c < nchunks; c += blockDim.x) off[c] = sup[c >> 6] + off[c];   // super-chunk 0 adds nothing
         __syncthreads();
     }
+    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 6);                                              // chunk offsets scanned
     const int32_t t = (int32_t)bx * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const PackedParticle *g = glob_all + (size_t)mi * n_global;
@@ -1199,6 +1201,7 @@ resample_body(const PackedParticle *__restrict__ glob_all, int64_t n_global, int
             if (amb) atomicAdd(&stats[mi].n_ambiguous, 1);
         }
     }
+    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 7);                                              // source found
     const PackedParticle pp = g[src];
     const size_t o = (size_t)mi * n + t;
     pose2[3 * o] = pp.x; pose2[3 * o + 1] = pp.y; pose2[3 * o + 2] = pp.theta;

@@ -17,7 +17,7 @@ STAGES = {
     2: ("k_norm_raycast", {0: "entered", 1: "ray: pose folded", 2: "far: rays set up", 3: "far: recurrence done (producer)", 4: "far: first consumer done",
                            5: "far: box committed", 9: "near: tile cleared", 10: "near: 64 steps counted", 11: "near: tile flushed", 12: "near: box committed",
                            14: "normalise: left", 15: "apply: left"}),
-    3: ("k_lik_resample", {0: "entered", 1: "resample: left", 3: "likelihood: first tile staged", 4: "likelihood: first tile H pass done (non-uniform)", 2: "likelihood: left"}),
+    3: ("k_lik_resample", {0: "entered", 5: "resample: Neff folded", 6: "resample: chunk offsets scanned", 7: "resample: source found (thread 0)", 1: "resample: left", 3: "likelihood: first tile staged", 4: "likelihood: first tile H pass done (non-uniform)", 2: "likelihood: left"}),
 }
 
 
