@@ -928,6 +928,14 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
     torch.cuda.synchronize()
     pair = (time.perf_counter() - t0) / steps
     rsm = max(pair - upd, 0.0)
+    # the reference's loop with its rule decided on the device (gms_slam_resample_maps_if): update + conditional resample, nothing read back
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm_frames + 3 * steps + i)
+        s.resample_if(float(r01[(217 + i) % 4096]), 0.5)
+    torch.cuda.synchronize()
+    rev = (time.perf_counter() - t0) / steps
     # ... and `steps` draws back to back: every call first brings likelihoodData up to date, so both arrays move per call
     t0 = time.perf_counter()
     for i in range(steps):
@@ -966,6 +974,7 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
            "resample_ms": rsm * 1e3, "resample_what": ("in the update / resample loop; logData copied, likelihoodData's copy deferred (overwritten by the next "
                                                        "update's computeLikelihoodMap before anything reads it; materialised on demand)" if lazy else
                                                        "in the update / resample loop; both arrays copied at once"),
+           "revolution_ms": rev * 1e3, "revolution_what": "SLAM.update + `if (neff < n / 2) resample()` (GridMapApp.java:185-186) with the rule decided on the device: no host round trip",
            "resample_both_arrays_ms": rsm_both * 1e3, "resample_copy_TBps_algorithmic": copy_b / rsm_both / 1e12, "resample_copy_hbm_frac": copy_b / rsm_both / 8e12,
            "gridmapdata_bytes_on_device": 4.0 * 8 * cells * particles, "neff_last": st["neff"], "n_zero_weights": st["n_zero"],
            "kernels": kern}

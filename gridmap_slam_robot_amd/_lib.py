@@ -201,6 +201,7 @@ def load() -> C.CDLL:
     sig("gms_slam_update_per_particle", C.c_int, vp, vp, i32, i32, f64, f64, C.c_uint64, C.c_uint64, sp)
     sig("gms_slam_update_per_particle_dev", C.c_int, vp, vp, i32, i32, f64, f64, C.c_uint64, C.c_uint64, sp)
     sig("gms_slam_resample_maps", C.c_int, vp, f64, vp, vp)
+    sig("gms_slam_resample_maps_if", C.c_int, vp, f64, f64)
     sig("gms_slam_download_map", C.c_int, vp, i32, vp, vp)
     sig("gms_slam_upload_map", C.c_int, vp, i32, vp, vp)
     sig("gms_slam_download_maps", C.c_int, vp, vp, vp)

@@ -130,13 +130,15 @@ static int slam_lik_current(gms_slam *s) {
     return GMS_OK;
 }
 
-// SLAM.resample() (SLAM.java:133-153): the systematic draw over the particles' weights, then every slot's deep copy
-int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n_ambiguous) {
-    REQUIRE(s, "null handle");
+// SLAM.resample() (SLAM.java:133-153): the systematic draw over the particles' weights, then every slot's deep copy; fraction >= 0:
+// only where Neff < fraction * n (GridMapApp.java:185-186), decided on the device -- the copies are made either way, slot m from slot m
+// where the rule says no
+static int slam_resample(gms_slam *s, double r01, double fraction, int32_t *indices, int32_t *n_ambiguous) {
     gms_map *m = s->map;
     HIPCHK(hipSetDevice(m->device));
     int rc = slam_lik_current(s);                                                                          // (two resample() calls in a row)
-    if (!rc) rc = gms_pf_resample(s->pf, &r01, indices, n_ambiguous);                                      // :136-145 + pose, weight (:42-43)
+    if (!rc) rc = fraction >= 0.0 ? gms_pf_resample_if(s->pf, &r01, fraction)
+                                  : gms_pf_resample(s->pf, &r01, indices, n_ambiguous);                    // :136-145 + pose, weight (:42-43)
     if (rc) return rc;
     if (s->lazy_lik) {
         // logData now (GridMap.java:120); likelihoodData (:121) when it is asked for: SLAM.update starts with computeLikelihoodMap of
@@ -150,6 +152,17 @@ int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n
     s->copies += s->n;
     HIPCHK(hipGetLastError());
     return GMS_OK;
+}
+
+int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n_ambiguous) {
+    REQUIRE(s, "null handle");
+    return slam_resample(s, r01, -1.0, indices, n_ambiguous);
+}
+
+int gms_slam_resample_maps_if(gms_slam *s, double r01, double fraction) {
+    REQUIRE(s, "null handle");
+    REQUIRE(fraction >= 0.0, "gms_slam_resample_maps_if: fraction must be non-negative");
+    return slam_resample(s, r01, fraction, nullptr, nullptr);
 }
 
 static int slam_map_xfer(gms_slam *s, int32_t i, int32_t count, double *dev_base, double *host, bool to_device) {

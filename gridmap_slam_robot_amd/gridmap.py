@@ -804,6 +804,12 @@ class SLAMParticleMaps:
         check(load().gms_slam_resample_maps(self._h, r, ptr(idx) if want_indices else None, C.byref(amb) if want_indices else None))
         return (idx, amb.value) if want_indices else None
 
+    def resample_if(self, r01: Optional[float] = None, fraction: float = 0.5):
+        """`if (neff < fraction * n) resample()` (GridMapApp.java:185-186) decided on the device from the last update's Neff: no host
+        round trip (update_dev + resample_if is one revolution); pf.last_resample_indices() tells afterwards what happened"""
+        r = float(np.random.random() if r01 is None else r01)
+        check(load().gms_slam_resample_maps_if(self._h, r, float(fraction)))
+
     def get_weighted_pose(self) -> np.ndarray:
         return self.pf.weighted_pose()                                                                   # :165-178
 

@@ -304,6 +304,11 @@ int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int
  * anything on the path does (what a caller can see is the deep copy either way; GMS_SLAM_LAZY_LIK_COPY=0 moves both at once).
  * indices [n] / n_ambiguous as gms_pf_resample (either may be NULL). */
 int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n_ambiguous);
+/* `if (neff < fraction * n) resample()` -- the rule of SLAM.update's caller (J/app/GridMapApp.java:185-186) -- decided ON THE DEVICE from the
+ * Neff of the last update: nothing is read back, so update + this is one revolution without a host round trip.  Where the rule says no,
+ * every slot keeps its own particle and map (the copy is made all the same, slot m from slot m: the handle's generations flip either
+ * way).  gms_pf_last_resample_indices (on the filter of gms_slam_handles) tells afterwards what happened. */
+int gms_slam_resample_maps_if(gms_slam *s, double r01, double fraction);
 /* Particle i's GridMapData (SLAM.java:33; GridMap.java:72-74): W * H doubles each, either pointer may be NULL. */
 int gms_slam_download_map(gms_slam *s, int32_t i, double *log_data, double *lik);
 int gms_slam_upload_map(gms_slam *s, int32_t i, const double *log_data, const double *lik);

@@ -310,6 +310,8 @@ public:
     }
     /** resample() (:133-153); r01 stands for Math.random() */
     void resample(double r01) { check(gms_slam_resample_maps(h_, r01, nullptr, nullptr)); }
+    // `if (neff < fraction * n) resample()` (GridMapApp.java:185-186) decided on the device: update + this is a revolution without a host round trip
+    void resampleIf(double r01, double fraction = 0.5) { check(gms_slam_resample_maps_if(h_, r01, fraction)); }
     Pose getWeightedPose() { float o[3]; check(gms_pf_weighted_pose(pf_, o)); return Pose(o[0], o[1], o[2]); }      // :165-178
     double calculateNeff() { gms_pf_stats s{}; check(gms_pf_get_stats(pf_, &s)); return s.neff; }                    // :180-190
     std::vector<Particle> getParticles() {                                                  // :192

@@ -351,6 +351,7 @@ JNIEXPORT void JNICALL CLS(pmUpdate)(JNIEnv *env, jclass c, jlong s, jdoubleArra
 }
 /* SLAM.resample() (:133-153) with r = Math.random() drawn on the Java side */
 JNIEXPORT void JNICALL CLS(pmResample)(JNIEnv *env, jclass c, jlong s, jdouble r01) { throw_gms(env, gms_slam_resample_maps(SLAM(s), r01, NULL, NULL)); }
+JNIEXPORT void JNICALL CLS(pmResampleIf)(JNIEnv *env, jclass c, jlong s, jdouble r01, jdouble fraction) { throw_gms(env, gms_slam_resample_maps_if(SLAM(s), r01, fraction)); }
 /* getParticles() without the maps: {x, y, theta} and weight of every particle */
 JNIEXPORT void JNICALL CLS(pmGetParticles)(JNIEnv *env, jclass c, jlong s, jfloatArray xyt, jdoubleArray w, jint n) {
     gms_pf *pf = NULL;

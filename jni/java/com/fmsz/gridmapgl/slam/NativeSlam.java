@@ -46,6 +46,7 @@ final class NativeSlam {
     static native void pmReset(long s);
     static native void pmUpdate(long s, double[] beams, int B, boolean sampleMotion, double dCenter, double dTheta, long seed, long sequence, double[] weightSumNeffStrongest);
     static native void pmResample(long s, double r01);
+    static native void pmResampleIf(long s, double r01, double fraction);      // the rule of GridMapApp.java:185-186, decided on the device
     static native void pmGetParticles(long s, float[] xytheta, double[] weights, int n);
     static native void pmWeightedPose(long s, float[] out3);
     static native void pmDownloadMap(long s, int i, double[] logDataOrNull, double[] likelihoodDataOrNull);

@@ -56,6 +56,9 @@ public class SLAMGpu extends SLAM {
     @Override
     public void resample() { NativeSlam.pmResample(handle, Math.random()); }        // SLAM.java:133-153
 
+    /** {@code if (neff < fraction * n) resample()} (GridMapApp.java:185-186) without reading Neff back: update(z, u) then this is one revolution on the device */
+    public void resampleIf(double fraction) { NativeSlam.pmResampleIf(handle, Math.random(), fraction); }
+
     @Override
     public Pose getWeightedPose() {                                                 // SLAM.java:165-178
         float[] o = new float[3];

@@ -273,6 +273,47 @@ def test_resample_copies_likelihood_data_late_or_at_once(lazy, monkeypatch):
     dev.close()
 
 
+def test_the_resampling_rule_decided_on_the_device():
+    """update (nothing read back) + resample_if(r, 0.5) per revolution -- GridMapApp.java:185-186 without the host round trip -- against
+    the oracle's `if (update(z, u) < n / 2) resample()`: the same steps resample (the indices say which), the same maps at the end.  A
+    second filter whose weights never collapse (every scan empty: Neff = n) must never resample: identity indices, maps as they were."""
+    ext, res, B, N, T = 4.0, 0.05, 60, 64, 14
+    tr = synth.make_trace(ext, res, B, T=T, seed=23)
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    dev = SLAMParticleMaps(ext, ext, res, (-ext / 2, -ext / 2), num_particles=N, max_beams=128)
+    o = orc.Slam(g, N)
+    P = synth.make_particles(tr.poses[0], N, seed=2, sigma_xy=0.05, sigma_theta_deg=3.0)
+    dev.set_poses(P); o.set_poses(P)
+    rng = np.random.default_rng(3)
+    did = 0
+    for k in range(T):
+        z = tr.scans[k]
+        dev.update(z, None, fetch=False)
+        neff_o = o.update(z, None, threads=THREADS)
+        r01 = float(rng.random())
+        dev.resample_if(r01, 0.5)
+        idx = dev.pf.last_resample_indices().reshape(-1)
+        if neff_o < N / 2:
+            want, _ = o.resample(r01)
+            assert np.array_equal(idx, want), f"scan {k}"
+            did += 1
+        else:
+            assert np.array_equal(idx, np.arange(N)), f"scan {k}: no resampling step was due"
+    assert 0 < did
+    _compare_maps(dev, o, "after the last revolution")
+    assert np.array_equal(dev.get_particles()[0], o.poses)
+    # never due
+    dev.reset(); dev.set_poses(P)
+    dev.update(tr.scans[0], None)
+    logs = dev.maps().copy()
+    for k in range(3):
+        dev.update(tr.scans[0][:0], None, fetch=False)
+        dev.resample_if(0.3, 0.5)
+        assert np.array_equal(dev.pf.last_resample_indices().reshape(-1), np.arange(N))
+    assert np.array_equal(dev.maps(), logs)
+    dev.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_call_sequences_against_the_oracle(seed):
     """forty calls drawn at random -- update (with and without the motion sample, sometimes with a turn that skips the integration),

@@ -9,6 +9,7 @@ import numpy as np, torch
 from gridmap_slam_robot_amd import SLAMParticleMaps, synth
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+DEVICE_RULE = len(sys.argv) > 3 and sys.argv[3] == "device"        # the rule decided on the device (resample_if): no round trip per scan
 ext, res, B, T = 6.0, 0.05, 90, 48
 frames, truth = synth.make_recording(ext, B, T=T, seed=77)
 start = synth.true_pose(synth.make_world(ext, 77), -1, T)
@@ -19,15 +20,23 @@ rng = np.random.default_rng(1)
 t0 = time.perf_counter(); k = 0; resampled = 0; worst = 0.0
 while time.perf_counter() - t0 < seconds:
     z, u = scans[k % T]
-    neff = s.update(z, u, seed=3, sequence=k)
-    assert np.isfinite(neff) and 1.0 - 1e-9 <= neff <= N + 1e-6, (k, neff)
-    if neff < N / 2:
-        s.resample(float(rng.random())); resampled += 1
+    if DEVICE_RULE:
+        s.update(z, u, seed=3, sequence=k, fetch=False)
+        s.resample_if(float(rng.random()), 0.5)
+        if k % 1024 == 0:
+            resampled += int(np.asarray(s.pf.did_resample()).reshape(-1)[0])           # (a sample: one scan in 1024)
+    else:
+        neff = s.update(z, u, seed=3, sequence=k)
+        assert np.isfinite(neff) and 1.0 - 1e-9 <= neff <= N + 1e-6, (k, neff)
+        if neff < N / 2:
+            s.resample(float(rng.random())); resampled += 1
     if k % T == T - 1:
         wp = s.get_weighted_pose(); tp = truth[T - 1]
         worst = max(worst, float(np.hypot(wp[0] - tp[0], wp[1] - tp[1])))
     k += 1
 el = time.perf_counter() - t0
 w = s.get_particles()[1]
-print(f"{k} scans in {el:.1f} s ({el / k * 1e6:.0f} us per scan, host round trip included), {resampled} resampling steps, weights finite: {bool(np.isfinite(w).all())}, "
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+print(f"{k} scans in {el:.1f} s ({el / k * 1e6:.0f} us per scan, {'rule decided on the device, no round trip' if DEVICE_RULE else 'host round trip included'}), {resampled} resampling steps{' (of the one scan in 1024 that was asked)' if DEVICE_RULE else ''}, weights finite: {bool(np.isfinite(w).all())}, "
       f"sum {w.sum():.15f}, worst end-of-lap distance of the weighted pose from the true one {worst:.3f} m, maps copied {s.maps_copied()}")
