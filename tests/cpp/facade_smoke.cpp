@@ -29,6 +29,8 @@ int main() {
         double neff2 = 0.0;
         for (int k = 0; k < 3; k++) neff2 = pm.update(z, u, 7, (uint64_t)k);
         pm.resample(0.3);
+        pm.update(z, u, 7, 3);
+        pm.resampleIf(0.6, 0.5);                                                            // GridMapApp.java:185-186, decided on the device
         const std::vector<double> m0 = pm.mapOf(0), comb = pm.calculateCombined();
         bool touched = false;
         for (double v : m0) touched = touched || v != 0.0;
