@@ -198,6 +198,7 @@ def load() -> C.CDLL:
     sig("gms_slam_reset", C.c_int, vp)
     sig("gms_slam_count", C.c_int, vp, vp, vp, vp)
     sig("gms_slam_handles", C.c_int, vp, C.POINTER(vp), C.POINTER(vp))
+    sig("gms_slam_set_refine", C.c_int, vp, i32)
     sig("gms_slam_update_per_particle", C.c_int, vp, vp, i32, i32, f64, f64, C.c_uint64, C.c_uint64, sp)
     sig("gms_slam_update_per_particle_dev", C.c_int, vp, vp, i32, i32, f64, f64, C.c_uint64, C.c_uint64, sp)
     sig("gms_slam_resample_maps", C.c_int, vp, f64, vp, vp)

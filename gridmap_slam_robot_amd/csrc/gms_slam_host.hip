@@ -51,6 +51,8 @@ int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out) { 
     const size_t bytes = (size_t)n_particles * (size_t)m->gd.cells * sizeof(double);
     const char *lazy_env = getenv("GMS_SLAM_LAZY_LIK_COPY");
     s->lazy_lik = !(lazy_env && lazy_env[0] == '0');
+    const char *rl_env = getenv("GMS_SLAM_REFINE_LDS");
+    s->refine_lds = rl_env && rl_env[0] == '0' ? 0 : -1;
     bool ok = true;
     for (int k = 0; k < 2; k++)
         ok = ok && hipMalloc(&s->d_log[k], bytes) == hipSuccess && hipMalloc(&s->d_lik[k], bytes) == hipSuccess;
@@ -75,6 +77,12 @@ int gms_slam_reset(gms_slam *s) {                                               
     gms_launch_pf_init(s->pf);                                                               // Pose(0, 0, 0), weight 1 / numParticles (:68-71)
     s->pf->pending_nseg = 0; s->pf->have_global = 0; s->pf->stats_current = 0; s->pf->score_fresh = 0;
     HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+
+int gms_slam_set_refine(gms_slam *s, int32_t on) {                                          // SLAM.java:96
+    REQUIRE(s, "null handle");
+    s->refine = on != 0;
     return GMS_OK;
 }
 
@@ -106,7 +114,13 @@ int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int
     mo.d_center = d_center; mo.d_theta = d_theta; mo.seed = seed; mo.sequence = sequence;
     gms_launch_slam_likelihood(m, s->d_log[s->cur], s->d_lik[s->cur], s->n);                                // :93 for every particle
     s->lik_behind = 0;                                                                                     // (every cell of every field has just been written)
-    gms_launch_slam_particle(pf, dev_beams, B, s->d_log[s->cur], s->d_lik[s->cur], sample_motion ? &mo : nullptr, skip_update ? 0 : 1);   // :90, :99, :102-107
+    bool drawn = false;
+    if (s->refine) {                                                                                        // :90, then :96 (the lattice form of :97)
+        if (!gms_launch_slam_refine(pf, dev_beams, B, s->d_lik[s->cur], sample_motion ? &mo : nullptr, s->refine_lds))
+            return gms_fail(GMS_ERR_INVALID, "gms_slam_update_per_particle: the pose refinement's tables do not fit the LDS for a scan of %d beams", B);
+        drawn = true;
+    }
+    gms_launch_slam_particle(pf, dev_beams, B, s->d_log[s->cur], s->d_lik[s->cur], sample_motion && !drawn ? &mo : nullptr, skip_update ? 0 : 1);   // :90, :99, :102-107
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());

@@ -386,6 +386,253 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// GridMap.findBestPose inside SLAM.update (SLAM.java:96 -> GridMap.java:319-346), every particle against ITS OWN field.
+// One workgroup per particle.  The lattice is the reference's: float loop counters `d += step` (:328-330), 11 x 11 x 10 poses, each
+// scored by probabilityOf (:261-294): 1210 x (hit beams) look-ups per particle.
+//   * The particle's field is 115 KB at the reference's 120 x 120 cells: it is staged ONCE into the CU's LDS as the per-cell FACTOR of
+//     probabilityOf (:285-288) with a border of the neutral factor 1.0 (a beam that ends outside the map leaves the product alone,
+//     :276).  (k_refine, the shared-map form, gathers from memory and is bound by the L1 address pipe.)
+//   * A look-up's cell is (gx, gy) = ((int)((x c - y s + px - posx) / res), (int)((x s + y c + py - posy) / res)): gx depends on
+//     the lattice pose through (theta step, dx step) only and gy through (theta step, dy step) only.  Both are therefore computed
+//     once per (theta, dx | dy, beam) -- 10 x 22 x beams coordinates instead of 1210 x 2 x beams, the reference's expressions in
+//     the reference's order (Transform.java:23,28; GridMap.java:273-274) -- into LDS tables of 16-bit entries: min(gx, W) and
+//     min(gy, H) x pitch, so that a look-up is  factor[tx[j] + ty[j]]  and the border does the bounds test.  A lane (= one lattice
+//     pose) reads its two table rows eight beams at a time (they are contiguous in j) and multiplies its factors beam by beam in
+//     beam order: the reference's plain double product (:262-288).
+//   * wave task = (theta step, 64 of the (dx, dy) pairs).  argmax with the reference's rule: strict `>` against maxProb = 0 in loop
+//     order, i.e. the first maximum wins (:334).
+// (First built with the cell arithmetic per look-up -- 23 vector instructions each, the busiest SIMD issuing 6 tasks x 86 beams of
+// them: 67 us per launch at 500 x 120 x 120 x 90, of which the LDS gather itself was 6: profiles/r06/refine_notes.md.)
+// LDSF = false: the field stays in memory (maps too large for the LDS: 256 x 256 cells are 512 KB), factor formed at the look-up.
+// The motion-model sample (SLAM.java:90) is drawn here when refinement is on: it precedes findBestPose (:90 -> :96).
+// ---------------------------------------------------------------------------------------------
+#define SR_NT 640                       // ten wavefronts: the lattice is 10 theta steps x 2 wavefronts of (dx, dy) pairs
+#define SR_MAXSTEPS 16
+// the reference's float loop `for (float d = -span; d < span; d += step)` (GridMap.java:328-330): the offsets and how many
+__host__ __device__ inline int32_t slam_lattice_steps(float span, float step, float *out) {
+    int32_t c = 0;
+    for (float d = -span; d < span && c < SR_MAXSTEPS; d += step) { if (out) out[c] = d; c++; }
+    return c;
+}
+#define SR_XSPAN 0.20f
+#define SR_TRANS_STEP 0.04f
+#define SR_THETA_SPAN ((float)(15 * (3.141592653589793 / 180.0)))       // GridMap.java:324
+#define SR_THETA_STEP (SR_THETA_SPAN / 5)                               // :325
+
+template <bool LDSF>
+__global__ void __launch_bounds__(SR_NT)
+k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, const double *__restrict__ lik_all,
+              float *__restrict__ pose, float *__restrict__ cs, MotionArgs mo, int32_t fp, int32_t nt_batch) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NW = SR_NT / 64;
+    double *s_f = reinterpret_cast<double *>(smem);                            // [H + 1][fp] factors, column W and row H neutral (LDSF)
+    // (every carve offset a multiple of 16: a 16-byte LDS access off its alignment is replayed at 64 cycles -- 121 x 121 doubles are not)
+    double2 *s_hb = reinterpret_cast<double2 *>(s_f + (LDSF ? (((size_t)(g.H + 1) * fp + 1) & ~(size_t)1) : 0));    // [Bpad] the hit beams' (localX, localY), in beam order
+    uint16_t *s_tab = reinterpret_cast<uint16_t *>(s_hb + Bpad);               // [nt_batch][nx + ny][Bpad] cell coordinates (see above)
+    __shared__ float s_dx[SR_MAXSTEPS], s_dy[SR_MAXSTEPS], s_dt[SR_MAXSTEPS], s_c[SR_MAXSTEPS], s_s[SR_MAXSTEPS];
+    __shared__ int32_t s_n[3], s_nhit;
+    __shared__ float s_pose[3];
+    __shared__ double s_best[NW];
+    __shared__ int32_t s_bestq[NW];
+    const int32_t p = blockIdx.x;
+    const int32_t lane = threadIdx.x & 63;
+    const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6));
+    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 0);
+
+    if (wave == 0) {                                   // sampleMotionModel (SLAM.java:90), as k_slam_particle draws it; the theta steps' trig
+        float x = pose[3 * (size_t)p], y = pose[3 * (size_t)p + 1], th = pose[3 * (size_t)p + 2], c, sn;
+        if (mo.on) {
+            motion_apply(x, y, th, c, sn, (uint64_t)p, mo.d_center, mo.d_theta, mo.d_center_sd, mo.d_theta_sd, mo.seed, mo.sequence);
+            if (lane == 0) {
+                pose[3 * (size_t)p] = x; pose[3 * (size_t)p + 1] = y; pose[3 * (size_t)p + 2] = th;
+                cs[2 * (size_t)p] = c; cs[2 * (size_t)p + 1] = sn;
+            }
+        }
+        if (lane == 0) { s_pose[0] = x; s_pose[1] = y; s_pose[2] = th; }
+        // lane l: the l-th value of the reference's float counter dTheta (:330) and Transform.fromRobotToWorld's float trig of
+        // theta + dTheta (Transform.java:15-16)
+        float d = -SR_THETA_SPAN;
+        int32_t cnt = 0;
+        bool mine = false;
+        for (int32_t k = 0; k < SR_MAXSTEPS; k++) {
+            if (!(d < SR_THETA_SPAN)) break;
+            cnt++;
+            if (k == lane) { mine = true; break; }
+            d += SR_THETA_STEP;
+        }
+        if (mine) {
+            float tc, ts;
+            pose_trig(th + d, tc, ts);
+            s_dt[lane] = d; s_c[lane] = tc; s_s[lane] = ts;
+        }
+        if (lane == SR_MAXSTEPS) s_n[2] = cnt;         // (a lane beyond the last step has counted them all)
+        GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 1);
+    } else if (wave == 1) {                            // the lattice's translations (GridMap.java:324-329)
+        if (lane == 0) s_n[0] = slam_lattice_steps(SR_XSPAN, SR_TRANS_STEP, s_dx);
+        if (lane == 1) s_n[1] = slam_lattice_steps(SR_XSPAN, SR_TRANS_STEP, s_dy);
+    } else if (wave == 2) {                            // `if (!m.wasHit) continue` (:269): the hit beams, order kept
+        int32_t base = 0;
+        for (int32_t b0 = 0; b0 < B; b0 += 64) {
+            const int32_t b = b0 + lane;
+            const bool hit = b < B && beams[b].hit != 0;
+            const unsigned long long mask = __ballot(hit);
+            if (hit) s_hb[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_double2(beams[b].local_x, beams[b].local_y);
+            base += __popcll(mask);
+        }
+        if (lane == 0) s_nhit = base;
+    }
+    const double *lik = lik_all + (size_t)p * (size_t)g.cells;
+    if (LDSF) {
+        // the factor of every cell (:285-288): wavefront = rows, lane = a pair of columns, a row's loads issued together; then the border
+        // (wavefront 0 joins when its pose and trig are done -- 2.6 us, which its share of the rows would otherwise follow: it takes none)
+        if ((g.W & 1) == 0) {
+            constexpr int NS = NW - 1;
+            const int32_t w2 = g.W >> 1;
+            for (int32_t y0r = wave - 1; wave > 0 && y0r < g.H; y0r += 4 * NS) {
+                double2 v[4];
+                for (int32_t x2 = lane; x2 < w2; x2 += 64) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = reinterpret_cast<const double2 *>(lik + (size_t)min(y0r + u * NS, g.H - 1) * g.W)[x2];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (y0r + u * NS < g.H) {
+                            double *row = s_f + (size_t)(y0r + u * NS) * fp + 2 * x2;
+                            row[0] = lik_factor(g, v[u].x); row[1] = lik_factor(g, v[u].y);
+                        }
+                }
+            }
+        } else {
+            for (int32_t i = threadIdx.x; i < g.W * g.H; i += SR_NT) {
+                const int32_t y = i / g.W, x = i - y * g.W;
+                s_f[y * fp + x] = lik_factor(g, lik[i]);
+            }
+        }
+        for (int32_t i = threadIdx.x; i < g.H; i += SR_NT) s_f[i * fp + g.W] = 1.0;
+        for (int32_t i = threadIdx.x; i <= g.W; i += SR_NT) s_f[g.H * fp + i] = 1.0;
+    }
+    GMS_STAMP_T(SR_NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 2);
+    __syncthreads();
+    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 3);
+#if defined(SR_EXP) && SR_EXP == 1            // experiment: staging only
+    if (s_nhit >= 0) return;
+#endif
+    const int32_t nx = s_n[0], ny = s_n[1], nt = s_n[2], nhit = s_nhit;
+    const float x0 = s_pose[0], y0 = s_pose[1], t0 = s_pose[2];
+    const int32_t nc = nx + ny;
+    const int32_t nxy = nx * ny, nhalf = (nxy + 63) >> 6;
+    double best = 0.0;                                 // maxProb = 0 (:321)
+    int32_t bestq = INT32_MAX;                         // none yet: the start pose stays (:320)
+    for (int32_t it0 = 0; it0 < nt; it0 += nt_batch) {         // (all theta steps at once where the tables fit beside the field)
+        const int32_t ntb = min(nt_batch, nt - it0);
+        if (it0 > 0) __syncthreads();                  // the previous batch's tables have been read
+        // ---- the tables: entry (theta step, coordinate c, beam j), j fastest.  A work item is one (theta step, x | y, beam): the
+        //      rotated beam once, then the nx (ny) lattice offsets along that axis.  One expression for both coordinates:
+        //      x s + y c == x s - y (-c) bit for bit (negation is exact), so gy is gx's arithmetic with (s, -c) for (c, s).
+        for (int32_t i = threadIdx.x; i < ntb * 2 * nhit; i += SR_NT) {
+            const int32_t j = i % nhit, r2 = i / nhit, itl = r2 >> 1;
+            const bool isx = (r2 & 1) == 0;
+            const float cf = s_c[it0 + itl], sf = s_s[it0 + itl];
+            const double A = (double)(isx ? cf : sf), Bn = (double)(isx ? sf : -cf);
+            const double2 bm = s_hb[j];
+            const double rot = bm.x * A - bm.y * Bn;                                       // Transform.java:23,28 before `+ px`
+            const double pos = isx ? g.posx : g.posy;
+            const uint32_t lim = (uint32_t)(isx ? g.W : g.H), mul = LDSF && !isx ? (uint32_t)fp : 1u;
+            const float base = isx ? x0 : y0;
+            const float *dd = isx ? s_dx : s_dy;
+            const int32_t nk = isx ? nx : ny;
+            uint16_t *out = s_tab + ((size_t)(itl * nc + (isx ? 0 : nx)) * Bpad + j);
+            bool guard = false;                            // (one for the work item: the loop below has no branch and is unrolled)
+#pragma unroll 4
+            for (int32_t k = 0; k < nk; k++) {
+                const double w = rot + (double)(base + dd[k]) - pos;                       // :332 (a float sum) ... - position (:273-274)
+                out[(size_t)k * Bpad] = (uint16_t)(min((uint32_t)j_cell_fast(w, g.rinv, guard), lim) * mul);
+            }
+            if (__builtin_expect(guard, 0))                // a quotient within 2^-19 of an integer: the reference's division decides
+                for (int32_t k = 0; k < nk; k++) {
+                    const double w = rot + (double)(base + dd[k]) - pos;
+                    out[(size_t)k * Bpad] = (uint16_t)(min((uint32_t)j_cell_exact(w, g.res), lim) * mul);
+                }
+        }
+        GMS_STAMP_T(SR_NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 4);
+        __syncthreads();
+        GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 5);
+#if defined(SR_EXP) && SR_EXP == 2            // experiment: staging and tables
+        continue;
+#endif
+        // ---- the look-ups
+        for (int32_t task = wave; task < ntb * nhalf; task += NW) {
+            const int32_t itl = task / nhalf, e = (task - itl * nhalf) * 64 + lane;
+            const bool live = e < nxy;
+            const int32_t ec = live ? e : 0;
+            const int32_t ix = ec / ny, iy = ec - ix * ny;
+            const uint16_t *tx = s_tab + (size_t)(itl * nc + ix) * Bpad, *ty = s_tab + (size_t)(itl * nc + nx + iy) * Bpad;
+            auto factor_at = [&](uint32_t ex, uint32_t ey) -> double {
+                if (LDSF) {
+                    return s_f[ex + ey];
+                } else {
+                    const bool in = ex < (uint32_t)g.W && ey < (uint32_t)g.H;                      // :276
+                    const double v = lik[in ? (size_t)ey * g.W + ex : 0];
+                    return in ? lik_factor(g, v) : 1.0;
+                }
+            };
+            double prod = 1.0;                                                             // :262
+            // Eight beams per pass, software-pipelined: with two or three wavefronts per SIMD a pass that read its table rows,
+            // waited, read its factors, waited, and multiplied took 470 clocks per wavefront (three LDS latencies in a row).  Now
+            // pass i multiplies while pass i + 1's factors and pass i + 2's table rows are in flight (LDS returns in order).
+            const int32_t npass = nhit >> 3;               // (Bpad is a multiple of 8: the rows are 16-byte aligned)
+            uint4 ta = make_uint4(0, 0, 0, 0), tb = ta;
+            double fc[8], fn[8];
+            auto issue = [&](double (&f)[8]) {
+                const uint32_t ax[4] = {ta.x, ta.y, ta.z, ta.w}, bx[4] = {tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    f[2 * u] = factor_at(ax[u] & 0xffffu, bx[u] & 0xffffu);
+                    f[2 * u + 1] = factor_at(ax[u] >> 16, bx[u] >> 16);
+                }
+            };
+            if (npass > 0) {
+                ta = *reinterpret_cast<const uint4 *>(tx); tb = *reinterpret_cast<const uint4 *>(ty);
+                issue(fc);
+                if (npass > 1) { ta = *reinterpret_cast<const uint4 *>(tx + 8); tb = *reinterpret_cast<const uint4 *>(ty + 8); }
+            }
+            for (int32_t ps = 0; ps < npass; ps++) {
+                if (ps + 1 < npass) {
+                    issue(fn);
+                    if (ps + 2 < npass) { ta = *reinterpret_cast<const uint4 *>(tx + 8 * (ps + 2)); tb = *reinterpret_cast<const uint4 *>(ty + 8 * (ps + 2)); }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) prod *= fc[u];                                 // beams in order (:267-288)
+#pragma unroll
+                for (int u = 0; u < 8; u++) fc[u] = fn[u];
+            }
+            int32_t j = npass << 3;
+            for (; j < nhit; j++) prod *= factor_at(tx[j], ty[j]);
+            const int32_t q = (ix * ny + iy) * nt + it0 + itl;                             // the reference's loop order: theta fastest
+            if (live && (prod > best || (prod == best && prod > 0.0 && q < bestq))) { best = prod; bestq = q; }   // :334
+        }
+    }
+    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 6); GMS_STAMP_T(SR_NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 7); GMS_STAMP_T(128, GMS_STAMP_ROW(3, blockIdx.x), 8);
+    // the first maximum over the lattice: the larger probability wins, of equal ones the earlier pose
+#define GMS_STEP_(O) { const double v2 = wave_xor<O>(best); const int32_t q2 = wave_xor<O>(bestq); \
+                       if (v2 > best || (v2 == best && q2 < bestq)) { best = v2; bestq = q2; } }
+    GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
+    if (lane == 0) { s_best[wave] = best; s_bestq[wave] = bestq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b = 0.0; int32_t bq = INT32_MAX;
+        for (int k = 0; k < NW; k++)
+            if (s_best[k] > b || (s_best[k] == b && s_bestq[k] < bq)) { b = s_best[k]; bq = s_bestq[k]; }
+        if (bq != INT32_MAX) {
+            const int32_t it = bq % nt, iy = (bq / nt) % ny, ix = bq / (nt * ny);
+            pose[3 * (size_t)p] = x0 + s_dx[ix]; pose[3 * (size_t)p + 1] = y0 + s_dy[iy]; pose[3 * (size_t)p + 2] = t0 + s_dt[it];
+            cs[2 * (size_t)p] = s_c[it]; cs[2 * (size_t)p + 1] = s_s[it];
+        }
+    }
+    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 9);
+}
+
 // resample()'s deep copies (SLAM.java:147 -> :41-45 -> GridMap.java:106-124): slot m of the new generation receives both arrays of
 // particle idx[m]'s map.  grid = (chunks, N); a workgroup streams its chunk of both arrays, 16 bytes per lane, four loads in flight.
 __global__ void __launch_bounds__(256)
@@ -529,6 +776,46 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, do
 #undef PS_LAUNCH
     pf->pending_nseg = 0;
     pf->score_fresh = 1;
+}
+
+// findBestPose for every particle of pf against its own field d_lik [n][cells] (SLAM.java:96); motion (may be NULL): the motion-model
+// sample of SLAM.java:90 is drawn first.  field_in_lds: -1 the launcher decides (whenever it fits), 0 never (tests of the other form).
+// Returns false (nothing launched) where a theta step's tables do not fit a workgroup's LDS (scans of more than ~2600 beams) or a
+// map side does not fit their 16-bit entries.
+bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, const double *d_lik, const MotionModel *motion, int32_t field_in_lds) {
+    gms_map *m = pf->map;
+    if (m->gd.W > 65535 || m->gd.H > 65535) return false;
+    MotionArgs mo;
+    mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0;
+    if (motion) {
+        mo.on = 1; mo.d_center = motion->d_center; mo.d_theta = motion->d_theta; mo.seed = motion->seed; mo.sequence = motion->sequence;
+        mo.d_center_sd = (0.01 + fabs(motion->d_center) * 0.05) / 2;             // Odometry.java:63
+        mo.d_theta_sd = 5 * (3.141592653589793 / 180.0) + 0.1 * fabs(motion->d_theta);   // :64
+    }
+    const int32_t Bpad = B < 8 ? 8 : (B + 7) & ~7;
+    const int32_t nt = slam_lattice_steps(SR_THETA_SPAN, SR_THETA_STEP, nullptr);
+    const int32_t nc = 2 * slam_lattice_steps(SR_XSPAN, SR_TRANS_STEP, nullptr);
+    const int32_t fp = m->gd.W + 1;
+    const size_t beams_b = (size_t)Bpad * 16, tab1_b = (size_t)nc * Bpad * 2, field_b = (((size_t)(m->gd.H + 1) * fp + 1) & ~(size_t)1) * 8;
+    const size_t room = (size_t)m->lds_per_cu - 2048;                            // (static LDS: 0.5 KB; allocation granularity)
+    if (beams_b + tab1_b > room) return false;
+    ProfScope ps(m, GMS_K_REFINE);
+    // the field in LDS: its 16-bit table entries must hold (H + 1) * pitch, and one theta step's tables must fit beside it
+    const bool ldsf = field_in_lds != 0 && (size_t)(m->gd.H + 1) * fp <= 65535 && field_b + beams_b + tab1_b <= room;
+    const size_t left = (ldsf ? room - field_b : std::max((size_t)96 * 1024, beams_b + tab1_b)) - beams_b;
+    int32_t nt_batch = (int32_t)(left / tab1_b);
+    if (nt_batch > nt) nt_batch = nt;
+    if (nt_batch < 1) nt_batch = 1;
+    const size_t smem = (ldsf ? field_b : 0) + beams_b + (size_t)nt_batch * tab1_b;
+#define SR_LAUNCH(LF)                                                                                                                  \
+    do {                                                                                                                                \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_refine<LF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((k_slam_refine<LF>), dim3((unsigned)pf->n), dim3(SR_NT), smem, m->stream, m->gd, d_beams, B, Bpad, d_lik,      \
+                           pf->d_pose, pf->d_cs, mo, fp, nt_batch);                                                                    \
+    } while (0)
+    if (ldsf) SR_LAUNCH(true); else SR_LAUNCH(false);
+#undef SR_LAUNCH
+    return true;
 }
 
 void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx, int32_t *d_idx_keep) {

@@ -771,6 +771,11 @@ class SLAMParticleMaps:
     def reset(self):
         check(load().gms_slam_reset(self._h))                                                            # :65-77
 
+    def set_refine(self, on: bool = True):
+        """update() runs GridMap.findBestPose (J/slam/GridMap.java:319-346) for every particle against its own likelihood field
+        before weighting it (SLAM.java:96; the reference calls findBestPoseOptim, :97, and keeps this search commented out beside it)"""
+        check(load().gms_slam_set_refine(self._h, int(bool(on))))
+
     def update(self, z, odometry=None, seed: int = 0, sequence: Optional[int] = None, fetch: bool = True, sample_motion: bool = True):
         """update(z, u) (:80-131); odometry = (dCenter, dTheta) or None (= (0, 0) and no motion sample: `u == null` in
         sampleMotionModel, :159); sample_motion = False keeps the poses (dTheta still decides skipUpdate, :82); returns Neff"""
@@ -837,6 +842,9 @@ class SLAMParticleMaps:
     def set_map(self, i: int, log=None, lik=None):
         lg = None if log is None else np.ascontiguousarray(log, dtype=np.float64)
         lk = None if lik is None else np.ascontiguousarray(lik, dtype=np.float64)
+        for name, a in (("log", lg), ("lik", lk)):          # (the library copies W * H doubles from the pointer it is given)
+            if a is not None and a.size != self.W * self.H:
+                raise ValueError(f"set_map: {name} has {a.size} values, the map has {self.W} x {self.H} cells")
         check(load().gms_slam_upload_map(self._h, int(i), None if lg is None else ptr(lg), None if lk is None else ptr(lk)))
 
     def calculate_combined(self) -> np.ndarray:

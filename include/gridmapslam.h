@@ -297,6 +297,14 @@ int gms_slam_update_per_particle(gms_slam *s, const gms_beam *beams, int32_t B, 
                                  uint64_t seed, uint64_t sequence, gms_pf_stats *stats);
 int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
                                      uint64_t seed, uint64_t sequence, gms_pf_stats *stats);
+/* SLAM.update's pose refinement (SLAM.java:96-97): on != 0, every update runs GridMap.findBestPose (J/slam/GridMap.java:319-346: the
+ * lattice of 11 x 11 x 10 poses around the motion-model sample, float loop counters, strict `>` against maxProb = 0 so that the first
+ * maximum wins) for every particle against ITS OWN likelihood field, between computeLikelihoodMap(p.m) (:93) and the weighting (:99);
+ * the particle is then weighted, and its map updated, at the refined pose.  The reference calls findBestPoseOptim (:97: BOBYQA from
+ * commons-math on an objective that is 0 / NaN) and keeps this search commented out beside it (:96).  One workgroup per
+ * particle; the particle's field is staged into the CU's LDS as probabilityOf's factors when it fits (120 x 120 cells: 115 KB of 160),
+ * read from memory otherwise (GMS_SLAM_REFINE_LDS=0 forces that form).  Default off. */
+int gms_slam_set_refine(gms_slam *s, int32_t on);
 /* SLAM.resample() (SLAM.java:133-153) with Math.random() = r01: the systematic draw over the particles' weights, then every slot's
  * deep copy -- pose, weight (:42-43) and both arrays of the map (:44, GridMap.java:118-121): map[m] <- map[idx[m]], double-buffered,
  * a pure HBM stream.  logData moves at once (16 bytes per cell); likelihoodData's copy is made when something reads it -- a download,

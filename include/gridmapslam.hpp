@@ -179,6 +179,7 @@ public:
         return out;
     }
     void setPoses(const std::vector<Pose> &poses) {
+        if (poses.size() < (size_t)n_) throw Error(GMS_ERR_INVALID, "SlamParticleMaps::setPoses: fewer poses than particles");
         std::vector<float> p((size_t)n_ * 3);
         for (int i = 0; i < n_; i++) { p[3 * i] = poses[i].x; p[3 * i + 1] = poses[i].y; p[3 * i + 2] = poses[i].theta; }
         check(gms_pf_set_poses(h_, p.data()));
@@ -300,6 +301,8 @@ public:
     SlamParticleMaps &operator=(const SlamParticleMaps &) = delete;
 
     void reset() { check(gms_slam_reset(h_)); }                                             // :65-77
+    /** update() refines every particle's pose with GridMap.findBestPose against the particle's own field before weighting it (:96) */
+    void setRefine(bool on) { check(gms_slam_set_refine(h_, on ? 1 : 0)); }
     /** update(z, u) (:80-131); returns Neff.  seed / sequence select the motion model's variates (one sequence per frame). */
     double update(const Observation &z, const Odometry &u, uint64_t seed, uint64_t sequence, bool sampleMotion = true) {
         gms_pf_stats st{};
@@ -324,6 +327,7 @@ public:
         return out;
     }
     void setPoses(const std::vector<Pose> &poses) {
+        if (poses.size() < (size_t)n_) throw Error(GMS_ERR_INVALID, "SlamParticleMaps::setPoses: fewer poses than particles");
         std::vector<float> p((size_t)n_ * 3);
         for (int i = 0; i < n_; i++) { p[3 * i] = poses[i].x; p[3 * i + 1] = poses[i].y; p[3 * i + 2] = poses[i].theta; }
         check(gms_pf_set_poses(pf_, p.data()));

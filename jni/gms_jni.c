@@ -338,6 +338,7 @@ JNIEXPORT jlong JNICALL CLS(pmCreate)(JNIEnv *env, jclass c, jfloat w, jfloat h,
 }
 JNIEXPORT void JNICALL CLS(pmDestroy)(JNIEnv *env, jclass c, jlong s) { throw_gms(env, gms_slam_destroy(SLAM(s))); }
 JNIEXPORT void JNICALL CLS(pmReset)(JNIEnv *env, jclass c, jlong s) { throw_gms(env, gms_slam_reset(SLAM(s))); }     /* SLAM.reset() :65-77 */
+JNIEXPORT void JNICALL CLS(pmSetRefine)(JNIEnv *env, jclass c, jlong s, jboolean on) { throw_gms(env, gms_slam_set_refine(SLAM(s), on ? 1 : 0)); }   /* :96 */
 /* SLAM.update(z, u) (:80-131): out3 = {weightSum, neff, strongest}; the motion-model variates are Philox(seed; particle, sequence) */
 JNIEXPORT void JNICALL CLS(pmUpdate)(JNIEnv *env, jclass c, jlong s, jdoubleArray beams, jint B, jboolean sampleMotion, jdouble dCenter,
                                      jdouble dTheta, jlong seed, jlong sequence, jdoubleArray out3) {

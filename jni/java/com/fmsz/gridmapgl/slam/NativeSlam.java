@@ -44,6 +44,7 @@ final class NativeSlam {
     static native long pmCreate(float w, float h, float res, float px, float py, double lFree, double lOcc, double[] kernel, int maxBeams, int device, int numParticles);
     static native void pmDestroy(long s);
     static native void pmReset(long s);
+    static native void pmSetRefine(long s, boolean on);                         // SLAM.java:96: findBestPose of every particle against its own field
     static native void pmUpdate(long s, double[] beams, int B, boolean sampleMotion, double dCenter, double dTheta, long seed, long sequence, double[] weightSumNeffStrongest);
     static native void pmResample(long s, double r01);
     static native void pmResampleIf(long s, double r01, double fraction);      // the rule of GridMapApp.java:185-186, decided on the device

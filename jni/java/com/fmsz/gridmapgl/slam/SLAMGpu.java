@@ -23,9 +23,18 @@ public class SLAMGpu extends SLAM {
     private final double[] stats = new double[3];       // weightSum, neff, strongest
     private final long seed;
     private long frame;
+    private final ArrayList<Particle> mine;
 
     public SLAMGpu(int numParticles, long seed, int device) {
         super();                                                                    // SLAM.java:56-62 (its Java-side maps stay blank)
+        // the superclass's list has SLAM.numParticles = 500 entries whatever numParticles is (a private field, SLAM.java:50): the
+        // Java-side snapshot of THIS filter is a list of its own, one Particle per device particle
+        this.mine = new ArrayList<>(numParticles);
+        for (int i = 0; i < numParticles; i++) {                                    // SLAM.java:35-38,68-71
+            Particle p = new Particle(new Pose(0, 0, 0), getGridMap().createMapData(null));
+            p.weight = 1.0 / numParticles;
+            mine.add(p);
+        }
         GridMap g = getGridMap();
         float res = g.getResolution();
         double sigma = Math.sqrt(0.05 / res);                                       // GridMap.java:94-95
@@ -44,6 +53,12 @@ public class SLAMGpu extends SLAM {
         if (handle != 0) NativeSlam.pmReset(handle);
         frame = 0;
     }
+
+    /**
+     * update() refines every particle's pose with GridMap.findBestPose (GridMap.java:319-346) against the particle's own likelihood
+     * field before weighting it: the search SLAM.java:96 keeps commented out beside findBestPoseOptim (:97)
+     */
+    public void setRefine(boolean on) { NativeSlam.pmSetRefine(handle, on); }
 
     /** update(z, u) (SLAM.java:80-131); returns Neff */
     @Override
@@ -72,9 +87,9 @@ public class SLAMGpu extends SLAM {
     /** getParticles() (SLAM.java:192): poses and weights refreshed from the device; a particle's maps are filled by mapOf(i) */
     @Override
     public ArrayList<Particle> getParticles() {
-        ArrayList<Particle> list = super.getParticles();
+        ArrayList<Particle> list = mine;
         NativeSlam.pmGetParticles(handle, poses, weights, n);
-        for (int i = 0; i < n && i < list.size(); i++) {
+        for (int i = 0; i < n; i++) {
             Particle p = list.get(i);
             p.pose = new Pose(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2]);
             p.weight = weights[i];
