@@ -458,13 +458,36 @@ def measure(wl: Workload, steps: int, warmup: int):
     # An untimed pre-roll in front of the warm-up: a timed region of the driver's 20 steps is one millisecond long and starts 0.3 ms
     # after the process's first scan step -- clocks still ramping, first-use allocations of the runtime still ahead
     # (GMS_BENCH_PREROLL=0 turns it off; the count is in the report).
+    # ... and in front of THAT, the protocol of rounds 1-4 as it was: `warmup` steps, then ONE region of `steps` steps, timed cold -- the
+    # process's first scan steps.  Reported as first_region_ms_per_step so that rounds stay comparable; never `value`.
+    cold = None
     if not wl.loop:
+        for i in range(warmup):
+            wl.step(i)
+        wl.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            wl.step(warmup + i)
+        wl.barrier()
+        cold = time.perf_counter() - t0
+        if wl.world > 1 and dist.is_initialized():
+            tt = torch.tensor([cold], dtype=torch.float64, device=wl.dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            cold = float(tt.item())
         for i in range(preroll_steps()):
             wl.step(i % max(warmup + steps, 1))
         wl.barrier()
     import gc
     gc.collect()
     gc.disable()                              # (a collection inside a one-millisecond region is half of it: one process in ten read 70 us per step)
+    try:
+        return _measure_timed(wl, steps, warmup, bracket_ms, noop_ms, cold)
+    finally:
+        gc.enable()
+
+
+def _measure_timed(wl: Workload, steps: int, warmup: int, bracket_ms: float, noop_ms: float, cold):
+    m, torch, dist = wl.m, wl.torch, wl.dist
     for i in range(warmup):
         wl.step(i)
     # The timed region -- exactly `steps` steps between two barriers -- is taken timed_regions() times over, back to back, and the
@@ -488,6 +511,7 @@ def measure(wl: Workload, steps: int, warmup: int):
             dist.all_gather(allt, tt)
             pr = [float(x.item()) for x in allt]
         regions.append((max(pr), issue_r, pr))
+    import gc
     gc.enable()
     elapsed, issue, per_rank = sorted(regions, key=lambda x: x[0])[len(regions) // 2]
     if wl.loop:
@@ -528,7 +552,8 @@ def measure(wl: Workload, steps: int, warmup: int):
     compute = [k for k in prof if prof[k][1] > 0 and k != "exchange"]
     dominant = max(compute, key=lambda k: prof[k][0], default="score")
     return dict(elapsed=elapsed, issue=issue, per_rank=per_rank, dominant=dominant, prof=prof, nb=nb, steady=steady, steady_steps=ns, tiles=tiles,
-                preroll=0 if wl.loop else preroll_steps(), regions=[x[0] for x in regions],
+                preroll=0 if wl.loop else preroll_steps(), regions=[x[0] for x in regions], cold_region=cold,
+                warmup_effective=warmup if wl.loop else warmup + steps + preroll_steps() + warmup,
                 bracket_us=bracket_ms * 1e3, noop_us=noop_ms * 1e3)
 
 
@@ -662,6 +687,9 @@ def report(wl: Workload, meas: dict, steps: int, warmup: int):
         "preroll_steps": meas.get("preroll", 0),            # untimed, in front of the warm-up (measure)
         "timed_regions": len(meas.get("regions", [1])),     # regions of `steps` steps timed back to back; ms_per_step is the median one's
         "region_ms_per_step": [round(x / steps * 1e3, 6) for x in meas.get("regions", [])],
+        # the protocol of rounds 1-4 (W warm-up steps, then one region of K steps, the process's first): for comparison across rounds
+        "first_region_ms_per_step": (round(meas["cold_region"] / steps * 1e3, 6) if meas.get("cold_region") else None),
+        "warmup_effective": meas.get("warmup_effective", warmup),   # untimed steps in front of the reported regions: warm-up + cold region + pre-roll + warm-up
         "host_issue_ms_per_step": meas["issue"] / steps * 1e3,
         "config": {
             "workload": (f"{wl.name}: {wl.M} maps x {m.W}x{m.H} @ {wl.res} m x {wl.n_local} particles x {wl.B} beams ({wl.n_hit} hits), batched handle, "
@@ -876,7 +904,7 @@ def trace_replay(path: str, steps: int, warmup: int, particles: int, extent: flo
 
 
 def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res: float, beams: int, steps: int, warm_frames: int = 12,
-                      cpu_seconds: float = 0.0):
+                      cpu_seconds: float = 0.0, refine: bool = False):
     """The reference's own filter shape (SLAM.java: one GridMapData per particle; gms_slam_*): `particles` particles with a map of
     extent x extent metres each, scans of `beams` measurements of a synthetic drive through a room that fits the map.  Timed, inputs
     resident in HBM, nothing read back: `steps` SLAM.update calls (motion model inside, no resampling: the maps keep growing), then
@@ -892,9 +920,12 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
     s = SLAMParticleMaps(extent, extent, res, (-extent / 2, -extent / 2), num_particles=particles, device=local_rank, max_beams=max(128, beams))
     s.grid_map.set_stream(torch.cuda.current_stream().cuda_stream)
     s.set_poses(np.tile(np.asarray(start, np.float32), (particles, 1)))
-    scans, odo = [], []
+    if refine:
+        s.set_refine(True)           # SLAM.java:96: findBestPose of every particle against its own field before it is weighted
+    scans, odo, hits = [], [], []
     for f in frames:
         obs = s.grid_map.deskew(f.angle, f.distance, f.hit, f.d_center, f.d_theta)
+        hits.append(int(obs.beams["hit"].astype(bool).sum()))
         scans.append(torch.from_numpy(obs.beams.view(np.uint8).reshape(-1).copy()).to(dev))
         odo.append((f.d_center, f.d_theta))
     cells = s.W * s.H
@@ -964,12 +995,23 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
                                what=("resample()'s deep copy of logData, map[m] <- map[idx[m]] (SLAM.java:41-45, GridMap.java:120): 16 B per cell moved; likelihoodData's "
                                      "(:121) is deferred and never needed on the path" if lazy else
                                      "resample()'s deep copies, map[m] <- map[idx[m]] for both arrays (SLAM.java:41-45, GridMap.java:118-121): 32 B per cell"))
+    if "refine" in kern:
+        # GridMap.findBestPose per particle (GridMap.java:319-346): 11 x 11 x 10 lattice poses x the scan's hit beams look-ups of the particle's
+        # own field.  Yardsticks: the L1 gather ceiling that binds the shared-map k_refine / k_score_c (profiles/r04/microbench.json: 828 G
+        # independent 8-byte look-ups per second) -- this kernel reads its field from LDS instead and runs past it --
+        look = 1210.0 * float(np.mean(hits)) * particles
+        kern["refine"].update(lookups_per_launch=look, lookups_per_s=look / (kern["refine"]["avg_launch_us"] * 1e-6),
+                              l1_gather_ceiling_per_s=828e9, over_l1_gather_ceiling=look / (kern["refine"]["avg_launch_us"] * 1e-6) / 828e9,
+                              what="k_slam_refine: findBestPose of every particle against its own field (SLAM.java:96): the field staged in the CU's LDS "
+                                   "as probabilityOf's factors where it fits (120 x 120 cells), cell coordinates per (theta, dx | dy, beam) in 16-bit LDS tables, "
+                                   "the product per lattice pose in beam order; maps too large for the LDS are read from memory")
     if "score" in kern:
         kern["score"]["what"] = "k_slam_particle: motion sample, probabilityOf against the particle's own field (one lane's product in beam order), integrateObservation into the particle's own map through an LDS count tile"
     out = {"workload": f"SLAM.java's own shape: {particles} particles x one {s.W}x{s.H} map each @ {res} m, {beams} beams per scan; SLAM.update per particle "
-                       "(motion model, computeLikelihoodMap, probabilityOf, integrateObservation), SLAM.resample with its deep copies of the maps ("
+                       "(motion model, computeLikelihoodMap, " + ("findBestPose against the particle's own field, " if refine else "") +
+                       "probabilityOf, integrateObservation), SLAM.resample with its deep copies of the maps ("
                        + ("logData at once, likelihoodData when it is read: the next update overwrites it first" if lazy else "both arrays at once") + ")",
-           "particles": particles, "grid": [s.W, s.H], "beams": beams, "steps": steps,
+           "particles": particles, "grid": [s.W, s.H], "beams": beams, "steps": steps, "refine": bool(refine), "mean_hit_beams": float(np.mean(hits)),
            "update_ms": upd * 1e3, "updates_per_s": 1.0 / upd, "particle_scan_evals_per_s": particles / upd,
            "resample_ms": rsm * 1e3, "resample_what": ("in the update / resample loop; logData copied, likelihoodData's copy deferred (overwritten by the next "
                                                        "update's computeLikelihoodMap before anything reads it; materialised on demand)" if lazy else
@@ -1115,7 +1157,7 @@ def compact_line(full: dict, report_file: str | None) -> str:
                                      "scaling", "vs_baseline", "dtype", "data")}
     line["config"] = {k: cfg[k] for k in ("workload", "particles_total", "particles_per_gpu", "beams", "grid", "resolution_m", "maps", "maps_total",
                                           "parallelism", "exchange", "inputs") if cfg.get(k) is not None}
-    for k in ("timed_region_s", "timed_regions", "region_ms_per_step", "preroll_steps", "map_update_ms_per_scan", "map_update_ms_per_scan_exploring", "beam_evals_per_s", "scans_per_s", "per_rank_ms_per_step", "exchange_latency_us",
+    for k in ("timed_region_s", "timed_regions", "region_ms_per_step", "first_region_ms_per_step", "warmup_effective", "preroll_steps", "map_update_ms_per_scan", "map_update_ms_per_scan_exploring", "beam_evals_per_s", "scans_per_s", "per_rank_ms_per_step", "exchange_latency_us",
               "sharded_equals_standalone", "rccl_ranks"):
         if full.get(k) is not None:
             line[k] = full[k]
@@ -1243,6 +1285,7 @@ def main() -> int:
     ap.add_argument("--trace-extent", type=float, default=25.6, help="map extent (m) for --trace")
     ap.add_argument("--trace-res", type=float, default=0.05, help="map resolution (m) for --trace")
     ap.add_argument("--particle-maps", default="", help="run only the per-particle-map mode (SLAM.java's own shape): PARTICLES,EXTENT_M,BEAMS e.g. 500,6,90")
+    ap.add_argument("--refine", action="store_true", help="with --particle-maps: SLAM.update refines every particle's pose (findBestPose against its own field, SLAM.java:96)")
     ap.add_argument("--report", default=os.path.join(ROOT, "bench_report.json"),
                     help="where the full report goes (kernel table, secondary runs, notes); stdout carries one compact line that names it")
     args = ap.parse_args()
@@ -1254,6 +1297,9 @@ def main() -> int:
     # (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>), as a CHILD process and before
     # this process has touched the GPU (nothing above imports torch or loads the library): rank 0's single JSON line reaches our
     # stdout through the child's, and we leave with the child's exit code.
+    if args.particle_maps and (args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1):
+        print("bench.py: --particle-maps is a one-GPU run; use --gpus 1", file=sys.stderr)
+        return 2
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus, sys.argv[1:])
 
@@ -1287,8 +1333,12 @@ def main() -> int:
             dist.init_process_group(backend)
 
     if args.particle_maps:
+        if world > 1:                # (every rank would run the whole single-GPU benchmark and print a line of its own)
+            print("bench.py: --particle-maps is a one-GPU run; use --gpus 1", file=sys.stderr)
+            return 2
         n_, ext_, b_ = args.particle_maps.split(",")
-        pm = particle_maps_run(torch, local_rank, int(n_), float(ext_), 0.05, int(b_), args.steps, cpu_seconds=0.0 if args.no_cpu_baseline else 5.0)
+        pm = particle_maps_run(torch, local_rank, int(n_), float(ext_), 0.05, int(b_), args.steps, cpu_seconds=0.0 if (args.no_cpu_baseline or args.refine) else 5.0,
+                               refine=args.refine)
         out = {"metric": "particle-scan evals/sec", "value": pm["particle_scan_evals_per_s"], "unit": "particle-scan evals/s", "n_gpus": 1,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": pm["update_ms"], "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": pm["workload"]},
@@ -1509,9 +1559,11 @@ def main() -> int:
                 sec[name] = {"error": repr(e)}
         # the reference's own filter shape (SLAM.java: one GridMapData per particle) at its operating point and at a size that
         # no longer fits the caches
-        for name, (n_, ext_, b_, k_) in (("per_particle_maps", (500, 6.0, 90, 50)), ("per_particle_maps_4096x256", (4096, 12.8, 180, 10))):
+        for name, (n_, ext_, b_, k_) in (("per_particle_maps", (500, 6.0, 90, 50)), ("per_particle_maps_refine", (500, 6.0, 90, 50)),
+                                         ("per_particle_maps_4096x256", (4096, 12.8, 180, 10))):
             try:
-                pm = particle_maps_run(torch, local_rank, n_, ext_, 0.05, b_, k_, cpu_seconds=(3.0 if (want_cpu and n_ <= 1000) else 0.0))
+                rf = name.endswith("_refine")
+                pm = particle_maps_run(torch, local_rank, n_, ext_, 0.05, b_, k_, cpu_seconds=(3.0 if (want_cpu and n_ <= 1000 and not rf) else 0.0), refine=rf)
                 pm["ms_per_step"] = pm["update_ms"]
                 sec[name] = pm
             except Exception as e:
