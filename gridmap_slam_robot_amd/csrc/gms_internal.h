@@ -220,6 +220,10 @@ struct gms_slam {
                                     // computeLikelihoodMap overwrites every cell of it before anything on the path reads one (GMS_SLAM_LAZY_LIK_COPY=0: both at once)
     int32_t lik_behind;             // d_lik[cur] does not hold the last resample()'s copies yet: slot m's field is d_lik[1 - cur][d_idx_lik[m]]
     int32_t *d_idx_lik;             // [n] the source indices of that resample()
+    uint32_t *d_code[2];            // [n][2][code_words] every particle's class planes (gms_slam_kernels.hip), double-buffered with logData; NULL: not kept
+                                    // (the blur kernel is wider than the on-demand evaluation takes, the plane does not fit the LDS, or GMS_SLAM_EAGER_LIK=1)
+    int64_t code_words;             // 32-bit words per plane
+    int32_t lik_from_codes;         // d_lik[cur] is behind: every particle's likelihoodData is the field of plane 1 of its class planes (made on demand)
     int32_t refine;                 // gms_slam_set_refine: update() runs findBestPose on every particle against its own field before weighting it (SLAM.java:96)
     int32_t refine_lds;             // -1 the field is staged in LDS whenever it fits, 0 never (GMS_SLAM_REFINE_LDS=0: tests of the other form)
     int64_t copies;                 // maps copied by resampling steps so far (measurement)
@@ -298,10 +302,15 @@ void gms_launch_pf_resample_seq(gms_pf *pf, double fraction);
 // one GridMapData per particle (gms_slam_kernels.hip)
 void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, int32_t n);
 void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, double *d_log, const double *d_lik, const MotionModel *motion,
-                              int32_t integrate);
+                              int32_t integrate, uint32_t *d_code = nullptr, int64_t code_words = 0);
+void gms_launch_slam_likelihood_codes(gms_map *m, const uint32_t *d_code, int64_t code_words, double *d_lik, int32_t n);
+void gms_launch_slam_codes_from_log(gms_map *m, const double *d_log, int32_t count, uint32_t *d_code, int64_t code_words);
+int64_t gms_slam_code_words(int64_t cells);
+void gms_launch_slam_gather_codes(gms_pf *pf, const uint32_t *src_code, uint32_t *dst_code, int64_t code_words);
 bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, const double *d_lik, const MotionModel *motion, int32_t field_in_lds);
 void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik);
-void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx, int32_t *d_idx_keep);   // one array: dst[m] <- src[d_idx[m]]; d_idx_keep (may be NULL) receives d_idx
+void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx, int32_t *d_idx_keep, const uint32_t *src_code = nullptr,
+                                uint32_t *dst_code = nullptr, int64_t code_words = 0);   // one array: dst[m] <- src[d_idx[m]]; d_idx_keep (may be NULL) receives d_idx
 void gms_launch_slam_combine(gms_map *dst, const double *d_logs, int32_t n);
 
 // profiling brackets

@@ -686,13 +686,22 @@ k_apply(GridDev g, double *__restrict__ logd, uint32_t *__restrict__ cnt, const 
 #else
 #define LIK_STORE(p, v) (*(p) = (v))
 #endif
-template <int KH, int SPLIT = 1>   // KH > 0: compile-time half width; KH == 0: runtime g.khalf (generic, slower).  SPLIT = 2 (KH > 0, dirty
-                                  // tiles only): a tile's horizontal and vertical sums are shared by TWO workgroups, see "split" below
+// A cell's class from a packed 2-bit plane (the per-particle maps keep one beside logData, gms_slam_kernels.hip): 0 logData == 0 (or
+// NaN), 1 logData < 0, 2 logData > 0 -- returned as a stand-in log-odds value of that sign, which is all computeLikelihoodMap reads
+// of logData (GridMap.java:239-244).
+__device__ __forceinline__ double plane_log_sign(const uint32_t *__restrict__ plane, size_t cell) {
+    const uint32_t e = (plane[cell >> 4] >> (2u * ((uint32_t)cell & 15u))) & 3u;
+    return e == 2u ? 1.0 : (e == 1u ? -1.0 : 0.0);
+}
+template <int KH, int SPLIT = 1, bool CODES = false>   // KH > 0: compile-time half width; KH == 0: runtime g.khalf (generic, slower).  SPLIT = 2 (KH > 0, dirty
+                                  // tiles only): a tile's horizontal and vertical sums are shared by TWO workgroups, see "split" below.
+                                  // CODES: `logd` is a packed 2-bit class plane per map (code_stride 32-bit words apart) instead of logData
 __device__ __forceinline__ void
 likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__restrict__ lik, double *__restrict__ fac,
                 int64_t fac_stride, const double *__restrict__ taps_g, const int32_t *__restrict__ bbox, int32_t dirty_only,
                 int32_t tiles_x, int32_t tiles_y, uint32_t bx, uint32_t by, uint32_t gdx, unsigned char *smem,
-                const uint32_t *__restrict__ cnt_pending = nullptr, uint8_t *__restrict__ tile_state = nullptr, int32_t mode = 3) {
+                const uint32_t *__restrict__ cnt_pending = nullptr, uint8_t *__restrict__ tile_state = nullptr, int32_t mode = 3,
+                int64_t code_stride = 0) {
     // mode: bit 0 = write likelihoodData, bit 1 = write the factor table (and keep tile_state, which describes the factor table).
     // The scan steps' dirty-tile rebuilds write the factor table only (mode 2): nothing on the hot path reads likelihoodData
     // (GridMap.java:150-156,371-388 are its only readers: getLikelihood and the renderer), so it is brought up to date on demand by a
@@ -723,7 +732,8 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     uint32_t ts_left = 0, ts_const_kept = 0, ts_const_written = 0, ts_blurred = 0;
 
     const int32_t mi = (int32_t)by;
-    const double *mlog = logd + (size_t)mi * g.cells;
+    const double *mlog = CODES ? logd : logd + (size_t)mi * g.cells;
+    const uint32_t *mcode = reinterpret_cast<const uint32_t *>(logd) + (CODES ? (size_t)mi * (size_t)code_stride : 0);
     // cnt_pending: the scan's counts have not been added to logData yet (the apply pass runs later, beside another
     // kernel); a staged cell is logData + its increment, the expression of apply_body (GridMap.java:223), not stored
     const uint32_t *mcnt = cnt_pending ? cnt_pending + (size_t)mi * g.cells : nullptr;
@@ -786,13 +796,13 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
         for (int q = 0; q < QM; q++) {
             const int32_t gy = min(max(lty0 - KH + e_wave + 4 * q, 0), g.H - 1);
             const size_t row = (size_t)gy * (size_t)g.W;
-            lv[q] = (mlog + row)[gxm];
+            lv[q] = CODES ? plane_log_sign(mcode, row + gxm) : (mlog + row)[gxm];
             cv[q] = mcnt ? (mcnt + row)[gxm] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < QS; j++) {
             const int32_t gy = min(max(lty0 - KH + s_r[j], 0), g.H - 1), gx = min(max(ltx0 - KH + s_c[j], 0), g.W - 1);
-            lv[QM + j] = mlog[(size_t)gy * g.W + gx];
+            lv[QM + j] = CODES ? plane_log_sign(mcode, (size_t)gy * g.W + gx) : mlog[(size_t)gy * g.W + gx];
             cv[QM + j] = mcnt ? mcnt[(size_t)gy * g.W + gx] : 0u;
         }
     };
@@ -895,7 +905,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
                 const int32_t gy = ty0 - k + r, gx = tx0 - k + c;
                 double val = 0.0;
                 if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
-                    double v = mlog[(size_t)gy * g.W + gx];
+                    double v = CODES ? plane_log_sign(mcode, (size_t)gy * g.W + gx) : mlog[(size_t)gy * g.W + gx];
                     const uint32_t cc = mcnt ? mcnt[(size_t)gy * g.W + gx] : 0u;
                     if (cc) v = v + ((double)(cc & 0xffffu) * g.l_free + (double)(cc >> 16) * g.l_occ);
                     const int32_t code = v > 0.0 ? 2 : (v < 0.0 ? 0 : 1);             // GridMap.java:239-244

@@ -25,6 +25,7 @@ int gms_slam_destroy(gms_slam *s) {
     if (s->map) { hipSetDevice(s->map->device); hipStreamSynchronize(s->map->stream); }
     for (int k = 0; k < 2; k++) { hipFree(s->d_log[k]); hipFree(s->d_lik[k]); }
     hipFree(s->d_idx_lik);
+    hipFree(s->d_code[0]); hipFree(s->d_code[1]);
     if (s->pf) gms_pf_destroy(s->pf);
     if (s->map) gms_map_destroy(s->map);
     delete s;
@@ -57,6 +58,15 @@ int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out) { 
     for (int k = 0; k < 2; k++)
         ok = ok && hipMalloc(&s->d_log[k], bytes) == hipSuccess && hipMalloc(&s->d_lik[k], bytes) == hipSuccess;
     ok = ok && hipMalloc(&s->d_idx_lik, (size_t)n_particles * sizeof(int32_t)) == hipSuccess;
+    // The class planes (gms_slam_kernels.hip): kept unless the blur kernel is wider than the on-demand evaluation takes, a plane would
+    // crowd the count tile out of a workgroup's LDS, or GMS_SLAM_EAGER_LIK=1 asks for the reference's own schedule -- every cell of every
+    // particle's likelihoodData rebuilt by every update (the like-for-like figure of bench.py)
+    const char *eager_env = getenv("GMS_SLAM_EAGER_LIK");
+    s->code_words = gms_slam_code_words(m->gd.cells);
+    if (!(eager_env && eager_env[0] == '1') && m->gd.khalf <= 7 && s->code_words * 4 <= 24 * 1024 && m->gd.W <= 65535 && m->gd.H <= 65535) {
+        const size_t cb = (size_t)n_particles * 2 * (size_t)s->code_words * sizeof(uint32_t);
+        for (int k = 0; k < 2; k++) ok = ok && hipMalloc(&s->d_code[k], cb) == hipSuccess;
+    }
     if (!ok) {
         gms_slam_destroy(s);
         return gms_fail(GMS_ERR_NOMEM, "gms_slam_create: device allocation failed (%d particles x %lld cells x 32 bytes)", n_particles, (long long)m->gd.cells);
@@ -73,7 +83,9 @@ int gms_slam_reset(gms_slam *s) {                                               
     // createMapData(null) per particle (GridMap.java:106-117): logData = logOdds(0.5) = 0.0, likelihoodData a fresh double[] = 0.0
     HIPCHK(hipMemsetAsync(s->d_log[s->cur], 0, bytes, m->stream));
     HIPCHK(hipMemsetAsync(s->d_lik[s->cur], 0, bytes, m->stream));
+    if (s->d_code[s->cur]) HIPCHK(hipMemsetAsync(s->d_code[s->cur], 0, (size_t)s->n * 2 * (size_t)s->code_words * sizeof(uint32_t), m->stream));   // every class "logData == 0"
     s->lik_behind = 0;
+    s->lik_from_codes = 0;
     gms_launch_pf_init(s->pf);                                                               // Pose(0, 0, 0), weight 1 / numParticles (:68-71)
     s->pf->pending_nseg = 0; s->pf->have_global = 0; s->pf->stats_current = 0; s->pf->score_fresh = 0;
     HIPCHK(hipGetLastError());
@@ -112,15 +124,22 @@ int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int
     const bool skip_update = fabs(d_theta) > (3.141592653589793 / 180.0) * 30;                              // :82
     MotionModel mo;
     mo.d_center = d_center; mo.d_theta = d_theta; mo.seed = seed; mo.sequence = sequence;
-    gms_launch_slam_likelihood(m, s->d_log[s->cur], s->d_lik[s->cur], s->n);                                // :93 for every particle
-    s->lik_behind = 0;                                                                                     // (every cell of every field has just been written)
+    // :93 for every particle.  With the class planes and no refinement the field is not written here: probabilityOf reads it under the
+    // scan's end points only (GridMap.java:273-277), and k_slam_particle evaluates exactly those cells from the particle's plane; what a
+    // caller may read afterwards -- the field of logData as it stands NOW -- stays defined by plane 1 and is written when asked for
+    // (slam_lik_current).  The pose refinement looks up most of a field: it gets all of it.
+    const bool on_demand = s->d_code[s->cur] != nullptr && !s->refine;
+    if (!on_demand) gms_launch_slam_likelihood(m, s->d_log[s->cur], s->d_lik[s->cur], s->n);
+    s->lik_behind = 0;                                                                                     // (every cell of every field is rewritten: an owed copy is moot)
+    s->lik_from_codes = on_demand ? 1 : 0;
     bool drawn = false;
     if (s->refine) {                                                                                        // :90, then :96 (the lattice form of :97)
         if (!gms_launch_slam_refine(pf, dev_beams, B, s->d_lik[s->cur], sample_motion ? &mo : nullptr, s->refine_lds))
             return gms_fail(GMS_ERR_INVALID, "gms_slam_update_per_particle: the pose refinement's tables do not fit the LDS for a scan of %d beams", B);
         drawn = true;
     }
-    gms_launch_slam_particle(pf, dev_beams, B, s->d_log[s->cur], s->d_lik[s->cur], sample_motion && !drawn ? &mo : nullptr, skip_update ? 0 : 1);   // :90, :99, :102-107
+    gms_launch_slam_particle(pf, dev_beams, B, s->d_log[s->cur], on_demand ? nullptr : s->d_lik[s->cur], sample_motion && !drawn ? &mo : nullptr,
+                             skip_update ? 0 : 1, s->d_code[s->cur], s->code_words);                       // :90, :99, :102-107
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
@@ -137,6 +156,12 @@ int gms_slam_update_per_particle(gms_slam *s, const gms_beam *beams, int32_t B, 
 
 // likelihoodData as the last resample() left it, for whoever reads it before the next update (downloads; a second resample())
 static int slam_lik_current(gms_slam *s) {
+    if (s->lik_from_codes) {                                                                               // computeLikelihoodMap(p.m) of the last update (:93), late
+        gms_launch_slam_likelihood_codes(s->map, s->d_code[s->cur], s->code_words, s->d_lik[s->cur], s->n);
+        s->lik_from_codes = 0;
+        HIPCHK(hipGetLastError());
+        return GMS_OK;
+    }
     if (!s->lik_behind) return GMS_OK;
     gms_launch_slam_gather_one(s->pf, s->d_lik[1 - s->cur], s->d_lik[s->cur], s->d_idx_lik, nullptr);      // GridMap.java:121, late
     s->lik_behind = 0;
@@ -150,17 +175,22 @@ static int slam_lik_current(gms_slam *s) {
 static int slam_resample(gms_slam *s, double r01, double fraction, int32_t *indices, int32_t *n_ambiguous) {
     gms_map *m = s->map;
     HIPCHK(hipSetDevice(m->device));
-    int rc = slam_lik_current(s);                                                                          // (two resample() calls in a row)
+    int rc = s->lik_behind ? slam_lik_current(s) : GMS_OK;                                                 // (two resample() calls in a row)
     if (!rc) rc = fraction >= 0.0 ? gms_pf_resample_if(s->pf, &r01, fraction)
                                   : gms_pf_resample(s->pf, &r01, indices, n_ambiguous);                    // :136-145 + pose, weight (:42-43)
     if (rc) return rc;
-    if (s->lazy_lik) {
+    if (s->lik_from_codes) {
+        // likelihoodData is the field of plane 1 of a particle's class planes: they travel with logData, and so does it
+        gms_launch_slam_gather_one(s->pf, s->d_log[s->cur], s->d_log[1 - s->cur], s->pf->d_idx, nullptr, s->d_code[s->cur], s->d_code[1 - s->cur], s->code_words);
+    } else if (s->lazy_lik) {
         // logData now (GridMap.java:120); likelihoodData (:121) when it is asked for: SLAM.update starts with computeLikelihoodMap of
         // every particle (:93), which overwrites every cell of it -- nothing on the path ever reads the copies
-        gms_launch_slam_gather_one(s->pf, s->d_log[s->cur], s->d_log[1 - s->cur], s->pf->d_idx, s->d_idx_lik);      // (keeps the indices for that)
+        gms_launch_slam_gather_one(s->pf, s->d_log[s->cur], s->d_log[1 - s->cur], s->pf->d_idx, s->d_idx_lik, s->d_code[s->cur], s->d_code[1 - s->cur],
+                                   s->code_words);                                                                   // (keeps the indices for that)
         s->lik_behind = 1;
     } else {
         gms_launch_slam_gather_maps(s->pf, s->d_log[s->cur], s->d_lik[s->cur], s->d_log[1 - s->cur], s->d_lik[1 - s->cur]);   // :44
+        if (s->d_code[s->cur]) gms_launch_slam_gather_codes(s->pf, s->d_code[s->cur], s->d_code[1 - s->cur], s->code_words);
     }
     s->cur = 1 - s->cur;                                                                                   // :152
     s->copies += s->n;
@@ -215,7 +245,12 @@ int gms_slam_upload_map(gms_slam *s, int32_t i, const double *log_data, const do
     REQUIRE(s && i >= 0 && i < s->n, "gms_slam_upload_map: particle index out of range");
     HIPCHK(hipSetDevice(s->map->device));
     int rc = lik ? slam_lik_current(s) : GMS_OK;                  // (the other slots' fields first, then this one's over its copy)
-    if (!rc && log_data) rc = slam_map_xfer(s, i, 1, s->d_log[s->cur], const_cast<double *>(log_data), true);
+    if (!rc && log_data) {
+        rc = slam_map_xfer(s, i, 1, s->d_log[s->cur], const_cast<double *>(log_data), true);
+        if (!rc && s->d_code[s->cur])                             // the slot's class plane 0 follows its logData (plane 1, its field's, does not)
+            gms_launch_slam_codes_from_log(s->map, s->d_log[s->cur] + (size_t)i * (size_t)s->map->gd.cells, 1,
+                                           s->d_code[s->cur] + (size_t)i * 2 * (size_t)s->code_words, s->code_words);
+    }
     if (!rc && lik) rc = slam_map_xfer(s, i, 1, s->d_lik[s->cur], const_cast<double *>(lik), true);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->map->stream));

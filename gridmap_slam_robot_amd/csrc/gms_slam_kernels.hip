@@ -41,6 +41,49 @@ k_slam_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict
     likelihood_body<KH>(g, logd, lik, lik, 0, taps_g, nullptr, 0, tiles_x, tiles_y, bx, by, gridDim.x, smem, nullptr, nullptr, 1);
 }
 
+// ---- the class plane of a particle's map ------------------------------------------------------------------------------------
+// computeLikelihoodMap reads of logData only its sign (GridMap.java:239-244), and probabilityOf reads of the field it produces only
+// the cells under the scan's end points (:273-277).  So every particle keeps, beside logData, a packed plane of 2 bits per cell --
+// 0 logData == 0 (or NaN), 1 logData < 0, 2 logData > 0; 1/32 of logData's bytes, all zero for a fresh map -- kept in step with
+// logData by everything that writes it (the apply pass of k_slam_particle, uploads, the resampling copy), in two copies per particle:
+// plane 0 as logData stands, plane 1 as it stood at the START of the last update, which is the logData the particle's likelihoodData
+// is the field of (SLAM.java:93 runs before :105).  update() then needs no k_slam_likelihood launch: k_slam_particle stages plane 0 in
+// LDS and blurs just the end points' neighbourhoods ("on_demand" there); likelihoodData is written, from plane 1, only when somebody asks for
+// it (k_slam_likelihood_codes: a download, an upload of a field, the pose refinement).
+#define PS_CODE_MAX_KHALF 7             // on-demand evaluation: up to 15 taps (a row's window of 2-bit classes is one 64-bit read; 16 lanes per end point)
+__host__ __device__ inline int64_t slam_code_words(int64_t cells) { return ((cells + 15) / 16 + 1 + 3) & ~(int64_t)3; }   // per plane: one spare word, 16-byte multiples
+
+// likelihoodData of every particle from plane 1 of its class planes (mode 1 of likelihood_body, as k_slam_likelihood)
+template <int KH>
+__global__ void __launch_bounds__(256)
+k_slam_likelihood_codes(GridDev g, const uint32_t *__restrict__ planes, int64_t code_stride, double *__restrict__ lik, const double *__restrict__ taps_g,
+                        int32_t tiles_x, int32_t tiles_y) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.x == 8u) {
+        const uint32_t L = blockIdx.x + 8u * blockIdx.y, grp = L >> 6;
+        if (grp * 8u + 8u <= gridDim.y) { by = grp * 8u + (L & 7u); bx = (L >> 3) & 7u; }
+    }
+    likelihood_body<KH, 1, true>(g, reinterpret_cast<const double *>(planes), lik, lik, 0, taps_g, nullptr, 0, tiles_x, tiles_y, bx, by, gridDim.x, smem,
+                                 nullptr, nullptr, 1, code_stride);
+}
+
+// plane 0 of `count` particles' class planes from their logData (uploads): a thread per word of 16 cells
+__global__ void __launch_bounds__(256)
+k_slam_codes_from_log(const double *__restrict__ logd, int64_t cells, uint32_t *__restrict__ planes, int64_t code_stride, int64_t words) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= words) return;
+    const double *ml = logd + (size_t)blockIdx.y * (size_t)cells;
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int64_t c = 16 * w + k;
+        const double v = c < cells ? ml[c] : 0.0;
+        word |= (v > 0.0 ? 2u : (v < 0.0 ? 1u : 0u)) << (2 * k);
+    }
+    planes[(size_t)blockIdx.y * (size_t)code_stride + w] = word;
+}
+
 // GridMap.integrateObservation's per-beam locals (GridMap.java:175-188) from a transform that is already at hand (make_ray takes
 // the pose and its trig)
 __device__ __forceinline__ RayIn ps_make_ray(const GridDev &g, const XformDev &t, const gms_beam &m) {
@@ -120,11 +163,12 @@ __device__ __forceinline__ void ps_phase_b(const GridDev &g, const PsRay &mt, co
 // (A lane per ray running the reference's loop as it stands -- walk, distance, class, count -- was built and measured: 80 instructions
 // per step on one or two wavefronts per SIMD, which issue one instruction per ~4.6 clocks: 29 us of walking for 90 rays against 17 for
 // this split form, whose cell work spreads over every wavefront of the workgroup.)
-template <int NT, int NP, bool NA>      // NA: 16-bit count cells are on offer (the map does not fit as 32-bit cells)
+template <int NT, int NP, bool NA, bool CODES>      // NA: 16-bit count cells are on offer (the map does not fit as 32-bit cells); CODES: the class planes are kept
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4)))       // (2 x 512 or 1024 lanes per CU: 128 registers)
 k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, double *__restrict__ log_all,
                 const double *__restrict__ lik_all, float *__restrict__ pose, float *__restrict__ cs, double *__restrict__ w,
-                double *__restrict__ logw, MotionArgs mo, int32_t integrate, int32_t tile_bytes) {
+                double *__restrict__ logw, MotionArgs mo, int32_t integrate, int32_t tile_bytes, uint32_t *__restrict__ code_all, int32_t code_words,
+                const double *__restrict__ taps_g) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NW = NT / 64, GR = 64 * NP;
     static_assert(NW > NP, "at least one wavefront that only consumes");
@@ -132,6 +176,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     uint64_t *s_slots = reinterpret_cast<uint64_t *>(s_fac + Bpad);            // [PS_WORDS][GR]
     PsRay *s_ray = reinterpret_cast<PsRay *>(s_slots + PS_WORDS * GR);         // [GR]
     uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_ray + GR);               // [tile_bytes / 4] words: 32-bit cells, or 16-bit cells two to a word
+    uint32_t *s_plane = s_tile + (tile_bytes >> 2);                            // [code_words] the particle's class plane 0 (CODES)
     __shared__ float s_pose[5];                                                // x, y, theta, (float)cos, (float)sin
     __shared__ int32_t s_box[4];                                               // the scan's box x0, y0, x1, y1 (inclusive)
     __shared__ int32_t s_grp_words[NP];
@@ -139,12 +184,29 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     __shared__ uint16_t s_work[GR];                                            // a round's cell work: the rays that have cells in it
     __shared__ int32_t s_nwork, s_next;
     __shared__ int32_t s_nzero;                                                // rays of zero length: the only ones that visit a cell more than once
+    __shared__ double s_taps[CODES ? 2 * PS_CODE_MAX_KHALF + 2 : 2];           // the blur kernel (CODES)
+    __shared__ int32_t s_changed;                                              // a cell of this particle changed its class (CODES): plane 0 is written back
     const int32_t p = blockIdx.x;
     const int32_t lane = threadIdx.x & 63;
     const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6));
     GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 0);
+    uint32_t *s_cell = s_plane + code_words;                                   // [Bpad] the end point's cell of every beam, for the on-demand field (CODES)
+    uint32_t *gplane = CODES ? code_all + (size_t)p * 2 * (size_t)code_words : nullptr;
 
     // ---- the particle's pose: sampleMotionModel (SLAM.java:90, Odometry.java:77-96) or the pose as it stands
+    if (CODES && wave != 0) {
+        // the class plane as logData stands now -- the start of this update -- into LDS, by the other wavefronts while wavefront 0 draws
+        // the pose; twelve loads in flight per lane (a plane is at most 24 KiB: gms_slam_create)
+        constexpr int PLB = 12;
+        for (int32_t i0 = (int32_t)threadIdx.x - 64; i0 < code_words; i0 += PLB * (NT - 64)) {
+            uint32_t plw[PLB];
+#pragma unroll
+            for (int u = 0; u < PLB; u++) plw[u] = gplane[min(i0 + u * (NT - 64), code_words - 1)];
+#pragma unroll
+            for (int u = 0; u < PLB; u++)
+                if (i0 + u * (NT - 64) < code_words) s_plane[i0 + u * (NT - 64)] = plw[u];
+        }
+    }
     if (wave == 0) {
         float x = pose[3 * (size_t)p], y = pose[3 * (size_t)p + 1], th = pose[3 * (size_t)p + 2], c, sn;
         if (mo.on) {                                                           // (uniform)
@@ -162,7 +224,11 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     }
     if (threadIdx.x >= 64 && threadIdx.x < 68) s_box[threadIdx.x - 64] = threadIdx.x < 66 ? INT32_MAX : INT32_MIN;
     if (threadIdx.x == 68) s_nzero = 0;
+    if (CODES && threadIdx.x >= 128 && (int32_t)threadIdx.x - 128 < g.ktaps) s_taps[threadIdx.x - 128] = taps_g[threadIdx.x - 128];
+    if (CODES && threadIdx.x == 69) s_changed = 0;
     __syncthreads();
+    if (CODES)                                         // ... and into plane 1, which defines the particle's likelihoodData from here on (SLAM.java:93);
+        for (int32_t i = threadIdx.x; i < code_words; i += NT) gplane[code_words + i] = s_plane[i];    // after the barrier, which would wait for the stores (it fences memory)
     GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 1);
     XformDev t;
     t.px = (double)s_pose[0]; t.py = (double)s_pose[1]; t.c = (double)s_pose[3]; t.s = (double)s_pose[4];      // Transform.java:13-21
@@ -170,6 +236,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     // ---- probabilityOf(p.m, z, p.pose): the factors in parallel, the product by one lane in beam order (GridMap.java:262-288);
     //      beside it every beam's ray box (GridMap.java:175-188 + ray_meta) for the count tile
     const double *lik = lik_all + (size_t)p * (size_t)g.cells;
+    const bool on_demand = CODES && lik_all == nullptr;                        // no field in memory: the end points' cells are evaluated from the class plane
     double lsum = 0.0;
     int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN, nzero = 0;
     // the ray of beam threadIdx.x, kept: the producer lane of that beam in the first group of rays below is this very thread
@@ -180,13 +247,17 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     for (int32_t b = (int32_t)threadIdx.x; b < B; b += NT) {
         const gms_beam bm = beams[b];
         double f = 1.0;                                                        // a beam that is skipped leaves the product as it is: x * 1.0 == x
+        uint32_t cell = 0xffffffffu;
         if (bm.hit) {                                                          // :269
             const int32_t gx = j_cell_exact(xform_x(t, bm.local_x, bm.local_y) - g.posx, g.res);      // :273
             const int32_t gy = j_cell_exact(xform_y(t, bm.local_x, bm.local_y) - g.posy, g.res);      // :274
-            if (!(gx < 0 || gy < 0 || gx >= g.W || gy >= g.H))                                        // :276
-                f = lik_factor(g, lik[(size_t)gy * g.W + gx]);                                        // :277-288
+            if (!(gx < 0 || gy < 0 || gx >= g.W || gy >= g.H)) {                                      // :276
+                if (on_demand) cell = (uint32_t)gx | ((uint32_t)gy << 16);                            // (its factor: the pass below)
+                else f = lik_factor(g, lik[(size_t)gy * g.W + gx]);                                   // :277-288
+            }
         }
         s_fac[b] = f;
+        if (CODES) s_cell[b] = cell;
         lsum += log(f);
         if (integrate) {
             RayDev r;
@@ -199,8 +270,10 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
             }
         }
     }
-    lsum = wave_sum_f64(lsum);
-    if (lane == 0) s_red[wave] = lsum;
+    if (!on_demand) {
+        lsum = wave_sum_f64(lsum);
+        if (lane == 0) s_red[wave] = lsum;
+    }
     if (integrate) {
 #define GMS_STEP_(O) { bx0 = min(bx0, wave_xor<O>(bx0)); by0 = min(by0, wave_xor<O>(by0)); bx1 = max(bx1, wave_xor<O>(bx1)); by1 = max(by1, wave_xor<O>(by1)); nzero += wave_xor<O>(nzero); }
         GMS_BUTTERFLY(GMS_STEP_)
@@ -211,6 +284,58 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
         }
     }
     __syncthreads();
+    if (on_demand) {
+        // likelihoodData[gx + gy * W] under the end points as computeLikelihoodMap would have written it (GridMap.java:239-249 ->
+        // Util.doGaussianBlurdSeparable, Util.java:378-426): for every row gy + i inside the map (:418) the horizontal sum of that row at
+        // column gx (`total = 0; total += kernel[j + k] * in[...]` over the columns inside the map, :391-401), then the vertical sum of
+        // those (:413-422) -- the reference's operations in the reference's order, for these cells only.  Spread over the workgroup:
+        // L lanes per beam (L = 8 / 16 for up to 7 / 15 taps), lane r the horizontal sum of row gy - k + r; then every lane of
+        // the group adds the rows' sums in row order and the first stores the factor.
+        // (One lane per beam doing all (2 k + 1)^2 taps took 7 us on three wavefronts while the others waited: profiles/r06.)
+        const int32_t kh = g.khalf, ntaps = 2 * kh + 1;
+        auto field_pass = [&](auto width) {            // (the group width at compile time: both loops unroll, their LDS reads and shuffles fly together)
+            constexpr int L = decltype(width)::value, SH = L == 8 ? 3 : 4;
+            const int32_t r = lane & (L - 1), grp = lane & ~(L - 1);
+            for (int32_t base = 0; base < (B << SH); base += NT) {             // (every lane stays in the loop: the shuffles read all of a group)
+                const int32_t item = base + (int32_t)threadIdx.x;
+                const int32_t b = min(item >> SH, B - 1);
+                const uint32_t cell = (item >> SH) < B ? s_cell[b] : 0xffffffffu;
+                const int32_t gx = (int32_t)(cell & 0xffffu), gy = (int32_t)(cell >> 16);
+                const int32_t y = gy - kh + r;
+                double h = 0.0;
+                if (cell != 0xffffffffu && r < ntaps && y >= 0 && y < g.H) {   // Util.java:418
+                    const int32_t jlo = max(-kh, -gx), jhi = min(kh, g.W - 1 - gx);     // columns inside the map (:396)
+                    const int32_t c0 = y * g.W + gx + jlo;
+                    const uint32_t w0 = s_plane[c0 >> 4], w1 = s_plane[(c0 >> 4) + 1];  // (a spare word follows the plane)
+                    const uint64_t win = (((uint64_t)w1 << 32) | w0) >> (2 * (c0 & 15));
+#pragma unroll
+                    for (int t = 0; t < (L < 2 * PS_CODE_MAX_KHALF + 1 ? L : 2 * PS_CODE_MAX_KHALF + 1); t++) {
+                        const int32_t j = jlo + t;
+                        const uint32_t e = (uint32_t)(win >> (2 * t)) & 3u;
+                        const double term = s_taps[min(j + kh, ntaps - 1)] * (e == 0u ? 0.5 : (e == 2u ? 1.0 : 0.0));   // GridMap.java:239-244; Util.java:399
+                        if (j <= jhi) h += term;
+                    }
+                }
+                double total = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < (L < 2 * PS_CODE_MAX_KHALF + 1 ? L : 2 * PS_CODE_MAX_KHALF + 1); rr++) {
+                    const double hh = __shfl(h, grp + rr);
+                    const int32_t yy = gy - kh + rr;
+                    if (rr < ntaps && yy >= 0 && yy < g.H) total += s_taps[min(rr, ntaps - 1)] * hh;   // :418-420
+                }
+                if (r == 0 && cell != 0xffffffffu) {
+                    const double f = lik_factor(g, total);                     // GridMap.java:277-288
+                    s_fac[b] = f;
+                    lsum += log(f);
+                }
+            }
+        };
+        if (ntaps <= 8) field_pass(std::integral_constant<int, 8>{});
+        else field_pass(std::integral_constant<int, 16>{});
+        lsum = wave_sum_f64(lsum);
+        if (lane == 0) s_red[wave] = lsum;
+        __syncthreads();
+    }
     GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 2);
     if (threadIdx.x == NT - 64) {
         // the last wavefront's first lane, while the others set up the ray cast: product *= factor, beam by beam (:262, :286-288)
@@ -375,7 +500,18 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                 asm volatile("" : "+v"(y), "+v"(x));           // (the addresses are formed again, not kept in 2 PS_APPLY registers)
 #pragma unroll
                 for (int u = 0; u < PS_APPLY; u++) {
-                    if (c[u]) mlog[(size_t)(ty0 + y) * g.W + X0 + x] = v[u] + ((double)(c[u] & 0xffffu) * g.l_free + (double)(c[u] >> 16) * g.l_occ);
+                    if (c[u]) {
+                        const double nv = v[u] + ((double)(c[u] & 0xffffu) * g.l_free + (double)(c[u] >> 16) * g.l_occ);
+                        mlog[(size_t)(ty0 + y) * g.W + X0 + x] = nv;
+                        if (CODES && (((v[u] > 0.0) != (nv > 0.0)) | ((v[u] < 0.0) != (nv < 0.0)))) {      // the cell's class changes: the old one is known, one exclusive-or
+                            const uint32_t e0 = v[u] > 0.0 ? 2u : (v[u] < 0.0 ? 1u : 0u), e1 = nv > 0.0 ? 2u : (nv < 0.0 ? 1u : 0u);
+                            {
+                                s_changed = 1;
+                                const uint32_t ci = (uint32_t)((ty0 + y) * g.W + X0 + x);
+                                __hip_atomic_fetch_xor((gms_lds_u32 *)(s_plane) + (ci >> 4), (e0 ^ e1) << (2u * (ci & 15u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
                     x += pr; y += pq;
                     if (x >= tw) { x -= tw; y++; }
                 }
@@ -384,6 +520,8 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
         __syncthreads();
         if (ty0 == Y0) GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 7);
     }
+    if (CODES && s_changed)                                                    // plane 0 follows logData
+        for (int32_t i = threadIdx.x; i < code_words; i += NT) gplane[i] = s_plane[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -670,10 +808,15 @@ k_slam_gather_maps(const double *__restrict__ src_log, const double *__restrict_
 #endif
 __global__ void __launch_bounds__(256)
 k_slam_gather_one(const double *__restrict__ src, double *__restrict__ dst, const int32_t *__restrict__ idx, int64_t cells,
-                  int32_t *__restrict__ idx_keep) {
+                  int32_t *__restrict__ idx_keep, const uint32_t *__restrict__ src_code, uint32_t *__restrict__ dst_code, int64_t code_words2) {
     const int32_t m = blockIdx.y;
     const int32_t i = idx[m];
     if (idx_keep && blockIdx.x == 0 && threadIdx.x == 0) idx_keep[m] = i;      // for the copy that is still owed (gms_slam::d_idx_lik)
+    if (src_code && blockIdx.x == gridDim.x - 1) {                             // the particle's two class planes travel with its logData (16-byte multiples)
+        const uint4 *sc = reinterpret_cast<const uint4 *>(src_code + (size_t)i * (size_t)code_words2);
+        uint4 *dc = reinterpret_cast<uint4 *>(dst_code + (size_t)m * (size_t)code_words2);
+        for (int64_t e = threadIdx.x; e < code_words2 / 4; e += 256) dc[e] = sc[e];
+    }
     const size_t so = (size_t)i * (size_t)cells, dof = (size_t)m * (size_t)cells;
     if ((cells & 1) == 0) {
         const int64_t n2 = cells >> 1;
@@ -693,6 +836,15 @@ k_slam_gather_one(const double *__restrict__ src, double *__restrict__ dst, cons
     } else {
         for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < cells; e += (int64_t)gridDim.x * 256) dst[dof + e] = src[so + e];
     }
+}
+
+// the class planes alone (the resampling copy that moves both arrays at once, k_slam_gather_maps, does not carry them)
+__global__ void __launch_bounds__(256)
+k_slam_gather_codes(const uint32_t *__restrict__ src_code, uint32_t *__restrict__ dst_code, const int32_t *__restrict__ idx, int64_t code_words2) {
+    const int32_t m = blockIdx.x;
+    const uint4 *sc = reinterpret_cast<const uint4 *>(src_code + (size_t)idx[m] * (size_t)code_words2);
+    uint4 *dc = reinterpret_cast<uint4 *>(dst_code + (size_t)m * (size_t)code_words2);
+    for (int64_t e = threadIdx.x; e < code_words2 / 4; e += 256) dc[e] = sc[e];
 }
 
 // createMapData(null) for every particle (SLAM.reset, SLAM.java:65-77): logData = logOdds(0.5) = 0.0, likelihoodData = 0.0
@@ -727,14 +879,54 @@ void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, 
 #undef SLK_LAUNCH
 }
 
+int64_t gms_slam_code_words(int64_t cells) { return slam_code_words(cells); }
+void gms_launch_slam_gather_codes(gms_pf *pf, const uint32_t *src_code, uint32_t *dst_code, int64_t code_words) {
+    hipLaunchKernelGGL(k_slam_gather_codes, dim3((unsigned)pf->n), dim3(256), 0, pf->map->stream, src_code, dst_code, pf->d_idx, 2 * code_words);
+}
+
+// likelihoodData of all n particles from plane 1 of their class planes (d_code [n][2][code_words])
+void gms_launch_slam_likelihood_codes(gms_map *m, const uint32_t *d_code, int64_t code_words, double *d_lik, int32_t n) {
+    ProfScope ps(m, GMS_K_LIKELIHOOD);
+    const int32_t k = m->lik_kh;
+    const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
+    const size_t smem = gms_likelihood_lds_bytes(m->gd.khalf, k != 0);
+    int32_t blocks = tiles_x * tiles_y;
+    int32_t per_cu = (int32_t)((size_t)m->lds_per_cu / (smem + 256));
+    if (per_cu > GMS_LIK_WG_PER_CU) per_cu = GMS_LIK_WG_PER_CU;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t resident = (int64_t)per_cu * m->n_cus;
+    while (blocks > 1 && (int64_t)blocks * n > 32 * resident) blocks = (blocks + 1) / 2;
+    dim3 grid((unsigned)blocks, (unsigned)n);
+#define SLK_LAUNCH(KH)                                                                                                          \
+    do {                                                                                                                          \
+        if (smem > 48 * 1024)                                                                                                     \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_likelihood_codes<KH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((k_slam_likelihood_codes<KH>), grid, dim3(256), smem, m->stream, m->gd, d_code + code_words, 2 * code_words, d_lik, m->d_taps, \
+                           tiles_x, tiles_y);                                                                                     \
+    } while (0)
+    if (k == 3) SLK_LAUNCH(3);
+    else if (k == 5) SLK_LAUNCH(5);
+    else SLK_LAUNCH(0);
+#undef SLK_LAUNCH
+}
+
+// plane 0 of `count` particles from their logData (d_log, d_code: the first of them)
+void gms_launch_slam_codes_from_log(gms_map *m, const double *d_log, int32_t count, uint32_t *d_code, int64_t code_words) {
+    const int64_t words = (m->gd.cells + 15) / 16;
+    hipLaunchKernelGGL(k_slam_codes_from_log, dim3((unsigned)((words + 255) / 256), (unsigned)count), dim3(256), 0, m->stream, d_log, m->gd.cells, d_code,
+                       2 * code_words, words);
+}
+
 // dynamic LDS of k_slam_particle<NT, NP> without its count tile
 static inline size_t slam_particle_fixed_lds(int32_t Bpad, int np) {
     return (size_t)Bpad * sizeof(double) + (size_t)PS_WORDS * 64 * np * sizeof(uint64_t) + (size_t)64 * np * sizeof(PsRay);
 }
 
 // SLAM.update's per-particle body for all n particles of pf (one map each, d_log / d_lik [n][cells]); motion may be NULL
+// d_code (may be NULL): the particles' class planes [n][2][code_words], kept in step with logData; with them d_lik may be NULL: the
+// field is then evaluated at the scan's end points from the planes
 void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, double *d_log, const double *d_lik, const MotionModel *motion,
-                              int32_t integrate) {
+                              int32_t integrate, uint32_t *d_code, int64_t code_words) {
     gms_map *m = pf->map;
     MotionArgs mo;
     mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0;
@@ -746,7 +938,7 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, do
     ProfScope ps(m, GMS_K_SCORE);
     const int32_t Bpad = (B + 7) & ~7;
     constexpr int NP = 2;
-    const size_t fixed = slam_particle_fixed_lds(Bpad, NP);
+    const size_t fixed = slam_particle_fixed_lds(Bpad, NP) + (d_code ? (size_t)code_words * 4 + (size_t)Bpad * 4 : 0);
     // the count tile: the whole map when two workgroups then still share a CU's LDS, else whatever one workgroup can have (the kernel
     // walks the scan's box in bands of rows when it is larger)
     const size_t lds_wg = (size_t)m->lds_per_cu - 4096;                         // (static LDS of the kernel -- 1.2 KiB per workgroup --, allocation granularity)
@@ -765,14 +957,16 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, do
     // the read-modify-write of the touched cells -- overlap), 1024 when the tile leaves room for one only.  GMS_SLAM_THREADS forces one.
     int32_t threads = smem <= lds_wg / 2 ? 512 : 1024;
     if (m->slam_threads == 512 || m->slam_threads == 1024) threads = m->slam_threads;
-#define PS_LAUNCH(NT, NA)                                                                                                               \
+#define PS_LAUNCH(NT, NA, CD)                                                                                                           \
     do {                                                                                                                                \
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_particle<NT, NP, NA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((k_slam_particle<NT, NP, NA>), dim3((unsigned)pf->n), dim3(NT), smem, m->stream, m->gd, d_beams, B, Bpad, d_log, d_lik, \
-                           pf->d_pose, pf->d_cs, pf->d_w, pf->d_logw, mo, integrate, (int32_t)(tile * 4));                             \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_particle<NT, NP, NA, CD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((k_slam_particle<NT, NP, NA, CD>), dim3((unsigned)pf->n), dim3(NT), smem, m->stream, m->gd, d_beams, B, Bpad, d_log, d_lik, \
+                           pf->d_pose, pf->d_cs, pf->d_w, pf->d_logw, mo, integrate, (int32_t)(tile * 4), d_code, (int32_t)code_words, m->d_taps); \
     } while (0)
-    if (threads == 512) { if (narrow_allowed) PS_LAUNCH(512, true); else PS_LAUNCH(512, false); }
-    else { if (narrow_allowed) PS_LAUNCH(1024, true); else PS_LAUNCH(1024, false); }
+#define PS_LAUNCH2(NT, NA) do { if (d_code) PS_LAUNCH(NT, NA, true); else PS_LAUNCH(NT, NA, false); } while (0)
+    if (threads == 512) { if (narrow_allowed) PS_LAUNCH2(512, true); else PS_LAUNCH2(512, false); }
+    else { if (narrow_allowed) PS_LAUNCH2(1024, true); else PS_LAUNCH2(1024, false); }
+#undef PS_LAUNCH2
 #undef PS_LAUNCH
     pf->pending_nseg = 0;
     pf->score_fresh = 1;
@@ -818,7 +1012,8 @@ bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, cons
     return true;
 }
 
-void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx, int32_t *d_idx_keep) {
+void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx, int32_t *d_idx_keep, const uint32_t *src_code,
+                                uint32_t *dst_code, int64_t code_words) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_MAPCOPY);
     const int64_t cells = m->gd.cells;
@@ -830,7 +1025,8 @@ void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, cons
     int64_t chunks = (cells / 2 + per - 1) / per;
     if (chunks < 1) chunks = 1;
     while (chunks > 1 && chunks * pf->n > 262144) chunks = (chunks + 1) / 2;
-    hipLaunchKernelGGL(k_slam_gather_one, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, src, dst, d_idx, cells, d_idx_keep);
+    hipLaunchKernelGGL(k_slam_gather_one, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, src, dst, d_idx, cells, d_idx_keep, src_code, dst_code,
+                       2 * code_words);
 }
 
 void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik) {
