@@ -208,6 +208,7 @@ def load() -> C.CDLL:
     sig("gms_slam_download_maps", C.c_int, vp, vp, vp)
     sig("gms_slam_combined", C.c_int, vp)
     sig("gms_slam_copies", C.c_int, vp, C.POINTER(C.c_int64))
+    sig("gms_slam_trace_scan", C.c_int, vp, i32, vp, i32, vp, vp, i32, vp)
     sig("gms_debug_set_stamps", C.c_int, vp, vp)
     _lib = L
     return L

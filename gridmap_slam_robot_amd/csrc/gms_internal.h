@@ -306,6 +306,7 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, do
 void gms_launch_slam_likelihood_codes(gms_map *m, const uint32_t *d_code, int64_t code_words, double *d_lik, int32_t n);
 void gms_launch_slam_codes_from_log(gms_map *m, const double *d_log, int32_t count, uint32_t *d_code, int64_t code_words);
 int64_t gms_slam_code_words(int64_t cells);
+void gms_launch_slam_trace(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t particle, int32_t *d_cells, uint8_t *d_cls, int32_t cap, int32_t *d_counts);
 void gms_launch_slam_gather_codes(gms_pf *pf, const uint32_t *src_code, uint32_t *dst_code, int64_t code_words);
 bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, const double *d_lik, const MotionModel *motion, int32_t field_in_lds);
 void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik);

@@ -271,6 +271,34 @@ int gms_slam_combined(gms_slam *s) {
     return gms_map_build_likelihood(m);                                                       // :457
 }
 
+// The cell walk of SLAM.update's integrateObservation(p.m, z, p.pose) for particle i at its current pose, as k_slam_particle walks and
+// classifies it, written out instead of counted (tests): gms_map_trace_scan's layout.
+int gms_slam_trace_scan(gms_slam *s, int32_t i, const gms_beam *beams, int32_t B, int32_t *cells_xy, uint8_t *classes, int32_t cap, int32_t *counts) {
+    REQUIRE(s && beams && counts, "null argument");
+    REQUIRE(i >= 0 && i < s->n, "gms_slam_trace_scan: particle index out of range");
+    REQUIRE(B >= 0 && B <= s->map->max_beams && cap >= 0, "gms_slam_trace_scan: beam count or capacity out of range");
+    gms_map *m = s->map;
+    HIPCHK(hipSetDevice(m->device));
+    int rc = gms_stage_beams(m, beams, B);
+    if (rc) return rc;
+    int32_t *d_cells = nullptr, *d_counts = nullptr;
+    uint8_t *d_cls = nullptr;
+    const size_t n = (size_t)B * (size_t)cap;
+    bool ok = hipMalloc(&d_cells, (n ? n : 1) * 2 * sizeof(int32_t)) == hipSuccess && hipMalloc(&d_cls, n ? n : 1) == hipSuccess &&
+              hipMalloc(&d_counts, (size_t)(B ? B : 1) * sizeof(int32_t)) == hipSuccess;
+    if (ok) {
+        gms_launch_slam_trace(s->pf, m->d_beams, B, i, d_cells, d_cls, cap, d_counts);
+        ok = hipGetLastError() == hipSuccess;
+        if (ok && B) ok = hipMemcpyAsync(counts, d_counts, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream) == hipSuccess;
+        if (ok && n && cells_xy) ok = hipMemcpyAsync(cells_xy, d_cells, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream) == hipSuccess;
+        if (ok && n && classes) ok = hipMemcpyAsync(classes, d_cls, n, hipMemcpyDeviceToHost, m->stream) == hipSuccess;
+        ok = hipStreamSynchronize(m->stream) == hipSuccess && ok;
+    }
+    hipFree(d_cells); hipFree(d_cls); hipFree(d_counts);
+    if (!ok) return gms_fail(GMS_ERR_HIP, "gms_slam_trace_scan: device allocation, launch or copy failed");
+    return GMS_OK;
+}
+
 int gms_slam_copies(const gms_slam *s, int64_t *maps_copied) {
     REQUIRE(s && maps_copied, "null argument");
     *maps_copied = s->copies;

@@ -111,14 +111,23 @@ struct PsRay {                          // what a consumer needs of a ray
 // phase B of the ray cast (ray_phase_b) for an LDS tile of 32-bit cells n_free | n_occ << 16 -- a whole scan's visits of one cell fit
 // (gms_map_create: (1 + extra) * beams < 65536) -- or, NARROW, of 16-bit cells n_free | n_occ << 8, covering [tx0, tx0 + tw) x [ty0, ty0 + th); cells outside it belong to another band
 // one lane's cell of a ray: step k of the walk, from the decision word `sl` that covers it (its y steps before the word in the high half)
+// step k of a ray's walk: its cell, rebuilt from the decision word that covers it, and the sensor class of that cell (what
+// k_slam_particle counts and gms_slam_trace_scan lists: one function, so the trace IS the counting kernel's walk and classifier)
+struct PsCell { int32_t cx, cy, cls; };
+__device__ __forceinline__ PsCell ps_cell_of(const PsRay &mt, uint64_t sl, int32_t k, int32_t lane) {
+    const int32_t ny = (int32_t)(((uint32_t)(sl >> 32) & ~RC_VALID) + __popc((uint32_t)sl & ((1u << (lane & 31)) - 1u)));
+    const int32_t nx = k - ny;
+    PsCell c;
+    c.cx = mt.x0 + __mul24(mt.x_inc, nx); c.cy = mt.y0 + __mul24(mt.y_inc, ny);              // (|n| <= W + H + 1 < 2^23: gms_map_create)
+    const float dX = mt.sx - ((float)c.cx + 0.5f), dY = mt.sy - ((float)c.cy + 0.5f);        // GridMap.java:215-216
+    c.cls = sensor_class_sq(dX * dX + dY * dY, RayThr{mt.s_free, mt.s_prior}, mt.hit);       // :217, :223
+    return c;
+}
 template <bool NARROW>
 __device__ __forceinline__ void ps_count_cell(const GridDev &g, const PsRay &mt, uint64_t sl, int32_t k, int32_t lane, uint32_t *__restrict__ tile,
                                               int32_t tx0, int32_t ty0, int32_t tw, int32_t th) {
-    const int32_t ny = (int32_t)(((uint32_t)(sl >> 32) & ~RC_VALID) + __popc((uint32_t)sl & ((1u << (lane & 31)) - 1u)));
-    const int32_t nx = k - ny;
-    const int32_t cx = mt.x0 + __mul24(mt.x_inc, nx), cy = mt.y0 + __mul24(mt.y_inc, ny);     // (|n| <= W + H + 1 < 2^23: gms_map_create)
-    const float dX = mt.sx - ((float)cx + 0.5f), dY = mt.sy - ((float)cy + 0.5f);            // GridMap.java:215-216
-    const int32_t cls = sensor_class_sq(dX * dX + dY * dY, RayThr{mt.s_free, mt.s_prior}, mt.hit);   // :217, :223
+    const PsCell pc = ps_cell_of(mt, sl, k, lane);
+    const int32_t cx = pc.cx, cy = pc.cy, cls = pc.cls;
     const uint32_t ux = (uint32_t)(cx - tx0), uy = (uint32_t)(cy - ty0);
     // inside the map (RayIterator.java:108; the tile lies inside it), of this band, and not `+= logOdds(0.5)` = 0.0
     if (k < mt.n_eff && (uint32_t)cx < (uint32_t)g.W && (uint32_t)cy < (uint32_t)g.H && ux < (uint32_t)tw && uy < (uint32_t)th && cls != 1) {
@@ -522,6 +531,77 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     }
     if (CODES && s_changed)                                                    // plane 0 follows logData
         for (int32_t i = threadIdx.x; i < code_words; i += NT) gplane[i] = s_plane[i];
+}
+
+// The cell walk of k_slam_particle for ONE particle without touching its map (tests): the same ray set-up (ps_make_ray, ray_meta,
+// ray_thresholds), the same recurrence (ray_phase_a) and the same per-step function (ps_cell_of) as the counting kernel, but every
+// emitted step -- prior-class visits included -- is written out in walk order: for beam b, counts[b] cells (x, y) and their classes,
+// [B][cap] entries (RayIterator.java:107-130: the walk stops at the first cell outside the map).  One workgroup; wavefront 0 walks 64
+// rays per group, all four list their cells.
+__global__ void __launch_bounds__(256)
+k_slam_trace(GridDev g, const gms_beam *__restrict__ beams, int32_t B, const float *__restrict__ pose, const float *__restrict__ cs, int32_t p,
+             int32_t *__restrict__ t_cells, uint8_t *__restrict__ t_cls, int32_t cap, int32_t *__restrict__ t_counts) {
+    __shared__ uint64_t s_slots[PS_WORDS * 64];
+    __shared__ PsRay s_ray[64];
+    __shared__ int32_t s_count[64];
+    __shared__ int32_t s_nwm;
+    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    XformDev t;
+    t.px = (double)pose[3 * (size_t)p]; t.py = (double)pose[3 * (size_t)p + 1]; t.c = (double)cs[2 * (size_t)p]; t.s = (double)cs[2 * (size_t)p + 1];
+    for (int32_t g0 = 0; g0 < B; g0 += 64) {
+        RayDev r;
+        r.dx = r.dy = r.error = 0.0f; r.x = r.y = r.x_inc = r.y_inc = r.n = 0;
+        int32_t my_nwords = 0;
+        if (wave == 0) {
+            const int32_t ri = g0 + lane;
+            PsRay pr;
+            pr.n_eff = 0; pr.x0 = pr.y0 = pr.x_inc = pr.y_inc = pr.hit = 0; pr.sx = pr.sy = pr.s_free = pr.s_prior = 0.0f;
+            if (ri < B) {
+                const RayMeta mt = ray_meta(g, ps_make_ray(g, t, beams[ri]), r);
+                const RayThr thr = ray_thresholds(mt.measured, mt.hit, g.half_tol);
+                pr.x0 = mt.x0; pr.y0 = mt.y0; pr.x_inc = mt.x_inc; pr.y_inc = mt.y_inc; pr.n_eff = mt.n_eff; pr.hit = mt.hit;
+                pr.sx = mt.sx; pr.sy = mt.sy; pr.s_free = thr.s_free; pr.s_prior = thr.s_prior;
+            }
+            s_ray[lane] = pr;
+            s_count[lane] = 0;
+            my_nwords = (pr.n_eff + 31) >> 5;
+            int32_t nwm = my_nwords;
+#define GMS_STEP_(O) nwm = max(nwm, wave_xor<O>(nwm));
+            GMS_BUTTERFLY(GMS_STEP_)
+#undef GMS_STEP_
+            if (lane == 0) s_nwm = nwm;
+        }
+        __syncthreads();
+        const int32_t nwords_max = s_nwm;
+        RayWalk wk = ray_walk_begin(r);
+        for (int32_t wb = 0; wb < nwords_max; wb += PS_WORDS) {
+            for (int32_t i = threadIdx.x; i < PS_WORDS * 64; i += 256) s_slots[i] = 0ull;
+            __syncthreads();
+            if (wave == 0 && wb < my_nwords) ray_phase_a(wk, wb, min(my_nwords, wb + PS_WORDS), s_slots, 64, lane);
+            __syncthreads();
+            const int32_t blk0 = wb >> 1;
+            for (int32_t pair = wave; pair < 64 * (PS_WORDS / 2); pair += 4) {
+                const int32_t slot = pair & 63, blk = blk0 + (pair >> 6);
+                const PsRay ray = s_ray[slot];
+                if (blk * 64 >= ray.n_eff) continue;                           // (uniform per wavefront)
+                const int32_t nwords = (ray.n_eff + 31) >> 5;
+                uint64_t a, c;
+                ps_wait_words(s_slots, (2 * blk - wb) * 64 + slot, (min(2 * blk + 1, nwords - 1) - wb) * 64 + slot, a, c);
+                const int32_t k = blk * 64 + lane;
+                const PsCell pc = ps_cell_of(ray, lane < 32 ? a : c, k, lane);
+                const bool inside = k < ray.n_eff && (uint32_t)pc.cx < (uint32_t)g.W && (uint32_t)pc.cy < (uint32_t)g.H;      // RayIterator.java:108
+                if (inside && k < cap) {
+                    const size_t o = (size_t)(g0 + slot) * cap + k;
+                    t_cells[2 * o] = pc.cx; t_cells[2 * o + 1] = pc.cy; t_cls[o] = (uint8_t)pc.cls;
+                }
+                const int32_t n = __popcll(__ballot(inside));
+                if (lane == 0 && n) atomicAdd(&s_count[slot], n);
+            }
+            __syncthreads();
+        }
+        if (wave == 0 && g0 + lane < B) t_counts[g0 + lane] = s_count[lane];
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -970,6 +1050,11 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, do
 #undef PS_LAUNCH
     pf->pending_nseg = 0;
     pf->score_fresh = 1;
+}
+
+void gms_launch_slam_trace(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t particle, int32_t *d_cells, uint8_t *d_cls, int32_t cap, int32_t *d_counts) {
+    gms_map *m = pf->map;
+    hipLaunchKernelGGL(k_slam_trace, dim3(1), dim3(256), 0, m->stream, m->gd, d_beams, B, pf->d_pose, pf->d_cs, particle, d_cells, d_cls, cap, d_counts);
 }
 
 // findBestPose for every particle of pf against its own field d_lik [n][cells] (SLAM.java:96); motion (may be NULL): the motion-model

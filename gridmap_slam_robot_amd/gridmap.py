@@ -853,6 +853,17 @@ class SLAMParticleMaps:
         check(load().gms_slam_combined(self._h))
         return self.grid_map.download_log()
 
+    def trace_scan(self, i: int, z, cap: int = 0):
+        """(cells [B][cap][2], classes [B][cap], counts [B]): the cell walk of integrateObservation for particle i at its current pose
+        as the update kernel walks and classifies it (prior-class visits included), in walk order; nothing is written to a map"""
+        b = _beams_of(z)
+        cap = int(cap) if cap > 0 else self.W + self.H + 8
+        cells = np.zeros((len(b), cap, 2), dtype=np.int32)
+        cls = np.zeros((len(b), cap), dtype=np.uint8)
+        counts = np.zeros(len(b), dtype=np.int32)
+        check(load().gms_slam_trace_scan(self._h, int(i), ptr(b), len(b), ptr(cells), ptr(cls), cap, ptr(counts)))
+        return cells, cls, counts
+
     def maps_copied(self) -> int:
         v = C.c_int64(0)
         check(load().gms_slam_copies(self._h, C.byref(v)))

@@ -324,6 +324,11 @@ int gms_slam_download_maps(gms_slam *s, double *log_all, double *lik_all);      
 /* GridMapApp.calculateCombined (J/app/GridMapApp.java:439-458) over the particles' maps, likelihood field included (:457), into the
  * GridMapData of the handle's own map (gms_slam_handles -> gms_map_download_log / gms_map_download_likelihood). */
 int gms_slam_combined(gms_slam *s);
+/* Diagnostics: the cell walk of integrateObservation(p.m, z, p.pose) (SLAM.java:105 -> GridMap.java:173-228) for particle i at its
+ * current pose, exactly as the per-particle update kernel walks and classifies it, written out instead of counted: for beam b,
+ * counts[b] cells in walk order (RayIterator.java:107-130), cells_xy / classes [B][cap] entries as gms_map_trace_scan (class 0 free,
+ * 1 prior, 2 occupied; either may be NULL).  Touches no map.  Synchronises. */
+int gms_slam_trace_scan(gms_slam *s, int32_t i, const gms_beam *beams, int32_t B, int32_t *cells_xy, uint8_t *classes, int32_t cap, int32_t *counts);
 /* maps copied by resampling steps since creation (measurement: bytes moved = copies * W * H * 32) */
 int gms_slam_copies(const gms_slam *s, int64_t *maps_copied);
 

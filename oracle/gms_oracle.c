@@ -312,6 +312,27 @@ int64_t orc_integrate(const orc_grid *g, double *log_data, const orc_beam *beams
     return visits;
 }
 
+/* The integer content of integrateObservation (GridMap.java:173-191): how often the scan's rays visit every cell, per sensor class
+ * (counts[3 * cell + class], class 0 free / 1 prior / 2 occupied; SensorModel.java:31-41) -- what `logData[c] += logOdds(...)` (:223)
+ * is a function of.  Test infrastructure for the integer parity of the device's ray casts; returns the number of visits. */
+int64_t orc_scan_counts(const orc_grid *g, const orc_beam *beams, int32_t B, const float pose[3], uint32_t *counts) {
+    int64_t visits = 0;
+    float ray[6];
+    int32_t cap = g->W + g->H + 8;
+    int32_t *cells = (int32_t *)malloc((size_t)cap * 2 * sizeof(int32_t));
+    uint8_t *cls = (uint8_t *)malloc((size_t)cap);
+    memset(counts, 0, (size_t)g->W * (size_t)g->H * 3 * sizeof(uint32_t));
+    for (int32_t b = 0; b < B; b++) {                /* :182 in list order */
+        orc_scan_rays(g, &beams[b], 1, pose, ray);
+        int32_t n = orc_apply_measurement(g, NULL, ray[0], ray[1], ray[2], ray[3], ray[4], beams[b].hit != 0, cells, cls, cap);
+        if (n > cap) n = cap;                        /* (a walk is at most W + H + 1 + extra steps long) */
+        for (int32_t k = 0; k < n; k++) counts[3 * ((size_t)cells[2 * k] + (size_t)cells[2 * k + 1] * g->W) + cls[k]]++;
+        visits += n;
+    }
+    free(cells); free(cls);
+    return visits;
+}
+
 /* ---- J/slam/GridMap.java:233-250 + J/app/Util.java:378-426 --------------------------------- */
 
 void orc_build_likelihood(const orc_grid *g, const double *log_data, double *lik, double *scratch) {

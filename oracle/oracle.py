@@ -78,6 +78,8 @@ def lib() -> C.CDLL:
         L.orc_scan_rays.argtypes = [gp, vp, C.c_int32, fp, fp]
         L.orc_integrate.restype = C.c_int64
         L.orc_integrate.argtypes = [gp, dp, vp, C.c_int32, fp]
+        L.orc_scan_counts.restype = C.c_int64
+        L.orc_scan_counts.argtypes = [gp, vp, C.c_int32, fp, vp]
         L.orc_build_likelihood.restype = None
         L.orc_build_likelihood.argtypes = [gp, dp, dp, dp]
         L.orc_probability_of.restype = C.c_double
@@ -234,6 +236,13 @@ class Grid:
         pose = np.asarray(pose, dtype=np.float32)
         out = np.empty((len(beams), 6), dtype=np.float32)
         lib().orc_scan_rays(C.byref(self.g), beams.ctypes.data, len(beams), _fp(pose), _fp(out))
+        return out
+
+    def scan_counts(self, beams: np.ndarray, pose) -> np.ndarray:
+        """[H * W][3] visits of every cell by the scan's rays per sensor class (free, prior, occupied): integrateObservation's integers"""
+        pose = np.asarray(pose, dtype=np.float32)
+        out = np.empty((self.W * self.H, 3), dtype=np.uint32)
+        lib().orc_scan_counts(C.byref(self.g), beams.ctypes.data, len(beams), _fp(pose), out.ctypes.data)
         return out
 
     def integrate(self, log: np.ndarray, beams: np.ndarray, pose) -> int:

@@ -123,3 +123,67 @@ def test_the_scan_step_in_reference_order_and_the_options_it_excludes():
     want = g.score(g.build_likelihood(log), tr.scans[6], P)                # (the step above has integrated scan 6 into the map)
     big = want > 1e-290
     assert np.max(np.abs(pf.get_weights()[big] - want[big]) / want[big]) <= 1e-11
+
+
+def test_a_batched_handle_in_reference_order_two_maps_of_config_5():
+    """Equality with the oracle is not a single-map statement: two independent maps of config 5's shape (1024 x 1024 cells, 4096
+    particles, 1080 beams each) in ONE batched handle, the audit path on: every raw weight of both maps bit for bit, each map's weight
+    sum, strongest particle, Neff and weighted pose, and every resampling index of both draws with no allowance; then the batched scan
+    step of that filter (separate launches) with the map updates at the two weighted poses."""
+    c = synth.CONFIGS["C5"]
+    M, B, N, ext, res = 2, c["beams"], c["particles"], c["extent"], c["resolution"]
+    traces = [synth.make_trace(ext, res, B, T=8, seed=700 + i, n_scans=6) for i in range(M)]
+    g = orc.Grid(ext, ext, res, -ext / 2, -ext / 2)
+    mb = GridMap(ext, ext, res, (-ext / 2, -ext / 2), n_maps=M, max_beams=B)
+    assert (mb.W, mb.H, mb.n_maps) == (1024, 1024, 2)
+    logs = [g.new_log() for _ in range(M)]
+    for t in range(3):
+        mb.update(np.stack([tr.scans[t] for tr in traces]), np.stack([tr.poses[t] for tr in traces]))
+        for i in range(M):
+            g.integrate(logs[i], traces[i].scans[t], traces[i].poses[t])
+    liks = mb.download_likelihood().reshape(M, -1)
+    for i in range(M):
+        assert np.array_equal(liks[i], g.build_likelihood(mb.download_log().reshape(M, -1)[i]))
+    pf = ParticleFilter(mb, N)
+    pf.set_reference_order(True)
+    # a cloud wide enough that many products underflow (1080 factors) and a tight one, one per map
+    Ph = np.stack([synth.make_particles(traces[0].poses[3], N, seed=1), synth.make_particles(traces[1].poses[3], N, seed=2, sigma_xy=0.02, sigma_theta_deg=0.3)])
+    scans3 = np.stack([tr.scans[3] for tr in traces])
+    pf.set_poses(Ph)
+    pf.score(scans3)
+    w = pf.get_weights()
+    wants = [g.score(liks[i], scans3[i], Ph[i]) for i in range(M)]
+    assert int((wants[0] == 0).sum()) > 0, "the wide cloud must exercise exact zeros"
+    for i in range(M):
+        assert np.array_equal(w[i], wants[i]), f"map {i}: {int((w[i] != wants[i]).sum())} raw weights differ"
+    sts = pf.normalize()
+    wn = pf.get_weights()
+    wps = pf.weighted_pose()
+    r01 = np.array([0.37, 0.81])
+    idx, amb = pf.resample(r01, want_indices=True)
+    for i in range(M):
+        x = wants[i].copy()
+        ws, strongest = orc.normalize(x)
+        assert sts[i]["weight_sum"] == ws and sts[i]["strongest"] == strongest and sts[i]["neff"] == orc.neff(x)
+        assert np.array_equal(wn[i], x)
+        assert np.array_equal(wps[i], orc.weighted_pose(Ph[i], x))
+        want_idx, clamped = orc.resample_indices(x.copy(), float(r01[i]))
+        assert clamped == 0 and np.array_equal(idx[i], want_idx) and int(np.asarray(amb).reshape(-1)[i]) == 0
+    assert np.array_equal(pf.get_poses(), np.stack([Ph[i][idx[i]] for i in range(M)]))
+    # the batched scan step of the audit filter: scored, normalised and resampled in the reference's order, each map updated at its own weighted pose
+    P4 = np.stack([synth.make_particles(traces[i].poses[4], N, seed=10 + i, sigma_xy=0.03, sigma_theta_deg=0.5) for i in range(M)])
+    scans4 = np.stack([tr.scans[4] for tr in traces])
+    liks_now = mb.download_likelihood().reshape(M, -1)
+    st = pf.slam_update(P4, scans4, np.array([0.11, 0.52]), 2.0, True, fetch=True)       # fraction 2: always resample
+    last_idx = pf.last_resample_indices()
+    logs_after = mb.download_log().reshape(M, -1)
+    for i in range(M):
+        x = g.score(liks_now[i], scans4[i], P4[i])
+        ws, strongest = orc.normalize(x)
+        assert st[i]["weight_sum"] == ws and st[i]["strongest"] == strongest and st[i]["neff"] == orc.neff(x)
+        want_idx, _ = orc.resample_indices(x.copy(), float([0.11, 0.52][i]))
+        assert np.array_equal(last_idx[i], want_idx)
+        wp = orc.weighted_pose(P4[i], x)
+        g.integrate(logs[i], scans4[i], wp)
+        assert np.array_equal(logs_after[i] != 0, logs[i] != 0) and np.max(np.abs(logs_after[i] - logs[i])) < 1e-10
+    pf.close(); mb.close()
