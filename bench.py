@@ -967,6 +967,17 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
         s.resample_if(float(r01[(217 + i) % 4096]), 0.5)
     torch.cuda.synchronize()
     rev = (time.perf_counter() - t0) / steps
+    # the same revolution while no resampling step is due (fraction 0: Neff < 0 never holds): the rule is evaluated on the device, nothing
+    # is drawn, and no map is copied -- which generation of the maps is current is a device-side fact (gms_slam_resample_maps_if)
+    copied0 = s.maps_copied()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm_frames + 4 * steps + i)
+        s.resample_if(float(r01[(317 + i) % 4096]), 0.0)
+    torch.cuda.synchronize()
+    rev_idle = (time.perf_counter() - t0) / steps
+    assert s.maps_copied() == copied0, "a revolution whose rule says no must not copy a map"
     # ... and `steps` draws back to back: every call first brings likelihoodData up to date, so both arrays move per call
     t0 = time.perf_counter()
     for i in range(steps):
@@ -1016,6 +1027,8 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
            "resample_ms": rsm * 1e3, "resample_what": ("in the update / resample loop; logData copied, likelihoodData's copy deferred (overwritten by the next "
                                                        "update's computeLikelihoodMap before anything reads it; materialised on demand)" if lazy else
                                                        "in the update / resample loop; both arrays copied at once"),
+           "revolution_no_resample_ms": rev_idle * 1e3,
+           "revolution_no_resample_what": "the same revolution while no resampling step is due: the rule decided on the device, no draw, no map copied (the reference does nothing either)",
            "revolution_ms": rev * 1e3, "revolution_what": "SLAM.update + `if (neff < n / 2) resample()` (GridMapApp.java:185-186) with the rule decided on the device: no host round trip",
            "resample_both_arrays_ms": rsm_both * 1e3, "resample_copy_TBps_algorithmic": copy_b / rsm_both / 1e12, "resample_copy_hbm_frac": copy_b / rsm_both / 8e12,
            "gridmapdata_bytes_on_device": 4.0 * 8 * cells * particles, "neff_last": st["neff"], "n_zero_weights": st["n_zero"],

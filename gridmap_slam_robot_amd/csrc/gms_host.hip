@@ -962,6 +962,8 @@ int gms_pf_create(gms_map *m, int32_t n, gms_pf **out) {               // Partic
 
 int gms_pf_set_shard(gms_pf *pf, int64_t offset, int64_t n_global) {
     REQUIRE(pf, "null filter");
+    if (pf->slam_owned && !pf->d_epoch2)
+        return fail(GMS_ERR_STATE, "this filter's particles own maps (gms_slam): resample through gms_slam_resample_maps[_if], update through gms_slam_update_per_particle");
     REQUIRE(offset >= 0 && offset % GMS_BLOCK == 0, "shard offset must be a multiple of GMS_BLOCK");
     REQUIRE(n_global >= offset + pf->n && n_global <= GMS_MAX_PARTICLES, "shard does not fit n_global (at most GMS_MAX_PARTICLES in all)");
     HIPCHK(hipSetDevice(pf->map->device));
@@ -1257,6 +1259,8 @@ static int commit_r01(gms_pf *pf) {
 
 static int do_resample(gms_pf *pf, const double *r01, double fraction, int32_t *indices, int32_t *n_ambiguous) {
     REQUIRE(pf && r01, "null argument");
+    if (pf->slam_owned && !pf->d_epoch2)
+        return fail(GMS_ERR_STATE, "this filter's particles own maps (gms_slam): resample through gms_slam_resample_maps[_if], update through gms_slam_update_per_particle");
     gms_map *m = pf->map;
     HIPCHK(hipSetDevice(m->device));
     int rc = GMS_OK;
@@ -1343,6 +1347,8 @@ int gms_slam_update_u_dev(gms_pf *pf, double d_center, double d_theta, uint64_t 
 static int slam_update_impl(gms_pf *pf, const float *dev_xytheta, const MotionModel *motion, const gms_beam *dev_beams, int32_t B,
                             const double *r01, double resample_fraction, int32_t integrate) {
     REQUIRE(pf && dev_beams && r01, "null argument");
+    if (pf->slam_owned && !pf->d_epoch2)
+        return fail(GMS_ERR_STATE, "this filter's particles own maps (gms_slam): resample through gms_slam_resample_maps[_if], update through gms_slam_update_per_particle");
     gms_map *m = pf->map;
     if (pf->offset != 0 || pf->n_global != pf->n)
         return fail(GMS_ERR_STATE, "sharded filter: the collectives belong to the caller (see distributed.py)");

@@ -194,6 +194,8 @@ struct gms_pf {
                                     // cumulative weights) as ONE chain in the reference's order (tests; slow)
     int32_t score_spread;           // -1 the launcher decides (launches of two or more workgroups per CU), 0 / 1 forced (GMS_SCORE_SPREAD, read at creation)
     int32_t order_mode;             // -1 the launcher decides (large launches only), 0 never, 1 always (GMS_SCORE_ORDER; results do not depend on it)
+    int32_t slam_owned;             // the filter of a gms_slam: its particles own maps, so resampling, sharding and the shared-map scan steps are refused on it
+    int32_t *d_epoch2;              // the filter of a gms_slam, during gms_slam_resample_maps[_if]: {draws that ran so far, the last resample() drew}, kept by the resampling kernels (NULL otherwise)
 };
 
 // one rank's side of the RCCL exchanges of a sharded filter (gms_host.hip)
@@ -208,6 +210,16 @@ struct gms_comm {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
+// Every particle's GridMapData of a gms_slam, both generations, as the kernels see it.  WHICH generation is current is a device-side
+// fact: resample() writes its deep copies into the other one, and `if (neff < n / 2) resample()` (GridMapApp.java:185-186) is decided on
+// the device, so the host cannot know without a round trip.  epoch[0] counts the draws that ran (kept by the resampling kernels,
+// gms_pf::d_epoch2): its parity is the current generation; epoch[1] says whether the last resample() drew.
+struct SlamBufs {
+    double *log[2], *lik[2];        // [n][H][W]
+    uint32_t *code[2];              // [n][2][code_words] class planes, or NULL
+    int32_t *epoch;
+};
+
 // SLAM as the reference has it (J/slam/SLAM.java): N particles, each with its own GridMapData (gms_slam_host.hip, gms_slam_kernels.hip)
 struct gms_slam {
     gms_map *map;                   // ONE map's worth of handle: the GridMap (geometry, constants, taps), the stream, staging, profiling; its own
@@ -215,18 +227,18 @@ struct gms_slam {
     gms_pf *pf;                     // the N particles' poses, weights, statistics and resampling indices (one "map" of N particles)
     int32_t n;
     double *d_log[2], *d_lik[2];    // [n][H][W] every particle's GridMapData, double-buffered for resample()'s deep copies
-    int32_t cur;                    // the buffer that holds the current generation
+    int32_t *d_epoch;               // {draws that ran so far, the last resample() drew}: the current generation is d_epoch[0] & 1 (SlamBufs)
+    int64_t copies_base;            // maps copied by resampling steps before the last reset (the rest: d_epoch[0] * n)
     int32_t lazy_lik;               // resample() copies logData at once and likelihoodData when somebody asks for it: the next update's
                                     // computeLikelihoodMap overwrites every cell of it before anything on the path reads one (GMS_SLAM_LAZY_LIK_COPY=0: both at once)
-    int32_t lik_behind;             // d_lik[cur] does not hold the last resample()'s copies yet: slot m's field is d_lik[1 - cur][d_idx_lik[m]]
+    int32_t lik_behind;             // the current generation's likelihoodData does not hold the last resample()'s copies yet (if it drew): slot m's field is the other generation's [d_idx_lik[m]]
     int32_t *d_idx_lik;             // [n] the source indices of that resample()
     uint32_t *d_code[2];            // [n][2][code_words] every particle's class planes (gms_slam_kernels.hip), double-buffered with logData; NULL: not kept
                                     // (the blur kernel is wider than the on-demand evaluation takes, the plane does not fit the LDS, or GMS_SLAM_EAGER_LIK=1)
     int64_t code_words;             // 32-bit words per plane
-    int32_t lik_from_codes;         // d_lik[cur] is behind: every particle's likelihoodData is the field of plane 1 of its class planes (made on demand)
+    int32_t lik_from_codes;         // likelihoodData is behind: every particle's is the field of plane 1 of its class planes (made on demand)
     int32_t refine;                 // gms_slam_set_refine: update() runs findBestPose on every particle against its own field before weighting it (SLAM.java:96)
     int32_t refine_lds;             // -1 the field is staged in LDS whenever it fits, 0 never (GMS_SLAM_REFINE_LDS=0: tests of the other form)
-    int64_t copies;                 // maps copied by resampling steps so far (measurement)
 };
 
 // the thread's last-error text + code (gms_host.hip); every C-ABI file reports through it
@@ -299,20 +311,20 @@ void gms_launch_pf_resample(gms_pf *pf, double fraction /* <0: unconditional */)
 void gms_launch_pf_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t beam_stride);
 void gms_launch_pf_normalize_seq(gms_pf *pf, PfStatsDev *d_stats_out, bool normalise);
 void gms_launch_pf_resample_seq(gms_pf *pf, double fraction);
-// one GridMapData per particle (gms_slam_kernels.hip)
-void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, int32_t n);
-void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, double *d_log, const double *d_lik, const MotionModel *motion,
-                              int32_t integrate, uint32_t *d_code = nullptr, int64_t code_words = 0);
-void gms_launch_slam_likelihood_codes(gms_map *m, const uint32_t *d_code, int64_t code_words, double *d_lik, int32_t n);
-void gms_launch_slam_codes_from_log(gms_map *m, const double *d_log, int32_t count, uint32_t *d_code, int64_t code_words);
+// one GridMapData per particle (gms_slam_kernels.hip); the buffers' current generation is read on the device (SlamBufs)
+SlamBufs gms_slam_bufs(const gms_slam *s);
+void gms_launch_slam_likelihood(gms_map *m, const SlamBufs &sb, int32_t n);
+void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, const SlamBufs &sb, bool field_in_memory, const MotionModel *motion,
+                              int32_t integrate, int64_t code_words);
+void gms_launch_slam_likelihood_codes(gms_map *m, const SlamBufs &sb, int64_t code_words, int32_t n);
+void gms_launch_slam_codes_from_log(gms_map *m, const SlamBufs &sb, int32_t first, int32_t count, int64_t code_words);
 int64_t gms_slam_code_words(int64_t cells);
 void gms_launch_slam_trace(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t particle, int32_t *d_cells, uint8_t *d_cls, int32_t cap, int32_t *d_counts);
-void gms_launch_slam_gather_codes(gms_pf *pf, const uint32_t *src_code, uint32_t *dst_code, int64_t code_words);
-bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, const double *d_lik, const MotionModel *motion, int32_t field_in_lds);
-void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik);
-void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx, int32_t *d_idx_keep, const uint32_t *src_code = nullptr,
-                                uint32_t *dst_code = nullptr, int64_t code_words = 0);   // one array: dst[m] <- src[d_idx[m]]; d_idx_keep (may be NULL) receives d_idx
-void gms_launch_slam_combine(gms_map *dst, const double *d_logs, int32_t n);
+bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, const SlamBufs &sb, const MotionModel *motion, int32_t field_in_lds);
+// resample()'s copies into the generation the draw has just made current, where it drew (epoch[1]); what: bit 0 logData (+ the class
+// planes), bit 1 likelihoodData; d_idx_keep (may be NULL) receives the indices for a likelihoodData copy that is still owed
+void gms_launch_slam_gather(gms_pf *pf, const SlamBufs &sb, int32_t what, const int32_t *d_idx, int32_t *d_idx_keep, int64_t code_words);
+void gms_launch_slam_combine(gms_map *dst, const SlamBufs &sb, int32_t n);
 
 // profiling brackets
 void gms_prof_begin(gms_map *m, int32_t k);

@@ -1114,7 +1114,7 @@ __global__ void k_factors(GridDev g, const double *__restrict__ lik, double *__r
 
 // GridMapApp.calculateCombined (J/app/GridMapApp.java:439-458): one combined map out of the n_maps of a batch,
 // log-odds of 1 - prod(1 - p_m), the maps multiplied in index order (Util.invLogOdds / logOdds: Util.java:35-48).
-__global__ void k_combine(const double *__restrict__ logs, int32_t n_maps, int64_t cells, double *__restrict__ out) {
+__device__ __forceinline__ void combine_body(const double *__restrict__ logs, int32_t n_maps, int64_t cells, double *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
         double product = 1.0;
         for (int32_t m = 0; m < n_maps; m++) {
@@ -1125,6 +1125,7 @@ __global__ void k_combine(const double *__restrict__ logs, int32_t n_maps, int64
         out[i] = log(odds / ((double)1.0f - odds));
     }
 }
+__global__ void k_combine(const double *__restrict__ logs, int32_t n_maps, int64_t cells, double *__restrict__ out) { combine_body(logs, n_maps, cells, out); }
 
 // The de-skew loop of GridMapApp.onHandleData (J/app/GridMapApp.java:143-175) + Measurement(x, y, wasHit, dummy)
 // (J/slam/Observation.java:69-76): raw polar measurements {angle, distance, hit} -> beams, on the device.

@@ -1220,10 +1220,17 @@ k_resample(const PackedParticle *__restrict__ glob_all, int64_t n_global, int64_
            const double *__restrict__ cum_all, const double *__restrict__ chunk_off, const double *__restrict__ r01,
            double r01_scalar, double fraction, int32_t n, int64_t offset, float *__restrict__ pose2, float *__restrict__ cs2,
            double *__restrict__ w2, int32_t *__restrict__ idx_out, const double *__restrict__ p2_all, int64_t nblk_global,
-           PfStatsDev *__restrict__ stats, int32_t raw_weights) {
+           PfStatsDev *__restrict__ stats, int32_t raw_weights, int32_t *__restrict__ epoch2) {
     extern __shared__ __align__(16) unsigned char smem[];
     resample_body(glob_all, n_global, nchunks, cum_all, chunk_off, r01, r01_scalar, fraction, n, offset, pose2, cs2, w2, idx_out,
                   p2_all, nblk_global, stats, blockIdx.x, blockIdx.y, smem, raw_weights != 0);
+    // a filter whose particles own maps (gms_slam): which generation of the maps is current is a device-side fact -- epoch2[0] counts the
+    // draws that ran (the generation is its parity), epoch2[1] says whether this one did; the thread that published did_resample adds it up
+    if (epoch2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const int32_t did = stats[0].did_resample;
+        epoch2[1] = did;
+        if (did) epoch2[0] = epoch2[0] + 1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1439,7 +1446,7 @@ k_normalize_seq(double *__restrict__ w_all, const double *__restrict__ logw_all,
 
 // resample() (SLAM.java:133-153) as the reference's own loop: ONE lane, c += weight in particle order.  One thread per map.
 __global__ void k_resample_seq_idx(const double *__restrict__ w_all, int32_t n, const double *__restrict__ r01_maps, double r01_scalar,
-                                   double fraction, int32_t *__restrict__ idx_all, PfStatsDev *__restrict__ stats_all) {
+                                   double fraction, int32_t *__restrict__ idx_all, PfStatsDev *__restrict__ stats_all, int32_t *__restrict__ epoch2) {
     const int32_t mi = blockIdx.x;
     if (threadIdx.x != 0) return;
     const double *w = w_all + (size_t)mi * n;
@@ -1448,6 +1455,7 @@ __global__ void k_resample_seq_idx(const double *__restrict__ w_all, int32_t n, 
     const bool go = fraction < 0.0 || (1.0 / st->sq_sum) < fraction * (double)n;        // GridMapApp.java:185
     st->did_resample = go ? 1 : 0;
     st->n_ambiguous = 0;
+    if (epoch2 && mi == 0) { epoch2[1] = go ? 1 : 0; if (go) epoch2[0] = epoch2[0] + 1; }   // (see k_resample)
     if (!go) { for (int32_t m = 0; m < n; m++) idx[m] = m; return; }
     const double N = (double)n;
     const double r = (r01_maps ? r01_maps[mi] : r01_scalar) * 1.0 / N;                  // :136
@@ -1711,7 +1719,7 @@ void gms_launch_pf_resample(gms_pf *pf, double fraction) {
     hipLaunchKernelGGL(k_resample, dim3((pf->n + 255) / 256, pf->n_maps), dim3(256), smem, m->stream, pf->d_global,
                        pf->n_global, nch, pf->d_cum, pf->d_chunk_tot, pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01_src,
                        pf->r01_scalar, fraction, pf->n, pf->offset,
-                       pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats, pf->global_raw);
+                       pf->d_pose2, pf->d_cs2, pf->d_w2, pf->d_idx, pf->d_p2, nblk_global_of(pf), pf->d_stats, pf->global_raw, pf->d_epoch2);
     pf->neff_folded = 1;
 }
 
@@ -1737,7 +1745,7 @@ void gms_launch_pf_resample_seq(gms_pf *pf, double fraction) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_RESAMPLE);
     hipLaunchKernelGGL(k_resample_seq_idx, dim3(pf->n_maps), dim3(64), 0, m->stream, pf->d_w, pf->n,
-                       pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01_src, pf->r01_scalar, fraction, pf->d_idx, pf->d_stats);
+                       pf->n_maps == 1 ? (const double *)nullptr : pf->d_r01_src, pf->r01_scalar, fraction, pf->d_idx, pf->d_stats, pf->d_epoch2);
     hipLaunchKernelGGL(k_resample_seq_gather, dim3((unsigned)((pf->n + 255) / 256), pf->n_maps), dim3(256), 0, m->stream, pf->d_idx, pf->d_pose,
                        pf->d_cs, pf->d_w, pf->n, pf->d_pose2, pf->d_cs2, pf->d_w2);
 }

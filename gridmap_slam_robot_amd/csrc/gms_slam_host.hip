@@ -18,6 +18,24 @@
         if (!(cond)) return gms_fail(GMS_ERR_INVALID, "%s", msg);  \
     } while (0)
 
+SlamBufs gms_slam_bufs(const gms_slam *s) {
+    SlamBufs b;
+    for (int k = 0; k < 2; k++) { b.log[k] = s->d_log[k]; b.lik[k] = s->d_lik[k]; b.code[k] = s->d_code[k]; }
+    b.epoch = s->d_epoch;
+    return b;
+}
+
+// The current generation on the HOST: a stream synchronise and an 8-byte read.  Only where the host itself must address a particle's
+// arrays -- downloads, uploads, reset, the copy counter -- never on the update / resample path.
+static int slam_host_gen(gms_slam *s, int32_t *gen, int64_t *draws = nullptr) {
+    int32_t e[2] = {0, 0};
+    HIPCHK(hipStreamSynchronize(s->map->stream));
+    HIPCHK(hipMemcpy(e, s->d_epoch, sizeof(e), hipMemcpyDeviceToHost));
+    if (gen) *gen = e[0] & 1;
+    if (draws) *draws = e[0];
+    return GMS_OK;
+}
+
 extern "C" {
 
 int gms_slam_destroy(gms_slam *s) {
@@ -26,6 +44,7 @@ int gms_slam_destroy(gms_slam *s) {
     for (int k = 0; k < 2; k++) { hipFree(s->d_log[k]); hipFree(s->d_lik[k]); }
     hipFree(s->d_idx_lik);
     hipFree(s->d_code[0]); hipFree(s->d_code[1]);
+    hipFree(s->d_epoch);
     if (s->pf) gms_pf_destroy(s->pf);
     if (s->map) gms_map_destroy(s->map);
     delete s;
@@ -58,6 +77,8 @@ int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out) { 
     for (int k = 0; k < 2; k++)
         ok = ok && hipMalloc(&s->d_log[k], bytes) == hipSuccess && hipMalloc(&s->d_lik[k], bytes) == hipSuccess;
     ok = ok && hipMalloc(&s->d_idx_lik, (size_t)n_particles * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&s->d_epoch, 2 * sizeof(int32_t)) == hipSuccess && hipMemset(s->d_epoch, 0, 2 * sizeof(int32_t)) == hipSuccess;
+    s->pf->slam_owned = 1;          // its particles own maps: resampling goes through gms_slam_resample_maps[_if], which moves them
     // The class planes (gms_slam_kernels.hip): kept unless the blur kernel is wider than the on-demand evaluation takes, a plane would
     // crowd the count tile out of a workgroup's LDS, or GMS_SLAM_EAGER_LIK=1 asks for the reference's own schedule -- every cell of every
     // particle's likelihoodData rebuilt by every update (the like-for-like figure of bench.py)
@@ -80,10 +101,15 @@ int gms_slam_reset(gms_slam *s) {                                               
     gms_map *m = s->map;
     HIPCHK(hipSetDevice(m->device));
     const size_t bytes = (size_t)s->n * (size_t)m->gd.cells * sizeof(double);
+    int64_t draws = 0;
+    int rc0 = slam_host_gen(s, nullptr, &draws);
+    if (rc0) return rc0;
+    s->copies_base += draws * s->n;                                                          // (the copy counter outlives a reset)
+    HIPCHK(hipMemsetAsync(s->d_epoch, 0, 2 * sizeof(int32_t), m->stream));                   // generation 0 is current again
     // createMapData(null) per particle (GridMap.java:106-117): logData = logOdds(0.5) = 0.0, likelihoodData a fresh double[] = 0.0
-    HIPCHK(hipMemsetAsync(s->d_log[s->cur], 0, bytes, m->stream));
-    HIPCHK(hipMemsetAsync(s->d_lik[s->cur], 0, bytes, m->stream));
-    if (s->d_code[s->cur]) HIPCHK(hipMemsetAsync(s->d_code[s->cur], 0, (size_t)s->n * 2 * (size_t)s->code_words * sizeof(uint32_t), m->stream));   // every class "logData == 0"
+    HIPCHK(hipMemsetAsync(s->d_log[0], 0, bytes, m->stream));
+    HIPCHK(hipMemsetAsync(s->d_lik[0], 0, bytes, m->stream));
+    if (s->d_code[0]) HIPCHK(hipMemsetAsync(s->d_code[0], 0, (size_t)s->n * 2 * (size_t)s->code_words * sizeof(uint32_t), m->stream));   // every class "logData == 0"
     s->lik_behind = 0;
     s->lik_from_codes = 0;
     gms_launch_pf_init(s->pf);                                                               // Pose(0, 0, 0), weight 1 / numParticles (:68-71)
@@ -128,18 +154,18 @@ int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int
     // scan's end points only (GridMap.java:273-277), and k_slam_particle evaluates exactly those cells from the particle's plane; what a
     // caller may read afterwards -- the field of logData as it stands NOW -- stays defined by plane 1 and is written when asked for
     // (slam_lik_current).  The pose refinement looks up most of a field: it gets all of it.
-    const bool on_demand = s->d_code[s->cur] != nullptr && !s->refine;
-    if (!on_demand) gms_launch_slam_likelihood(m, s->d_log[s->cur], s->d_lik[s->cur], s->n);
+    const bool on_demand = s->d_code[0] != nullptr && !s->refine;
+    const SlamBufs sb = gms_slam_bufs(s);
+    if (!on_demand) gms_launch_slam_likelihood(m, sb, s->n);
     s->lik_behind = 0;                                                                                     // (every cell of every field is rewritten: an owed copy is moot)
     s->lik_from_codes = on_demand ? 1 : 0;
     bool drawn = false;
     if (s->refine) {                                                                                        // :90, then :96 (the lattice form of :97)
-        if (!gms_launch_slam_refine(pf, dev_beams, B, s->d_lik[s->cur], sample_motion ? &mo : nullptr, s->refine_lds))
+        if (!gms_launch_slam_refine(pf, dev_beams, B, sb, sample_motion ? &mo : nullptr, s->refine_lds))
             return gms_fail(GMS_ERR_INVALID, "gms_slam_update_per_particle: the pose refinement's tables do not fit the LDS for a scan of %d beams", B);
         drawn = true;
     }
-    gms_launch_slam_particle(pf, dev_beams, B, s->d_log[s->cur], on_demand ? nullptr : s->d_lik[s->cur], sample_motion && !drawn ? &mo : nullptr,
-                             skip_update ? 0 : 1, s->d_code[s->cur], s->code_words);                       // :90, :99, :102-107
+    gms_launch_slam_particle(pf, dev_beams, B, sb, !on_demand, sample_motion && !drawn ? &mo : nullptr, skip_update ? 0 : 1, s->code_words);   // :90, :99, :102-107
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
@@ -157,43 +183,44 @@ int gms_slam_update_per_particle(gms_slam *s, const gms_beam *beams, int32_t B, 
 // likelihoodData as the last resample() left it, for whoever reads it before the next update (downloads; a second resample())
 static int slam_lik_current(gms_slam *s) {
     if (s->lik_from_codes) {                                                                               // computeLikelihoodMap(p.m) of the last update (:93), late
-        gms_launch_slam_likelihood_codes(s->map, s->d_code[s->cur], s->code_words, s->d_lik[s->cur], s->n);
+        gms_launch_slam_likelihood_codes(s->map, gms_slam_bufs(s), s->code_words, s->n);
         s->lik_from_codes = 0;
         HIPCHK(hipGetLastError());
         return GMS_OK;
     }
     if (!s->lik_behind) return GMS_OK;
-    gms_launch_slam_gather_one(s->pf, s->d_lik[1 - s->cur], s->d_lik[s->cur], s->d_idx_lik, nullptr);      // GridMap.java:121, late
+    gms_launch_slam_gather(s->pf, gms_slam_bufs(s), 2, s->d_idx_lik, nullptr, s->code_words);              // GridMap.java:121, late (if that resample() drew)
     s->lik_behind = 0;
     HIPCHK(hipGetLastError());
     return GMS_OK;
 }
 
-// SLAM.resample() (SLAM.java:133-153): the systematic draw over the particles' weights, then every slot's deep copy; fraction >= 0:
-// only where Neff < fraction * n (GridMapApp.java:185-186), decided on the device -- the copies are made either way, slot m from slot m
-// where the rule says no
+// SLAM.resample() (SLAM.java:133-153): the systematic draw over the particles' weights, then every slot's deep copy into the OTHER
+// generation of the maps, which the draw makes current (:152); fraction >= 0: only where Neff < fraction * n (GridMapApp.java:185-186),
+// decided on the device -- where the rule says no, nothing is drawn, no generation changes and the copy kernels return at once (the
+// reference does nothing either)
 static int slam_resample(gms_slam *s, double r01, double fraction, int32_t *indices, int32_t *n_ambiguous) {
     gms_map *m = s->map;
     HIPCHK(hipSetDevice(m->device));
     int rc = s->lik_behind ? slam_lik_current(s) : GMS_OK;                                                 // (two resample() calls in a row)
-    if (!rc) rc = fraction >= 0.0 ? gms_pf_resample_if(s->pf, &r01, fraction)
-                                  : gms_pf_resample(s->pf, &r01, indices, n_ambiguous);                    // :136-145 + pose, weight (:42-43)
     if (rc) return rc;
+    s->pf->d_epoch2 = s->d_epoch;                      // the draw counts itself (k_resample): the maps' generation follows it
+    rc = fraction >= 0.0 ? gms_pf_resample_if(s->pf, &r01, fraction)
+                         : gms_pf_resample(s->pf, &r01, indices, n_ambiguous);                             // :136-145 + pose, weight (:42-43)
+    s->pf->d_epoch2 = nullptr;
+    if (rc) return rc;
+    const SlamBufs sb = gms_slam_bufs(s);
     if (s->lik_from_codes) {
         // likelihoodData is the field of plane 1 of a particle's class planes: they travel with logData, and so does it
-        gms_launch_slam_gather_one(s->pf, s->d_log[s->cur], s->d_log[1 - s->cur], s->pf->d_idx, nullptr, s->d_code[s->cur], s->d_code[1 - s->cur], s->code_words);
+        gms_launch_slam_gather(s->pf, sb, 1, s->pf->d_idx, nullptr, s->code_words);
     } else if (s->lazy_lik) {
         // logData now (GridMap.java:120); likelihoodData (:121) when it is asked for: SLAM.update starts with computeLikelihoodMap of
         // every particle (:93), which overwrites every cell of it -- nothing on the path ever reads the copies
-        gms_launch_slam_gather_one(s->pf, s->d_log[s->cur], s->d_log[1 - s->cur], s->pf->d_idx, s->d_idx_lik, s->d_code[s->cur], s->d_code[1 - s->cur],
-                                   s->code_words);                                                                   // (keeps the indices for that)
+        gms_launch_slam_gather(s->pf, sb, 1, s->pf->d_idx, s->d_idx_lik, s->code_words);                   // (keeps the indices for that)
         s->lik_behind = 1;
     } else {
-        gms_launch_slam_gather_maps(s->pf, s->d_log[s->cur], s->d_lik[s->cur], s->d_log[1 - s->cur], s->d_lik[1 - s->cur]);   // :44
-        if (s->d_code[s->cur]) gms_launch_slam_gather_codes(s->pf, s->d_code[s->cur], s->d_code[1 - s->cur], s->code_words);
+        gms_launch_slam_gather(s->pf, sb, 3, s->pf->d_idx, nullptr, s->code_words);                        // :44
     }
-    s->cur = 1 - s->cur;                                                                                   // :152
-    s->copies += s->n;
     HIPCHK(hipGetLastError());
     return GMS_OK;
 }
@@ -223,8 +250,10 @@ int gms_slam_download_map(gms_slam *s, int32_t i, double *log_data, double *lik)
     REQUIRE(s && i >= 0 && i < s->n, "gms_slam_download_map: particle index out of range");
     HIPCHK(hipSetDevice(s->map->device));
     int rc = lik ? slam_lik_current(s) : GMS_OK;
-    if (!rc && log_data) rc = slam_map_xfer(s, i, 1, s->d_log[s->cur], log_data, false);
-    if (!rc && lik) rc = slam_map_xfer(s, i, 1, s->d_lik[s->cur], lik, false);
+    int32_t cur = 0;
+    if (!rc) rc = slam_host_gen(s, &cur);
+    if (!rc && log_data) rc = slam_map_xfer(s, i, 1, s->d_log[cur], log_data, false);
+    if (!rc && lik) rc = slam_map_xfer(s, i, 1, s->d_lik[cur], lik, false);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->map->stream));
     return GMS_OK;
@@ -234,8 +263,10 @@ int gms_slam_download_maps(gms_slam *s, double *log_all, double *lik_all) {
     REQUIRE(s, "null handle");
     HIPCHK(hipSetDevice(s->map->device));
     int rc = lik_all ? slam_lik_current(s) : GMS_OK;
-    if (!rc && log_all) rc = slam_map_xfer(s, 0, s->n, s->d_log[s->cur], log_all, false);
-    if (!rc && lik_all) rc = slam_map_xfer(s, 0, s->n, s->d_lik[s->cur], lik_all, false);
+    int32_t cur = 0;
+    if (!rc) rc = slam_host_gen(s, &cur);
+    if (!rc && log_all) rc = slam_map_xfer(s, 0, s->n, s->d_log[cur], log_all, false);
+    if (!rc && lik_all) rc = slam_map_xfer(s, 0, s->n, s->d_lik[cur], lik_all, false);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->map->stream));
     return GMS_OK;
@@ -245,13 +276,14 @@ int gms_slam_upload_map(gms_slam *s, int32_t i, const double *log_data, const do
     REQUIRE(s && i >= 0 && i < s->n, "gms_slam_upload_map: particle index out of range");
     HIPCHK(hipSetDevice(s->map->device));
     int rc = lik ? slam_lik_current(s) : GMS_OK;                  // (the other slots' fields first, then this one's over its copy)
+    int32_t cur = 0;
+    if (!rc) rc = slam_host_gen(s, &cur);
     if (!rc && log_data) {
-        rc = slam_map_xfer(s, i, 1, s->d_log[s->cur], const_cast<double *>(log_data), true);
-        if (!rc && s->d_code[s->cur])                             // the slot's class plane 0 follows its logData (plane 1, its field's, does not)
-            gms_launch_slam_codes_from_log(s->map, s->d_log[s->cur] + (size_t)i * (size_t)s->map->gd.cells, 1,
-                                           s->d_code[s->cur] + (size_t)i * 2 * (size_t)s->code_words, s->code_words);
+        rc = slam_map_xfer(s, i, 1, s->d_log[cur], const_cast<double *>(log_data), true);
+        if (!rc && s->d_code[0])                                  // the slot's class plane 0 follows its logData (plane 1, its field's, does not)
+            gms_launch_slam_codes_from_log(s->map, gms_slam_bufs(s), i, 1, s->code_words);
     }
-    if (!rc && lik) rc = slam_map_xfer(s, i, 1, s->d_lik[s->cur], const_cast<double *>(lik), true);
+    if (!rc && lik) rc = slam_map_xfer(s, i, 1, s->d_lik[cur], const_cast<double *>(lik), true);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->map->stream));
     return GMS_OK;
@@ -265,7 +297,7 @@ int gms_slam_combined(gms_slam *s) {
     HIPCHK(hipSetDevice(m->device));
     gms_ensure_lik(m);
     gms_flush_apply(m);
-    gms_launch_slam_combine(m, s->d_log[s->cur], s->n);                                       // :441-455
+    gms_launch_slam_combine(m, gms_slam_bufs(s), s->n);                                       // :441-455
     m->need_full_build = 1; m->fac_current = 0;
     HIPCHK(hipGetLastError());
     return gms_map_build_likelihood(m);                                                       // :457
@@ -301,7 +333,12 @@ int gms_slam_trace_scan(gms_slam *s, int32_t i, const gms_beam *beams, int32_t B
 
 int gms_slam_copies(const gms_slam *s, int64_t *maps_copied) {
     REQUIRE(s && maps_copied, "null argument");
-    *maps_copied = s->copies;
+    int64_t draws = 0;
+    gms_slam *sm = const_cast<gms_slam *>(s);
+    HIPCHK(hipSetDevice(sm->map->device));
+    int rc = slam_host_gen(sm, nullptr, &draws);               // (the draws are counted on the device: a conditional resample() may not have run)
+    if (rc) return rc;
+    *maps_copied = s->copies_base + draws * s->n;
     return GMS_OK;
 }
 

@@ -27,9 +27,11 @@
 // likelihoodData of every particle's map from its logData (mode 1 of likelihood_body: no factor table, no tile states, every tile)
 template <int KH>
 __global__ void __launch_bounds__(256)
-k_slam_likelihood(GridDev g, const double *__restrict__ logd, double *__restrict__ lik, const double *__restrict__ taps_g,
-                  int32_t tiles_x, int32_t tiles_y) {
+k_slam_likelihood(GridDev g, SlamBufs sb, const double *__restrict__ taps_g, int32_t tiles_x, int32_t tiles_y) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const int32_t cur = sb.epoch[0] & 1;               // the current generation (SlamBufs)
+    const double *__restrict__ logd = sb.log[cur];
+    double *__restrict__ lik = sb.lik[cur];
     // Eight workgroups walk a map's tiles (the launcher's usual shape): they are given ids that differ by 8, i.e. ONE XCD, so that
     // the tiles' halos are read from that XCD's L2 instead of once per XCD from memory.  Workgroups are dispatched to the XCDs round
     // robin by their linear id: of 64 consecutive ones, id & 7 picks the map of a group of eight and (id >> 3) & 7 the walker.
@@ -56,9 +58,12 @@ __host__ __device__ inline int64_t slam_code_words(int64_t cells) { return ((cel
 // likelihoodData of every particle from plane 1 of its class planes (mode 1 of likelihood_body, as k_slam_likelihood)
 template <int KH>
 __global__ void __launch_bounds__(256)
-k_slam_likelihood_codes(GridDev g, const uint32_t *__restrict__ planes, int64_t code_stride, double *__restrict__ lik, const double *__restrict__ taps_g,
-                        int32_t tiles_x, int32_t tiles_y) {
+k_slam_likelihood_codes(GridDev g, SlamBufs sb, int64_t code_words, const double *__restrict__ taps_g, int32_t tiles_x, int32_t tiles_y) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const int32_t cur = sb.epoch[0] & 1;
+    const uint32_t *__restrict__ planes = sb.code[cur] + code_words;           // plane 1 of every particle
+    const int64_t code_stride = 2 * code_words;
+    double *__restrict__ lik = sb.lik[cur];
     uint32_t bx = blockIdx.x, by = blockIdx.y;
     if (gridDim.x == 8u) {
         const uint32_t L = blockIdx.x + 8u * blockIdx.y, grp = L >> 6;
@@ -70,9 +75,13 @@ k_slam_likelihood_codes(GridDev g, const uint32_t *__restrict__ planes, int64_t 
 
 // plane 0 of `count` particles' class planes from their logData (uploads): a thread per word of 16 cells
 __global__ void __launch_bounds__(256)
-k_slam_codes_from_log(const double *__restrict__ logd, int64_t cells, uint32_t *__restrict__ planes, int64_t code_stride, int64_t words) {
+k_slam_codes_from_log(SlamBufs sb, int64_t cells, int32_t first, int64_t code_words, int64_t words) {
     const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (w >= words) return;
+    const int32_t cur = sb.epoch[0] & 1;
+    const double *__restrict__ logd = sb.log[cur] + (size_t)first * (size_t)cells;
+    uint32_t *__restrict__ planes = sb.code[cur] + (size_t)first * 2 * (size_t)code_words;
+    const int64_t code_stride = 2 * code_words;
     const double *ml = logd + (size_t)blockIdx.y * (size_t)cells;
     uint32_t word = 0;
 #pragma unroll
@@ -174,11 +183,15 @@ __device__ __forceinline__ void ps_phase_b(const GridDev &g, const PsRay &mt, co
 // this split form, whose cell work spreads over every wavefront of the workgroup.)
 template <int NT, int NP, bool NA, bool CODES>      // NA: 16-bit count cells are on offer (the map does not fit as 32-bit cells); CODES: the class planes are kept
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4)))       // (2 x 512 or 1024 lanes per CU: 128 registers)
-k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, double *__restrict__ log_all,
-                const double *__restrict__ lik_all, float *__restrict__ pose, float *__restrict__ cs, double *__restrict__ w,
-                double *__restrict__ logw, MotionArgs mo, int32_t integrate, int32_t tile_bytes, uint32_t *__restrict__ code_all, int32_t code_words,
+k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, SlamBufs sb, int32_t field_in_memory,
+                float *__restrict__ pose, float *__restrict__ cs, double *__restrict__ w,
+                double *__restrict__ logw, MotionArgs mo, int32_t integrate, int32_t tile_bytes, int32_t code_words,
                 const double *__restrict__ taps_g) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const int32_t cur = sb.epoch[0] & 1;               // the current generation of the particles' maps (SlamBufs)
+    double *__restrict__ log_all = sb.log[cur];
+    const double *__restrict__ lik_all = field_in_memory ? sb.lik[cur] : nullptr;
+    uint32_t *__restrict__ code_all = sb.code[cur];
     constexpr int NW = NT / 64, GR = 64 * NP;
     static_assert(NW > NP, "at least one wavefront that only consumes");
     double *s_fac = reinterpret_cast<double *>(smem);                          // [Bpad]
@@ -640,9 +653,10 @@ __host__ __device__ inline int32_t slam_lattice_steps(float span, float step, fl
 
 template <bool LDSF>
 __global__ void __launch_bounds__(SR_NT)
-k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, const double *__restrict__ lik_all,
+k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, SlamBufs sb,
               float *__restrict__ pose, float *__restrict__ cs, MotionArgs mo, int32_t fp, int32_t nt_batch) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const double *__restrict__ lik_all = sb.lik[sb.epoch[0] & 1];
     constexpr int NW = SR_NT / 64;
     double *s_f = reinterpret_cast<double *>(smem);                            // [H + 1][fp] factors, column W and row H neutral (LDSF)
     // (every carve offset a multiple of 16: a 16-byte LDS access off its alignment is replayed at 64 cycles -- 121 x 121 doubles are not)
@@ -854,8 +868,11 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
 // resample()'s deep copies (SLAM.java:147 -> :41-45 -> GridMap.java:106-124): slot m of the new generation receives both arrays of
 // particle idx[m]'s map.  grid = (chunks, N); a workgroup streams its chunk of both arrays, 16 bytes per lane, four loads in flight.
 __global__ void __launch_bounds__(256)
-k_slam_gather_maps(const double *__restrict__ src_log, const double *__restrict__ src_lik, double *__restrict__ dst_log,
-                   double *__restrict__ dst_lik, const int32_t *__restrict__ idx, int64_t cells) {
+k_slam_gather_maps(SlamBufs sb, const int32_t *__restrict__ idx, int64_t cells) {
+    if (!sb.epoch[1]) return;                          // the rule said no (GridMapApp.java:185): nothing was drawn, nothing moves
+    const int32_t cur = sb.epoch[0] & 1;               // the generation the draw has just made current receives the copies
+    const double *__restrict__ src_log = sb.log[cur ^ 1], *__restrict__ src_lik = sb.lik[cur ^ 1];
+    double *__restrict__ dst_log = sb.log[cur], *__restrict__ dst_lik = sb.lik[cur];
     const int32_t m = blockIdx.y;
     const int32_t i = idx[m];
     const size_t so = (size_t)i * (size_t)cells, dof = (size_t)m * (size_t)cells;
@@ -887,8 +904,13 @@ k_slam_gather_maps(const double *__restrict__ src_log, const double *__restrict_
 #define GATHER_U 8
 #endif
 __global__ void __launch_bounds__(256)
-k_slam_gather_one(const double *__restrict__ src, double *__restrict__ dst, const int32_t *__restrict__ idx, int64_t cells,
-                  int32_t *__restrict__ idx_keep, const uint32_t *__restrict__ src_code, uint32_t *__restrict__ dst_code, int64_t code_words2) {
+k_slam_gather_one(SlamBufs sb, int32_t lik_array, const int32_t *__restrict__ idx, int64_t cells, int32_t *__restrict__ idx_keep, int64_t code_words2) {
+    if (!sb.epoch[1]) return;                          // the rule said no (GridMapApp.java:185): nothing was drawn, nothing moves
+    const int32_t cur = sb.epoch[0] & 1;               // the generation the draw has just made current receives the copies
+    const double *__restrict__ src = lik_array ? sb.lik[cur ^ 1] : sb.log[cur ^ 1];
+    double *__restrict__ dst = lik_array ? sb.lik[cur] : sb.log[cur];
+    const uint32_t *__restrict__ src_code = lik_array || code_words2 == 0 ? nullptr : sb.code[cur ^ 1];
+    uint32_t *__restrict__ dst_code = sb.code[cur];
     const int32_t m = blockIdx.y;
     const int32_t i = idx[m];
     if (idx_keep && blockIdx.x == 0 && threadIdx.x == 0) idx_keep[m] = i;      // for the copy that is still owed (gms_slam::d_idx_lik)
@@ -920,7 +942,11 @@ k_slam_gather_one(const double *__restrict__ src, double *__restrict__ dst, cons
 
 // the class planes alone (the resampling copy that moves both arrays at once, k_slam_gather_maps, does not carry them)
 __global__ void __launch_bounds__(256)
-k_slam_gather_codes(const uint32_t *__restrict__ src_code, uint32_t *__restrict__ dst_code, const int32_t *__restrict__ idx, int64_t code_words2) {
+k_slam_gather_codes(SlamBufs sb, const int32_t *__restrict__ idx, int64_t code_words2) {
+    if (!sb.epoch[1]) return;
+    const int32_t cur = sb.epoch[0] & 1;
+    const uint32_t *__restrict__ src_code = sb.code[cur ^ 1];
+    uint32_t *__restrict__ dst_code = sb.code[cur];
     const int32_t m = blockIdx.x;
     const uint4 *sc = reinterpret_cast<const uint4 *>(src_code + (size_t)idx[m] * (size_t)code_words2);
     uint4 *dc = reinterpret_cast<uint4 *>(dst_code + (size_t)m * (size_t)code_words2);
@@ -933,7 +959,7 @@ k_slam_gather_codes(const uint32_t *__restrict__ src_code, uint32_t *__restrict_
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, int32_t n) {
+void gms_launch_slam_likelihood(gms_map *m, const SlamBufs &sb, int32_t n) {
     ProfScope ps(m, GMS_K_LIKELIHOOD);
     const int32_t k = m->lik_kh;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
@@ -951,7 +977,7 @@ void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, 
     do {                                                                                                                          \
         if (smem > 48 * 1024)                                                                                                     \
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_likelihood<KH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((k_slam_likelihood<KH>), grid, dim3(256), smem, m->stream, m->gd, d_log, d_lik, m->d_taps, tiles_x, tiles_y); \
+        hipLaunchKernelGGL((k_slam_likelihood<KH>), grid, dim3(256), smem, m->stream, m->gd, sb, m->d_taps, tiles_x, tiles_y);          \
     } while (0)
     if (k == 3) SLK_LAUNCH(3);
     else if (k == 5) SLK_LAUNCH(5);
@@ -960,12 +986,8 @@ void gms_launch_slam_likelihood(gms_map *m, const double *d_log, double *d_lik, 
 }
 
 int64_t gms_slam_code_words(int64_t cells) { return slam_code_words(cells); }
-void gms_launch_slam_gather_codes(gms_pf *pf, const uint32_t *src_code, uint32_t *dst_code, int64_t code_words) {
-    hipLaunchKernelGGL(k_slam_gather_codes, dim3((unsigned)pf->n), dim3(256), 0, pf->map->stream, src_code, dst_code, pf->d_idx, 2 * code_words);
-}
-
 // likelihoodData of all n particles from plane 1 of their class planes (d_code [n][2][code_words])
-void gms_launch_slam_likelihood_codes(gms_map *m, const uint32_t *d_code, int64_t code_words, double *d_lik, int32_t n) {
+void gms_launch_slam_likelihood_codes(gms_map *m, const SlamBufs &sb, int64_t code_words, int32_t n) {
     ProfScope ps(m, GMS_K_LIKELIHOOD);
     const int32_t k = m->lik_kh;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
@@ -981,8 +1003,7 @@ void gms_launch_slam_likelihood_codes(gms_map *m, const uint32_t *d_code, int64_
     do {                                                                                                                          \
         if (smem > 48 * 1024)                                                                                                     \
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_likelihood_codes<KH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((k_slam_likelihood_codes<KH>), grid, dim3(256), smem, m->stream, m->gd, d_code + code_words, 2 * code_words, d_lik, m->d_taps, \
-                           tiles_x, tiles_y);                                                                                     \
+        hipLaunchKernelGGL((k_slam_likelihood_codes<KH>), grid, dim3(256), smem, m->stream, m->gd, sb, code_words, m->d_taps, tiles_x, tiles_y); \
     } while (0)
     if (k == 3) SLK_LAUNCH(3);
     else if (k == 5) SLK_LAUNCH(5);
@@ -990,11 +1011,11 @@ void gms_launch_slam_likelihood_codes(gms_map *m, const uint32_t *d_code, int64_
 #undef SLK_LAUNCH
 }
 
-// plane 0 of `count` particles from their logData (d_log, d_code: the first of them)
-void gms_launch_slam_codes_from_log(gms_map *m, const double *d_log, int32_t count, uint32_t *d_code, int64_t code_words) {
+// plane 0 of particles first .. first + count - 1 from their logData
+void gms_launch_slam_codes_from_log(gms_map *m, const SlamBufs &sb, int32_t first, int32_t count, int64_t code_words) {
     const int64_t words = (m->gd.cells + 15) / 16;
-    hipLaunchKernelGGL(k_slam_codes_from_log, dim3((unsigned)((words + 255) / 256), (unsigned)count), dim3(256), 0, m->stream, d_log, m->gd.cells, d_code,
-                       2 * code_words, words);
+    hipLaunchKernelGGL(k_slam_codes_from_log, dim3((unsigned)((words + 255) / 256), (unsigned)count), dim3(256), 0, m->stream, sb, m->gd.cells, first,
+                       code_words, words);
 }
 
 // dynamic LDS of k_slam_particle<NT, NP> without its count tile
@@ -1003,10 +1024,11 @@ static inline size_t slam_particle_fixed_lds(int32_t Bpad, int np) {
 }
 
 // SLAM.update's per-particle body for all n particles of pf (one map each, d_log / d_lik [n][cells]); motion may be NULL
-// d_code (may be NULL): the particles' class planes [n][2][code_words], kept in step with logData; with them d_lik may be NULL: the
-// field is then evaluated at the scan's end points from the planes
-void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, double *d_log, const double *d_lik, const MotionModel *motion,
-                              int32_t integrate, uint32_t *d_code, int64_t code_words) {
+// sb.code (may be NULL): the particles' class planes [n][2][code_words], kept in step with logData; with them field_in_memory may be
+// false: the field is then evaluated at the scan's end points from the planes instead of read from sb.lik
+void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, const SlamBufs &sb, bool field_in_memory, const MotionModel *motion,
+                              int32_t integrate, int64_t code_words) {
+    const uint32_t *d_code = sb.code[0];
     gms_map *m = pf->map;
     MotionArgs mo;
     mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0;
@@ -1040,8 +1062,9 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, do
 #define PS_LAUNCH(NT, NA, CD)                                                                                                           \
     do {                                                                                                                                \
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_particle<NT, NP, NA, CD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((k_slam_particle<NT, NP, NA, CD>), dim3((unsigned)pf->n), dim3(NT), smem, m->stream, m->gd, d_beams, B, Bpad, d_log, d_lik, \
-                           pf->d_pose, pf->d_cs, pf->d_w, pf->d_logw, mo, integrate, (int32_t)(tile * 4), d_code, (int32_t)code_words, m->d_taps); \
+        hipLaunchKernelGGL((k_slam_particle<NT, NP, NA, CD>), dim3((unsigned)pf->n), dim3(NT), smem, m->stream, m->gd, d_beams, B, Bpad, sb,           \
+                           field_in_memory ? 1 : 0, pf->d_pose, pf->d_cs, pf->d_w, pf->d_logw, mo, integrate, (int32_t)(tile * 4), (int32_t)code_words, \
+                           m->d_taps);                                                                                                  \
     } while (0)
 #define PS_LAUNCH2(NT, NA) do { if (d_code) PS_LAUNCH(NT, NA, true); else PS_LAUNCH(NT, NA, false); } while (0)
     if (threads == 512) { if (narrow_allowed) PS_LAUNCH2(512, true); else PS_LAUNCH2(512, false); }
@@ -1057,11 +1080,11 @@ void gms_launch_slam_trace(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32
     hipLaunchKernelGGL(k_slam_trace, dim3(1), dim3(256), 0, m->stream, m->gd, d_beams, B, pf->d_pose, pf->d_cs, particle, d_cells, d_cls, cap, d_counts);
 }
 
-// findBestPose for every particle of pf against its own field d_lik [n][cells] (SLAM.java:96); motion (may be NULL): the motion-model
+// findBestPose for every particle of pf against its own field sb.lik [n][cells] (SLAM.java:96); motion (may be NULL): the motion-model
 // sample of SLAM.java:90 is drawn first.  field_in_lds: -1 the launcher decides (whenever it fits), 0 never (tests of the other form).
 // Returns false (nothing launched) where a theta step's tables do not fit a workgroup's LDS (scans of more than ~2600 beams) or a
 // map side does not fit their 16-bit entries.
-bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, const double *d_lik, const MotionModel *motion, int32_t field_in_lds) {
+bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, const SlamBufs &sb, const MotionModel *motion, int32_t field_in_lds) {
     gms_map *m = pf->map;
     if (m->gd.W > 65535 || m->gd.H > 65535) return false;
     MotionArgs mo;
@@ -1089,7 +1112,7 @@ bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, cons
 #define SR_LAUNCH(LF)                                                                                                                  \
     do {                                                                                                                                \
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_refine<LF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((k_slam_refine<LF>), dim3((unsigned)pf->n), dim3(SR_NT), smem, m->stream, m->gd, d_beams, B, Bpad, d_lik,      \
+        hipLaunchKernelGGL((k_slam_refine<LF>), dim3((unsigned)pf->n), dim3(SR_NT), smem, m->stream, m->gd, d_beams, B, Bpad, sb,         \
                            pf->d_pose, pf->d_cs, mo, fp, nt_batch);                                                                    \
     } while (0)
     if (ldsf) SR_LAUNCH(true); else SR_LAUNCH(false);
@@ -1097,12 +1120,20 @@ bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, cons
     return true;
 }
 
-void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, const int32_t *d_idx, int32_t *d_idx_keep, const uint32_t *src_code,
-                                uint32_t *dst_code, int64_t code_words) {
+void gms_launch_slam_gather(gms_pf *pf, const SlamBufs &sb, int32_t what, const int32_t *d_idx, int32_t *d_idx_keep, int64_t code_words) {
     gms_map *m = pf->map;
     ProfScope ps(m, GMS_K_MAPCOPY);
     const int64_t cells = m->gd.cells;
-    // 256 lanes x 16 bytes x GATHER_U in flight = 32 KiB of the array per workgroup pass
+    if (what == 3) {
+        // both arrays at once: 256 lanes x 16 bytes x 2 in flight per array = 8 KiB of each array per workgroup pass
+        int64_t chunks = (cells / 2 + 511) / 512;
+        if (chunks < 1) chunks = 1;
+        while (chunks > 1 && chunks * pf->n > 65536) chunks = (chunks + 1) / 2;
+        hipLaunchKernelGGL(k_slam_gather_maps, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, sb, d_idx, cells);
+        if (sb.code[0]) hipLaunchKernelGGL(k_slam_gather_codes, dim3((unsigned)pf->n), dim3(256), 0, m->stream, sb, d_idx, 2 * code_words);
+        return;
+    }
+    // one array: 256 lanes x 16 bytes x GATHER_U in flight = 32 KiB of the array per workgroup pass
     // ... while that is a residency or two of workgroups (500 maps of 120 x 120: 2000); a copy that streams from memory does better with
     // a quarter of that per workgroup and pass (4096 x 256 x 256: 443 us at 32 KiB, 409 at 16, 367 at 8, 496 at 4; 1024 x 256 x 256: 147 / 122)
     int64_t per = 256 * GATHER_U;
@@ -1110,23 +1141,12 @@ void gms_launch_slam_gather_one(gms_pf *pf, const double *src, double *dst, cons
     int64_t chunks = (cells / 2 + per - 1) / per;
     if (chunks < 1) chunks = 1;
     while (chunks > 1 && chunks * pf->n > 262144) chunks = (chunks + 1) / 2;
-    hipLaunchKernelGGL(k_slam_gather_one, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, src, dst, d_idx, cells, d_idx_keep, src_code, dst_code,
-                       2 * code_words);
-}
-
-void gms_launch_slam_gather_maps(gms_pf *pf, const double *src_log, const double *src_lik, double *dst_log, double *dst_lik) {
-    gms_map *m = pf->map;
-    ProfScope ps(m, GMS_K_MAPCOPY);
-    const int64_t cells = m->gd.cells;
-    // 256 lanes x 16 bytes x 2 in flight per array = 8 KiB of each array per workgroup pass
-    int64_t chunks = (cells / 2 + 511) / 512;
-    if (chunks < 1) chunks = 1;
-    while (chunks > 1 && chunks * pf->n > 65536) chunks = (chunks + 1) / 2;
-    hipLaunchKernelGGL(k_slam_gather_maps, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, src_log, src_lik, dst_log, dst_lik,
-                       pf->d_idx, cells);
+    hipLaunchKernelGGL(k_slam_gather_one, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, sb, what == 2 ? 1 : 0, d_idx, cells, d_idx_keep,
+                       what == 1 && sb.code[0] ? 2 * code_words : (int64_t)0);
 }
 
 // GridMapApp.calculateCombined over the particles' maps (J/app/GridMapApp.java:439-458) into a single map's logData
-void gms_launch_slam_combine(gms_map *dst, const double *d_logs, int32_t n) {
-    hipLaunchKernelGGL(k_combine, dim3(2048), dim3(256), 0, dst->stream, d_logs, n, dst->gd.cells, dst->d_log);
+__global__ void k_slam_combine(SlamBufs sb, int32_t n, int64_t cells, double *__restrict__ out) { combine_body(sb.log[sb.epoch[0] & 1], n, cells, out); }
+void gms_launch_slam_combine(gms_map *dst, const SlamBufs &sb, int32_t n) {
+    hipLaunchKernelGGL(k_slam_combine, dim3(2048), dim3(256), 0, dst->stream, sb, n, dst->gd.cells, dst->d_log);
 }

@@ -282,7 +282,8 @@ int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out);
 int gms_slam_destroy(gms_slam *s);
 int gms_slam_reset(gms_slam *s);                                    /* SLAM.reset() (SLAM.java:65-77) */
 int gms_slam_count(const gms_slam *s, int32_t *n_particles, int32_t *W, int32_t *H);
-/* The handles behind it, owned by the gms_slam (do not destroy them): *map = SLAM.getGridMap() (:200) -- geometry, constants, the
+/* The handles behind it, owned by the gms_slam (do not destroy them; the filter refuses gms_pf_resample[_if], gms_pf_set_shard and the
+ * shared-map scan steps with GMS_ERR_STATE: they would move its particles without their maps): *map = SLAM.getGridMap() (:200) -- geometry, constants, the
  * stream every call of this handle runs on, and a GridMapData of its own that receives gms_slam_combined; *pf = getParticles()
  * (:192) without the maps: poses, weights and statistics through gms_pf_get_poses / gms_pf_set_poses / gms_pf_get_weights /
  * gms_pf_set_weights / gms_pf_get_stats / gms_pf_weighted_pose (getWeightedPose, :165-178) / gms_pf_last_step (strongest particle). */
@@ -314,8 +315,11 @@ int gms_slam_set_refine(gms_slam *s, int32_t on);
 int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n_ambiguous);
 /* `if (neff < fraction * n) resample()` -- the rule of SLAM.update's caller (J/app/GridMapApp.java:185-186) -- decided ON THE DEVICE from the
  * Neff of the last update: nothing is read back, so update + this is one revolution without a host round trip.  Where the rule says no,
- * every slot keeps its own particle and map (the copy is made all the same, slot m from slot m: the handle's generations flip either
- * way).  gms_pf_last_resample_indices (on the filter of gms_slam_handles) tells afterwards what happened. */
+ * nothing is drawn and NOTHING IS COPIED, as in the reference: which of the two generations of the maps is current is itself a device-side
+ * fact (a counter of the draws that ran, kept by the resampling kernel; every kernel of the handle picks the generation from its
+ * parity), and the copy kernels return at once.  gms_pf_last_resample_indices (on the filter of gms_slam_handles) tells afterwards what
+ * happened.  The threshold is fraction * n in doubles; the reference's `numParticles / 2` is an integer division, so for an odd
+ * particle count its threshold is half a particle lower than fraction = 0.5's. */
 int gms_slam_resample_maps_if(gms_slam *s, double r01, double fraction);
 /* Particle i's GridMapData (SLAM.java:33; GridMap.java:72-74): W * H doubles each, either pointer may be NULL. */
 int gms_slam_download_map(gms_slam *s, int32_t i, double *log_data, double *lik);

@@ -302,15 +302,31 @@ def test_the_resampling_rule_decided_on_the_device():
     assert 0 < did
     _compare_maps(dev, o, "after the last revolution")
     assert np.array_equal(dev.get_particles()[0], o.poses)
+    assert dev.maps_copied() == did * N                   # the revolutions whose rule said no moved nothing (the draws are counted on the device)
     # never due
     dev.reset(); dev.set_poses(P)
     dev.update(tr.scans[0], None)
     logs = dev.maps().copy()
+    liks = dev.maps(likelihood=True).copy()
+    copied = dev.maps_copied()
     for k in range(3):
         dev.update(tr.scans[0][:0], None, fetch=False)
         dev.resample_if(0.3, 0.5)
         assert np.array_equal(dev.pf.last_resample_indices().reshape(-1), np.arange(N))
+        assert dev.maps_copied() == copied, "no resampling step was due: no map may be copied"
     assert np.array_equal(dev.maps(), logs)
+    # ... and the filter goes on from the generation it is in: one more real revolution against the oracle
+    o2 = orc.Slam(g, N)
+    o2.set_poses(dev.get_particles()[0])
+    for i in range(N):
+        o2.set_log(i, logs[i].reshape(-1)); o2.set_lik(i, liks[i].reshape(-1))
+    dev.update(tr.scans[1], None); o2.update(tr.scans[1], None, threads=THREADS)
+    _compare_maps(dev, o2, "after revolutions without a resampling step")
+    # the filter of a gms_slam refuses what would move its particles without their maps
+    from gridmap_slam_robot_amd._lib import GMS_ERR_STATE, GmsError
+    with pytest.raises(GmsError) as e:
+        dev.pf.resample(0.5)
+    assert e.value.code == GMS_ERR_STATE
     dev.close()
 
 
