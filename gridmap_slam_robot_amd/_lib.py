@@ -209,6 +209,13 @@ def load() -> C.CDLL:
     sig("gms_slam_combined", C.c_int, vp)
     sig("gms_slam_copies", C.c_int, vp, C.POINTER(C.c_int64))
     sig("gms_slam_trace_scan", C.c_int, vp, i32, vp, i32, vp, vp, i32, vp)
+    sig("gms_slam_create_shard", C.c_int, pp, i32, C.c_int64, C.c_int64, C.POINTER(vp))
+    sig("gms_slam_update_local", C.c_int, vp, vp, i32, i32, f64, f64, C.c_uint64, C.c_uint64)
+    sig("gms_slam_update_local_dev", C.c_int, vp, vp, i32, i32, f64, f64, C.c_uint64, C.c_uint64)
+    sig("gms_slam_shard_draw", C.c_int, vp, f64, f64, C.POINTER(C.c_int32), vp)
+    sig("gms_slam_record_doubles", C.c_int, vp, C.POINTER(C.c_int64))
+    sig("gms_slam_shard_export", C.c_int, vp, vp, i32, vp)
+    sig("gms_slam_shard_gather", C.c_int, vp, vp, vp, vp)
     sig("gms_debug_set_stamps", C.c_int, vp, vp)
     _lib = L
     return L

@@ -229,6 +229,7 @@ struct gms_slam {
     double *d_log[2], *d_lik[2];    // [n][H][W] every particle's GridMapData, double-buffered for resample()'s deep copies
     int32_t *d_epoch;               // {draws that ran so far, the last resample() drew}: the current generation is d_epoch[0] & 1 (SlamBufs)
     int64_t copies_base;            // maps copied by resampling steps before the last reset (the rest: d_epoch[0] * n)
+    int32_t *d_plan;                // a shard's resample(): [3][n] device staging of {export list | local sources | positions in the received buffer}
     int32_t lazy_lik;               // resample() copies logData at once and likelihoodData when somebody asks for it: the next update's
                                     // computeLikelihoodMap overwrites every cell of it before anything on the path reads one (GMS_SLAM_LAZY_LIK_COPY=0: both at once)
     int32_t lik_behind;             // the current generation's likelihoodData does not hold the last resample()'s copies yet (if it drew): slot m's field is the other generation's [d_idx_lik[m]]
@@ -325,6 +326,8 @@ bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, cons
 // planes), bit 1 likelihoodData; d_idx_keep (may be NULL) receives the indices for a likelihoodData copy that is still owed
 void gms_launch_slam_gather(gms_pf *pf, const SlamBufs &sb, int32_t what, const int32_t *d_idx, int32_t *d_idx_keep, int64_t code_words);
 void gms_launch_slam_combine(gms_map *dst, const SlamBufs &sb, int32_t n);
+void gms_launch_slam_export_records(gms_pf *pf, const SlamBufs &sb, const int32_t *d_list, int32_t count, int64_t code_words, double *d_dst);
+void gms_launch_slam_shard_gather(gms_pf *pf, const SlamBufs &sb, const int32_t *d_src_local, const int32_t *d_recv_pos, const double *d_recv, int64_t code_words);
 
 // profiling brackets
 void gms_prof_begin(gms_map *m, int32_t k);

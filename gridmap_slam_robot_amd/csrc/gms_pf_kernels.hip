@@ -59,6 +59,7 @@ struct MotionArgs {
     int32_t on;
     double d_center, d_theta, d_center_sd, d_theta_sd;
     uint64_t seed, sequence;
+    int64_t index0;             // global index of the launch's particle 0 (a shard's offset): the variates are keyed by the GLOBAL index
 };
 __device__ __forceinline__ void motion_apply(float &x, float &y, float &th, float &fc, float &fs, uint64_t index, double d_center,
                                              double d_theta, double d_center_sd, double d_theta_sd, uint64_t seed, uint64_t sequence) {
@@ -1564,7 +1565,7 @@ void gms_launch_pf_score(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t
         return;
     }
     MotionArgs mo;
-    mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0;
+    mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0; mo.index0 = 0;
     const int64_t nseg = score_segments(B, pf->n_maps > 1);
     // The locality order (k_order) costs a launch of its own, ~8 us for 4096 particles per map, and takes a fifth to a
     // quarter off the scoring kernel: it pays once the scoring launch is several rounds of workgroups deep (C5: 6144

@@ -45,13 +45,27 @@ int gms_slam_destroy(gms_slam *s) {
     hipFree(s->d_idx_lik);
     hipFree(s->d_code[0]); hipFree(s->d_code[1]);
     hipFree(s->d_epoch);
+    hipFree(s->d_plan);
     if (s->pf) gms_pf_destroy(s->pf);
     if (s->map) gms_map_destroy(s->map);
     delete s;
     return GMS_OK;
 }
 
+static int slam_create(const gms_params *p, int32_t n_particles, int64_t offset, int64_t n_global, gms_slam **out);
+
 int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out) {            // SLAM.java:56-62
+    return slam_create(p, n_particles, 0, n_particles, out);
+}
+
+// One rank's block [offset, offset + n_local) of a filter of n_global particles with their maps (equal blocks in rank order, multiples
+// of GMS_BLOCK): see gridmapslam.h "the reference-shape filter over several GPUs"
+int gms_slam_create_shard(const gms_params *p, int32_t n_local, int64_t offset, int64_t n_global, gms_slam **out) {
+    REQUIRE(n_global >= 1 && offset >= 0 && offset + n_local <= n_global, "gms_slam_create_shard: the block does not fit the population");
+    return slam_create(p, n_local, offset, n_global, out);
+}
+
+static int slam_create(const gms_params *p, int32_t n_particles, int64_t offset, int64_t n_global, gms_slam **out) {
     REQUIRE(p && out, "gms_slam_create: null argument");
     *out = nullptr;
     REQUIRE(p->n_maps == 1, "gms_slam_create: gms_params.n_maps must be 1 (every particle gets a map of its own)");
@@ -88,9 +102,22 @@ int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out) { 
         const size_t cb = (size_t)n_particles * 2 * (size_t)s->code_words * sizeof(uint32_t);
         for (int k = 0; k < 2; k++) ok = ok && hipMalloc(&s->d_code[k], cb) == hipSuccess;
     }
+    const bool sharded = offset != 0 || n_global != n_particles;
+    if (sharded) ok = ok && hipMalloc(&s->d_plan, (size_t)3 * n_particles * sizeof(int32_t)) == hipSuccess;
     if (!ok) {
         gms_slam_destroy(s);
         return gms_fail(GMS_ERR_NOMEM, "gms_slam_create: device allocation failed (%d particles x %lld cells x 32 bytes)", n_particles, (long long)m->gd.cells);
+    }
+    if (sharded) {
+        if (!s->d_code[0]) {
+            gms_slam_destroy(s);
+            return gms_fail(GMS_ERR_INVALID, "gms_slam_create_shard: a sharded filter moves a particle as logData + its class planes; this map's planes are "
+                                             "not kept (blur kernel wider than 15 taps, a plane over 24 KiB, or GMS_SLAM_EAGER_LIK=1)");
+        }
+        s->pf->d_epoch2 = s->d_epoch;                  // (lets gms_pf_set_shard through: the filter is otherwise closed to it)
+        rc = gms_pf_set_shard(s->pf, offset, n_global);
+        s->pf->d_epoch2 = nullptr;
+        if (rc) { gms_slam_destroy(s); return rc; }
     }
     *out = s;
     return gms_slam_reset(s);
@@ -139,9 +166,9 @@ int gms_slam_count(const gms_slam *s, int32_t *n, int32_t *W, int32_t *H) {
     return GMS_OK;
 }
 
-// SLAM.update(z, u) on a device-resident scan (SLAM.java:80-131)
-int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
-                                     uint64_t seed, uint64_t sequence, gms_pf_stats *stats) {
+// the per-particle body of SLAM.update(z, u) (SLAM.java:88-107) for the particles this handle holds; the weights stay raw
+static int slam_update_local(gms_slam *s, const gms_beam *dev_beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                             uint64_t seed, uint64_t sequence) {
     REQUIRE(s && dev_beams, "null argument");
     gms_map *m = s->map;
     gms_pf *pf = s->pf;
@@ -169,7 +196,33 @@ int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int
     pf->have_global = 0;
     pf->stats_current = 0;
     HIPCHK(hipGetLastError());
-    return gms_pf_normalize(pf, stats);                                                                    // :100, :110-124 (stats: synchronises)
+    return GMS_OK;
+}
+
+// SLAM.update(z, u) on a device-resident scan (SLAM.java:80-131)
+int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                                     uint64_t seed, uint64_t sequence, gms_pf_stats *stats) {
+    REQUIRE(s, "null handle");
+    if (s->pf->offset != 0 || s->pf->n_global != s->pf->n)
+        return gms_fail(GMS_ERR_STATE, "a shard of a filter: gms_slam_update_local_dev, then the weight exchange (gms_pf_local_partials / apply_partials / import_global)");
+    int rc = slam_update_local(s, dev_beams, B, sample_motion, d_center, d_theta, seed, sequence);
+    if (rc) return rc;
+    return gms_pf_normalize(s->pf, stats);                                                                 // :100, :110-124 (stats: synchronises)
+}
+
+// ... and for one rank's block of a sharded filter: the local half of update() -- motion sample (keyed by the GLOBAL particle index),
+// field, weight, map update of this block's particles; weightSum / strongest / normalise / Neff follow from the exchange of the block
+// partials (gms_pf_local_partials -> all-reduce -> gms_pf_apply_partials -> all-gather -> gms_pf_import_global), as for a sharded gms_pf
+int gms_slam_update_local_dev(gms_slam *s, const gms_beam *dev_beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                              uint64_t seed, uint64_t sequence) {
+    return slam_update_local(s, dev_beams, B, sample_motion, d_center, d_theta, seed, sequence);
+}
+int gms_slam_update_local(gms_slam *s, const gms_beam *beams, int32_t B, int32_t sample_motion, double d_center, double d_theta, uint64_t seed,
+                          uint64_t sequence) {
+    REQUIRE(s && beams, "null argument");
+    int rc = gms_stage_beams(s->map, beams, B);
+    if (rc) return rc;
+    return slam_update_local(s, s->map->d_beams, B, sample_motion, d_center, d_theta, seed, sequence);
 }
 
 int gms_slam_update_per_particle(gms_slam *s, const gms_beam *beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
@@ -227,11 +280,80 @@ static int slam_resample(gms_slam *s, double r01, double fraction, int32_t *indi
 
 int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n_ambiguous) {
     REQUIRE(s, "null handle");
+    if (s->pf->offset != 0 || s->pf->n_global != s->pf->n)
+        return gms_fail(GMS_ERR_STATE, "a shard of a filter: gms_slam_shard_draw / export / gather move its maps (the sources may live on other ranks)");
     return slam_resample(s, r01, -1.0, indices, n_ambiguous);
+}
+
+// ---- resample() of a sharded filter -------------------------------------------------------------------------------------------
+// 1. the draw for this rank's slots from the gathered population (every rank: the same r01): poses and weights are filled from it, the
+//    maps' generation advances if it drew.  sources[n_local] = the GLOBAL index of every slot's source particle; *did as the rule decided.
+int gms_slam_shard_draw(gms_slam *s, double r01, double fraction, int32_t *did, int32_t *sources) {
+    REQUIRE(s && did && sources, "null argument");
+    gms_map *m = s->map;
+    HIPCHK(hipSetDevice(m->device));
+    if (s->lik_behind || !s->lik_from_codes) {
+        // a shard's likelihoodData is never copied: it is the field of plane 1 of the class planes, which travel.  Whatever was written
+        // out for a reader is dropped here (the planes still define it).
+        s->lik_behind = 0;
+        s->lik_from_codes = 1;
+    }
+    s->pf->d_epoch2 = s->d_epoch;
+    int rc = fraction >= 0.0 ? gms_pf_resample_if(s->pf, &r01, fraction) : gms_pf_resample(s->pf, &r01, nullptr, nullptr);
+    s->pf->d_epoch2 = nullptr;
+    if (rc) return rc;
+    int32_t e[2] = {0, 0};
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(e, s->d_epoch, sizeof(e), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sources, s->pf->d_idx, (size_t)s->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    *did = e[1];
+    return GMS_OK;
+}
+// doubles per record of a particle: logData + its two class planes
+int gms_slam_record_doubles(const gms_slam *s, int64_t *doubles) {
+    REQUIRE(s && doubles, "null argument");
+    REQUIRE(s->d_code[0], "gms_slam_record_doubles: the class planes are not kept on this handle");
+    *doubles = s->map->gd.cells + s->code_words;
+    return GMS_OK;
+}
+// 2. the records of `count` local particles (indices into this rank's block) as they stood BEFORE the draw, into dev_dst
+//    [count][record_doubles]: what the ranks whose slots drew them receive
+int gms_slam_shard_export(gms_slam *s, const int32_t *local_indices, int32_t count, double *dev_dst) {
+    REQUIRE(s && (count == 0 || (local_indices && dev_dst)), "null argument");
+    REQUIRE(s->d_plan && count >= 0 && count <= s->n, "gms_slam_shard_export: not a shard, or more records than particles");
+    if (count == 0) return GMS_OK;
+    gms_map *m = s->map;
+    HIPCHK(hipSetDevice(m->device));
+    for (int32_t k = 0; k < count; k++) REQUIRE(local_indices[k] >= 0 && local_indices[k] < s->n, "gms_slam_shard_export: particle index out of range");
+    HIPCHK(hipMemcpyAsync(s->d_plan, local_indices, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));           // (the host array may be pageable: the copy must not outlive the call)
+    gms_launch_slam_export_records(s->pf, gms_slam_bufs(s), s->d_plan, count, s->code_words, dev_dst);
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
+}
+// 3. the copies: slot m of the new generation <- local particle src_local[m] of the previous one, or, where src_local[m] < 0, record
+//    recv_pos[m] of dev_recv (the records this rank received).  Both arrays [n_local], host.
+int gms_slam_shard_gather(gms_slam *s, const int32_t *src_local, const int32_t *recv_pos, const double *dev_recv) {
+    REQUIRE(s && src_local && recv_pos, "null argument");
+    REQUIRE(s->d_plan, "gms_slam_shard_gather: not a shard");
+    gms_map *m = s->map;
+    HIPCHK(hipSetDevice(m->device));
+    for (int32_t k = 0; k < s->n; k++) {
+        REQUIRE(src_local[k] < s->n, "gms_slam_shard_gather: local source out of range");
+        REQUIRE(src_local[k] >= 0 || (dev_recv && recv_pos[k] >= 0), "gms_slam_shard_gather: a remote source without a received record");
+    }
+    HIPCHK(hipMemcpyAsync(s->d_plan + s->n, src_local, (size_t)s->n * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(s->d_plan + 2 * (size_t)s->n, recv_pos, (size_t)s->n * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    gms_launch_slam_shard_gather(s->pf, gms_slam_bufs(s), s->d_plan + s->n, s->d_plan + 2 * (size_t)s->n, dev_recv, s->code_words);
+    HIPCHK(hipGetLastError());
+    return GMS_OK;
 }
 
 int gms_slam_resample_maps_if(gms_slam *s, double r01, double fraction) {
     REQUIRE(s, "null handle");
+    if (s->pf->offset != 0 || s->pf->n_global != s->pf->n)
+        return gms_fail(GMS_ERR_STATE, "a shard of a filter: gms_slam_shard_draw / export / gather move its maps (the sources may live on other ranks)");
     REQUIRE(fraction >= 0.0, "gms_slam_resample_maps_if: fraction must be non-negative");
     return slam_resample(s, r01, fraction, nullptr, nullptr);
 }

@@ -232,7 +232,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     if (wave == 0) {
         float x = pose[3 * (size_t)p], y = pose[3 * (size_t)p + 1], th = pose[3 * (size_t)p + 2], c, sn;
         if (mo.on) {                                                           // (uniform)
-            motion_apply(x, y, th, c, sn, (uint64_t)p, mo.d_center, mo.d_theta, mo.d_center_sd, mo.d_theta_sd, mo.seed, mo.sequence);
+            motion_apply(x, y, th, c, sn, (uint64_t)(mo.index0 + p), mo.d_center, mo.d_theta, mo.d_center_sd, mo.d_theta_sd, mo.seed, mo.sequence);
         } else {
             c = cs[2 * (size_t)p]; sn = cs[2 * (size_t)p + 1];                 // (cs[] always matches pose[]: k_pose_trig)
         }
@@ -675,7 +675,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
     if (wave == 0) {                                   // sampleMotionModel (SLAM.java:90), as k_slam_particle draws it; the theta steps' trig
         float x = pose[3 * (size_t)p], y = pose[3 * (size_t)p + 1], th = pose[3 * (size_t)p + 2], c, sn;
         if (mo.on) {
-            motion_apply(x, y, th, c, sn, (uint64_t)p, mo.d_center, mo.d_theta, mo.d_center_sd, mo.d_theta_sd, mo.seed, mo.sequence);
+            motion_apply(x, y, th, c, sn, (uint64_t)(mo.index0 + p), mo.d_center, mo.d_theta, mo.d_center_sd, mo.d_theta_sd, mo.seed, mo.sequence);
             if (lane == 0) {
                 pose[3 * (size_t)p] = x; pose[3 * (size_t)p + 1] = y; pose[3 * (size_t)p + 2] = th;
                 cs[2 * (size_t)p] = c; cs[2 * (size_t)p + 1] = sn;
@@ -953,6 +953,45 @@ k_slam_gather_codes(SlamBufs sb, const int32_t *__restrict__ idx, int64_t code_w
     for (int64_t e = threadIdx.x; e < code_words2 / 4; e += 256) dc[e] = sc[e];
 }
 
+// ---- a sharded filter's resample(): the maps whose source particle lives on another rank travel as RECORDS -------------------
+// record of a particle = logData [cells] doubles | class planes [2][code_words] words (likelihoodData is the field of plane 1: it
+// needs no bytes of its own).  rec_doubles = cells + code_words.
+// export: records of the listed local particles, read from the PREVIOUS generation (the one the last draw left behind)
+__global__ void __launch_bounds__(256)
+k_slam_export_records(SlamBufs sb, const int32_t *__restrict__ list, int64_t cells, int64_t code_words, double *__restrict__ dst) {
+    const int32_t prev = (sb.epoch[0] & 1) ^ 1;
+    const int32_t i = list[blockIdx.y];
+    const int64_t rec = cells + code_words;
+    const double *log = sb.log[prev] + (size_t)i * (size_t)cells;
+    const double *code = reinterpret_cast<const double *>(sb.code[prev] + (size_t)i * 2 * (size_t)code_words);      // (2 code_words words = code_words doubles; 16-byte multiples)
+    double *out = dst + (size_t)blockIdx.y * (size_t)rec;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < rec; e += (int64_t)gridDim.x * 256) out[e] = e < cells ? log[e] : code[e - cells];
+}
+// the copies of a sharded resample(): slot m of the CURRENT generation <- local particle src_local[m] of the previous one, or (src_local[m]
+// < 0) record recv_pos[m] of the buffer received from the other ranks
+__global__ void __launch_bounds__(256)
+k_slam_shard_gather(SlamBufs sb, const int32_t *__restrict__ src_local, const int32_t *__restrict__ recv_pos, const double *__restrict__ recv,
+                    int64_t cells, int64_t code_words) {
+    const int32_t cur = sb.epoch[0] & 1, prev = cur ^ 1;
+    const int32_t m = blockIdx.y;
+    const int32_t i = src_local[m];
+    const int64_t rec = cells + code_words;
+    const double *log, *code;
+    if (i >= 0) {
+        log = sb.log[prev] + (size_t)i * (size_t)cells;
+        code = reinterpret_cast<const double *>(sb.code[prev] + (size_t)i * 2 * (size_t)code_words);
+    } else {
+        log = recv + (size_t)recv_pos[m] * (size_t)rec;
+        code = log + cells;
+    }
+    double *dlog = sb.log[cur] + (size_t)m * (size_t)cells;
+    double *dcode = reinterpret_cast<double *>(sb.code[cur] + (size_t)m * 2 * (size_t)code_words);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < rec; e += (int64_t)gridDim.x * 256) {
+        if (e < cells) dlog[e] = log[e];
+        else dcode[e - cells] = code[e - cells];
+    }
+}
+
 // createMapData(null) for every particle (SLAM.reset, SLAM.java:65-77): logData = logOdds(0.5) = 0.0, likelihoodData = 0.0
 // (hipMemsetAsync does it: both are all-zero bit patterns)
 
@@ -1031,7 +1070,7 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, co
     const uint32_t *d_code = sb.code[0];
     gms_map *m = pf->map;
     MotionArgs mo;
-    mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0;
+    mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0; mo.index0 = pf->offset;
     if (motion) {
         mo.on = 1; mo.d_center = motion->d_center; mo.d_theta = motion->d_theta; mo.seed = motion->seed; mo.sequence = motion->sequence;
         mo.d_center_sd = (0.01 + fabs(motion->d_center) * 0.05) / 2;             // Odometry.java:63
@@ -1088,7 +1127,7 @@ bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, cons
     gms_map *m = pf->map;
     if (m->gd.W > 65535 || m->gd.H > 65535) return false;
     MotionArgs mo;
-    mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0;
+    mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0; mo.index0 = pf->offset;
     if (motion) {
         mo.on = 1; mo.d_center = motion->d_center; mo.d_theta = motion->d_theta; mo.seed = motion->seed; mo.sequence = motion->sequence;
         mo.d_center_sd = (0.01 + fabs(motion->d_center) * 0.05) / 2;             // Odometry.java:63
@@ -1146,6 +1185,24 @@ void gms_launch_slam_gather(gms_pf *pf, const SlamBufs &sb, int32_t what, const 
 }
 
 // GridMapApp.calculateCombined over the particles' maps (J/app/GridMapApp.java:439-458) into a single map's logData
+void gms_launch_slam_export_records(gms_pf *pf, const SlamBufs &sb, const int32_t *d_list, int32_t count, int64_t code_words, double *d_dst) {
+    gms_map *m = pf->map;
+    ProfScope ps(m, GMS_K_MAPCOPY);
+    const int64_t rec = m->gd.cells + code_words;
+    int64_t chunks = (rec + 256 * 8 - 1) / (256 * 8);
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(k_slam_export_records, dim3((unsigned)chunks, (unsigned)count), dim3(256), 0, m->stream, sb, d_list, m->gd.cells, code_words, d_dst);
+}
+void gms_launch_slam_shard_gather(gms_pf *pf, const SlamBufs &sb, const int32_t *d_src_local, const int32_t *d_recv_pos, const double *d_recv, int64_t code_words) {
+    gms_map *m = pf->map;
+    ProfScope ps(m, GMS_K_MAPCOPY);
+    const int64_t rec = m->gd.cells + code_words;
+    int64_t chunks = (rec + 256 * 8 - 1) / (256 * 8);
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(k_slam_shard_gather, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, sb, d_src_local, d_recv_pos, d_recv, m->gd.cells,
+                       code_words);
+}
+
 __global__ void k_slam_combine(SlamBufs sb, int32_t n, int64_t cells, double *__restrict__ out) { combine_body(sb.log[sb.epoch[0] & 1], n, cells, out); }
 void gms_launch_slam_combine(gms_map *dst, const SlamBufs &sb, int32_t n) {
     hipLaunchKernelGGL(k_slam_combine, dim3(2048), dim3(256), 0, dst->stream, sb, n, dst->gd.cells, dst->d_log);

@@ -162,12 +162,15 @@ class RcclComm:
 class ShardedParticleFilter:
     """ParticleFilter whose particles are split over the ranks of a process group."""
 
-    def __init__(self, n_global: int, ops, group=None):
+    def __init__(self, n_global: int, ops, group=None, coll=None):
+        """coll (optional): an object with rank, world, all_reduce_sum(tensor) and all_gather_into(out, mine) that performs the two
+        collectives instead of torch.distributed (tests run several shards as threads of one process on one GPU with it)"""
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.coll = coll
+        self.world = coll.world if coll is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         # measurement aid: run the collectives even on a one-rank group (GMS_FORCE_COLLECTIVES=1)
-        self.force = dist.is_initialized() and os.environ.get("GMS_FORCE_COLLECTIVES") == "1"
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.force = coll is None and dist.is_initialized() and os.environ.get("GMS_FORCE_COLLECTIVES") == "1"
+        self.rank = coll.rank if coll is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
         self.n_global = n_global
         self.n_local, self.offset = self.shard_of(n_global, self.world, self.rank)
         self.ops = ops
@@ -205,6 +208,9 @@ class ShardedParticleFilter:
         if self.world == 1 and not self.force:
             self.packed_global.copy_(self.packed_local)
             return None
+        if self.coll is not None:
+            self.coll.all_gather_into(self.packed_global, self.packed_local)
+            return None
         try:
             return dist.all_gather_into_tensor(self.packed_global, self.packed_local, group=self.group, async_op=True)
         except (RuntimeError, NotImplementedError, TypeError):
@@ -219,7 +225,10 @@ class ShardedParticleFilter:
         RCCL runs the all-gather on its own stream beside it."""
         with self._on_stream():
             self.ops.local_partials(self.partials)
-            if self.world > 1 or self.force:
+            if self.coll is not None:
+                if self.world > 1:
+                    self.coll.all_reduce_sum(self.partials)
+            elif self.world > 1 or self.force:
                 dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
             self.ops.apply_partials(self.partials, self.packed_local)
             self._pending = self._all_gather_start()
@@ -270,7 +279,10 @@ class ShardedParticleFilter:
         with self._on_stream():
             self.ops.local_partials(self.partials)
             if self.world > 1:
-                dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
+                if self.coll is not None:
+                    self.coll.all_reduce_sum(self.partials)
+                else:
+                    dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
             self.ops.stats_from_partials(self.partials)
 
     def stats(self) -> dict:
@@ -278,3 +290,226 @@ class ShardedParticleFilter:
 
     def weighted_pose(self) -> np.ndarray:
         return self.ops.weighted_pose()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The reference's own filter shape over several GPUs: particles WITH their maps (SLAM.java: one GridMapData per particle), no replica.
+# ---------------------------------------------------------------------------------------------------------------------------------
+class TorchCollectives:
+    """the collectives of ShardedSlamParticleMaps over torch.distributed (backend "nccl" = RCCL on the GPUs of a node; gloo in the
+    CPU tests).  Variable-size exchanges are all_to_all_single where the backend has it, pairwise isend / irecv otherwise."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather_into(self, out: torch.Tensor, mine: torch.Tensor):
+        if self.world == 1:
+            out.copy_(mine)
+            return
+        try:
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+        except (RuntimeError, NotImplementedError, TypeError):
+            dist.all_gather(list(out.chunk(self.world)), mine.clone(), group=self.group)
+
+    def all_gather_host(self, a: np.ndarray) -> np.ndarray:
+        """[world][len(a)] of a small host array (the resampling sources: 4 bytes per particle)"""
+        if self.world == 1:
+            return a[None].copy()
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        dev = None
+        if dist.get_backend(self.group) == "nccl":
+            dev = torch.device("cuda", torch.cuda.current_device())
+            t = t.to(dev)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return np.stack([o.cpu().numpy() for o in out])
+
+    def exchange(self, send: list, recv_counts: list, rec: int, like: torch.Tensor) -> list:
+        """send[q]: [k_q][rec] tensor for rank q (k_q may be 0); returns recv[q]: [recv_counts[q]][rec] from rank q"""
+        recv = [like.new_empty((int(c), rec)) for c in recv_counts]
+        if self.world == 1:
+            return recv
+        ops = []
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            if send[q] is not None and send[q].numel():
+                ops.append(dist.P2POp(dist.isend, send[q].contiguous(), dist.get_global_rank(self.group, q) if self.group is not None else q, self.group))
+            if recv[q].numel():
+                ops.append(dist.P2POp(dist.irecv, recv[q], dist.get_global_rank(self.group, q) if self.group is not None else q, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return recv
+
+
+def plan_map_exchange(all_sources: np.ndarray, rank: int, n_local: int):
+    """What one rank sends and receives in a sharded resample().  all_sources [world][n_local]: the global source index of every slot
+    of every rank (non-decreasing: systematic resampling keeps the order).  Returns (send_lists, recv_counts, src_local, recv_pos):
+    send_lists[q] = this rank's local particle indices whose records rank q needs (ascending, each once); recv_counts[q] = records
+    that arrive from rank q (in ascending order of their global index); src_local[m] = the local source of this rank's slot m or -1;
+    recv_pos[m] = for a remote source, its position in the concatenation of the received buffers in rank order."""
+    world = all_sources.shape[0]
+    lo = rank * n_local
+    send_lists, recv_counts = [], []
+    mine = all_sources[rank]
+    owner = mine // n_local
+    src_local = np.where(owner == rank, mine - lo, -1).astype(np.int32)
+    recv_pos = np.full(n_local, -1, dtype=np.int32)
+    base = 0
+    for q in range(world):
+        if q == rank:
+            send_lists.append(np.zeros(0, np.int32)); recv_counts.append(0)
+            continue
+        wanted_by_q = np.unique(all_sources[q][(all_sources[q] // n_local) == rank])        # ascending, each once
+        send_lists.append((wanted_by_q - lo).astype(np.int32))
+        from_q = np.unique(mine[owner == q])
+        recv_counts.append(int(from_q.size))
+        if from_q.size:
+            sel = owner == q
+            recv_pos[sel] = base + np.searchsorted(from_q, mine[sel]).astype(np.int32)
+        base += int(from_q.size)
+    return send_lists, recv_counts, src_local, recv_pos
+
+
+class SlamShardOps:
+    """One rank's block of the particles WITH their maps, through the C-ABI (gms_slam_create_shard): the shard-local half of
+    SLAM.update / SLAM.resample plus the weight-exchange hooks ShardedParticleFilter drives.  No CPU path."""
+
+    def __init__(self, width, height, resolution, position, n_local: int, offset: int, n_global: int, device: Optional[int] = None, max_beams: int = 0):
+        import ctypes as C
+        if not torch.cuda.is_available():
+            raise RuntimeError("SlamShardOps needs a HIP device (there is no CPU path)")
+        from .gridmap import SLAMParticleMaps
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.slam = SLAMParticleMaps.__new__(SLAMParticleMaps)
+        self.slam._init_shard(width, height, resolution, position, n_local, offset, n_global, self.device.index, max_beams)
+        self.pf = self.slam.pf
+        self.n, self.offset, self.n_global = n_local, offset, n_global
+        cur = torch.cuda.current_stream(self.device)
+        self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(device=self.device)
+        self.slam.grid_map.set_stream(self.stream.cuda_stream)
+        v = C.c_int64(0)
+        _lib.check(_lib.load().gms_slam_record_doubles(self.slam._h, C.byref(v)))
+        self.record_doubles = int(v.value)
+
+    # -- the weight exchange (ShardedParticleFilter's ops interface)
+    def new_buffer(self, n_doubles: int) -> torch.Tensor:
+        return torch.zeros(n_doubles, dtype=torch.float64, device=self.device)
+
+    def partials_len(self) -> int:
+        return self.pf.partials_len()
+
+    def local_partials(self, partials):
+        self.pf.local_partials(partials.data_ptr())
+
+    def apply_partials(self, partials, packed_local):
+        self.pf.apply_partials(partials.data_ptr(), packed_local.data_ptr())
+
+    def stats_from_partials(self, partials):
+        self.pf.stats_from_partials(partials.data_ptr())
+
+    def import_global(self, packed_global):
+        self.pf.import_global(packed_global.data_ptr())
+
+    def stats(self) -> dict:
+        return self.pf.stats()
+
+    def weighted_pose(self) -> np.ndarray:
+        return self.pf.weighted_pose()
+
+    # -- the shard-local halves
+    def update_local(self, z, odometry, seed: int, sequence: int, sample_motion: bool = True):
+        from .gridmap import _beams_of
+        b = _beams_of(z)
+        have = odometry is not None and sample_motion
+        dc, dt = odometry if odometry is not None else (0.0, 0.0)
+        _lib.check(_lib.load().gms_slam_update_local(self.slam._h, _lib.ptr(b), len(b), int(have), float(dc), float(dt), int(seed), int(sequence)))
+
+    def draw(self, r01: float, fraction: Optional[float]):
+        import ctypes as C
+        did = C.c_int32(0)
+        src = np.empty(self.n, dtype=np.int32)
+        _lib.check(_lib.load().gms_slam_shard_draw(self.slam._h, float(r01), -1.0 if fraction is None else float(fraction), C.byref(did), _lib.ptr(src)))
+        return bool(did.value), src
+
+    def export(self, local_indices: np.ndarray) -> torch.Tensor:
+        idx = np.ascontiguousarray(local_indices, dtype=np.int32)
+        out = torch.empty((idx.size, self.record_doubles), dtype=torch.float64, device=self.device)
+        if idx.size:
+            import ctypes as C
+            _lib.check(_lib.load().gms_slam_shard_export(self.slam._h, _lib.ptr(idx), int(idx.size), C.c_void_p(out.data_ptr())))
+        return out
+
+    def gather(self, src_local: np.ndarray, recv_pos: np.ndarray, recv: Optional[torch.Tensor]):
+        import ctypes as C
+        a, b = np.ascontiguousarray(src_local, dtype=np.int32), np.ascontiguousarray(recv_pos, dtype=np.int32)
+        _lib.check(_lib.load().gms_slam_shard_gather(self.slam._h, _lib.ptr(a), _lib.ptr(b), C.c_void_p(recv.data_ptr()) if recv is not None and recv.numel() else None))
+
+    def like(self) -> torch.Tensor:
+        return torch.empty(0, dtype=torch.float64, device=self.device)
+
+    def synchronize(self):
+        self.slam.grid_map.synchronize()
+
+
+class ShardedSlamParticleMaps:
+    """SLAM (J/slam/SLAM.java) with one GridMapData per particle, the particles AND their maps split over the ranks: rank r holds the
+    block [r n, (r + 1) n) and no replica of anything.  update(): every rank runs the per-particle body for its block, then the two
+    small collectives of ShardedParticleFilter (block partials all-reduced, packed particles all-gathered): weightSum, strongest, Neff,
+    weighted pose as on one GPU.  resample(): every rank draws its own slots from the gathered population; the ranks all-gather the
+    slots' sources (4 bytes per particle) and exchange the RECORDS (logData + class planes) of exactly the particles that crossed a
+    rank boundary -- systematic resampling keeps the particle order, so these are the blocks' edges unless the weights have collapsed --
+    and every rank makes its copies from its own previous generation and the received records.  Poses, weights and maps equal the
+    one-GPU filter's for any number of ranks (same block shape of every reduction, same draw, bit-identical copies).
+    `ops`: SlamShardOps (HIP) -- or a stand-in with the same methods (the gloo tests); `coll`: TorchCollectives or a stand-in."""
+
+    def __init__(self, n_global: int, ops, coll=None, group=None):
+        self.coll = coll if coll is not None else TorchCollectives(group)
+        self.ops = ops
+        self.n_global = n_global
+        self.world, self.rank = self.coll.world, self.coll.rank
+        self.n_local, self.offset = ShardedParticleFilter.shard_of(n_global, self.world, self.rank)
+        self.weights = ShardedParticleFilter(n_global, ops, group=group, coll=self.coll)
+        self.records_sent = 0
+        self.records_received = 0
+        self.resamples = 0
+
+    def update(self, z, odometry=None, seed: int = 0, sequence: int = 0, sample_motion: bool = True) -> float:
+        """SLAM.update(z, u) (SLAM.java:80-131); returns Neff (every rank: the same)"""
+        self.ops.update_local(z, odometry, seed, sequence, sample_motion)
+        self.weights.normalize()
+        return self.weights.stats()["neff"]
+
+    def resample(self, r01: float, fraction: Optional[float] = None) -> bool:
+        """SLAM.resample() (SLAM.java:133-153); with `fraction`: only if Neff < fraction * N (GridMapApp.java:185-186), decided alike on
+        every rank from the same statistics.  Every rank passes the same r01.  Returns whether it drew."""
+        did, src = self.ops.draw(r01, fraction)
+        flags = self.coll.all_gather_host(np.array([int(did)], dtype=np.int32))
+        assert (flags == int(did)).all(), "the ranks disagree on the resampling rule: their statistics differ"
+        if not did:
+            return False
+        all_src = self.coll.all_gather_host(src)                                   # [world][n_local]
+        send_lists, recv_counts, src_local, recv_pos = plan_map_exchange(all_src, self.rank, self.n_local)
+        send = [self.ops.export(l) if l.size else None for l in send_lists]
+        getattr(self.ops, "synchronize", lambda: None)()                           # the records are complete before they travel
+        recv = self.coll.exchange(send, recv_counts, self.ops.record_doubles, self.ops.like())
+        buf = torch.cat([r for r in recv if r.numel()]) if any(r.numel() for r in recv) else None
+        self.ops.gather(src_local, recv_pos, buf)
+        getattr(self.ops, "synchronize", lambda: None)()                           # (buf may be freed on return)
+        self.records_sent += int(sum(l.size for l in send_lists))
+        self.records_received += int(sum(recv_counts))
+        self.resamples += 1
+        return True
+
+    def stats(self) -> dict:
+        return self.weights.stats()
+
+    def weighted_pose(self) -> np.ndarray:
+        return self.weights.weighted_pose()

@@ -756,6 +756,25 @@ class SLAMParticleMaps:
         self.neff = float(num_particles)
         self.sequence = 0
 
+    def _init_shard(self, width, height, resolution, position, n_local, offset, n_global, device=0, max_beams=0):
+        """one rank's block of a sharded filter (gms_slam_create_shard): distributed.SlamShardOps"""
+        L = load()
+        p = GmsParams()
+        check(L.gms_params_default(C.byref(p), width, height, resolution, position[0], position[1]))
+        p.device = device or 0
+        p.max_beams = max_beams
+        self.params = p
+        self.num_particles = int(n_local)
+        self._h = C.c_void_p()
+        check(L.gms_slam_create_shard(C.byref(p), int(n_local), int(offset), int(n_global), C.byref(self._h)))
+        mh, ph = C.c_void_p(), C.c_void_p()
+        check(L.gms_slam_handles(self._h, C.byref(mh), C.byref(ph)))
+        self.grid_map = _BorrowedMap(mh, p)
+        self.pf = _BorrowedFilter(ph, self.grid_map, self.num_particles)
+        self.pf.offset, self.pf.n_global = int(offset), int(n_global)
+        self.W, self.H = self.grid_map.W, self.grid_map.H
+        self.strongest, self.neff, self.sequence = 0, float(n_global), 0
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.grid_map.close(); self.pf.close()

@@ -321,6 +321,30 @@ int gms_slam_resample_maps(gms_slam *s, double r01, int32_t *indices, int32_t *n
  * happened.  The threshold is fraction * n in doubles; the reference's `numParticles / 2` is an integer division, so for an odd
  * particle count its threshold is half a particle lower than fraction = 0.5's. */
 int gms_slam_resample_maps_if(gms_slam *s, double r01, double fraction);
+/* ---- the reference-shape filter over several GPUs: particles WITH their maps, no replica ------------------------------------------
+ * Rank r holds the contiguous block [r * n_local, (r + 1) * n_local) of the n_global particles (n_local a multiple of GMS_BLOCK) and
+ * nothing else.  update(): gms_slam_update_local[_dev] (the per-particle body of SLAM.java:88-107 for this block; the motion model's
+ * variates are keyed by the GLOBAL particle index), then the weight exchange of a sharded gms_pf on the filter of gms_slam_handles --
+ * gms_pf_local_partials -> all-reduce(SUM) -> gms_pf_apply_partials -> all-gather -> gms_pf_import_global -- which gives every rank
+ * weightSum, strongest, Neff and the weighted pose (SLAM.java:100-124,165-190) bit-identical to the one-GPU filter.  resample():
+ * gms_slam_shard_draw on every rank with the same r01 (this rank's slots drawn from the gathered population; systematic resampling is
+ * order-preserving, so a slot's source lives on this rank or a neighbouring one unless the weights have collapsed); the ranks
+ * all-gather their `sources`, each sends the records (gms_slam_shard_export: logData + class planes, gms_slam_record_doubles doubles
+ * per particle) of its particles that other ranks drew, and gms_slam_shard_gather makes the copies from the rank's own previous
+ * generation and the received records.  The collectives stay with the caller (gridmap_slam_robot_amd/distributed.py:
+ * ShardedSlamParticleMaps over torch.distributed = RCCL).  Poses, weights and every map equal the one-GPU gms_slam's for any number of
+ * ranks.  A sharded handle needs the class planes (see gms_slam_create_shard's error text); its likelihoodData is produced on demand. */
+int gms_slam_create_shard(const gms_params *p, int32_t n_local, int64_t offset, int64_t n_global, gms_slam **out);
+int gms_slam_update_local(gms_slam *s, const gms_beam *beams, int32_t B, int32_t sample_motion, double d_center, double d_theta, uint64_t seed,
+                          uint64_t sequence);
+int gms_slam_update_local_dev(gms_slam *s, const gms_beam *dev_beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                              uint64_t seed, uint64_t sequence);
+/* fraction < 0: unconditional; else `if (neff < fraction * n_global) resample()`.  *did: it drew; sources [n_local]: global source indices.
+ * Synchronises. */
+int gms_slam_shard_draw(gms_slam *s, double r01, double fraction, int32_t *did, int32_t *sources);
+int gms_slam_record_doubles(const gms_slam *s, int64_t *doubles);
+int gms_slam_shard_export(gms_slam *s, const int32_t *local_indices, int32_t count, double *dev_dst);
+int gms_slam_shard_gather(gms_slam *s, const int32_t *src_local, const int32_t *recv_pos, const double *dev_recv);
 /* Particle i's GridMapData (SLAM.java:33; GridMap.java:72-74): W * H doubles each, either pointer may be NULL. */
 int gms_slam_download_map(gms_slam *s, int32_t i, double *log_data, double *lik);
 int gms_slam_upload_map(gms_slam *s, int32_t i, const double *log_data, const double *lik);
