@@ -1058,6 +1058,74 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
     return out
 
 
+def particle_maps_sharded_run(torch, dist, rank: int, world: int, local_rank: int, particles: int, extent: float, res: float, beams: int, steps: int):
+    """The reference's own filter shape over the ranks of this run: particles WITH their maps, no replica (gms_slam_create_shard +
+    distributed.ShardedSlamParticleMaps over torch.distributed = RCCL).  `particles` is the WHOLE population (fixed: strong scaling);
+    every rank holds particles / world of them and their maps.  Timed between barriers, maximum over the ranks: `steps` SLAM.update calls
+    (the per-particle body + the two small weight collectives), then update / resample pairs with the caller's rule (the draw, the
+    all-gather of the sources, the records of the particles that crossed a rank boundary).  This pool has one GPU per box: with more
+    than one rank this path has only ever run as two gloo ranks on one device (tests/test_gpu_bench_two_ranks.py); unmeasured on xGMI."""
+    from gridmap_slam_robot_amd import synth
+    from gridmap_slam_robot_amd._lib import GMS_BLOCK
+    from gridmap_slam_robot_amd.distributed import ShardedSlamParticleMaps, SlamShardOps, TorchCollectives
+    assert particles % world == 0 and (world == 1 or (particles // world) % GMS_BLOCK == 0), "equal blocks of a multiple of GMS_BLOCK particles"
+    n = particles // world
+    T = 48
+    frames, _ = synth.make_recording(extent, beams, T=T, seed=77)
+    start = synth.true_pose(synth.make_world(extent, 77), -1, T)
+    ops = SlamShardOps(extent, extent, res, (-extent / 2, -extent / 2), n, rank * n, particles, device=local_rank, max_beams=max(128, beams))
+    ops.slam.set_poses(np.tile(np.asarray(start, np.float32), (n, 1)))
+    f = ShardedSlamParticleMaps(particles, ops, coll=TorchCollectives())
+    scans = [(ops.slam.grid_map.deskew(fr.angle, fr.distance, fr.hit, fr.d_center, fr.d_theta), (fr.d_center, fr.d_theta)) for fr in frames]
+    r01 = np.random.default_rng(5).random(4096)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def timed(fn, count):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(count):
+            fn(i)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=ops.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el / count
+    for i in range(24 + (preroll_steps() * 2) // 3):     # untimed: the maps are explored and the clocks have ramped when the timed regions start
+        f.update(scans[i % T][0], scans[i % T][1], seed=11, sequence=i)
+        if i % 4 == 3:
+            f.resample(float(r01[i % 4096]))
+    upd = timed(lambda i: f.update(scans[(24 + i) % T][0], scans[(24 + i) % T][1], seed=11, sequence=100 + i), steps)
+    sent0, res0 = f.records_sent, f.resamples
+
+    def pair(i):
+        f.update(scans[(24 + i) % T][0], scans[(24 + i) % T][1], seed=11, sequence=1000 + i)
+        f.resample(float(r01[100 + i]), 0.5)
+    pr = timed(pair, steps)
+    nres = f.resamples - res0
+    moved = torch.tensor([float(f.records_sent - sent0)], dtype=torch.float64, device=ops.device)
+    if world > 1:
+        dist.all_reduce(moved)
+    rec_bytes = ops.record_doubles * 8
+    out = {"workload": f"SLAM.java's own shape sharded: {particles} particles x one {ops.slam.W}x{ops.slam.H} map each @ {res} m over {world} rank(s) "
+                       f"({n} particles and their maps per rank, no replica), {beams} beams per scan; SLAM.update = per-particle body + block partials "
+                       "all-reduced + packed particles all-gathered; SLAM.resample = the draw per rank + the records of the particles that crossed a rank boundary",
+           "particles": particles, "particles_per_rank": n, "ranks": world, "grid": [ops.slam.W, ops.slam.H], "beams": beams, "steps": steps,
+           "update_ms": upd * 1e3, "particle_scan_evals_per_s": particles / upd, "update_resample_pair_ms": pr * 1e3,
+           "resample_ms": max(pr - upd, 0.0) * 1e3, "resampling_steps_timed": nres,
+           "records_moved_per_resample": (float(moved.item()) / nres) if nres else 0.0, "record_bytes": rec_bytes,
+           "bytes_moved_per_resample": (float(moved.item()) / nres * rec_bytes) if nres else 0.0,
+           "neff_last": f.stats()["neff"],
+           "measured_on": "one GPU per box in this pool: figures with more than one rank come from ranks sharing a device over gloo, never from xGMI"}
+    ops.slam.close()
+    return out
+
+
 def explore_run(args, torch, local_rank: int, skip: bool, passes: int = 5):
     """Config 3 on a map that is being EXPLORED: the map starts empty and the timed steps are the drive's first T/2 scans, so every
     scan pushes the frontier on and the tiles along it change their thresholded codes (the headline step runs on a pre-built map
@@ -1310,8 +1378,8 @@ def main() -> int:
     # (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>), as a CHILD process and before
     # this process has touched the GPU (nothing above imports torch or loads the library): rank 0's single JSON line reaches our
     # stdout through the child's, and we leave with the child's exit code.
-    if args.particle_maps and (args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1):
-        print("bench.py: --particle-maps is a one-GPU run; use --gpus 1", file=sys.stderr)
+    if args.particle_maps and args.refine and (args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1):
+        print("bench.py: --particle-maps --refine is a one-GPU run; use --gpus 1", file=sys.stderr)
         return 2
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus, sys.argv[1:])
@@ -1345,10 +1413,21 @@ def main() -> int:
         else:
             dist.init_process_group(backend)
 
+    if args.particle_maps and (world > 1 or args.force_sharded):
+        # the reference-shape filter sharded over the ranks: particles with their maps (fixed population: strong scaling)
+        n_, ext_, b_ = args.particle_maps.split(",")
+        pm = particle_maps_sharded_run(torch, dist, rank, world, local_rank, int(n_), float(ext_), 0.05, int(b_), args.steps)
+        if rank == 0:
+            out = {"metric": "particle-scan evals/sec", "value": pm["particle_scan_evals_per_s"], "unit": "particle-scan evals/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": pm["update_ms"], "higher_is_better": True, "scaling": "strong",
+                   "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": pm["workload"], "parallelism": f"particles with their maps over {world} rank(s)"},
+                   "per_particle_maps_sharded": pm, "roofline": None, "cpu_baseline": None}
+            emit(out, result_fd, args.report)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
     if args.particle_maps:
-        if world > 1:                # (every rank would run the whole single-GPU benchmark and print a line of its own)
-            print("bench.py: --particle-maps is a one-GPU run; use --gpus 1", file=sys.stderr)
-            return 2
         n_, ext_, b_ = args.particle_maps.split(",")
         pm = particle_maps_run(torch, local_rank, int(n_), float(ext_), 0.05, int(b_), args.steps, cpu_seconds=0.0 if (args.no_cpu_baseline or args.refine) else 5.0,
                                refine=args.refine)

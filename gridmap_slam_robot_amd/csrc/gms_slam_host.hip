@@ -52,7 +52,7 @@ int gms_slam_destroy(gms_slam *s) {
     return GMS_OK;
 }
 
-static int slam_create(const gms_params *p, int32_t n_particles, int64_t offset, int64_t n_global, gms_slam **out);
+static int slam_create(const gms_params *p, int32_t n_particles, int64_t offset, int64_t n_global, gms_slam **out, bool shard_api = false);
 
 int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out) {            // SLAM.java:56-62
     return slam_create(p, n_particles, 0, n_particles, out);
@@ -62,10 +62,10 @@ int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out) { 
 // of GMS_BLOCK): see gridmapslam.h "the reference-shape filter over several GPUs"
 int gms_slam_create_shard(const gms_params *p, int32_t n_local, int64_t offset, int64_t n_global, gms_slam **out) {
     REQUIRE(n_global >= 1 && offset >= 0 && offset + n_local <= n_global, "gms_slam_create_shard: the block does not fit the population");
-    return slam_create(p, n_local, offset, n_global, out);
+    return slam_create(p, n_local, offset, n_global, out, true);       // (a "shard" that is the whole population is both: one rank's view of a one-rank group)
 }
 
-static int slam_create(const gms_params *p, int32_t n_particles, int64_t offset, int64_t n_global, gms_slam **out) {
+static int slam_create(const gms_params *p, int32_t n_particles, int64_t offset, int64_t n_global, gms_slam **out, bool shard_api) {
     REQUIRE(p && out, "gms_slam_create: null argument");
     *out = nullptr;
     REQUIRE(p->n_maps == 1, "gms_slam_create: gms_params.n_maps must be 1 (every particle gets a map of its own)");
@@ -102,7 +102,7 @@ static int slam_create(const gms_params *p, int32_t n_particles, int64_t offset,
         const size_t cb = (size_t)n_particles * 2 * (size_t)s->code_words * sizeof(uint32_t);
         for (int k = 0; k < 2; k++) ok = ok && hipMalloc(&s->d_code[k], cb) == hipSuccess;
     }
-    const bool sharded = offset != 0 || n_global != n_particles;
+    const bool sharded = shard_api || offset != 0 || n_global != n_particles;
     if (sharded) ok = ok && hipMalloc(&s->d_plan, (size_t)3 * n_particles * sizeof(int32_t)) == hipSuccess;
     if (!ok) {
         gms_slam_destroy(s);

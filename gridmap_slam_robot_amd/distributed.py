@@ -299,33 +299,44 @@ class TorchCollectives:
     """the collectives of ShardedSlamParticleMaps over torch.distributed (backend "nccl" = RCCL on the GPUs of a node; gloo in the
     CPU tests).  Variable-size exchanges are all_to_all_single where the backend has it, pairwise isend / irecv otherwise."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force: bool = False):
+        """force: run the collectives even on a one-rank group (the RCCL calls themselves, where only one GPU exists)"""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.force = bool(force) and dist.is_initialized()
+        # device tensors travel as they are over RCCL; any other backend (gloo: two test ranks on one GPU) gets host copies
+        self.device_ok = dist.is_initialized() and dist.get_backend(group) == "nccl"
+
+    def _host(self, t: torch.Tensor) -> torch.Tensor:
+        return t if (self.device_ok or not t.is_cuda) else t.cpu()
 
     def all_reduce_sum(self, t: torch.Tensor):
-        if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if self.world > 1 or self.force:
+            h = self._host(t)
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            if h is not t:
+                t.copy_(h)
 
     def all_gather_into(self, out: torch.Tensor, mine: torch.Tensor):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             out.copy_(mine)
             return
+        ho, hm = self._host(out), self._host(mine)
         try:
-            dist.all_gather_into_tensor(out, mine, group=self.group)
+            dist.all_gather_into_tensor(ho, hm, group=self.group)
         except (RuntimeError, NotImplementedError, TypeError):
-            dist.all_gather(list(out.chunk(self.world)), mine.clone(), group=self.group)
+            dist.all_gather(list(ho.chunk(self.world)), hm.clone(), group=self.group)
+        if ho is not out:
+            out.copy_(ho)
 
     def all_gather_host(self, a: np.ndarray) -> np.ndarray:
         """[world][len(a)] of a small host array (the resampling sources: 4 bytes per particle)"""
         if self.world == 1:
             return a[None].copy()
         t = torch.from_numpy(np.ascontiguousarray(a))
-        dev = None
-        if dist.get_backend(self.group) == "nccl":
-            dev = torch.device("cuda", torch.cuda.current_device())
-            t = t.to(dev)
+        if self.device_ok:
+            t = t.to(torch.device("cuda", torch.cuda.current_device()))
         out = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(out, t, group=self.group)
         return np.stack([o.cpu().numpy() for o in out])
@@ -335,17 +346,23 @@ class TorchCollectives:
         recv = [like.new_empty((int(c), rec)) for c in recv_counts]
         if self.world == 1:
             return recv
+        staged = not self.device_ok and like.is_cuda
+        hrecv = [r.cpu() if staged else r for r in recv]
         ops = []
         for q in range(self.world):
             if q == self.rank:
                 continue
+            peer = dist.get_global_rank(self.group, q) if self.group is not None else q
             if send[q] is not None and send[q].numel():
-                ops.append(dist.P2POp(dist.isend, send[q].contiguous(), dist.get_global_rank(self.group, q) if self.group is not None else q, self.group))
-            if recv[q].numel():
-                ops.append(dist.P2POp(dist.irecv, recv[q], dist.get_global_rank(self.group, q) if self.group is not None else q, self.group))
+                ops.append(dist.P2POp(dist.isend, self._host(send[q]).contiguous(), peer, self.group))
+            if hrecv[q].numel():
+                ops.append(dist.P2POp(dist.irecv, hrecv[q], peer, self.group))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        if staged:
+            for r, h in zip(recv, hrecv):
+                r.copy_(h)
         return recv
 
 

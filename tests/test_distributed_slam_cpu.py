@@ -1,0 +1,129 @@
+"""The sharded reference-shape filter's PROTOCOL (gridmap_slam_robot_amd.distributed.ShardedSlamParticleMaps: particles with their
+maps split over the ranks) on CPU: a world_size-2 gloo process group and a numpy / oracle stand-in for the shard-local kernels (the
+product runs those in HIP: SlamShardOps; tests/test_gpu_slam_sharded.py runs them as shards on one GPU).  What is exercised here is
+the collective logic with REAL torch.distributed calls: the weight exchange, the all-gather of the resampling sources, the plan, the
+variable-size point-to-point exchange of the records, and that two ranks reproduce one rank -- and the oracle's literal SLAM loop --
+map for map."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gridmap_slam_robot_amd import _lib, synth
+from gridmap_slam_robot_amd.distributed import ShardedSlamParticleMaps, TorchCollectives
+from oracle import oracle as orc
+
+from test_distributed_cpu import NumpyShardOps, _free_port
+
+BLOCK = _lib.GMS_BLOCK
+EXT, RES, B, T = 2.0, 0.05, 24, 5
+
+
+class NumpySlamShardOps(NumpyShardOps):
+    """the weight-exchange stand-in of test_distributed_cpu.py plus a block of maps: update_local / draw / export / gather with the
+    oracle's per-function entry points (GridMap.java:173-294) on this block's particles"""
+
+    def __init__(self, grid, poses, offset, n_global):
+        super().__init__(poses, np.full(len(poses), 1.0 / n_global), offset, n_global)
+        self.g = grid
+        self.logs = np.stack([grid.new_log() for _ in range(self.n)])
+        self.record_doubles = self.logs.shape[1]
+
+    def update_local(self, z, odometry, seed, sequence, sample_motion=True):
+        assert not sample_motion                                   # (the caller sets the samples: one global draw, sliced per rank)
+        for i in range(self.n):
+            lik = self.g.build_likelihood(self.logs[i])                                    # SLAM.java:93
+            self.w[i] = self.g.probability_of(lik, z, self.pose[i])                        # :99
+            self.g.integrate(self.logs[i], z, self.pose[i])                                # :105
+
+    def draw(self, r01, fraction):
+        if fraction is not None and not (self.st["neff"] < fraction * self.n_global):
+            return False, np.arange(self.offset, self.offset + self.n, dtype=np.int32)
+        self.prev = self.logs.copy()
+        self.resample(r01, None)
+        return True, self.idx.astype(np.int32)
+
+    def export(self, local_indices):
+        return torch.from_numpy(self.prev[np.asarray(local_indices, dtype=np.int64)].copy())
+
+    def gather(self, src_local, recv_pos, recv):
+        r = recv.numpy() if recv is not None else None
+        for m in range(self.n):
+            self.logs[m] = self.prev[src_local[m]] if src_local[m] >= 0 else r[recv_pos[m]]
+
+    def like(self):
+        return torch.empty(0, dtype=torch.float64)
+
+
+def _inputs(n_global):
+    tr = synth.make_trace(EXT, RES, B, T=T + 1, seed=17)
+    poses = [synth.make_particles(tr.poses[k], n_global, seed=30 + k, sigma_xy=0.04, sigma_theta_deg=3.0) for k in range(T)]
+    r01 = np.random.default_rng(4).random(T)
+    return tr, poses, r01
+
+
+def run(rank, world, n_global):
+    tr, poses, r01 = _inputs(n_global)
+    g = orc.Grid(EXT, EXT, RES, -EXT / 2, -EXT / 2)
+    n, off = n_global // world, rank * (n_global // world)
+    ops = NumpySlamShardOps(g, poses[0][off:off + n], off, n_global)
+    f = ShardedSlamParticleMaps(n_global, ops, coll=TorchCollectives())
+    hist = []
+    for k in range(T):
+        # the motion-model samples of frame k: here simply a fresh cloud around the true pose, sliced per rank (the maps are what
+        # follows the resampling; the protocol under test does not depend on where the poses come from)
+        ops.pose = poses[k][off:off + n].copy()
+        neff = f.update(tr.scans[k], None, sample_motion=False)
+        w_before = ops.w.copy()
+        did = f.resample(float(r01[k]), 0.5 if k % 2 == 0 else 1e-12)
+        hist.append(dict(neff=neff, did=did, w=w_before, strongest=f.stats()["strongest"], pose=ops.pose.copy(), src=getattr(ops, "idx", None) if did else None))
+    return dict(hist=hist, logs=ops.logs.copy(), sent=f.records_sent, received=f.records_received)
+
+
+def _worker(rank, world, port, n_global, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = run(rank, world, n_global)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_reproduce_one_rank_and_the_oracle_loop_map_for_map():
+    n_global, world = 2 * BLOCK, 2
+    single = run(0, 1, n_global)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n_global, ret), nprocs=world, join=True)
+    n = n_global // world
+    moved = 0
+    for r in range(world):
+        out, sl = ret[r], slice(r * n, (r + 1) * n)
+        for k in range(T):
+            a, b = out["hist"][k], single["hist"][k]
+            assert a["neff"] == b["neff"] and a["did"] == b["did"] and a["strongest"] == b["strongest"], (r, k)
+            assert np.array_equal(a["w"], b["w"][sl]) and np.array_equal(a["pose"], b["pose"][sl]), (r, k)
+            if a["did"]:
+                assert np.array_equal(a["src"], b["src"][sl])
+        assert np.array_equal(out["logs"], single["logs"][sl]), f"rank {r}: maps differ from the one-rank run"
+        moved += out["received"]
+    assert ret[0]["sent"] + ret[1]["sent"] == moved and moved > 0
+    assert any(h["did"] for h in single["hist"]) and not all(h["did"] for h in single["hist"])
+    # ... and the one-rank run against the oracle's literal loop (orc_slam_update / orc_slam_resample) driven with the same poses and draws
+    tr, poses, r01 = _inputs(n_global)
+    g = orc.Grid(EXT, EXT, RES, -EXT / 2, -EXT / 2)
+    o = orc.Slam(g, n_global)
+    for k in range(T):
+        o.set_poses(poses[k])
+        o.update(tr.scans[k], None, sample_motion=False)
+        h = single["hist"][k]
+        assert np.allclose(h["w"], o.weights, rtol=1e-12, atol=0)                  # (weightSum: blocked sums vs the sequential loop)
+        if h["did"]:
+            idx, _ = o.resample(float(r01[k]))
+            assert np.array_equal(h["src"], idx), f"frame {k}: the draw sits on a rounding boundary of the two weight sums; pick another seed"
+    assert np.array_equal(single["logs"], o.logs())

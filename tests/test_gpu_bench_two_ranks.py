@@ -110,3 +110,16 @@ def test_plain_python_bench_gpus_2_launches_its_own_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["config"]["particles_total"] == 2048
     assert d["sharded_equals_standalone"] is True and len(d["per_rank_ms_per_step"]) == 2
     assert "rccl_ranks" in d or d["config"]["exchange"].startswith("torch.distributed")     # (gloo here: no RCCL communicator spans two ranks on one GPU)
+
+
+def test_bench_particle_maps_sharded_over_two_ranks_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2 --particle-maps N,EXT,B`: the reference-shape filter sharded -- particles with their maps, no replica -- as two
+    ranks sharing device 0 with gloo collectives (records staged through the host): one well-formed line from rank 0, the population
+    fixed (strong scaling), maps crossing the rank boundary counted."""
+    rep = str(tmp_path / "report.json")
+    out = _run(["--gpus", "2", "--particle-maps", "512,4,72", "--steps", "4", "--report", rep], 240)
+    d, full = _line_and_report(out, rep)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    pm = full["per_particle_maps_sharded"]
+    assert pm["particles"] == 512 and pm["particles_per_rank"] == 256 and pm["ranks"] == 2
+    assert pm["update_ms"] > 0 and pm["resampling_steps_timed"] >= 1 and pm["records_moved_per_resample"] > 0

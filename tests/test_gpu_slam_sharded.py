@@ -133,3 +133,37 @@ def test_the_exchange_plan():
             for m in range(n):
                 g = src[r][m]
                 assert (src_local[m] + r * n == g) if src_local[m] >= 0 else (recv[pos[m]] == g)
+
+
+def test_one_rank_over_real_rccl_collectives():
+    """The pool has one GPU per box: the torch.distributed route of the sharded filter with backend nccl (= RCCL) and a group of ONE
+    rank, the collectives forced to run (TorchCollectives(force=True)) -- RCCL's all-reduce and all-gather on the library's own
+    buffers and stream, the plan and the gather kernel with no peer -- against the stand-alone handle."""
+    import socket
+    import torch.distributed as dist
+    from gridmap_slam_robot_amd.distributed import TorchCollectives
+    ext, res, B, N, T = 4.0, 0.05, 72, 2 * GMS_BLOCK, 5
+    scans, start = _scans(ext, B, T)
+    r01s = np.random.default_rng(2).random(T)
+    fractions = [0.5] * T
+    want, want_logs, want_liks = _stand_alone(ext, res, N, scans, start, r01s, fractions)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ops = SlamShardOps(ext, ext, res, (-ext / 2, -ext / 2), N, 0, N, max_beams=128)
+        ops.slam.set_poses(np.tile(np.asarray(start, np.float32), (N, 1)))
+        f = ShardedSlamParticleMaps(N, ops, coll=TorchCollectives(force=True))
+        for k, (z, u) in enumerate(scans):
+            neff = f.update(z, u, seed=5, sequence=k)
+            assert neff == want[k]["neff"] and np.array_equal(f.weighted_pose(), want[k]["wpose"]), k
+            assert f.resample(float(r01s[k]), fractions[k]) == want[k]["did"]
+            P, w = ops.slam.get_particles()
+            assert np.array_equal(P, want[k]["poses"]) and np.array_equal(w, want[k]["weights"]), k
+        assert np.array_equal(ops.slam.maps(), want_logs) and np.array_equal(ops.slam.maps(likelihood=True), want_liks)
+        ops.slam.close()
+    finally:
+        dist.destroy_process_group()
