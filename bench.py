@@ -1018,12 +1018,45 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
                                    "the product per lattice pose in beam order; maps too large for the LDS are read from memory")
     if "score" in kern:
         kern["score"]["what"] = "k_slam_particle: motion sample, probabilityOf against the particle's own field (one lane's product in beam order), integrateObservation into the particle's own map through an LDS count tile"
+    # the like-for-like figure: the same updates with every cell of every particle's likelihoodData rebuilt by every update, as the
+    # reference does (GMS_SLAM_EAGER_LIK=1, read when a handle is created); the default evaluates the field under the scan's end points
+    # only and writes likelihoodData when a caller asks for it -- the same values either way
+    eager_ms = None
+    on_demand = os.environ.get("GMS_SLAM_EAGER_LIK", "0") != "1" and not refine
+    if on_demand:
+        old_env = os.environ.get("GMS_SLAM_EAGER_LIK")
+        os.environ["GMS_SLAM_EAGER_LIK"] = "1"
+        try:
+            e = SLAMParticleMaps(extent, extent, res, (-extent / 2, -extent / 2), num_particles=particles, device=local_rank, max_beams=max(128, beams))
+        finally:
+            if old_env is None:
+                os.environ.pop("GMS_SLAM_EAGER_LIK", None)
+            else:
+                os.environ["GMS_SLAM_EAGER_LIK"] = old_env
+        e.grid_map.set_stream(torch.cuda.current_stream().cuda_stream)
+        e.set_poses(np.tile(np.asarray(start, np.float32), (particles, 1)))
+        for i in range(24):
+            e.update_dev(scans[i % T].data_ptr(), beams, odo[i % T], seed=11, sequence=i)
+            if i % 4 == 3:
+                e.resample(float(r01[i % 4096]))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            e.update_dev(scans[(24 + i) % T].data_ptr(), beams, odo[(24 + i) % T], seed=11, sequence=100 + i)
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) / steps * 1e3
+        e.close()
     out = {"workload": f"SLAM.java's own shape: {particles} particles x one {s.W}x{s.H} map each @ {res} m, {beams} beams per scan; SLAM.update per particle "
-                       "(motion model, computeLikelihoodMap, " + ("findBestPose against the particle's own field, " if refine else "") +
+                       "(motion model, computeLikelihoodMap" + (" evaluated under the scan's end points -- likelihoodData itself on demand, the same values; the every-cell rebuild is update_every_cell_rebuilt_ms" if on_demand else "") +
+                       ", " + ("findBestPose against the particle's own field, " if refine else "") +
                        "probabilityOf, integrateObservation), SLAM.resample with its deep copies of the maps ("
                        + ("logData at once, likelihoodData when it is read: the next update overwrites it first" if lazy else "both arrays at once") + ")",
            "particles": particles, "grid": [s.W, s.H], "beams": beams, "steps": steps, "refine": bool(refine), "mean_hit_beams": float(np.mean(hits)),
            "update_ms": upd * 1e3, "updates_per_s": 1.0 / upd, "particle_scan_evals_per_s": particles / upd,
+           "likelihood_on_demand": bool(on_demand),
+           "update_every_cell_rebuilt_ms": eager_ms,
+           "update_every_cell_rebuilt_what": "the same update with computeLikelihoodMap over every cell of every particle's map, as the reference and the CPU port run it "
+                                              "(GMS_SLAM_EAGER_LIK=1): the like-for-like figure; the default evaluates the field under the scan's end points only (same values)",
            "resample_ms": rsm * 1e3, "resample_what": ("in the update / resample loop; logData copied, likelihoodData's copy deferred (overwritten by the next "
                                                        "update's computeLikelihoodMap before anything reads it; materialised on demand)" if lazy else
                                                        "in the update / resample loop; both arrays copied at once"),

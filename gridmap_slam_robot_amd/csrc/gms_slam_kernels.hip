@@ -24,14 +24,20 @@
 //   k_slam_gather_maps  resample()'s deep copies: map[m] <- map[idx[m]] for both arrays, a pure HBM stream (32 bytes per cell)
 #include "gms_device.h"
 
+// a generation's arrays out of SlamBufs by SELECTION, never by a run-time index into the by-value kernel argument (that moves the
+// struct -- and whatever else the compiler then keeps addressable -- into scratch memory: k_slam_gather_one ran at a quarter of its speed)
+__device__ __forceinline__ double *sb_log(const SlamBufs &sb, int32_t g) { return g ? sb.log[1] : sb.log[0]; }
+__device__ __forceinline__ double *sb_lik(const SlamBufs &sb, int32_t g) { return g ? sb.lik[1] : sb.lik[0]; }
+__device__ __forceinline__ uint32_t *sb_code(const SlamBufs &sb, int32_t g) { return g ? sb.code[1] : sb.code[0]; }
+
 // likelihoodData of every particle's map from its logData (mode 1 of likelihood_body: no factor table, no tile states, every tile)
 template <int KH>
 __global__ void __launch_bounds__(256)
 k_slam_likelihood(GridDev g, SlamBufs sb, const double *__restrict__ taps_g, int32_t tiles_x, int32_t tiles_y) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int32_t cur = sb.epoch[0] & 1;               // the current generation (SlamBufs)
-    const double *__restrict__ logd = sb.log[cur];
-    double *__restrict__ lik = sb.lik[cur];
+    const double *__restrict__ logd = sb_log(sb, cur);
+    double *__restrict__ lik = sb_lik(sb, cur);
     // Eight workgroups walk a map's tiles (the launcher's usual shape): they are given ids that differ by 8, i.e. ONE XCD, so that
     // the tiles' halos are read from that XCD's L2 instead of once per XCD from memory.  Workgroups are dispatched to the XCDs round
     // robin by their linear id: of 64 consecutive ones, id & 7 picks the map of a group of eight and (id >> 3) & 7 the walker.
@@ -61,9 +67,9 @@ __global__ void __launch_bounds__(256)
 k_slam_likelihood_codes(GridDev g, SlamBufs sb, int64_t code_words, const double *__restrict__ taps_g, int32_t tiles_x, int32_t tiles_y) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int32_t cur = sb.epoch[0] & 1;
-    const uint32_t *__restrict__ planes = sb.code[cur] + code_words;           // plane 1 of every particle
+    const uint32_t *__restrict__ planes = sb_code(sb, cur) + code_words;           // plane 1 of every particle
     const int64_t code_stride = 2 * code_words;
-    double *__restrict__ lik = sb.lik[cur];
+    double *__restrict__ lik = sb_lik(sb, cur);
     uint32_t bx = blockIdx.x, by = blockIdx.y;
     if (gridDim.x == 8u) {
         const uint32_t L = blockIdx.x + 8u * blockIdx.y, grp = L >> 6;
@@ -79,8 +85,8 @@ k_slam_codes_from_log(SlamBufs sb, int64_t cells, int32_t first, int64_t code_wo
     const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (w >= words) return;
     const int32_t cur = sb.epoch[0] & 1;
-    const double *__restrict__ logd = sb.log[cur] + (size_t)first * (size_t)cells;
-    uint32_t *__restrict__ planes = sb.code[cur] + (size_t)first * 2 * (size_t)code_words;
+    const double *__restrict__ logd = sb_log(sb, cur) + (size_t)first * (size_t)cells;
+    uint32_t *__restrict__ planes = sb_code(sb, cur) + (size_t)first * 2 * (size_t)code_words;
     const int64_t code_stride = 2 * code_words;
     const double *ml = logd + (size_t)blockIdx.y * (size_t)cells;
     uint32_t word = 0;
@@ -189,9 +195,9 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                 const double *__restrict__ taps_g) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int32_t cur = sb.epoch[0] & 1;               // the current generation of the particles' maps (SlamBufs)
-    double *__restrict__ log_all = sb.log[cur];
-    const double *__restrict__ lik_all = field_in_memory ? sb.lik[cur] : nullptr;
-    uint32_t *__restrict__ code_all = sb.code[cur];
+    double *__restrict__ log_all = sb_log(sb, cur);
+    const double *__restrict__ lik_all = field_in_memory ? sb_lik(sb, cur) : nullptr;
+    uint32_t *__restrict__ code_all = sb_code(sb, cur);
     constexpr int NW = NT / 64, GR = 64 * NP;
     static_assert(NW > NP, "at least one wavefront that only consumes");
     double *s_fac = reinterpret_cast<double *>(smem);                          // [Bpad]
@@ -656,7 +662,7 @@ __global__ void __launch_bounds__(SR_NT)
 k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, SlamBufs sb,
               float *__restrict__ pose, float *__restrict__ cs, MotionArgs mo, int32_t fp, int32_t nt_batch) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const double *__restrict__ lik_all = sb.lik[sb.epoch[0] & 1];
+    const double *__restrict__ lik_all = sb_lik(sb, sb.epoch[0] & 1);
     constexpr int NW = SR_NT / 64;
     double *s_f = reinterpret_cast<double *>(smem);                            // [H + 1][fp] factors, column W and row H neutral (LDSF)
     // (every carve offset a multiple of 16: a 16-byte LDS access off its alignment is replayed at 64 cycles -- 121 x 121 doubles are not)
@@ -869,12 +875,12 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
 // particle idx[m]'s map.  grid = (chunks, N); a workgroup streams its chunk of both arrays, 16 bytes per lane, four loads in flight.
 __global__ void __launch_bounds__(256)
 k_slam_gather_maps(SlamBufs sb, const int32_t *__restrict__ idx, int64_t cells) {
-    if (!sb.epoch[1]) return;                          // the rule said no (GridMapApp.java:185): nothing was drawn, nothing moves
-    const int32_t cur = sb.epoch[0] & 1;               // the generation the draw has just made current receives the copies
-    const double *__restrict__ src_log = sb.log[cur ^ 1], *__restrict__ src_lik = sb.lik[cur ^ 1];
-    double *__restrict__ dst_log = sb.log[cur], *__restrict__ dst_lik = sb.lik[cur];
     const int32_t m = blockIdx.y;
-    const int32_t i = idx[m];
+    const int32_t did = sb.epoch[1], epoch = sb.epoch[0], i = idx[m];
+    if (!did) return;                                  // the rule said no (GridMapApp.java:185): nothing was drawn, nothing moves
+    const int32_t cur = epoch & 1;                     // the generation the draw has just made current receives the copies
+    const double *__restrict__ src_log = sb_log(sb, cur ^ 1), *__restrict__ src_lik = sb_lik(sb, cur ^ 1);
+    double *__restrict__ dst_log = sb_log(sb, cur), *__restrict__ dst_lik = sb_lik(sb, cur);
     const size_t so = (size_t)i * (size_t)cells, dof = (size_t)m * (size_t)cells;
     if ((cells & 1) == 0) {                            // every map starts on a 16-byte boundary
         const int64_t n2 = cells >> 1;
@@ -903,23 +909,10 @@ k_slam_gather_maps(SlamBufs sb, const int32_t *__restrict__ idx, int64_t cells) 
 #ifndef GATHER_U
 #define GATHER_U 8
 #endif
-__global__ void __launch_bounds__(256)
-k_slam_gather_one(SlamBufs sb, int32_t lik_array, const int32_t *__restrict__ idx, int64_t cells, int32_t *__restrict__ idx_keep, int64_t code_words2) {
-    if (!sb.epoch[1]) return;                          // the rule said no (GridMapApp.java:185): nothing was drawn, nothing moves
-    const int32_t cur = sb.epoch[0] & 1;               // the generation the draw has just made current receives the copies
-    const double *__restrict__ src = lik_array ? sb.lik[cur ^ 1] : sb.log[cur ^ 1];
-    double *__restrict__ dst = lik_array ? sb.lik[cur] : sb.log[cur];
-    const uint32_t *__restrict__ src_code = lik_array || code_words2 == 0 ? nullptr : sb.code[cur ^ 1];
-    uint32_t *__restrict__ dst_code = sb.code[cur];
-    const int32_t m = blockIdx.y;
-    const int32_t i = idx[m];
-    if (idx_keep && blockIdx.x == 0 && threadIdx.x == 0) idx_keep[m] = i;      // for the copy that is still owed (gms_slam::d_idx_lik)
-    if (src_code && blockIdx.x == gridDim.x - 1) {                             // the particle's two class planes travel with its logData (16-byte multiples)
-        const uint4 *sc = reinterpret_cast<const uint4 *>(src_code + (size_t)i * (size_t)code_words2);
-        uint4 *dc = reinterpret_cast<uint4 *>(dst_code + (size_t)m * (size_t)code_words2);
-        for (int64_t e = threadIdx.x; e < code_words2 / 4; e += 256) dc[e] = sc[e];
-    }
-    const size_t so = (size_t)i * (size_t)cells, dof = (size_t)m * (size_t)cells;
+// one array of one map: dst[dof ..) <- src[so ..), GATHER_U 16-byte loads in flight per lane.  (A function of its own with restrict
+// PARAMETERS: with the pointers picked inside the kernel the compiler kept the loads' registers addressable and parked them in
+// scratch memory between the loads and the stores -- the copy ran at a quarter of its speed.)
+__device__ __forceinline__ void gather_copy_array(const double *__restrict__ src, double *__restrict__ dst, size_t so, size_t dof, int64_t cells) {
     if ((cells & 1) == 0) {
         const int64_t n2 = cells >> 1;
         const double2 *sp = reinterpret_cast<const double2 *>(src + so);
@@ -939,14 +932,29 @@ k_slam_gather_one(SlamBufs sb, int32_t lik_array, const int32_t *__restrict__ id
         for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < cells; e += (int64_t)gridDim.x * 256) dst[dof + e] = src[so + e];
     }
 }
+__global__ void __launch_bounds__(256)
+k_slam_gather_one(SlamBufs sb, int32_t lik_array, const int32_t *__restrict__ idx, int64_t cells, int32_t *__restrict__ idx_keep, int64_t code_words2) {
+    const int32_t m = blockIdx.y;
+    const int32_t did = sb.epoch[1], epoch = sb.epoch[0], i = idx[m];          // (three independent scalar loads: one round trip in front of the data's)
+    if (!did) return;                                  // the rule said no (GridMapApp.java:185): nothing was drawn, nothing moves
+    const int32_t cur = epoch & 1;                     // the generation the draw has just made current receives the copies
+    if (idx_keep && blockIdx.x == 0 && threadIdx.x == 0) idx_keep[m] = i;      // for the copy that is still owed (gms_slam::d_idx_lik)
+    if (!lik_array && code_words2 && blockIdx.x == gridDim.x - 1) {            // the particle's two class planes travel with its logData (16-byte multiples)
+        const uint4 *sc = reinterpret_cast<const uint4 *>(sb_code(sb, cur ^ 1) + (size_t)i * (size_t)code_words2);
+        uint4 *dc = reinterpret_cast<uint4 *>(sb_code(sb, cur) + (size_t)m * (size_t)code_words2);
+        for (int64_t e = threadIdx.x; e < code_words2 / 4; e += 256) dc[e] = sc[e];
+    }
+    gather_copy_array(lik_array ? sb_lik(sb, cur ^ 1) : sb_log(sb, cur ^ 1), lik_array ? sb_lik(sb, cur) : sb_log(sb, cur), (size_t)i * (size_t)cells,
+                      (size_t)m * (size_t)cells, cells);
+}
 
 // the class planes alone (the resampling copy that moves both arrays at once, k_slam_gather_maps, does not carry them)
 __global__ void __launch_bounds__(256)
 k_slam_gather_codes(SlamBufs sb, const int32_t *__restrict__ idx, int64_t code_words2) {
     if (!sb.epoch[1]) return;
     const int32_t cur = sb.epoch[0] & 1;
-    const uint32_t *__restrict__ src_code = sb.code[cur ^ 1];
-    uint32_t *__restrict__ dst_code = sb.code[cur];
+    const uint32_t *__restrict__ src_code = sb_code(sb, cur ^ 1);
+    uint32_t *__restrict__ dst_code = sb_code(sb, cur);
     const int32_t m = blockIdx.x;
     const uint4 *sc = reinterpret_cast<const uint4 *>(src_code + (size_t)idx[m] * (size_t)code_words2);
     uint4 *dc = reinterpret_cast<uint4 *>(dst_code + (size_t)m * (size_t)code_words2);
@@ -962,8 +970,8 @@ k_slam_export_records(SlamBufs sb, const int32_t *__restrict__ list, int64_t cel
     const int32_t prev = (sb.epoch[0] & 1) ^ 1;
     const int32_t i = list[blockIdx.y];
     const int64_t rec = cells + code_words;
-    const double *log = sb.log[prev] + (size_t)i * (size_t)cells;
-    const double *code = reinterpret_cast<const double *>(sb.code[prev] + (size_t)i * 2 * (size_t)code_words);      // (2 code_words words = code_words doubles; 16-byte multiples)
+    const double *log = sb_log(sb, prev) + (size_t)i * (size_t)cells;
+    const double *code = reinterpret_cast<const double *>(sb_code(sb, prev) + (size_t)i * 2 * (size_t)code_words);      // (2 code_words words = code_words doubles; 16-byte multiples)
     double *out = dst + (size_t)blockIdx.y * (size_t)rec;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < rec; e += (int64_t)gridDim.x * 256) out[e] = e < cells ? log[e] : code[e - cells];
 }
@@ -978,14 +986,14 @@ k_slam_shard_gather(SlamBufs sb, const int32_t *__restrict__ src_local, const in
     const int64_t rec = cells + code_words;
     const double *log, *code;
     if (i >= 0) {
-        log = sb.log[prev] + (size_t)i * (size_t)cells;
-        code = reinterpret_cast<const double *>(sb.code[prev] + (size_t)i * 2 * (size_t)code_words);
+        log = sb_log(sb, prev) + (size_t)i * (size_t)cells;
+        code = reinterpret_cast<const double *>(sb_code(sb, prev) + (size_t)i * 2 * (size_t)code_words);
     } else {
         log = recv + (size_t)recv_pos[m] * (size_t)rec;
         code = log + cells;
     }
-    double *dlog = sb.log[cur] + (size_t)m * (size_t)cells;
-    double *dcode = reinterpret_cast<double *>(sb.code[cur] + (size_t)m * 2 * (size_t)code_words);
+    double *dlog = sb_log(sb, cur) + (size_t)m * (size_t)cells;
+    double *dcode = reinterpret_cast<double *>(sb_code(sb, cur) + (size_t)m * 2 * (size_t)code_words);
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < rec; e += (int64_t)gridDim.x * 256) {
         if (e < cells) dlog[e] = log[e];
         else dcode[e - cells] = code[e - cells];
@@ -1176,12 +1184,18 @@ void gms_launch_slam_gather(gms_pf *pf, const SlamBufs &sb, int32_t what, const 
     // ... while that is a residency or two of workgroups (500 maps of 120 x 120: 2000); a copy that streams from memory does better with
     // a quarter of that per workgroup and pass (4096 x 256 x 256: 443 us at 32 KiB, 409 at 16, 367 at 8, 496 at 4; 1024 x 256 x 256: 147 / 122)
     int64_t per = 256 * GATHER_U;
-    if (((cells / 2 + per - 1) / per) * pf->n > 4096) per = 512;
+    const bool streams = ((cells / 2 + per - 1) / per) * pf->n > 4096;
+    if (streams) per = 512;
     int64_t chunks = (cells / 2 + per - 1) / per;
     if (chunks < 1) chunks = 1;
     while (chunks > 1 && chunks * pf->n > 262144) chunks = (chunks + 1) / 2;
+    // the class planes ride in the copy's last workgroup of every map while the launch is one residency of workgroups (500 x 120 x 120:
+    // resample() 21.6 us against 24.1 with a launch of their own); where the copy streams from memory that workgroup's nine round
+    // trips in a row hold the launch's tail open (4096 x 256 x 256: 0.60 ms against 0.38): there they get a launch of their own
+    const bool separate = streams;
     hipLaunchKernelGGL(k_slam_gather_one, dim3((unsigned)chunks, (unsigned)pf->n), dim3(256), 0, m->stream, sb, what == 2 ? 1 : 0, d_idx, cells, d_idx_keep,
-                       what == 1 && sb.code[0] ? 2 * code_words : (int64_t)0);
+                       what == 1 && sb.code[0] && !separate ? 2 * code_words : (int64_t)0);
+    if (what == 1 && sb.code[0] && separate) hipLaunchKernelGGL(k_slam_gather_codes, dim3((unsigned)pf->n), dim3(256), 0, m->stream, sb, d_idx, 2 * code_words);
 }
 
 // GridMapApp.calculateCombined over the particles' maps (J/app/GridMapApp.java:439-458) into a single map's logData
@@ -1203,7 +1217,7 @@ void gms_launch_slam_shard_gather(gms_pf *pf, const SlamBufs &sb, const int32_t 
                        code_words);
 }
 
-__global__ void k_slam_combine(SlamBufs sb, int32_t n, int64_t cells, double *__restrict__ out) { combine_body(sb.log[sb.epoch[0] & 1], n, cells, out); }
+__global__ void k_slam_combine(SlamBufs sb, int32_t n, int64_t cells, double *__restrict__ out) { combine_body(sb_log(sb, sb.epoch[0] & 1), n, cells, out); }
 void gms_launch_slam_combine(gms_map *dst, const SlamBufs &sb, int32_t n) {
     hipLaunchKernelGGL(k_slam_combine, dim3(2048), dim3(256), 0, dst->stream, sb, n, dst->gd.cells, dst->d_log);
 }
