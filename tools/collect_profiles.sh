@@ -3,7 +3,7 @@
 # of bench.py (C3 default, C5) and of the dense-map likelihood rebuild; raw output under gpurun_out/prof/, the summaries
 # that are kept go to profiles/<round>/ afterwards (tools/kstats.py, tools/pmc_summary.py).
 # usage: collect_profiles.sh <round dir name, e.g. r02>
-R=${1:-r05}
+R=${1:-r06}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/prof_$R"
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -36,11 +36,23 @@ stats pm500 $PM --particle-maps 500,6,90 --steps 50 --report "$OUT/pm500_report.
 stats pm4096 $PM --particle-maps 4096,12.8,180 --steps 10 --report "$OUT/pm4096_report.json"
 pmc pm4096 FETCH_SIZE $PM --particle-maps 4096,12.8,180 --steps 6 --report "$OUT/pm4096_pmc_report.json"
 pmc pm4096 WRITE_SIZE $PM --particle-maps 4096,12.8,180 --steps 6 --report "$OUT/pm4096_pmc_report.json"
+# round 6: the small size's fabric traffic with likelihoodData on demand and with every cell rebuilt (the like-for-like form), the pose
+# refinement, the reference-shape filter through the sharded route on one rank
+pmc pm500 FETCH_SIZE $PM --particle-maps 500,6,90 --steps 30 --report "$OUT/pm500_pmc_report.json"
+pmc pm500 WRITE_SIZE $PM --particle-maps 500,6,90 --steps 30 --report "$OUT/pm500_pmc_report.json"
+GMS_SLAM_EAGER_LIK=1 pmc pm500eager FETCH_SIZE $PM --particle-maps 500,6,90 --steps 30 --report "$OUT/pm500e_pmc_report.json"
+GMS_SLAM_EAGER_LIK=1 pmc pm500eager WRITE_SIZE $PM --particle-maps 500,6,90 --steps 30 --report "$OUT/pm500e_pmc_report.json"
+GMS_SLAM_EAGER_LIK=1 pmc pm4096eager FETCH_SIZE $PM --particle-maps 4096,12.8,180 --steps 6 --report "$OUT/pm4096e_pmc_report.json"
+GMS_SLAM_EAGER_LIK=1 pmc pm4096eager WRITE_SIZE $PM --particle-maps 4096,12.8,180 --steps 6 --report "$OUT/pm4096e_pmc_report.json"
+stats pm500_refine $PM --particle-maps 500,6,90 --refine --steps 50 --report "$OUT/pm500_refine_report.json"
 stats trace_replay python3 $ROOT/bench.py --trace $ROOT/tests/golden/recording_360.bin --steps 300 --warmup 20
 cd "$ROOT"
 mkdir -p "$OUT/keep"
 python3 $ROOT/tools/pmc_kernels.py "$OUT/keep/per_particle_maps_kernels.json" k_slam "$OUT/pm4096_FETCH_SIZE" "$OUT/pm4096_WRITE_SIZE" "$OUT/pm4096" > "$OUT/keep/per_particle_maps_kernels.txt" 2>&1
-for n in c3_bench c5_bench dense_likelihood c3_full_rebuild trace_replay pm500 pm4096; do
+python3 $ROOT/tools/pmc_kernels.py "$OUT/keep/per_particle_maps_500_traffic.json" k_slam "$OUT/pm500_FETCH_SIZE" "$OUT/pm500_WRITE_SIZE" "$OUT/pm500" > "$OUT/keep/per_particle_maps_500_traffic.txt" 2>&1
+python3 $ROOT/tools/pmc_kernels.py "$OUT/keep/per_particle_maps_500_every_cell_traffic.json" k_slam "$OUT/pm500eager_FETCH_SIZE" "$OUT/pm500eager_WRITE_SIZE" > "$OUT/keep/per_particle_maps_500_every_cell_traffic.txt" 2>&1
+python3 $ROOT/tools/pmc_kernels.py "$OUT/keep/per_particle_maps_4096_every_cell_traffic.json" k_slam "$OUT/pm4096eager_FETCH_SIZE" "$OUT/pm4096eager_WRITE_SIZE" > "$OUT/keep/per_particle_maps_4096_every_cell_traffic.txt" 2>&1
+for n in c3_bench c5_bench dense_likelihood c3_full_rebuild trace_replay pm500 pm4096 pm500_refine; do
   cp "$OUT/${n}_kernel_stats.csv" "$OUT/keep/" 2>/dev/null
   cp "$OUT/$n.stdout" "$OUT/keep/${n}_under_rocprof.json" 2>/dev/null
 done
@@ -67,6 +79,13 @@ python3 bench.py --trace tests/golden/recording_360.bin --steps 300 --warmup 20 
 python3 bench.py --particle-maps 500,6,90 --steps 50 --report "$OUT/keep/bench_particle_maps_500_report.json" > "$OUT/keep/bench_particle_maps_500.json" 2>> "$OUT/bench.stderr"
 python3 bench.py --particle-maps 500,6,180 --steps 50 --no-cpu-baseline --report "$OUT/keep/bench_particle_maps_500_b180_report.json" > "$OUT/keep/bench_particle_maps_500_b180.json" 2>> "$OUT/bench.stderr"
 python3 bench.py --particle-maps 4096,12.8,180 --steps 20 --no-cpu-baseline --report "$OUT/keep/bench_particle_maps_4096_report.json" > "$OUT/keep/bench_particle_maps_4096.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --particle-maps 500,6,90 --refine --steps 50 --report "$OUT/keep/bench_particle_maps_500_refine_report.json" > "$OUT/keep/bench_particle_maps_500_refine.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --particle-maps 500,6,180 --refine --steps 50 --report "$OUT/keep/bench_particle_maps_500_b180_refine_report.json" > "$OUT/keep/bench_particle_maps_500_b180_refine.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --particle-maps 1024,6,90 --force-sharded --steps 200 --report "$OUT/keep/bench_particle_maps_sharded_one_rank_report.json" > "$OUT/keep/bench_particle_maps_sharded_one_rank.json" 2>> "$OUT/bench.stderr"
+python3 bench.py --particle-maps 4096,12.8,180 --force-sharded --steps 20 --report "$OUT/keep/bench_particle_maps_4096_sharded_one_rank_report.json" > "$OUT/keep/bench_particle_maps_4096_sharded_one_rank.json" 2>> "$OUT/bench.stderr"
+PM_CASES=3 python3 tools/pm_refine_probe.py > "$OUT/keep/pm_refine_probe.txt" 2>> "$OUT/bench.stderr"
+bash tools/pmc_refine.sh > "$OUT/keep/refine_counters.txt" 2>&1
+cp gpurun_out/pmc_refine/summary.json "$OUT/keep/refine_counters.json" 2>/dev/null
 bash tools/pmc_likelihood.sh > "$OUT/keep/dense_likelihood_counters.txt" 2>&1
 cp gpurun_out/pmc_lik/summary.json "$OUT/keep/dense_likelihood_counters.json" 2>/dev/null
 bash tools/nseg_table.sh > "$OUT/keep/nseg_8_vs_16.txt" 2>&1
@@ -82,7 +101,9 @@ if [ -f gridmap_slam_robot_amd/lib/exp_stamps.so ]; then
   GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/stamps.py > "$OUT/keep/c3_step_timeline.txt" 2>> "$OUT/bench.stderr"
   GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/stamps.py --config C2 2>> "$OUT/bench.stderr" | head -24 > "$OUT/keep/c2_step_timeline.txt"
 fi
+if [ -f build/exp/lib_stamps.so ]; then cp build/exp/lib_stamps.so gridmap_slam_robot_amd/lib/exp_stamps.so; fi
 if [ -f gridmap_slam_robot_amd/lib/exp_stamps.so ]; then
+  GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/refine_stamps.py > "$OUT/keep/refine500_timeline.txt" 2>> "$OUT/bench.stderr"
   GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/pm_stamps.py 500 6 90 > "$OUT/keep/pm500_timeline.txt" 2>> "$OUT/bench.stderr"
   GMS_LIBRARY=$ROOT/gridmap_slam_robot_amd/lib/exp_stamps.so python3 tools/pm_stamps.py 1024 12.8 180 > "$OUT/keep/pm1024x256_timeline.txt" 2>> "$OUT/bench.stderr"
 fi
