@@ -31,6 +31,14 @@ int main() {
         pm.resample(0.3);
         pm.update(z, u, 7, 3);
         pm.resampleIf(0.6, 0.5);                                                            // GridMapApp.java:185-186, decided on the device
+        pm.setRefine(true);                                                                 // SLAM.java:96: findBestPose of every particle against its own field
+        const auto before = pm.getParticles();
+        pm.update(z, u, 7, 4, /*sampleMotion=*/false);
+        const auto after = pm.getParticles();
+        bool moved = false;
+        for (size_t i = 0; i < after.size(); i++) moved = moved || after[i].pose.x != before[i].pose.x || after[i].pose.theta != before[i].pose.theta;
+        if (!moved) { std::printf("the pose refinement moved no particle\n"); return 1; }
+        pm.setRefine(false);
         const std::vector<double> m0 = pm.mapOf(0), comb = pm.calculateCombined();
         bool touched = false;
         for (double v : m0) touched = touched || v != 0.0;

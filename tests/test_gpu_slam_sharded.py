@@ -26,9 +26,10 @@ def _scans(ext, B, T):
     return [(orc.deskew(f.angle, f.distance, f.hit, f.d_center, f.d_theta), (f.d_center, f.d_theta)) for f in frames], start
 
 
-def _stand_alone(ext, res, N, scans, start, r01s, fractions):
+def _stand_alone(ext, res, N, scans, start, r01s, fractions, refine=False):
     dev = SLAMParticleMaps(ext, ext, res, (-ext / 2, -ext / 2), num_particles=N, max_beams=128)
     dev.set_poses(np.tile(np.asarray(start, np.float32), (N, 1)))
+    dev.set_refine(refine)                            # (SLAM.java:96: the motion draw then happens in the refinement launch, keyed by the global index alike)
     out = []
     for k, (z, u) in enumerate(scans):
         neff = dev.update(z, u, seed=5, sequence=k)
@@ -44,14 +45,14 @@ def _stand_alone(ext, res, N, scans, start, r01s, fractions):
     return out, logs, liks
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_shards_on_one_gpu_equal_the_stand_alone_filter(world):
-    ext, res, B, N, T = 6.0, 0.05, 90, 4 * GMS_BLOCK, 10
+@pytest.mark.parametrize("world,refine", [(2, False), (4, False), (2, True)])
+def test_shards_on_one_gpu_equal_the_stand_alone_filter(world, refine):
+    ext, res, B, N, T = 6.0, 0.05, 90, 4 * GMS_BLOCK, (10 if not refine else 5)
     # (the plain product's Neff collapses on every frame: every third frame runs the rule with a threshold nothing falls below)
     fractions = [1e-9 if k % 3 == 2 else 0.5 for k in range(T)]
     scans, start = _scans(ext, B, T)
     r01s = np.random.default_rng(9).random(T)
-    want, want_logs, want_liks = _stand_alone(ext, res, N, scans, start, r01s, fractions)
+    want, want_logs, want_liks = _stand_alone(ext, res, N, scans, start, r01s, fractions, refine)
     assert any(r["did"] for r in want) and not all(r["did"] for r in want), "the drive must exercise both sides of the resampling rule"
     n = N // world
     tw = ThreadWorld(world)
@@ -63,6 +64,7 @@ def test_shards_on_one_gpu_equal_the_stand_alone_filter(world):
             with torch.cuda.stream(torch.cuda.Stream()):
                 ops = SlamShardOps(ext, ext, res, (-ext / 2, -ext / 2), n, rank * n, N, max_beams=128)
                 ops.slam.set_poses(np.tile(np.asarray(start, np.float32), (n, 1)))
+                ops.slam.set_refine(refine)
                 f = ShardedSlamParticleMaps(N, ops, coll=tw.comm(rank))
                 per_frame = []
                 for k, (z, u) in enumerate(scans):
@@ -109,7 +111,7 @@ def test_shards_on_one_gpu_equal_the_stand_alone_filter(world):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         import json
-        with open(os.path.join(out, f"slam_sharded_{world}.json"), "w") as fh:
+        with open(os.path.join(out, f"slam_sharded_{world}{'_refine' if refine else ''}.json"), "w") as fh:
             json.dump({"what": "maps that crossed a shard boundary in resample(), shards as threads on one GPU", "shards": world, "particles": N,
                        "frames": T, "resampling_steps": n_res, "records_moved": moved, "records_moved_per_step": moved / max(1, n_res),
                        "fraction_of_maps_moved": moved / max(1, n_res) / N}, fh, indent=1)
