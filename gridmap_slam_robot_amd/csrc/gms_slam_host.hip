@@ -62,6 +62,8 @@ int gms_slam_create(const gms_params *p, int32_t n_particles, gms_slam **out) { 
 // of GMS_BLOCK): see gridmapslam.h "the reference-shape filter over several GPUs"
 int gms_slam_create_shard(const gms_params *p, int32_t n_local, int64_t offset, int64_t n_global, gms_slam **out) {
     REQUIRE(n_global >= 1 && offset >= 0 && offset + n_local <= n_global, "gms_slam_create_shard: the block does not fit the population");
+    REQUIRE(n_global == n_local || (n_local % GMS_BLOCK == 0 && offset % n_local == 0 && n_global % n_local == 0),
+            "gms_slam_create_shard: equal blocks in rank order, each a multiple of GMS_BLOCK particles (the reductions' blocks must not straddle ranks)");
     return slam_create(p, n_local, offset, n_global, out, true);       // (a "shard" that is the whole population is both: one rank's view of a one-rank group)
 }
 
