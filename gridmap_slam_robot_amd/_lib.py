@@ -216,6 +216,9 @@ def load() -> C.CDLL:
     sig("gms_slam_record_doubles", C.c_int, vp, C.POINTER(C.c_int64))
     sig("gms_slam_shard_export", C.c_int, vp, vp, i32, vp)
     sig("gms_slam_shard_gather", C.c_int, vp, vp, vp, vp)
+    sig("gms_slam_update_sharded_maps", C.c_int, vp, vp, vp, i32, i32, f64, f64, C.c_uint64, C.c_uint64, sp)
+    sig("gms_slam_resample_sharded_maps", C.c_int, vp, vp, f64, f64, C.POINTER(C.c_int32))
+    sig("gms_slam_plan_exchange", C.c_int, vp, i32, i32, i32, vp, vp, vp, vp, vp)
     sig("gms_debug_set_stamps", C.c_int, vp, vp)
     _lib = L
     return L

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "gms_internal.h"
@@ -1828,6 +1829,149 @@ int gms_slam_update_sharded(gms_pf *pf, gms_comm *c, const float *xytheta, const
     if (!rc) rc = stage_beams(m, beams, B);
     if (!rc) rc = gms_slam_update_sharded_dev(pf, c, nullptr, m->d_beams, B, r01, resample_fraction, integrate);
     if (!rc && stats) rc = gms_pf_get_stats(pf, stats);
+    return rc;
+}
+
+// ---- the reference-shape filter (particles with their maps) sharded, the exchanges inside the library -------------------------------
+// The plan of a sharded resample() as a pure host function (also gridmap_slam_robot_amd/distributed.py: plan_map_exchange; a CPU test
+// holds the two against each other).  all_sources [world][n_local]: the global source of every slot of every rank.  Out, for `rank`:
+// send_counts [world] and send_lists [world][n_local] (its local particle indices whose records rank q needs: ascending, each once),
+// recv_counts [world] (records arriving from rank q, in ascending order of their global index), src_local [n_local] (the slot's source
+// in this rank's own previous generation, or -1), recv_pos [n_local] (for a remote source: its position in the received records
+// concatenated in rank order).
+int gms_slam_plan_exchange(const int32_t *all_sources, int32_t world, int32_t rank, int32_t n_local, int32_t *send_counts, int32_t *send_lists,
+                           int32_t *recv_counts, int32_t *src_local, int32_t *recv_pos) {
+    REQUIRE(all_sources && send_counts && send_lists && recv_counts && src_local && recv_pos, "null argument");
+    REQUIRE(world >= 1 && rank >= 0 && rank < world && n_local >= 1, "rank / world / block size out of range");
+    const int64_t lo = (int64_t)rank * n_local;
+    const int32_t *mine = all_sources + (size_t)rank * n_local;
+    for (int32_t m = 0; m < n_local; m++) {
+        REQUIRE(mine[m] >= 0 && (int64_t)mine[m] < (int64_t)world * n_local, "a source index outside the population");
+        src_local[m] = mine[m] / n_local == rank ? (int32_t)(mine[m] - lo) : -1;
+        recv_pos[m] = -1;
+    }
+    std::vector<int32_t> uniq;
+    int32_t base = 0;
+    for (int32_t q = 0; q < world; q++) {
+        send_counts[q] = 0; recv_counts[q] = 0;
+        if (q == rank) continue;
+        // what q's slots drew of MY particles: distinct values, ascending (the sources of a systematic draw are non-decreasing, but
+        // nothing here depends on that)
+        uniq.clear();
+        const int32_t *theirs = all_sources + (size_t)q * n_local;
+        for (int32_t m = 0; m < n_local; m++)
+            if (theirs[m] / n_local == rank) uniq.push_back(theirs[m]);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        send_counts[q] = (int32_t)uniq.size();
+        for (size_t k = 0; k < uniq.size(); k++) send_lists[(size_t)q * n_local + k] = (int32_t)(uniq[k] - lo);
+        // what MY slots drew of q's particles
+        uniq.clear();
+        for (int32_t m = 0; m < n_local; m++)
+            if (mine[m] / n_local == q) uniq.push_back(mine[m]);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        recv_counts[q] = (int32_t)uniq.size();
+        for (int32_t m = 0; m < n_local; m++)
+            if (mine[m] / n_local == q)
+                recv_pos[m] = base + (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), mine[m]) - uniq.begin());
+        base += (int32_t)uniq.size();
+    }
+    return GMS_OK;
+}
+
+// SLAM.update(z, u) of a sharded reference-shape filter in one call: the per-particle body for this rank's block, then weightSum /
+// strongest / normalise / Neff over all ranks (RCCL all-reduce of the block partials + all-gather of the packed particles:
+// gms_pf_normalize_sharded_begin / _end on the handle's filter).  Every rank: the same scan, odometry, seed and sequence.
+int gms_slam_update_sharded_maps(gms_slam *s, gms_comm *c, const gms_beam *beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                                 uint64_t seed, uint64_t sequence, gms_pf_stats *stats) {
+    REQUIRE(s && c && beams, "null argument");
+    int rc = gms_slam_update_local(s, beams, B, sample_motion, d_center, d_theta, seed, sequence);
+    if (!rc) rc = gms_pf_normalize_sharded_begin(s->pf, c);
+    if (!rc) rc = gms_pf_normalize_sharded_end(s->pf, c);
+    if (!rc && stats) rc = gms_pf_get_stats(s->pf, stats);
+    return rc;
+}
+
+// SLAM.resample() of a sharded reference-shape filter in one call (fraction >= 0: the caller's rule, GridMapApp.java:185-186): the draw
+// for this rank's slots, an RCCL all-gather of the slots' sources, the plan, the records of the particles that crossed a rank boundary as
+// ONE grouped launch of ncclSend / ncclRecv, and the copies.  Every rank: the same r01.  *did (may be NULL): it drew.
+// (With more than one rank this has never executed: one GPU per box in the pool this was written on.  One rank: tests/test_gpu_slam_sharded.py.)
+int gms_slam_resample_sharded_maps(gms_slam *s, gms_comm *c, double r01, double fraction, int32_t *did_out) {
+    REQUIRE(s && c, "null argument");
+    gms_pf *pf = s->pf;
+    gms_map *m = s->map;
+    int rc = check_shard(pf, c);
+    if (rc) return rc;
+    if (c->broken) return fail(GMS_ERR_STATE, "communicator is broken (an earlier exchange failed): destroy it");
+    HIPCHK(hipSetDevice(m->device));
+    const int32_t n = pf->n, world = c->world;
+    std::vector<int32_t> src((size_t)n), all((size_t)n * world);
+    int32_t did = 0;
+    rc = gms_slam_shard_draw(s, r01, fraction, &did, src.data());
+    if (rc) return rc;
+    if (did_out) *did_out = did;
+    if (!did) return GMS_OK;                           // (every rank decides alike: the same statistics)
+    int64_t rec = 0;
+    rc = gms_slam_record_doubles(s, &rec);
+    if (rc) return rc;
+    // the sources of every rank's slots
+    int32_t *d_all = nullptr;
+    double *d_send = nullptr, *d_recv = nullptr;
+    auto cleanup = [&]() { hipFree(d_all); hipFree(d_send); hipFree(d_recv); };
+    if (hipMalloc(&d_all, (size_t)n * world * sizeof(int32_t)) != hipSuccess) return fail(GMS_ERR_NOMEM, "gms_slam_resample_sharded_maps: device allocation failed");
+    {
+        const int r_ = g_rccl.AllGather(pf->d_idx, d_all, (size_t)n * sizeof(int32_t), RCCL_INT8, c->nccl, m->stream);
+        if (r_ != 0) { c->broken = 1; cleanup(); return fail(GMS_ERR_HIP, "ncclAllGather (sources): %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"); }
+    }
+    if (hipStreamSynchronize(m->stream) != hipSuccess ||
+        hipMemcpy(all.data(), d_all, (size_t)n * world * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(GMS_ERR_HIP, "gms_slam_resample_sharded_maps: reading the sources back failed"); }
+    std::vector<int32_t> send_counts((size_t)world), send_lists((size_t)world * n), recv_counts((size_t)world), src_local((size_t)n), recv_pos((size_t)n);
+    rc = gms_slam_plan_exchange(all.data(), world, c->rank, n, send_counts.data(), send_lists.data(), recv_counts.data(), src_local.data(), recv_pos.data());
+    if (rc) { cleanup(); return rc; }
+    int64_t n_send = 0, n_recv = 0;
+    for (int32_t q = 0; q < world; q++) { n_send += send_counts[q]; n_recv += recv_counts[q]; }
+    if (n_send && hipMalloc(&d_send, (size_t)n_send * rec * sizeof(double)) != hipSuccess) { cleanup(); return fail(GMS_ERR_NOMEM, "gms_slam_resample_sharded_maps: %lld records to send do not fit", (long long)n_send); }
+    if (n_recv && hipMalloc(&d_recv, (size_t)n_recv * rec * sizeof(double)) != hipSuccess) { cleanup(); return fail(GMS_ERR_NOMEM, "gms_slam_resample_sharded_maps: %lld records to receive do not fit", (long long)n_recv); }
+    int64_t off = 0;
+    for (int32_t q = 0; q < world && !rc; q++) {
+        if (!send_counts[q]) continue;
+        rc = gms_slam_shard_export(s, send_lists.data() + (size_t)q * n, send_counts[q], d_send + (size_t)off * rec);
+        off += send_counts[q];
+    }
+    if (rc) { cleanup(); return rc; }
+    if (n_send || n_recv) {
+        if (!g_rccl.Send || !g_rccl.Recv) { cleanup(); return fail(GMS_ERR_STATE, "this RCCL has no ncclSend / ncclRecv"); }
+        int first = 0, end = 0;
+        const char *what = "";
+        {
+            ProfScope ps(m, GMS_K_EXCHANGE);
+            first = g_rccl.GroupStart();
+            int64_t so = 0, ro = 0;
+            for (int32_t q = 0; q < world; q++) {              // (inside the group an error must not return: see gms_slam_update_sharded_dev)
+                if (send_counts[q]) {
+                    if (!first) { first = g_rccl.Send(d_send + (size_t)so * rec, (size_t)send_counts[q] * rec, RCCL_FLOAT64, q, c->nccl, m->stream); if (first) what = "ncclSend"; }
+                    so += send_counts[q];
+                }
+                if (recv_counts[q]) {
+                    if (!first) { first = g_rccl.Recv(d_recv + (size_t)ro * rec, (size_t)recv_counts[q] * rec, RCCL_FLOAT64, q, c->nccl, m->stream); if (first) what = "ncclRecv"; }
+                    ro += recv_counts[q];
+                }
+            }
+            end = g_rccl.GroupEnd();
+        }
+        if (first || end) {
+            c->broken = 1;
+            hipStreamSynchronize(m->stream);
+            cleanup();
+            const int r_ = first ? first : end;
+            return fail(GMS_ERR_HIP, "%s: %s (communicator marked broken; the maps of this generation are incomplete)", first ? what : "ncclGroupEnd",
+                        g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error");
+        }
+    }
+    rc = gms_slam_shard_gather(s, src_local.data(), recv_pos.data(), d_recv);
+    hipStreamSynchronize(m->stream);                   // (the staging buffers are freed below)
+    cleanup();
     return rc;
 }
 

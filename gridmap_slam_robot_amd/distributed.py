@@ -475,6 +475,27 @@ class SlamShardOps:
     def synchronize(self):
         self.slam.grid_map.synchronize()
 
+    # -- the same two steps with the exchanges inside the library (RCCL): one C-ABI call each, no Python collective on the path
+    def update_rccl(self, comm: "RcclComm", z, odometry, seed: int, sequence: int, sample_motion: bool = True) -> dict:
+        """SLAM.update(z, u) over all ranks through gms_slam_update_sharded_maps; returns the statistics (every rank: the same)"""
+        from .gridmap import _beams_of
+        from ._lib import GmsPfStats
+        import ctypes as C
+        b = _beams_of(z)
+        have = odometry is not None and sample_motion
+        dc, dt = odometry if odometry is not None else (0.0, 0.0)
+        st = GmsPfStats()
+        _lib.check(_lib.load().gms_slam_update_sharded_maps(self.slam._h, comm._h, _lib.ptr(b), len(b), int(have), float(dc), float(dt), int(seed),
+                                                            int(sequence), C.byref(st)))
+        return {"weight_sum": st.weight_sum, "neff": st.neff, "strongest": st.strongest, "n_zero": st.n_zero}
+
+    def resample_rccl(self, comm: "RcclComm", r01: float, fraction: Optional[float] = None) -> bool:
+        """SLAM.resample() over all ranks through gms_slam_resample_sharded_maps; returns whether it drew"""
+        import ctypes as C
+        did = C.c_int32(0)
+        _lib.check(_lib.load().gms_slam_resample_sharded_maps(self.slam._h, comm._h, float(r01), -1.0 if fraction is None else float(fraction), C.byref(did)))
+        return bool(did.value)
+
 
 class ShardedSlamParticleMaps:
     """SLAM (J/slam/SLAM.java) with one GridMapData per particle, the particles AND their maps split over the ranks: rank r holds the

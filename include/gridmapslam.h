@@ -345,6 +345,17 @@ int gms_slam_shard_draw(gms_slam *s, double r01, double fraction, int32_t *did, 
 int gms_slam_record_doubles(const gms_slam *s, int64_t *doubles);
 int gms_slam_shard_export(gms_slam *s, const int32_t *local_indices, int32_t count, double *dev_dst);
 int gms_slam_shard_gather(gms_slam *s, const int32_t *src_local, const int32_t *recv_pos, const double *dev_recv);
+/* The same with the exchanges inside the library (RCCL; gms_comm_* below): SLAM.update(z, u) and SLAM.resample() of one rank's block as
+ * ONE call each -- what a Java host with one JVM per GPU calls through the shim.  update: gms_slam_update_local, then the all-reduce of
+ * the block partials and the all-gather of the packed particles (gms_pf_normalize_sharded_begin / _end); stats (may be NULL): identical
+ * on every rank.  resample: the draw, an all-gather of the sources, the plan (gms_slam_plan_exchange: a pure host function), the
+ * records that cross a rank boundary as one grouped launch of ncclSend / ncclRecv, the copies; *did (may be NULL).  With more than one
+ * rank these have never executed (one GPU per box where they were written); the torch.distributed route above is the tested one. */
+int gms_slam_update_sharded_maps(gms_slam *s, gms_comm *c, const gms_beam *beams, int32_t B, int32_t sample_motion, double d_center, double d_theta,
+                                 uint64_t seed, uint64_t sequence, gms_pf_stats *stats);
+int gms_slam_resample_sharded_maps(gms_slam *s, gms_comm *c, double r01, double fraction, int32_t *did);
+int gms_slam_plan_exchange(const int32_t *all_sources, int32_t world, int32_t rank, int32_t n_local, int32_t *send_counts, int32_t *send_lists,
+                           int32_t *recv_counts, int32_t *src_local, int32_t *recv_pos);
 /* Particle i's GridMapData (SLAM.java:33; GridMap.java:72-74): W * H doubles each, either pointer may be NULL. */
 int gms_slam_download_map(gms_slam *s, int32_t i, double *log_data, double *lik);
 int gms_slam_upload_map(gms_slam *s, int32_t i, const double *log_data, const double *lik);

@@ -296,6 +296,18 @@ public:
         check(gms_slam_handles(h_, &map_, &pf_));
         check(gms_slam_count(h_, nullptr, &w_, &hgt_));
     }
+    /** One rank's block [offset, offset + numParticlesLocal) of a filter of numParticlesGlobal particles sharded WITH their maps over
+     *  the GPUs of a node (gms_slam_create_shard; blocks of a multiple of 256 particles in rank order): updateSharded / resampleSharded */
+    SlamParticleMaps(int numParticlesLocal, long long offset, long long numParticlesGlobal, float width, float height, float resolution,
+                     float posX, float posY, int maxBeams = 0, int device = 0) : n_(numParticlesLocal) {
+        gms_params p{};
+        check(gms_params_default(&p, width, height, resolution, posX, posY));
+        p.max_beams = maxBeams;
+        p.device = device;
+        check(gms_slam_create_shard(&p, numParticlesLocal, offset, numParticlesGlobal, &h_));
+        check(gms_slam_handles(h_, &map_, &pf_));
+        check(gms_slam_count(h_, nullptr, &w_, &hgt_));
+    }
     ~SlamParticleMaps() { gms_slam_destroy(h_); }
     SlamParticleMaps(const SlamParticleMaps &) = delete;
     SlamParticleMaps &operator=(const SlamParticleMaps &) = delete;
@@ -310,6 +322,20 @@ public:
                                            seed, sequence, &st));
         strongest_ = st.strongest;
         return st.neff;
+    }
+    /** update(z, u) over all ranks of a sharded filter (every rank: the same scan, odometry, seed and sequence); returns Neff */
+    double updateSharded(Comm &comm, const Observation &z, const Odometry &u, uint64_t seed, uint64_t sequence, bool sampleMotion = true) {
+        gms_pf_stats st{};
+        check(gms_slam_update_sharded_maps(h_, comm.handle(), z.getMeasurements().data(), z.getNumberOfMeasurements(), sampleMotion ? 1 : 0, u.dCenter,
+                                           u.dTheta, seed, sequence, &st));
+        strongest_ = st.strongest;
+        return st.neff;
+    }
+    /** resample() over all ranks (every rank: the same r01; fraction < 0: unconditional); returns whether it drew */
+    bool resampleSharded(Comm &comm, double r01, double fraction = -1.0) {
+        int32_t did = 0;
+        check(gms_slam_resample_sharded_maps(h_, comm.handle(), r01, fraction, &did));
+        return did != 0;
     }
     /** resample() (:133-153); r01 stands for Math.random() */
     void resample(double r01) { check(gms_slam_resample_maps(h_, r01, nullptr, nullptr)); }

@@ -336,6 +336,39 @@ JNIEXPORT jlong JNICALL CLS(pmCreate)(JNIEnv *env, jclass c, jfloat w, jfloat h,
     throw_gms(env, rc);
     return (jlong)(intptr_t)s;
 }
+/* one rank's block of a filter whose particles AND maps are split over the ranks (one JVM per GPU): gms_slam_create_shard */
+JNIEXPORT jlong JNICALL CLS(pmCreateShard)(JNIEnv *env, jclass c, jfloat w, jfloat h, jfloat res, jfloat px, jfloat py, jdouble lFree, jdouble lOcc,
+                                           jdoubleArray kernel, jint maxBeams, jint device, jint nLocal, jlong offset, jlong nGlobal) {
+    gms_params p;
+    int rc = gms_params_default(&p, w, h, res, px, py);
+    if (rc) { throw_gms(env, rc); return 0; }
+    p.l_free = lFree; p.l_occ = lOcc; p.max_beams = maxBeams; p.device = device;
+    jsize k = (*env)->GetArrayLength(env, kernel);
+    if (k > GMS_MAX_TAPS) { throw_named(env, "java/lang/IllegalArgumentException", "likelihood kernel longer than GMS_MAX_TAPS"); return 0; }
+    (*env)->GetDoubleArrayRegion(env, kernel, 0, k, p.kernel);
+    p.ktaps = k;
+    gms_slam *s = NULL;
+    rc = gms_slam_create_shard(&p, nLocal, offset, nGlobal, &s);
+    throw_gms(env, rc);
+    return (jlong)(intptr_t)s;
+}
+/* SLAM.update(z, u) over all ranks (gms_slam_update_sharded_maps): every rank passes the same scan, odometry, seed and sequence */
+JNIEXPORT void JNICALL CLS(pmUpdateSharded)(JNIEnv *env, jclass c, jlong s, jlong cm, jdoubleArray beams, jint B, jboolean sampleMotion, jdouble dCenter,
+                                            jdouble dTheta, jlong seed, jlong sequence, jdoubleArray out3) {
+    gms_beam *buf = beams_from(env, beams, B);
+    if (!buf) return;
+    gms_pf_stats st;
+    const int rc = gms_slam_update_sharded_maps(SLAM(s), COMM(cm), buf, B, sampleMotion ? 1 : 0, dCenter, dTheta, (uint64_t)seed, (uint64_t)sequence, &st);
+    free(buf);
+    if (!rc) stats_out(env, out3, &st);
+    throw_gms(env, rc);
+}
+/* SLAM.resample() over all ranks (gms_slam_resample_sharded_maps; fraction < 0: unconditional): every rank the same r01; returns whether it drew */
+JNIEXPORT jboolean JNICALL CLS(pmResampleSharded)(JNIEnv *env, jclass c, jlong s, jlong cm, jdouble r01, jdouble fraction) {
+    int32_t did = 0;
+    throw_gms(env, gms_slam_resample_sharded_maps(SLAM(s), COMM(cm), r01, fraction, &did));
+    return (jboolean)(did != 0);
+}
 JNIEXPORT void JNICALL CLS(pmDestroy)(JNIEnv *env, jclass c, jlong s) { throw_gms(env, gms_slam_destroy(SLAM(s))); }
 JNIEXPORT void JNICALL CLS(pmReset)(JNIEnv *env, jclass c, jlong s) { throw_gms(env, gms_slam_reset(SLAM(s))); }     /* SLAM.reset() :65-77 */
 JNIEXPORT void JNICALL CLS(pmSetRefine)(JNIEnv *env, jclass c, jlong s, jboolean on) { throw_gms(env, gms_slam_set_refine(SLAM(s), on ? 1 : 0)); }   /* :96 */

@@ -42,6 +42,12 @@ final class NativeSlam {
 
     // SLAM with one GridMapData per particle (SLAM.java:26-204): SLAMGpu
     static native long pmCreate(float w, float h, float res, float px, float py, double lFree, double lOcc, double[] kernel, int maxBeams, int device, int numParticles);
+    // ... sharded with its maps over the GPUs of a node, one JVM per GPU (gms_slam_create_shard; the exchanges inside the library)
+    static native long pmCreateShard(float w, float h, float res, float px, float py, double lFree, double lOcc, double[] kernel, int maxBeams, int device,
+                                     int nLocal, long offset, long nGlobal);
+    static native void pmUpdateSharded(long s, long comm, double[] beams, int B, boolean sampleMotion, double dCenter, double dTheta, long seed, long sequence,
+                                       double[] weightSumNeffStrongest);
+    static native boolean pmResampleSharded(long s, long comm, double r01, double fraction);
     static native void pmDestroy(long s);
     static native void pmReset(long s);
     static native void pmSetRefine(long s, boolean on);                         // SLAM.java:96: findBestPose of every particle against its own field

@@ -25,6 +25,45 @@ public class SLAMGpu extends SLAM {
     private long frame;
     private final ArrayList<Particle> mine;
 
+    private long comm;              // != 0: this object is one rank's block of a filter sharded over the GPUs of a node (joinSharded)
+    private long shardOffset;
+
+    /**
+     * One rank's block of a filter whose particles AND maps are split over `world` GPUs, one JVM per GPU: numParticles is this rank's share
+     * (a multiple of 256); id128 comes from NativeSlam.commUniqueId on one rank and reaches the others by the host's own channel. update(z, u)
+     * and resample() then run over all ranks (every rank passes the same scan and odometry; resample()'s Math.random() must be the same number
+     * on every rank: resampleSharded(r01)).
+     */
+    public static SLAMGpu joinSharded(int numParticlesLocal, long seed, int device, byte[] id128, int rank, int world) {
+        SLAMGpu s = new SLAMGpu(numParticlesLocal, seed, device, (long) rank * numParticlesLocal, (long) world * numParticlesLocal);
+        s.comm = NativeSlam.commCreate(id128, rank, world, device);
+        return s;
+    }
+
+    private SLAMGpu(int numParticlesLocal, long seed, int device, long offset, long nGlobal) {
+        super();
+        this.mine = new ArrayList<>(numParticlesLocal);
+        for (int i = 0; i < numParticlesLocal; i++) {
+            Particle p = new Particle(new Pose(0, 0, 0), getGridMap().createMapData(null));
+            p.weight = 1.0 / nGlobal;
+            mine.add(p);
+        }
+        GridMap g = getGridMap();
+        float res = g.getResolution();
+        double sigma = Math.sqrt(0.05 / res);
+        double[] kernel = Util.generateGaussianKernel(sigma, (int) Math.ceil(sigma * 3));
+        this.n = numParticlesLocal;
+        this.seed = seed;
+        this.shardOffset = offset;
+        this.handle = NativeSlam.pmCreateShard(g.getWorldSize().getX(), g.getWorldSize().getY(), res, g.getPosition().getX(), g.getPosition().getY(),
+                Util.logOdds(SensorModel.P_FREE), Util.logOdds(SensorModel.P_OCCUPPIED), kernel, 0, device, numParticlesLocal, offset, nGlobal);
+        this.poses = new float[3 * numParticlesLocal];
+        this.weights = new double[numParticlesLocal];
+    }
+
+    /** resample() of a sharded filter: r01 stands for Math.random() and must be the same on every rank; fraction &lt; 0: unconditional */
+    public boolean resampleSharded(double r01, double fraction) { return NativeSlam.pmResampleSharded(handle, comm, r01, fraction); }
+
     public SLAMGpu(int numParticles, long seed, int device) {
         super();                                                                    // SLAM.java:56-62 (its Java-side maps stay blank)
         // the superclass's list has SLAM.numParticles = 500 entries whatever numParticles is (a private field, SLAM.java:50): the
@@ -63,6 +102,11 @@ public class SLAMGpu extends SLAM {
     /** update(z, u) (SLAM.java:80-131); returns Neff */
     @Override
     public double update(Observation z, Odometry u) {
+        if (comm != 0) {
+            NativeSlam.pmUpdateSharded(handle, comm, NativeSlam.flatten(z), z.getNumberOfMeasurements(), u != null, u != null ? u.dCenter : 0.0,
+                    u != null ? u.dTheta : 0.0, seed, frame++, stats);
+            return stats[1];
+        }
         NativeSlam.pmUpdate(handle, NativeSlam.flatten(z), z.getNumberOfMeasurements(), u != null, u != null ? u.dCenter : 0.0, u != null ? u.dTheta : 0.0,
                 seed, frame++, stats);
         return stats[1];
@@ -110,5 +154,8 @@ public class SLAMGpu extends SLAM {
     /** GridMapApp.calculateCombined (GridMapApp.java:439-458) on the device, into `combined` */
     public void calculateCombined(GridMapData combined) { NativeSlam.pmCombined(handle, combined.logData, combined.likelihoodData); }
 
-    public void dispose() { NativeSlam.pmDestroy(handle); }
+    public void dispose() {
+        NativeSlam.pmDestroy(handle);
+        if (comm != 0) NativeSlam.commDestroy(comm);
+    }
 }

@@ -127,3 +127,27 @@ def test_two_ranks_reproduce_one_rank_and_the_oracle_loop_map_for_map():
             idx, _ = o.resample(float(r01[k]))
             assert np.array_equal(h["src"], idx), f"frame {k}: the draw sits on a rounding boundary of the two weight sums; pick another seed"
     assert np.array_equal(single["logs"], o.logs())
+
+
+def test_the_library_plan_equals_the_python_plan():
+    """gms_slam_plan_exchange (the host function behind gms_slam_resample_sharded_maps) against distributed.plan_map_exchange on random
+    sorted and unsorted source tables: the same send lists, receive counts, local sources and positions for every rank"""
+    import ctypes as C
+    from gridmap_slam_robot_amd.distributed import plan_map_exchange
+    L = _lib.load()
+    rng = np.random.default_rng(8)
+    for world, n, sort in ((1, 7, True), (2, 8, True), (4, 16, True), (3, 5, True), (4, 16, False), (8, 32, True)):
+        N = world * n
+        flat = rng.integers(0, N, N)
+        src = (np.sort(flat) if sort else flat).reshape(world, n).astype(np.int32)
+        for rank in range(world):
+            sc, sl, rc_, loc, pos = (np.zeros(world, np.int32), np.full((world, n), -7, np.int32), np.zeros(world, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32))
+            _lib.check(L.gms_slam_plan_exchange(_lib.ptr(src), world, rank, n, _lib.ptr(sc), _lib.ptr(sl), _lib.ptr(rc_), _lib.ptr(loc), _lib.ptr(pos)))
+            send_lists, recv_counts, src_local, recv_pos = plan_map_exchange(src, rank, n)
+            assert np.array_equal(rc_, recv_counts) and np.array_equal(loc, src_local) and np.array_equal(pos, recv_pos), (world, rank)
+            for q in range(world):
+                assert sc[q] == send_lists[q].size and np.array_equal(sl[q, :sc[q]], send_lists[q]), (world, rank, q)
+    bad = np.array([[0, 9]], dtype=np.int32)
+    with pytest.raises(_lib.GmsError):
+        _lib.check(L.gms_slam_plan_exchange(_lib.ptr(bad), 1, 0, 2, _lib.ptr(np.zeros(1, np.int32)), _lib.ptr(np.zeros(2, np.int32)), _lib.ptr(np.zeros(1, np.int32)),
+                                            _lib.ptr(np.zeros(2, np.int32)), _lib.ptr(np.zeros(2, np.int32))))

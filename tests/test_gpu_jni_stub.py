@@ -29,6 +29,8 @@ SIG = {  # native -> (return type, argument types after JNIEnv*, jclass); P = a 
     "pfResample": (None, [L, D]), "pfWeightedPose": (None, [L, P]), "slamUpdate": (None, [L, P, I, P, I, D, D, Z, P]),
     "commUniqueId": (None, [P]), "commCreate": (L, [P, I, I, I]), "commDestroy": (None, [L]),
     "slamUpdateSharded": (None, [L, L, P, I, P, I, D, D, Z, P]),
+    "pmCreateShard": (L, [F, F, F, F, F, D, D, P, I, I, I, L, L]), "pmUpdateSharded": (None, [L, L, P, I, Z, D, D, L, L, P]),
+    "pmResampleSharded": (Z, [L, L, D, D]),
     "pmCreate": (L, [F, F, F, F, F, D, D, P, I, I, I]), "pmDestroy": (None, [L]), "pmReset": (None, [L]), "pmSetRefine": (None, [L, Z]),
     "pmUpdate": (None, [L, P, I, Z, D, D, L, L, P]), "pmResample": (None, [L, D]), "pmResampleIf": (None, [L, D, D]),
     "pmGetParticles": (None, [L, P, P, I]), "pmWeightedPose": (None, [L, P]), "pmDownloadMap": (None, [L, I, P, P]), "pmCombined": (None, [L, P, P]),
@@ -210,6 +212,29 @@ def test_every_native_called_once_against_the_ctypes_path():
     j.call("pmDownloadMap", s, 0, la, None)
     assert not j.view(la, 1, W * H).any()
     j.call("pmDestroy", s)
+    rs.close()
+    # ---- ... sharded with its maps: one rank's block (here: the whole population on a communicator of one rank) through the library's own exchanges
+    from gridmap_slam_robot_amd._lib import GMS_BLOCK
+    n = GMS_BLOCK
+    j.call("commUniqueId", ida)
+    cm = j.call("commCreate", ida, 0, 1, 0)
+    s = j.call("pmCreateShard", ext, ext, res, -ext / 2, -ext / 2, prm.l_free, prm.l_occ, karr, 256, 0, n, 0, n)
+    rs = SLAMParticleMaps(ext, ext, res, (-ext / 2, -ext / 2), num_particles=n, max_beams=256)
+    for t in (1, 2):
+        j.call("pmUpdateSharded", s, cm, scans[t], B, 1, 0.05, 0.02, 77, t, st)
+        rneff = rs.update(tr.scans[t], (0.05, 0.02), seed=77, sequence=t)
+        assert j.view(st, 1, 3)[1] == rneff and j.view(st, 1, 3)[2] == rs.strongest
+    assert j.call("pmResampleSharded", s, cm, 0.41, -1.0) == 1
+    rs.resample(0.41)
+    assert j.call("pmResampleSharded", s, cm, 0.41, 1e-9) == 0                      # the rule says no: nothing is drawn
+    xa, wa = j.array(np.zeros(3 * n), 2), j.array(np.zeros(n), 1)
+    j.call("pmGetParticles", s, xa, wa, n)
+    Pr, wr = rs.get_particles()
+    assert np.array_equal(j.view(xa, 2, 3 * n).reshape(n, 3), Pr) and np.array_equal(j.view(wa, 1, n), wr)
+    j.call("pmDownloadMap", s, 5, la, ka)
+    assert np.array_equal(j.view(la, 1, W * H), rs.map_of(5).reshape(-1)) and np.array_equal(j.view(ka, 1, W * H), rs.map_of(5, likelihood=True).reshape(-1))
+    j.call("pmCreateShard", ext, ext, res, -ext / 2, -ext / 2, prm.l_free, prm.l_occ, karr, 256, 0, 100, 0, 200, expect="java/lang/IllegalArgumentException")
+    j.call("pmDestroy", s); j.call("commDestroy", cm)
     rs.close()
     # every native NativeSlam.java declares has been through the stub, and the shim kept the JNI rules
     java = open(os.path.join(ROOT, "jni", "java", "com", "fmsz", "gridmapgl", "slam", "NativeSlam.java")).read()

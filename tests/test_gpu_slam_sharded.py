@@ -169,3 +169,31 @@ def test_one_rank_over_real_rccl_collectives():
         ops.slam.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_one_rank_through_the_library_route():
+    """gms_slam_update_sharded_maps / gms_slam_resample_sharded_maps: the exchanges inside the library (RCCL all-reduce and all-gathers on a
+    communicator of ONE rank -- what one GPU can run; the grouped ncclSend / ncclRecv of the records has no peer here and has never
+    executed) against the stand-alone handle, and a shard whose block is not the whole population refused by the one-rank communicator."""
+    from gridmap_slam_robot_amd.distributed import RcclComm
+    ext, res, B, N, T = 4.0, 0.05, 72, 2 * GMS_BLOCK, 5
+    scans, start = _scans(ext, B, T)
+    r01s = np.random.default_rng(2).random(T)
+    fractions = [0.5, 1e-9, 0.5, 0.5, 1e-9]
+    want, want_logs, want_liks = _stand_alone(ext, res, N, scans, start, r01s, fractions)
+    torch.cuda.set_device(0)
+    comm = RcclComm()
+    assert comm.world == 1
+    ops = SlamShardOps(ext, ext, res, (-ext / 2, -ext / 2), N, 0, N, max_beams=128)
+    ops.slam.set_poses(np.tile(np.asarray(start, np.float32), (N, 1)))
+    for k, (z, u) in enumerate(scans):
+        st = ops.update_rccl(comm, z, u, seed=5, sequence=k)
+        assert st["neff"] == want[k]["neff"] and st["strongest"] == want[k]["strongest"], k
+        assert ops.resample_rccl(comm, float(r01s[k]), fractions[k]) == want[k]["did"]
+        P, w = ops.slam.get_particles()
+        assert np.array_equal(P, want[k]["poses"]) and np.array_equal(w, want[k]["weights"]), k
+    assert np.array_equal(ops.slam.maps(), want_logs) and np.array_equal(ops.slam.maps(likelihood=True), want_liks)
+    half = SlamShardOps(ext, ext, res, (-ext / 2, -ext / 2), GMS_BLOCK, 0, N, max_beams=128)
+    with pytest.raises(GmsError):
+        half.update_rccl(comm, scans[0][0], scans[0][1], seed=5, sequence=0)      # half the population on a communicator of one rank
+    half.slam.close(); ops.slam.close(); comm.close()
