@@ -706,6 +706,9 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     // The scan steps' dirty-tile rebuilds write the factor table only (mode 2): nothing on the hot path reads likelihoodData
     // (GridMap.java:150-156,371-388 are its only readers: getLikelihood and the renderer), so it is brought up to date on demand by a
     // pass of mode 1 (gms_ensure_lik) -- half the stores of a rebuild, and half the dirty lines at the kernel's end.
+#if defined(GMS_LIK_EXP) && GMS_LIK_EXP == 4       // experiment: a likelihood pass that costs nothing (what the paired launch's other half then takes)
+    if (dirty_only) return;
+#endif
     const bool wr_lik = (mode & 1) != 0, wr_fac = (mode & 2) != 0;
     // bit 2: a tile none of whose staged cells changes its code under this scan's counts is left alone.  Its stored field is the
     // blur of exactly these codes already -- the launcher sets the bit only when the factor table is current (every change of
