@@ -239,6 +239,8 @@ struct gms_slam {
     int64_t code_words;             // 32-bit words per plane
     int32_t lik_from_codes;         // likelihoodData is behind: every particle's is the field of plane 1 of its class planes (made on demand)
     int32_t refine;                 // gms_slam_set_refine: update() runs findBestPose on every particle against its own field before weighting it (SLAM.java:96)
+    int32_t refine_field;           // the field in front of the refinement: -1 from the class plane where logData exceeds the infinity cache, 0 from logData
+                                    // always, 1 from the plane always (GMS_SLAM_REFINE_FIELD=log|codes: tests of both forms)
     int32_t refine_lds;             // -1 the field is staged in LDS whenever it fits, 0 never (GMS_SLAM_REFINE_LDS=0: tests of the other form)
 };
 
@@ -317,7 +319,7 @@ SlamBufs gms_slam_bufs(const gms_slam *s);
 void gms_launch_slam_likelihood(gms_map *m, const SlamBufs &sb, int32_t n);
 void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, const SlamBufs &sb, bool field_in_memory, const MotionModel *motion,
                               int32_t integrate, int64_t code_words);
-void gms_launch_slam_likelihood_codes(gms_map *m, const SlamBufs &sb, int64_t code_words, int32_t n);
+void gms_launch_slam_likelihood_codes(gms_map *m, const SlamBufs &sb, int64_t code_words, int32_t n, int32_t plane);
 void gms_launch_slam_codes_from_log(gms_map *m, const SlamBufs &sb, int32_t first, int32_t count, int64_t code_words);
 int64_t gms_slam_code_words(int64_t cells);
 void gms_launch_slam_trace(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t particle, int32_t *d_cells, uint8_t *d_cls, int32_t cap, int32_t *d_counts);

@@ -89,6 +89,8 @@ static int slam_create(const gms_params *p, int32_t n_particles, int64_t offset,
     s->lazy_lik = !(lazy_env && lazy_env[0] == '0');
     const char *rl_env = getenv("GMS_SLAM_REFINE_LDS");
     s->refine_lds = rl_env && rl_env[0] == '0' ? 0 : -1;
+    const char *rf_env = getenv("GMS_SLAM_REFINE_FIELD");
+    s->refine_field = rf_env && rf_env[0] == 'c' ? 1 : (rf_env && rf_env[0] == 'l' ? 0 : -1);
     bool ok = true;
     for (int k = 0; k < 2; k++)
         ok = ok && hipMalloc(&s->d_log[k], bytes) == hipSuccess && hipMalloc(&s->d_lik[k], bytes) == hipSuccess;
@@ -185,7 +187,13 @@ static int slam_update_local(gms_slam *s, const gms_beam *dev_beams, int32_t B, 
     // (slam_lik_current).  The pose refinement looks up most of a field: it gets all of it.
     const bool on_demand = s->d_code[0] != nullptr && !s->refine;
     const SlamBufs sb = gms_slam_bufs(s);
-    if (!on_demand) gms_launch_slam_likelihood(m, sb, s->n);
+    if (!on_demand) {
+        // (plane 0 == the classes of logData, 1/32 of the bytes: 623 us against 793 at 4096 x 256^2, where logData is 2 GB; at
+        //  500 x 120^2 -- 58 MB, inside the 256 MB infinity cache -- the blur's arithmetic binds and reading logData is 1.6 us FASTER)
+        const bool big = (size_t)s->n * (size_t)m->gd.cells * sizeof(double) > ((size_t)256 << 20);
+        if (s->d_code[0] && (s->refine_field < 0 ? big : s->refine_field == 1)) gms_launch_slam_likelihood_codes(m, sb, s->code_words, s->n, 0);
+        else gms_launch_slam_likelihood(m, sb, s->n);
+    }
     s->lik_behind = 0;                                                                                     // (every cell of every field is rewritten: an owed copy is moot)
     s->lik_from_codes = on_demand ? 1 : 0;
     bool drawn = false;
@@ -238,7 +246,7 @@ int gms_slam_update_per_particle(gms_slam *s, const gms_beam *beams, int32_t B, 
 // likelihoodData as the last resample() left it, for whoever reads it before the next update (downloads; a second resample())
 static int slam_lik_current(gms_slam *s) {
     if (s->lik_from_codes) {                                                                               // computeLikelihoodMap(p.m) of the last update (:93), late
-        gms_launch_slam_likelihood_codes(s->map, gms_slam_bufs(s), s->code_words, s->n);
+        gms_launch_slam_likelihood_codes(s->map, gms_slam_bufs(s), s->code_words, s->n, 1);
         s->lik_from_codes = 0;
         HIPCHK(hipGetLastError());
         return GMS_OK;

@@ -61,13 +61,15 @@ k_slam_likelihood(GridDev g, SlamBufs sb, const double *__restrict__ taps_g, int
 #define PS_CODE_MAX_KHALF 7             // on-demand evaluation: up to 15 taps (a row's window of 2-bit classes is one 64-bit read; 16 lanes per end point)
 __host__ __device__ inline int64_t slam_code_words(int64_t cells) { return ((cells + 15) / 16 + 1 + 3) & ~(int64_t)3; }   // per plane: one spare word, 16-byte multiples
 
-// likelihoodData of every particle from plane 1 of its class planes (mode 1 of likelihood_body, as k_slam_likelihood)
+// likelihoodData of every particle from a plane of its class planes (mode 1 of likelihood_body, as k_slam_likelihood): plane 1 -- the
+// field the last update saw, written late --, or plane 0: the field of logData as it stands, in front of the pose refinement (which
+// looks up most of a field; 1/32 of k_slam_likelihood's reads)
 template <int KH>
 __global__ void __launch_bounds__(256)
-k_slam_likelihood_codes(GridDev g, SlamBufs sb, int64_t code_words, const double *__restrict__ taps_g, int32_t tiles_x, int32_t tiles_y) {
+k_slam_likelihood_codes(GridDev g, SlamBufs sb, int64_t code_words, int32_t plane, const double *__restrict__ taps_g, int32_t tiles_x, int32_t tiles_y) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int32_t cur = sb.epoch[0] & 1;
-    const uint32_t *__restrict__ planes = sb_code(sb, cur) + code_words;           // plane 1 of every particle
+    const uint32_t *__restrict__ planes = sb_code(sb, cur) + (plane ? code_words : 0);           // that plane of every particle
     const int64_t code_stride = 2 * code_words;
     double *__restrict__ lik = sb_lik(sb, cur);
     uint32_t bx = blockIdx.x, by = blockIdx.y;
@@ -1033,8 +1035,8 @@ void gms_launch_slam_likelihood(gms_map *m, const SlamBufs &sb, int32_t n) {
 }
 
 int64_t gms_slam_code_words(int64_t cells) { return slam_code_words(cells); }
-// likelihoodData of all n particles from plane 1 of their class planes (d_code [n][2][code_words])
-void gms_launch_slam_likelihood_codes(gms_map *m, const SlamBufs &sb, int64_t code_words, int32_t n) {
+// likelihoodData of all n particles from plane `plane` of their class planes (d_code [n][2][code_words])
+void gms_launch_slam_likelihood_codes(gms_map *m, const SlamBufs &sb, int64_t code_words, int32_t n, int32_t plane) {
     ProfScope ps(m, GMS_K_LIKELIHOOD);
     const int32_t k = m->lik_kh;
     const int32_t tiles_x = (m->gd.W + LK_TW - 1) / LK_TW, tiles_y = (m->gd.H + LK_TH - 1) / LK_TH;
@@ -1050,7 +1052,7 @@ void gms_launch_slam_likelihood_codes(gms_map *m, const SlamBufs &sb, int64_t co
     do {                                                                                                                          \
         if (smem > 48 * 1024)                                                                                                     \
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_likelihood_codes<KH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((k_slam_likelihood_codes<KH>), grid, dim3(256), smem, m->stream, m->gd, sb, code_words, m->d_taps, tiles_x, tiles_y); \
+        hipLaunchKernelGGL((k_slam_likelihood_codes<KH>), grid, dim3(256), smem, m->stream, m->gd, sb, code_words, plane, m->d_taps, tiles_x, tiles_y); \
     } while (0)
     if (k == 3) SLK_LAUNCH(3);
     else if (k == 5) SLK_LAUNCH(5);

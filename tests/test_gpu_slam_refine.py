@@ -68,18 +68,23 @@ def test_refined_update_at_the_reference_operating_point():
     dev.close()
 
 
-@pytest.mark.parametrize("case", ["field_in_memory_forced", "256x256_does_not_fit", "2cm_11_taps", "ragged_map", "long_scan", "underflow_700_beams"])
+@pytest.mark.parametrize("case", ["field_in_memory_forced", "field_from_class_plane", "256x256_does_not_fit", "2cm_11_taps", "ragged_map", "long_scan", "underflow_700_beams"])
 def test_refined_update_other_shapes(case, monkeypatch):
-    """the form that reads the field from memory (forced on a small map; a 256 x 256 map, 512 KB, which no LDS holds), the 11-tap
+    """the form that reads the field from memory (forced on a small map; a 256 x 256 map, 512 KB, which no LDS holds), the field in
+    front of the refinement written from the particles' class planes (what a filter does whose logData exceeds the infinity cache:
+    gms_slam::refine_field), the 11-tap
     kernel of a 2 cm map, a map whose width is odd (the staging's scalar form), a scan of 300 beams (whose rotation table does not
     fit beside the field: rotated per look-up), and a scan of 700 beams in a map so much larger than the room that no lattice pose
     puts an end point outside it: every product underflows to 0, maxProb stays 0 and the start pose is kept (GridMap.java:320-321,
     334) -- and update() then divides 0 by 0, on both sides."""
-    W, H, res, B, N, T = {"field_in_memory_forced": (4.0, 4.0, 0.05, 72, 24, 4), "256x256_does_not_fit": (12.8, 12.8, 0.05, 120, 24, 3),
+    W, H, res, B, N, T = {"field_in_memory_forced": (4.0, 4.0, 0.05, 72, 24, 4), "field_from_class_plane": (4.0, 4.0, 0.05, 72, 24, 5),
+                          "256x256_does_not_fit": (12.8, 12.8, 0.05, 120, 24, 3),
                           "2cm_11_taps": (2.4, 2.4, 0.02, 72, 12, 3), "ragged_map": (2.55, 3.35, 0.05, 64, 10, 4),
                           "long_scan": (6.0, 6.0, 0.05, 300, 8, 3), "underflow_700_beams": (12.8, 12.8, 0.05, 700, 8, 2)}[case]
     if case == "field_in_memory_forced":
         monkeypatch.setenv("GMS_SLAM_REFINE_LDS", "0")
+    if case == "field_from_class_plane":
+        monkeypatch.setenv("GMS_SLAM_REFINE_FIELD", "codes")
     ext = min(W, H)
     tr = synth.make_trace(min(ext, 6.4), res, B, T=T + 1, seed=61)
     g = orc.Grid(W, H, res, -W / 2, -H / 2)
@@ -159,3 +164,32 @@ def test_refinement_edge_cases():
     assert np.array_equal(dev.get_particles()[0], n_before) and np.array_equal(n_before, o.poses)
     _compare_maps(dev, o, "refinement off again")
     dev.close()
+
+
+def test_both_forms_of_the_field_at_4096_maps_of_256_x_256(monkeypatch):
+    """at 4096 x 256^2 logData is 2 GB and the field in front of the refinement is written from the class planes (the launcher's own
+    rule); a second handle is told to read logData: poses, weights and the maps of a few particles EQUAL over three refined updates
+    with a resampling step between them."""
+    N, B, ext, T = 4096, 180, 12.8, 3
+    frames, _ = synth.make_recording(ext / 2, B, T=48, seed=78, n_frames=T)
+    scans = _frames_to_scans(frames)
+    start = synth.true_pose(synth.make_world(ext / 2, 78), -1, 48)
+    a = SLAMParticleMaps(ext, ext, 0.05, (-ext / 2, -ext / 2), num_particles=N, max_beams=256)
+    monkeypatch.setenv("GMS_SLAM_REFINE_FIELD", "log")
+    b = SLAMParticleMaps(ext, ext, 0.05, (-ext / 2, -ext / 2), num_particles=N, max_beams=256)
+    P0 = np.tile(np.asarray(start, np.float32), (N, 1))
+    for h in (a, b):
+        h.set_poses(P0); h.set_refine(True)
+    for k, (z, u) in enumerate(scans):
+        for h in (a, b):
+            h.update(z, u, seed=5, sequence=k)
+        Pa, wa = a.get_particles()
+        Pb, wb = b.get_particles()
+        assert np.array_equal(Pa, Pb) and np.array_equal(wa, wb), f"frame {k}"
+        assert (Pa != P0).any()
+        ia, _ = a.resample(0.37, want_indices=True)
+        ib, _ = b.resample(0.37, want_indices=True)
+        assert np.array_equal(ia, ib)
+    for i in (0, 1, 2047, 4095):
+        assert np.array_equal(a.map_of(i), b.map_of(i)) and np.array_equal(a.map_of(i, likelihood=True), b.map_of(i, likelihood=True))
+    a.close(); b.close()
