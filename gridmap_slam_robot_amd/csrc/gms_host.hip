@@ -329,9 +329,10 @@ int gms_map_create(const gms_params *p, gms_map **out) {
     g.inv_max = 1.0 / (double)p->max_range;                          // GridMap.java:286
     g.ktaps = p->ktaps; g.khalf = (p->ktaps - 1) / 2;                // Util.java:384
     m->lik_kh = (g.khalf == 3 || g.khalf == 5) ? g.khalf : 0;
+    m->taps_plain = 1;
     for (int32_t i = 0; i < p->ktaps; i++) {
         const double a = p->kernel[i];
-        if (std::signbit(a) || (a != 0.0 && !(a >= 0x1p-900 && a <= 0x1p900))) m->lik_kh = 0;
+        if (std::signbit(a) || (a != 0.0 && !(a >= 0x1p-900 && a <= 0x1p900))) m->lik_kh = m->taps_plain = 0;
     }
 
     const size_t cells = (size_t)g.cells * m->n_maps;

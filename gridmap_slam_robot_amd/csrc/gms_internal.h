@@ -118,6 +118,7 @@ struct gms_map {
     int32_t apply_pending;    // the last scan's counts are not in logData yet (deferred apply pass, gms_flush_apply)
     int32_t raycast_tile;     // batched ray casts accumulate in LDS tiles (k_raycast_tile; GMS_RAYCAST_TILE=0 turns it off)
     int32_t raycast_tile_min; // ... when the launch has more rays than this in all (default 4096; GMS_RAYCAST_TILE_MIN)
+    int32_t taps_plain;       // every tap is +0.0 or in [2^-900, 2^900]: sums of tap * {0, 1, 2} scale exactly by 0.5 and a tap * 0.0 may stand for a skipped one
     int32_t lik_kh;           // the likelihood kernels' compile-time half width (3 or 5), or 0 = the generic path: another kernel size, or a tap
                               // that is negative or outside 2^-900 .. 2^900 (the fast path computes twice the horizontal sums and halves them --
                               // exact only while nothing is subnormal -- and starts a sum with its first product instead of 0.0 + it -- the

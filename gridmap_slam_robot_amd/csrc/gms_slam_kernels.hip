@@ -58,6 +58,9 @@ k_slam_likelihood(GridDev g, SlamBufs sb, const double *__restrict__ taps_g, int
 // is the field of (SLAM.java:93 runs before :105).  update() then needs no k_slam_likelihood launch: k_slam_particle stages plane 0 in
 // LDS and blurs just the end points' neighbourhoods ("on_demand" there); likelihoodData is written, from plane 1, only when somebody asks for
 // it (k_slam_likelihood_codes: a download, an upload of a field, the pose refinement).
+#ifndef PS_PRECLEAR
+#define PS_PRECLEAR 1                   // the first band's count tile cleared while the class plane's loads fly (0: in the band loop, as every other band's)
+#endif
 #define PS_CODE_MAX_KHALF 7             // on-demand evaluation: up to 15 taps (a row's window of 2-bit classes is one 64-bit read; 16 lanes per end point)
 __host__ __device__ inline int64_t slam_code_words(int64_t cells) { return ((cells + 15) / 16 + 1 + 3) & ~(int64_t)3; }   // per plane: one spare word, 16-byte multiples
 
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4)))   
 k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, SlamBufs sb, int32_t field_in_memory,
                 float *__restrict__ pose, float *__restrict__ cs, double *__restrict__ w,
                 double *__restrict__ logw, MotionArgs mo, int32_t integrate, int32_t tile_bytes, int32_t code_words,
-                const double *__restrict__ taps_g) {
+                const double *__restrict__ taps_g, int32_t taps_plain) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int32_t cur = sb.epoch[0] & 1;               // the current generation of the particles' maps (SlamBufs)
     double *__restrict__ log_all = sb_log(sb, cur);
@@ -210,7 +213,6 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     __shared__ float s_pose[5];                                                // x, y, theta, (float)cos, (float)sin
     __shared__ int32_t s_box[4];                                               // the scan's box x0, y0, x1, y1 (inclusive)
     __shared__ int32_t s_grp_words[NP];
-    __shared__ double s_red[NW];
     __shared__ uint16_t s_work[GR];                                            // a round's cell work: the rays that have cells in it
     __shared__ int32_t s_nwork, s_next;
     __shared__ int32_t s_nzero;                                                // rays of zero length: the only ones that visit a cell more than once
@@ -223,15 +225,23 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     uint32_t *s_cell = s_plane + code_words;                                   // [Bpad] the end point's cell of every beam, for the on-demand field (CODES)
     uint32_t *gplane = CODES ? code_all + (size_t)p * 2 * (size_t)code_words : nullptr;
 
+    // (the first beam of this thread: on its way while the pose is drawn)
+    gms_beam bm_first{};
+    if (B > 0) bm_first = beams[min((int32_t)threadIdx.x, B - 1)];
     // ---- the particle's pose: sampleMotionModel (SLAM.java:90, Odometry.java:77-96) or the pose as it stands
     if (CODES && wave != 0) {
         // the class plane as logData stands now -- the start of this update -- into LDS, by the other wavefronts while wavefront 0 draws
-        // the pose; twelve loads in flight per lane (a plane is at most 24 KiB: gms_slam_create)
+        // the pose; twelve loads in flight per lane (a plane is at most 24 KiB: gms_slam_create).  While the first twelve fly, the
+        // count tile of the first band of rows is cleared.
         constexpr int PLB = 12;
-        for (int32_t i0 = (int32_t)threadIdx.x - 64; i0 < code_words; i0 += PLB * (NT - 64)) {
+        bool first = true;
+        for (int32_t i0 = (int32_t)threadIdx.x - 64; first || i0 < code_words; i0 += PLB * (NT - 64)) {
             uint32_t plw[PLB];
 #pragma unroll
             for (int u = 0; u < PLB; u++) plw[u] = gplane[min(i0 + u * (NT - 64), code_words - 1)];
+            if (PS_PRECLEAR && first && integrate)
+                for (int32_t i = (int32_t)threadIdx.x - 64; i < (tile_bytes >> 2); i += NT - 64) s_tile[i] = 0u;
+            first = false;
 #pragma unroll
             for (int u = 0; u < PLB; u++)
                 if (i0 + u * (NT - 64) < code_words) s_plane[i0 + u * (NT - 64)] = plw[u];
@@ -267,7 +277,6 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     //      beside it every beam's ray box (GridMap.java:175-188 + ray_meta) for the count tile
     const double *lik = lik_all + (size_t)p * (size_t)g.cells;
     const bool on_demand = CODES && lik_all == nullptr;                        // no field in memory: the end points' cells are evaluated from the class plane
-    double lsum = 0.0;
     int32_t bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = INT32_MIN, by1 = INT32_MIN, nzero = 0;
     // the ray of beam threadIdx.x, kept: the producer lane of that beam in the first group of rays below is this very thread
     RayDev r_first;
@@ -275,7 +284,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     r_first.dx = r_first.dy = r_first.error = 0.0f; r_first.x = r_first.y = r_first.x_inc = r_first.y_inc = r_first.n = 0;
     mt_first = RayMeta{};
     for (int32_t b = (int32_t)threadIdx.x; b < B; b += NT) {
-        const gms_beam bm = beams[b];
+        const gms_beam bm = b == (int32_t)threadIdx.x ? bm_first : beams[b];
         double f = 1.0;                                                        // a beam that is skipped leaves the product as it is: x * 1.0 == x
         uint32_t cell = 0xffffffffu;
         if (bm.hit) {                                                          // :269
@@ -288,7 +297,6 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
         }
         s_fac[b] = f;
         if (CODES) s_cell[b] = cell;
-        lsum += log(f);
         if (integrate) {
             RayDev r;
             const RayMeta mt = ray_meta(g, ps_make_ray(g, t, bm), r);
@@ -299,10 +307,6 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                 by0 = min(by0, min(mt.y0, mt.hy)); by1 = max(by1, max(mt.y0, mt.hy));
             }
         }
-    }
-    if (!on_demand) {
-        lsum = wave_sum_f64(lsum);
-        if (lane == 0) s_red[wave] = lsum;
     }
     if (integrate) {
 #define GMS_STEP_(O) { bx0 = min(bx0, wave_xor<O>(bx0)); by0 = min(by0, wave_xor<O>(by0)); bx1 = max(bx1, wave_xor<O>(bx1)); by1 = max(by1, wave_xor<O>(by1)); nzero += wave_xor<O>(nzero); }
@@ -353,17 +357,53 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                     const int32_t yy = gy - kh + rr;
                     if (rr < ntaps && yy >= 0 && yy < g.H) total += s_taps[min(rr, ntaps - 1)] * hh;   // :418-420
                 }
-                if (r == 0 && cell != 0xffffffffu) {
-                    const double f = lik_factor(g, total);                     // GridMap.java:277-288
-                    s_fac[b] = f;
-                    lsum += log(f);
-                }
+                if (r == 0 && cell != 0xffffffffu) s_fac[b] = lik_factor(g, total);       // GridMap.java:277-288
             }
         };
-        if (ntaps <= 8) field_pass(std::integral_constant<int, 8>{});
-        else field_pass(std::integral_constant<int, 16>{});
-        lsum = wave_sum_f64(lsum);
-        if (lane == 0) s_red[wave] = lsum;
+        // The same sums where every tap is +0.0 or a normal number well inside the range (gms_map::taps_plain; any Gaussian kernel):
+        // a likelihood value is 0.5 c with c in {0, 1, 2}, and tap * c, their running sum and its half are exact images of the
+        // reference's tap * value sums (scaling by two commutes with rounding where nothing is subnormal or overflows); a column or
+        // row outside the map enters as `total + tap * 0.0`, which leaves a total that is never -0.0 as it is.  So: the row's window
+        // of classes turned into the c's at once (bit-parallel), the outside columns masked to c = 0, the taps wave-uniform from the
+        // scalar cache, and four instructions per tap where the literal form needs sixteen.
+        auto field_pass_plain = [&](auto width) {
+            constexpr int L = decltype(width)::value, SH = L == 8 ? 3 : 4, NTP = L < 2 * PS_CODE_MAX_KHALF + 1 ? L : 2 * PS_CODE_MAX_KHALF + 1;
+            const int32_t r = lane & (L - 1), grp = lane & ~(L - 1);
+            double tp[NTP];
+#pragma unroll
+            for (int t = 0; t < NTP; t++) tp[t] = t < ntaps ? taps_g[t] : 0.0;
+            for (int32_t base = 0; base + wave * 64 < (B << SH); base += NT) {  // (a wavefront's lanes stay together: the shuffles read all of a group)
+                const int32_t item = base + (int32_t)threadIdx.x;
+                const int32_t b = min(item >> SH, B - 1);
+                const uint32_t cell = (item >> SH) < B ? s_cell[b] : 0xffffffffu;
+                const int32_t gx = (int32_t)(cell & 0xffffu), gy = (int32_t)(cell >> 16);
+                const int32_t y = gy - kh + r;
+                double h = 0.0;
+                if (cell != 0xffffffffu && r < ntaps && y >= 0 && y < g.H) {   // Util.java:418
+                    const int32_t c0 = y * g.W + gx - kh;                      // (>= -kh: word -1 is the count tile's last, its fields are masked)
+                    const uint32_t w0 = s_plane[c0 >> 4], w1 = s_plane[(c0 >> 4) + 1];  // (a spare word follows the plane)
+                    const uint32_t wv = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2 * (c0 & 15)));
+                    const int32_t tlo = max(0, kh - gx), thi = min(2 * kh, g.W - 1 - gx + kh);   // columns inside the map (:396)
+                    const uint32_t inside = (uint32_t)((1ull << (2 * thi + 2)) - 1ull) & ~((1u << (2 * tlo)) - 1u);
+                    // class 0 (logData == 0: 0.5) -> 1, class 1 (< 0: 0.0) -> 0, class 2 (> 0: 1.0) -> 2 (GridMap.java:239-244)
+                    const uint32_t cw = (((~(wv | (wv >> 1))) & 0x55555555u) | (wv & 0xaaaaaaaau)) & inside;
+#pragma unroll
+                    for (int t = 0; t < NTP; t++) h += tp[t] * (double)((cw >> (2 * t)) & 3u);    // Util.java:399, twice over
+                    h *= 0.5;
+                }
+                double total = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < NTP; rr++) total += tp[rr] * __shfl(h, grp + rr);          // :418-420 (a row outside the map: + tap * 0.0)
+                if (r == 0 && cell != 0xffffffffu) s_fac[b] = lik_factor(g, total);               // GridMap.java:277-288
+            }
+        };
+        if (taps_plain) {
+            if (ntaps <= 8) field_pass_plain(std::integral_constant<int, 8>{});
+            else field_pass_plain(std::integral_constant<int, 16>{});
+        } else {
+            if (ntaps <= 8) field_pass(std::integral_constant<int, 8>{});
+            else field_pass(std::integral_constant<int, 16>{});
+        }
         __syncthreads();
     }
     GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 2);
@@ -379,11 +419,16 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
             for (int k = 0; k < 8; k++) prod *= v[k];
         }
         for (; b < B; b++) prod *= s_fac[b];
-        double ls = 0.0;
-        for (int k = 0; k < NW; k++) ls += s_red[k];
         w[p] = prod;                                                           // p.weight (SLAM.java:99)
-        logw[p] = ls;                                                          // sum of log factors: the underflow-free companion
         GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(0, blockIdx.x), 3);
+    }
+    if (wave == NW - 2) {
+        // the sum of the log factors, the product's underflow-free companion (gms_pf_set_log_normalize): one wavefront's worth of
+        // double-precision logarithms, beside the ray set-up
+        double ls = 0.0;
+        for (int32_t b = lane; b < B; b += 64) ls += log(s_fac[b]);
+        ls = wave_sum_f64(ls);
+        if (lane == 0) logw[p] = ls;
     }
     if (!integrate) return;                                                    // skipUpdate (SLAM.java:82,102)
 
@@ -400,7 +445,8 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     double *mlog = log_all + (size_t)p * (size_t)g.cells;
     for (int32_t ty0 = Y0; ty0 <= Y1; ty0 += band_rows) {
         const int32_t th = min(band_rows, Y1 - ty0 + 1);
-        for (int32_t i = threadIdx.x; i < (narrow ? (tw * th + 1) >> 1 : tw * th); i += NT) s_tile[i] = 0u;
+        if (!(PS_PRECLEAR && CODES) || ty0 != Y0)
+            for (int32_t i = threadIdx.x; i < (narrow ? (tw * th + 1) >> 1 : tw * th); i += NT) s_tile[i] = 0u;
         for (int32_t g0 = 0; g0 < B; g0 += GR) {
             // this group's rays: a producer lane per ray
             RayDev r;
@@ -1113,7 +1159,7 @@ void gms_launch_slam_particle(gms_pf *pf, const gms_beam *d_beams, int32_t B, co
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_particle<NT, NP, NA, CD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
         hipLaunchKernelGGL((k_slam_particle<NT, NP, NA, CD>), dim3((unsigned)pf->n), dim3(NT), smem, m->stream, m->gd, d_beams, B, Bpad, sb,           \
                            field_in_memory ? 1 : 0, pf->d_pose, pf->d_cs, pf->d_w, pf->d_logw, mo, integrate, (int32_t)(tile * 4), (int32_t)code_words, \
-                           m->d_taps);                                                                                                  \
+                           m->d_taps, m->taps_plain);                                                                                   \
     } while (0)
 #define PS_LAUNCH2(NT, NA) do { if (d_code) PS_LAUNCH(NT, NA, true); else PS_LAUNCH(NT, NA, false); } while (0)
     if (threads == 512) { if (narrow_allowed) PS_LAUNCH2(512, true); else PS_LAUNCH2(512, false); }

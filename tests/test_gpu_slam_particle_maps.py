@@ -183,17 +183,24 @@ def test_edge_scans_the_band_walk_and_the_skip_rule(monkeypatch):
         dev.close()
 
 
-@pytest.mark.parametrize("case", ["2cm_11_taps", "ragged_map", "one_particle", "three_ray_groups"])
+@pytest.mark.parametrize("case", ["2cm_11_taps", "ragged_map", "one_particle", "three_ray_groups", "signed_taps", "tiny_tap_9", "fifteen_taps"])
 def test_other_geometries(case):
     """what the two sizes above do not reach: the 11-tap kernel of a 2 cm map (k_slam_likelihood<5>), a map that is no multiple of the
     64 x 32 likelihood tiles and narrower than one, a filter of one particle, a scan of more beams than one group of producer lanes
-    holds (128): several groups of rays per band."""
+    holds (128): several groups of rays per band.  Blur kernels given by the caller: one with negative taps and one with a tap of
+    1e-300 (the on-demand field's literal form: tap * value sums in which nothing may be rescaled), and fifteen plain taps (the widest
+    kernel the class planes are kept for; the scaled form, sixteen lanes per end point)."""
     W, H, res, B, N, T = {"2cm_11_taps": (3.2, 3.2, 0.02, 72, 12, 5), "ragged_map": (2.6, 4.45, 0.05, 64, 10, 5),
-                          "one_particle": (4.0, 4.0, 0.05, 90, 1, 5), "three_ray_groups": (4.0, 4.0, 0.05, 300, 6, 4)}[case]
+                          "one_particle": (4.0, 4.0, 0.05, 90, 1, 5), "three_ray_groups": (4.0, 4.0, 0.05, 300, 6, 4),
+                          "signed_taps": (4.0, 4.0, 0.05, 90, 8, 5), "tiny_tap_9": (4.0, 4.0, 0.05, 90, 8, 5), "fifteen_taps": (4.0, 3.0, 0.05, 90, 8, 5)}[case]
+    taps = {"signed_taps": [-0.03, 0.11, 0.26, 0.32, 0.26, 0.11, -0.03], "tiny_tap_9": [1e-300, 0.02, 0.1, 0.23, 0.3, 0.23, 0.1, 0.02, 1e-300],
+            "fifteen_taps": [0.002, 0.006, 0.016, 0.035, 0.065, 0.1, 0.13, 0.292, 0.13, 0.1, 0.065, 0.035, 0.016, 0.006, 0.002]}.get(case)
     ext = min(W, H)
     tr = synth.make_trace(ext, res, B, T=T, seed=31)
     g = orc.Grid(W, H, res, -W / 2, -H / 2)
-    dev = SLAMParticleMaps(W, H, res, (-W / 2, -H / 2), num_particles=N, max_beams=max(128, B))
+    if taps is not None:
+        g.set_kernel(taps)
+    dev = SLAMParticleMaps(W, H, res, (-W / 2, -H / 2), num_particles=N, max_beams=max(128, B), kernel=taps)
     o = orc.Slam(g, N)
     assert (dev.W, dev.H) == (g.W, g.H)
     P = synth.make_particles(tr.poses[0], N, seed=4, sigma_xy=0.03, sigma_theta_deg=2.0)
@@ -202,7 +209,11 @@ def test_other_geometries(case):
     for k in range(T):
         z = tr.scans[k]
         dev.update(z, None); o.update(z, None, threads=THREADS)
-        _compare_weights(dev.get_particles()[1], o.weights, f"{case} frame {k}")
+        if case == "signed_taps":                          # (factors, and with them weights, of either sign)
+            w, wo = dev.get_particles()[1], o.weights
+            assert np.isfinite(wo).all() and np.max(np.abs(w - wo) / np.abs(wo)) <= 1e-12, f"{case} frame {k}"
+        else:
+            _compare_weights(dev.get_particles()[1], o.weights, f"{case} frame {k}")
         _compare_maps(dev, o, f"{case} frame {k}")
         if N > 1 and k == T - 2:
             r01 = float(rng.random())

@@ -47,6 +47,11 @@ for i in order:
     print(f"    {i:4d}: {d[i, 4]:.1f} | {d[i, 5] - d[i, 4]:.1f} | {d[i, 6] - d[i, 5]:.1f} | {d[i, 7] - d[i, 6]:.1f}   total {tot[i]:.1f}")
 med = np.nanmedian(d[:n], axis=0)
 print(f"    median: {med[4]:.1f} | {med[5] - med[4]:.1f} | {med[6] - med[5]:.1f} | {med[7] - med[6]:.1f}   total {med[7]:.1f}")
+for nm_, sl in (("ids < 256 ", slice(0, min(n, 256))), ("ids >= 256", slice(256, n))):
+    if sl.stop > sl.start:
+        m_ = np.nanmedian(d[sl], axis=0)
+        print(f"  {nm_}: pose {m_[1]:.2f} | factors {m_[2]:.2f} | rays set up {m_[4]:.2f} | first round walked {m_[5]:.2f} | counted {m_[6]:.2f} | applied {m_[7]:.2f};"
+              f" entered {np.nanmedian(st[sl, 0] - t0) * 0.01:.2f} after the first")
 print("  median total by XCD (id & 7):", " ".join(f"{np.nanmedian(tot[x::8]):.1f}" for x in range(8)), "| ids < 256:", f"{np.nanmedian(tot[:256]):.1f}", "ids >= 256:", f"{np.nanmedian(tot[256:n]):.1f}")
 print("  max total by XCD:            ", " ".join(f"{np.nanmax(tot[x::8]):.1f}" for x in range(8)))
 print("  workgroups slower than median + 3 us:", int((tot > med[7] + 3).sum()), "of", n, "; their ids mod 32:", sorted(set(int(i) % 32 for i in np.where(tot > med[7] + 3)[0])))
