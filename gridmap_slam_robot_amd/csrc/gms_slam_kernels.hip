@@ -706,7 +706,7 @@ __host__ __device__ inline int32_t slam_lattice_steps(float span, float step, fl
 #define SR_THETA_STEP (SR_THETA_SPAN / 5)                               // :325
 
 template <bool LDSF>
-__global__ void __launch_bounds__(SR_NT)
+__global__ void __launch_bounds__(SR_NT) __attribute__((amdgpu_waves_per_eu(LDSF ? 3 : 8)))      // (the field in LDS: one workgroup per CU; in memory: three, 64 registers)
 k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, SlamBufs sb,
               float *__restrict__ pose, float *__restrict__ cs, MotionArgs mo, int32_t fp, int32_t nt_batch) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1199,10 +1199,14 @@ bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, cons
     ProfScope ps(m, GMS_K_REFINE);
     // the field in LDS: its 16-bit table entries must hold (H + 1) * pitch, and one theta step's tables must fit beside it
     const bool ldsf = field_in_lds != 0 && (size_t)(m->gd.H + 1) * fp <= 65535 && field_b + beams_b + tab1_b <= room;
-    const size_t left = (ldsf ? room - field_b : std::max((size_t)96 * 1024, beams_b + tab1_b)) - beams_b;
+    // (the field in memory: 48 KB of tables per workgroup, so that three workgroups -- 64 registers, 30 wavefronts -- share a CU and
+    //  hide each other's misses: 4096 x 256^2 x 180 beams 2.33 ms with 96 KB and one workgroup per CU, 1.69 with two, 1.61 with three)
+    static const size_t tab_budget = []() { const char *e = getenv("GMS_SLAM_REFINE_TAB_KB"); return (size_t)(e && atoi(e) > 0 ? atoi(e) : 48) * 1024; }();
+    const size_t left = (ldsf ? room - field_b : std::max(tab_budget, beams_b + tab1_b)) - beams_b;
     int32_t nt_batch = (int32_t)(left / tab1_b);
     if (nt_batch > nt) nt_batch = nt;
     if (nt_batch < 1) nt_batch = 1;
+    nt_batch = (nt + (nt + nt_batch - 1) / nt_batch - 1) / ((nt + nt_batch - 1) / nt_batch);          // batches of equal size (6 + 4 theta steps keep ten wavefronts busy for two rounds each)
     const size_t smem = (ldsf ? field_b : 0) + beams_b + (size_t)nt_batch * tab1_b;
 #define SR_LAUNCH(LF)                                                                                                                  \
     do {                                                                                                                                \
