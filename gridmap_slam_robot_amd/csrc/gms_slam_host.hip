@@ -80,7 +80,8 @@ static int slam_create(const gms_params *p, int32_t n_particles, int64_t offset,
     if (rc) { gms_slam_destroy(s); return rc; }
     gms_map *m = s->map;
     // the per-particle kernel keeps one row of the count tile at the very least (gms_launch_slam_particle)
-    if ((size_t)m->max_beams * 8 + 16384 + (size_t)m->gd.W * 4 + 4096 > (size_t)m->lds_per_cu) {
+    // (per beam: factor 8 B, thresholds 8 B, end-point cell 4 B; slots and ray records 13.3 KB; a class plane of at most 24 KiB)
+    if (((size_t)m->max_beams + 8) * 20 + 16384 + 24576 + (size_t)m->gd.W * 4 + 4096 > (size_t)m->lds_per_cu) {
         gms_slam_destroy(s);
         return gms_fail(GMS_ERR_INVALID, "gms_slam_create: %d beams and rows of %d cells do not fit a workgroup's LDS", m->max_beams, m->gd.W);
     }

@@ -187,7 +187,7 @@ __device__ __forceinline__ void ps_phase_b(const GridDev &g, const PsRay &mt, co
 }
 
 // One workgroup per particle.  NT threads; wavefronts 0 .. NP-1 walk 64 rays each (RayIterator's float recurrence, ray_phase_a), then
-// join the others in the cell work.  Dynamic LDS: factors [Bpad] f64 | decision slots [PS_WORDS][64 NP] u64 | ray records [64 NP] |
+// join the others in the cell work.  Dynamic LDS: factors [Bpad] f64 | thresholds [Bpad] 2 x f32 | decision slots [PS_WORDS][64 NP] u64 | ray records [64 NP] |
 // count tile [tile_bytes].
 // (A lane per ray running the reference's loop as it stands -- walk, distance, class, count -- was built and measured: 80 instructions
 // per step on one or two wavefronts per SIMD, which issue one instruction per ~4.6 clocks: 29 us of walking for 90 rays against 17 for
@@ -206,7 +206,8 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     constexpr int NW = NT / 64, GR = 64 * NP;
     static_assert(NW > NP, "at least one wavefront that only consumes");
     double *s_fac = reinterpret_cast<double *>(smem);                          // [Bpad]
-    uint64_t *s_slots = reinterpret_cast<uint64_t *>(s_fac + Bpad);            // [PS_WORDS][GR]
+    RayThr *s_thr = reinterpret_cast<RayThr *>(s_fac + Bpad);                  // [Bpad] every ray's squared class thresholds
+    uint64_t *s_slots = reinterpret_cast<uint64_t *>(s_thr + Bpad);            // [PS_WORDS][GR]
     PsRay *s_ray = reinterpret_cast<PsRay *>(s_slots + PS_WORDS * GR);         // [GR]
     uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_ray + GR);               // [tile_bytes / 4] words: 32-bit cells, or 16-bit cells two to a word
     uint32_t *s_plane = s_tile + (tile_bytes >> 2);                            // [code_words] the particle's class plane 0 (CODES)
@@ -226,8 +227,11 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     uint32_t *gplane = CODES ? code_all + (size_t)p * 2 * (size_t)code_words : nullptr;
 
     // (the first beam of this thread: on its way while the pose is drawn)
-    gms_beam bm_first{};
-    if (B > 0) bm_first = beams[min((int32_t)threadIdx.x, B - 1)];
+    gms_beam bm_first{}, bm_thr{};
+    if (B > 0) {
+        bm_first = beams[min((int32_t)threadIdx.x, B - 1)];
+        bm_thr = beams[min(NT - 1 - (int32_t)threadIdx.x, B - 1)];              // (the beam whose thresholds this thread finds: below)
+    }
     // ---- the particle's pose: sampleMotionModel (SLAM.java:90, Odometry.java:77-96) or the pose as it stands
     if (CODES && wave != 0) {
         // the class plane as logData stands now -- the start of this update -- into LDS, by the other wavefronts while wavefront 0 draws
@@ -309,6 +313,12 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
         }
     }
     if (integrate) {
+        // every ray's squared class thresholds (ray_thresholds: a few correctly rounded square roots each), beam b by thread NT - 1 - b:
+        // the LAST wavefronts' work while the first ones set up the rays -- on the producers it was 2.3 us in front of the first walk
+        for (int32_t b = NT - 1 - (int32_t)threadIdx.x; b < B; b += NT) {
+            const gms_beam bm = b == NT - 1 - (int32_t)threadIdx.x ? bm_thr : beams[b];
+            s_thr[b] = ray_thresholds((float)bm.distance / g.resf, bm.hit != 0, g.half_tol);        // GridMap.java:188; SensorModel.java:31-41
+        }
 #define GMS_STEP_(O) { bx0 = min(bx0, wave_xor<O>(bx0)); by0 = min(by0, wave_xor<O>(by0)); bx1 = max(bx1, wave_xor<O>(bx1)); by1 = max(by1, wave_xor<O>(by1)); nzero += wave_xor<O>(nzero); }
         GMS_BUTTERFLY(GMS_STEP_)
 #undef GMS_STEP_
@@ -429,6 +439,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
         for (int32_t b = lane; b < B; b += 64) ls += log(s_fac[b]);
         ls = wave_sum_f64(ls);
         if (lane == 0) logw[p] = ls;
+        GMS_STAMP_T(NT - 128, GMS_STAMP_ROW(0, blockIdx.x), 13);
     }
     if (!integrate) return;                                                    // skipUpdate (SLAM.java:82,102)
 
@@ -462,7 +473,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                     else mt = ray_meta(g, ps_make_ray(g, t, beams[ri]), r);    // the same arithmetic as the box pass above: same values
                     // a ray that never enters this band's rows is not walked for it (its box says so)
                     const bool in_band = mt.n_eff > 0 && !(max(mt.y0, mt.hy) < ty0 || min(mt.y0, mt.hy) >= ty0 + th);
-                    const RayThr thr = ray_thresholds(mt.measured, mt.hit, g.half_tol);
+                    const RayThr thr = s_thr[ri];
                     pr.x0 = mt.x0; pr.y0 = mt.y0; pr.x_inc = mt.x_inc; pr.y_inc = mt.y_inc; pr.n_eff = in_band ? mt.n_eff : 0; pr.hit = mt.hit;
                     pr.sx = mt.sx; pr.sy = mt.sy; pr.s_free = thr.s_free; pr.s_prior = thr.s_prior;
                 }
@@ -473,7 +484,9 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
                 GMS_BUTTERFLY(GMS_STEP_)
 #undef GMS_STEP_
                 if (lane == 0) s_grp_words[wave] = nwm;
+                if (g0 == 0 && ty0 == Y0) GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 14);
             }
+            if (g0 == 0 && ty0 == Y0) GMS_STAMP_T(128, GMS_STAMP_ROW(0, blockIdx.x), 15);
             __syncthreads();
             if (g0 == 0 && ty0 == Y0) GMS_STAMP(GMS_STAMP_ROW(0, blockIdx.x), 4);
             int32_t nwords_max = 0;
@@ -1115,7 +1128,7 @@ void gms_launch_slam_codes_from_log(gms_map *m, const SlamBufs &sb, int32_t firs
 
 // dynamic LDS of k_slam_particle<NT, NP> without its count tile
 static inline size_t slam_particle_fixed_lds(int32_t Bpad, int np) {
-    return (size_t)Bpad * sizeof(double) + (size_t)PS_WORDS * 64 * np * sizeof(uint64_t) + (size_t)64 * np * sizeof(PsRay);
+    return (size_t)Bpad * (sizeof(double) + sizeof(RayThr)) + (size_t)PS_WORDS * 64 * np * sizeof(uint64_t) + (size_t)64 * np * sizeof(PsRay);
 }
 
 // SLAM.update's per-particle body for all n particles of pf (one map each, d_log / d_lik [n][cells]); motion may be NULL

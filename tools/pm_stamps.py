@@ -52,6 +52,8 @@ for nm_, sl in (("ids < 256 ", slice(0, min(n, 256))), ("ids >= 256", slice(256,
         m_ = np.nanmedian(d[sl], axis=0)
         print(f"  {nm_}: pose {m_[1]:.2f} | factors {m_[2]:.2f} | rays set up {m_[4]:.2f} | first round walked {m_[5]:.2f} | counted {m_[6]:.2f} | applied {m_[7]:.2f};"
               f" entered {np.nanmedian(st[sl, 0] - t0) * 0.01:.2f} after the first")
+if np.isfinite(d[:n, 13]).any():
+    print(f"  before the ray set-up's barrier (median, after own entry): log-weight wavefront done {np.nanmedian(d[:n, 13]):.2f} | producer 0 ready {np.nanmedian(d[:n, 14]):.2f} | wavefront 2 there {np.nanmedian(d[:n, 15]):.2f}")
 print("  median total by XCD (id & 7):", " ".join(f"{np.nanmedian(tot[x::8]):.1f}" for x in range(8)), "| ids < 256:", f"{np.nanmedian(tot[:256]):.1f}", "ids >= 256:", f"{np.nanmedian(tot[256:n]):.1f}")
 print("  max total by XCD:            ", " ".join(f"{np.nanmax(tot[x::8]):.1f}" for x in range(8)))
 print("  workgroups slower than median + 3 us:", int((tot > med[7] + 3).sum()), "of", n, "; their ids mod 32:", sorted(set(int(i) % 32 for i in np.where(tot > med[7] + 3)[0])))
