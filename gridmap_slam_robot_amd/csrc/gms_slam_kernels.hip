@@ -227,6 +227,8 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     uint32_t *gplane = CODES ? code_all + (size_t)p * 2 * (size_t)code_words : nullptr;
 
     // (the first beam of this thread: on its way while the pose is drawn)
+    double tap_first = 0.0;                                                     // (the blur kernel's taps for the literal form of the on-demand field: on their way as well)
+    if (CODES && threadIdx.x >= 128 && (int32_t)threadIdx.x - 128 < g.ktaps) tap_first = taps_g[threadIdx.x - 128];
     gms_beam bm_first{}, bm_thr{};
     if (B > 0) {
         bm_first = beams[min((int32_t)threadIdx.x, B - 1)];
@@ -268,7 +270,7 @@ k_slam_particle(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_
     }
     if (threadIdx.x >= 64 && threadIdx.x < 68) s_box[threadIdx.x - 64] = threadIdx.x < 66 ? INT32_MAX : INT32_MIN;
     if (threadIdx.x == 68) s_nzero = 0;
-    if (CODES && threadIdx.x >= 128 && (int32_t)threadIdx.x - 128 < g.ktaps) s_taps[threadIdx.x - 128] = taps_g[threadIdx.x - 128];
+    if (CODES && threadIdx.x >= 128 && (int32_t)threadIdx.x - 128 < g.ktaps) s_taps[threadIdx.x - 128] = tap_first;
     if (CODES && threadIdx.x == 69) s_changed = 0;
     __syncthreads();
     if (CODES)                                         // ... and into plane 1, which defines the particle's likelihoodData from here on (SLAM.java:93);
