@@ -83,6 +83,13 @@ python3 bench.py --particle-maps 500,6,90 --refine --steps 50 --report "$OUT/kee
 python3 bench.py --particle-maps 500,6,180 --refine --steps 50 --report "$OUT/keep/bench_particle_maps_500_b180_refine_report.json" > "$OUT/keep/bench_particle_maps_500_b180_refine.json" 2>> "$OUT/bench.stderr"
 python3 bench.py --particle-maps 1024,6,90 --force-sharded --steps 200 --report "$OUT/keep/bench_particle_maps_sharded_one_rank_report.json" > "$OUT/keep/bench_particle_maps_sharded_one_rank.json" 2>> "$OUT/bench.stderr"
 python3 bench.py --particle-maps 4096,12.8,180 --force-sharded --steps 20 --report "$OUT/keep/bench_particle_maps_4096_sharded_one_rank_report.json" > "$OUT/keep/bench_particle_maps_4096_sharded_one_rank.json" 2>> "$OUT/bench.stderr"
+# one rank's SLAM.update at the shard sizes of 2 / 4 / 8 GPUs for 4096 x 256^2 (DESIGN.md section 7's table), and the refinement with the field in memory
+for n in 2048 1024 512; do
+  python3 bench.py --particle-maps $n,12.8,180 --steps 20 --no-cpu-baseline --report "$OUT/keep/pm_shard_${n}_report.json" > "$OUT/keep/pm_shard_$n.json" 2>> "$OUT/bench.stderr"
+done
+python3 tools/pm_refine_big.py > "$OUT/keep/pm_refine_4096.txt" 2>> "$OUT/bench.stderr"
+python3 tools/ab_update.py gridmap_slam_robot_amd/lib/libgridmapslam.so gridmap_slam_robot_amd/lib/libgridmapslam.so 500 6.0 90 2 > "$OUT/keep/pm500_update_unbracketed.txt" 2>> "$OUT/bench.stderr"
+python3 tools/ab_update.py gridmap_slam_robot_amd/lib/libgridmapslam.so gridmap_slam_robot_amd/lib/libgridmapslam.so 4096 12.8 180 2 > "$OUT/keep/pm4096_update_unbracketed.txt" 2>> "$OUT/bench.stderr"
 PM_CASES=3 python3 tools/pm_refine_probe.py > "$OUT/keep/pm_refine_probe.txt" 2>> "$OUT/bench.stderr"
 bash tools/pmc_refine.sh > "$OUT/keep/refine_counters.txt" 2>&1
 cp gpurun_out/pmc_refine/summary.json "$OUT/keep/refine_counters.json" 2>/dev/null
