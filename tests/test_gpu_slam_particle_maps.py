@@ -183,17 +183,20 @@ def test_edge_scans_the_band_walk_and_the_skip_rule(monkeypatch):
         dev.close()
 
 
-@pytest.mark.parametrize("case", ["2cm_11_taps", "ragged_map", "one_particle", "three_ray_groups", "signed_taps", "tiny_tap_9", "fifteen_taps"])
+@pytest.mark.parametrize("case", ["2cm_11_taps", "ragged_map", "one_particle", "three_ray_groups", "signed_taps", "tiny_tap_9", "fifteen_taps", "one_tap", "zero_end_taps"])
 def test_other_geometries(case):
     """what the two sizes above do not reach: the 11-tap kernel of a 2 cm map (k_slam_likelihood<5>), a map that is no multiple of the
     64 x 32 likelihood tiles and narrower than one, a filter of one particle, a scan of more beams than one group of producer lanes
     holds (128): several groups of rays per band.  Blur kernels given by the caller: one with negative taps and one with a tap of
     1e-300 (the on-demand field's literal form: tap * value sums in which nothing may be rescaled), and fifteen plain taps (the widest
-    kernel the class planes are kept for; the scaled form, sixteen lanes per end point)."""
+    kernel the class planes are kept for; the scaled form, sixteen lanes per end point), a kernel of one tap (no blur) and one whose
+    outer taps are 0.0."""
     W, H, res, B, N, T = {"2cm_11_taps": (3.2, 3.2, 0.02, 72, 12, 5), "ragged_map": (2.6, 4.45, 0.05, 64, 10, 5),
                           "one_particle": (4.0, 4.0, 0.05, 90, 1, 5), "three_ray_groups": (4.0, 4.0, 0.05, 300, 6, 4),
-                          "signed_taps": (4.0, 4.0, 0.05, 90, 8, 5), "tiny_tap_9": (4.0, 4.0, 0.05, 90, 8, 5), "fifteen_taps": (4.0, 3.0, 0.05, 90, 8, 5)}[case]
+                          "signed_taps": (4.0, 4.0, 0.05, 90, 8, 5), "tiny_tap_9": (4.0, 4.0, 0.05, 90, 8, 5), "fifteen_taps": (4.0, 3.0, 0.05, 90, 8, 5),
+                          "one_tap": (4.0, 4.0, 0.05, 90, 8, 4), "zero_end_taps": (4.0, 4.0, 0.05, 90, 8, 4)}[case]
     taps = {"signed_taps": [-0.03, 0.11, 0.26, 0.32, 0.26, 0.11, -0.03], "tiny_tap_9": [1e-300, 0.02, 0.1, 0.23, 0.3, 0.23, 0.1, 0.02, 1e-300],
+            "one_tap": [1.0], "zero_end_taps": [0.0, 0.25, 0.5, 0.25, 0.0],
             "fifteen_taps": [0.002, 0.006, 0.016, 0.035, 0.065, 0.1, 0.13, 0.292, 0.13, 0.1, 0.065, 0.035, 0.016, 0.006, 0.002]}.get(case)
     ext = min(W, H)
     tr = synth.make_trace(ext, res, B, T=T, seed=31)
