@@ -149,9 +149,12 @@ __device__ __forceinline__ void ps_count_cell(const GridDev &g, const PsRay &mt,
     const PsCell pc = ps_cell_of(mt, sl, k, lane);
     const int32_t cx = pc.cx, cy = pc.cy, cls = pc.cls;
     const uint32_t ux = (uint32_t)(cx - tx0), uy = (uint32_t)(cy - ty0);
-    // inside the map (RayIterator.java:108; the tile lies inside it), of this band, and not `+= logOdds(0.5)` = 0.0
-    if (k < mt.n_eff && (uint32_t)cx < (uint32_t)g.W && (uint32_t)cy < (uint32_t)g.H && ux < (uint32_t)tw && uy < (uint32_t)th && cls != 1) {
-        const uint32_t cell = __umul24(uy, (uint32_t)tw) + ux;
+    // inside the map (RayIterator.java:108) and of this band -- the tile is the scan's box, which lies inside the map (ray_meta clamps a
+    // ray's box into it), and a walk is monotonic in x and in y: a cell inside the tile is a cell the reference's loop reaches --, and
+    // not `+= logOdds(0.5)` = 0.0
+    if (k < mt.n_eff && ux < (uint32_t)tw && uy < (uint32_t)th && cls != 1) {
+        uint32_t cell;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cell) : "v"(uy), "v"((uint32_t)tw), "v"(ux));      // (one instruction; the compiler spread the byte scaling over both terms)
         if (NARROW)     // 16-bit cells n_free | n_occ << 8, two to a word (k_slam_particle decides: no field of this scan can pass 255)
             __hip_atomic_fetch_add((gms_lds_u32 *)(tile) + (cell >> 1), (cls == 0 ? 1u : 0x100u) << ((cell & 1u) << 4), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
