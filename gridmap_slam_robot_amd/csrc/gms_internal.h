@@ -242,7 +242,8 @@ struct gms_slam {
     int32_t refine;                 // gms_slam_set_refine: update() runs findBestPose on every particle against its own field before weighting it (SLAM.java:96)
     int32_t refine_field;           // the field in front of the refinement: -1 from the class plane where logData exceeds the infinity cache, 0 from logData
                                     // always, 1 from the plane always (GMS_SLAM_REFINE_FIELD=log|codes: tests of both forms)
-    int32_t refine_lds;             // -1 the field is staged in LDS whenever it fits, 0 never (GMS_SLAM_REFINE_LDS=0: tests of the other form)
+    int32_t refine_lds;             // -1 the field in LDS whenever it fits (computed there from the class plane where it can be), 0 never, 2 staged from
+                                    // memory wherever it fits (GMS_SLAM_REFINE_LDS: tests of the other forms)
 };
 
 // the thread's last-error text + code (gms_host.hip); every C-ABI file reports through it
@@ -324,7 +325,9 @@ void gms_launch_slam_likelihood_codes(gms_map *m, const SlamBufs &sb, int64_t co
 void gms_launch_slam_codes_from_log(gms_map *m, const SlamBufs &sb, int32_t first, int32_t count, int64_t code_words);
 int64_t gms_slam_code_words(int64_t cells);
 void gms_launch_slam_trace(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32_t particle, int32_t *d_cells, uint8_t *d_cls, int32_t cap, int32_t *d_counts);
-bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, const SlamBufs &sb, const MotionModel *motion, int32_t field_in_lds);
+bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, const SlamBufs &sb, const MotionModel *motion, int32_t field_in_lds,
+                            int64_t code_words);
+bool gms_slam_refine_from_planes(const gms_map *m, int32_t B, int32_t field_in_lds, int64_t code_words);
 // resample()'s copies into the generation the draw has just made current, where it drew (epoch[1]); what: bit 0 logData (+ the class
 // planes), bit 1 likelihoodData; d_idx_keep (may be NULL) receives the indices for a likelihoodData copy that is still owed
 void gms_launch_slam_gather(gms_pf *pf, const SlamBufs &sb, int32_t what, const int32_t *d_idx, int32_t *d_idx_keep, int64_t code_words);

@@ -89,7 +89,7 @@ static int slam_create(const gms_params *p, int32_t n_particles, int64_t offset,
     const char *lazy_env = getenv("GMS_SLAM_LAZY_LIK_COPY");
     s->lazy_lik = !(lazy_env && lazy_env[0] == '0');
     const char *rl_env = getenv("GMS_SLAM_REFINE_LDS");
-    s->refine_lds = rl_env && rl_env[0] == '0' ? 0 : -1;
+    s->refine_lds = rl_env && rl_env[0] == '0' ? 0 : (rl_env && rl_env[0] == '2' ? 2 : -1);
     const char *rf_env = getenv("GMS_SLAM_REFINE_FIELD");
     s->refine_field = rf_env && rf_env[0] == 'c' ? 1 : (rf_env && rf_env[0] == 'l' ? 0 : -1);
     bool ok = true;
@@ -186,7 +186,9 @@ static int slam_update_local(gms_slam *s, const gms_beam *dev_beams, int32_t B, 
     // scan's end points only (GridMap.java:273-277), and k_slam_particle evaluates exactly those cells from the particle's plane; what a
     // caller may read afterwards -- the field of logData as it stands NOW -- stays defined by plane 1 and is written when asked for
     // (slam_lik_current).  The pose refinement looks up most of a field: it gets all of it.
-    const bool on_demand = s->d_code[0] != nullptr && !s->refine;
+    // ... unless it computes it itself: a field that fits a workgroup's LDS is computed there from the same plane.
+    const bool planes = s->d_code[0] != nullptr;
+    const bool on_demand = planes && (!s->refine || gms_slam_refine_from_planes(m, B, s->refine_lds, s->code_words));
     const SlamBufs sb = gms_slam_bufs(s);
     if (!on_demand) {
         // (plane 0 == the classes of logData, 1/32 of the bytes: 623 us against 793 at 4096 x 256^2, where logData is 2 GB; at
@@ -199,7 +201,7 @@ static int slam_update_local(gms_slam *s, const gms_beam *dev_beams, int32_t B, 
     s->lik_from_codes = on_demand ? 1 : 0;
     bool drawn = false;
     if (s->refine) {                                                                                        // :90, then :96 (the lattice form of :97)
-        if (!gms_launch_slam_refine(pf, dev_beams, B, sb, sample_motion ? &mo : nullptr, s->refine_lds))
+        if (!gms_launch_slam_refine(pf, dev_beams, B, sb, sample_motion ? &mo : nullptr, s->refine_lds, planes ? s->code_words : 0))
             return gms_fail(GMS_ERR_INVALID, "gms_slam_update_per_particle: the pose refinement's tables do not fit the LDS for a scan of %d beams", B);
         drawn = true;
     }

@@ -723,10 +723,22 @@ __host__ __device__ inline int32_t slam_lattice_steps(float span, float step, fl
 #define SR_THETA_SPAN ((float)(15 * (3.141592653589793 / 180.0)))       // GridMap.java:324
 #define SR_THETA_STEP (SR_THETA_SPAN / 5)                               // :325
 
-template <bool LDSF>
+// KHF = 3 / 5 (with LDSF): the field is not read from memory -- no k_slam_likelihood launch writes it -- but COMPUTED in the workgroup's
+// LDS from the particle's class plane (3.6 KB at 120 x 120 instead of 115 KB), with the arithmetic of likelihood_body's compile-time
+// kernels (the classes' doubles {0, 1, 2} for the values {0, 0.5, 1}, the halved sum: exact for the taps gms_map::lik_kh admits) and
+// no halo to recompute, the whole map being one workgroup's:
+//   pass 1  a thread takes a strip of 8 (4) cells of a row: its 14 classes are one 64-bit window of the plane (read from memory: the
+//           plane is L1-resident and no barrier has to wait for the pose draw), turned into doubles once and shared by the strip's
+//           horizontal sums (Util.java:391-401), written where the factors will be;
+//   pass 2  a thread takes a column and a band of rows and marches down it with a ring of the 2 k + 1 horizontal sums (the rows it
+//           needs of the neighbouring bands are read before anybody overwrites anything), replacing them by the factor of the
+//           vertical sum (:413-422, GridMap.java:285-288): lane = column, so the LDS accesses are contiguous.
+template <bool LDSF, int KHF>
 __global__ void __launch_bounds__(SR_NT) __attribute__((amdgpu_waves_per_eu(LDSF ? 3 : 8)))      // (the field in LDS: one workgroup per CU; in memory: three, 64 registers)
 k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, SlamBufs sb,
-              float *__restrict__ pose, float *__restrict__ cs, MotionArgs mo, int32_t fp, int32_t nt_batch) {
+              float *__restrict__ pose, float *__restrict__ cs, MotionArgs mo, int32_t fp, int32_t nt_batch, int32_t code_words,
+              const double *__restrict__ taps_g) {
+    static_assert(KHF == 0 || LDSF, "the field is computed into LDS");
     extern __shared__ __align__(16) unsigned char smem[];
     const double *__restrict__ lik_all = sb_lik(sb, sb.epoch[0] & 1);
     constexpr int NW = SR_NT / 64;
@@ -787,7 +799,41 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
         if (lane == 0) s_nhit = base;
     }
     const double *lik = lik_all + (size_t)p * (size_t)g.cells;
-    if (LDSF) {
+    if (KHF > 0) {
+        // ---- pass 1: horizontal sums.  16 (the power of two that holds a row's strips) threads per row, thread = strip
+        constexpr int K = KHF > 0 ? KHF : 1, NTAP = 2 * K + 1, STRIP = K <= 3 ? 8 : 4, NV = STRIP + 2 * K;      // NV <= 14 classes: 28 bits
+        const uint32_t *__restrict__ gpl = sb_code(sb, sb.epoch[0] & 1) + (size_t)p * 2 * (size_t)code_words;    // plane 0: logData as it stands (the start of the update)
+        double tp[NTAP];
+#pragma unroll
+        for (int i = 0; i < NTAP; i++) tp[i] = taps_g[i];
+        const int32_t nstrips = (g.W + STRIP - 1) / STRIP;
+        const int32_t sh = nstrips > 1 ? 32 - __clz(nstrips - 1) : 0;          // (at most SR_NT threads per row: the launcher checks)
+        // (wavefront 0 takes none: its pose and trig end 2.6 us in, where the others' rows are nearly done -- unless a row needs more
+        //  threads than nine wavefronts have)
+        const int32_t skip = (SR_NT - 64) >> sh > 0 ? 64 : 0;
+        const int32_t st = ((int32_t)threadIdx.x - skip) & ((1 << sh) - 1), rows_it = (SR_NT - skip) >> sh;
+        for (int32_t y = ((int32_t)threadIdx.x - skip) >> sh; (int32_t)threadIdx.x >= skip && y < g.H && st < nstrips; y += rows_it) {
+            const int32_t c0 = st * STRIP, cw0 = c0 - K;                       // the strip's first cell, its window's first column
+            const int32_t ci = y * g.W + cw0, d = max(0, -ci), ci2 = ci + d;   // (row 0's window starts left of the plane: shifted in, those columns are masked)
+            const uint32_t w0 = gpl[ci2 >> 4], w1 = gpl[(ci2 >> 4) + 1];       // (a spare word follows the plane)
+            const uint32_t wv = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2 * (ci2 & 15))) << (2 * d);
+            const int32_t tlo = max(0, -cw0), thi = min(NV - 1, g.W - 1 - cw0);        // columns inside the map (:396)
+            const uint32_t inside = (uint32_t)((1ull << (2 * thi + 2)) - 1ull) & ~((1u << (2 * tlo)) - 1u);
+            // class 0 (logData == 0: 0.5) -> 1, class 1 (< 0: 0.0) -> 0, class 2 (> 0: 1.0) -> 2 (GridMap.java:239-244); outside: 0
+            const uint32_t cw = (((~(wv | (wv >> 1))) & 0x55555555u) | (wv & 0xaaaaaaaau)) & inside;
+            double v[NV];
+#pragma unroll
+            for (int t = 0; t < NV; t++) v[t] = (double)((cw >> (2 * t)) & 3u);
+            double *row = s_f + (size_t)y * fp + c0;
+#pragma unroll
+            for (int o = 0; o < STRIP; o++) {
+                double total = tp[0] * v[o];                                   // (== 0.0 + the product: no tap is negative)
+#pragma unroll
+                for (int i = 1; i < NTAP; i++) total += tp[i] * v[o + i];      // Util.java:399, twice over: a column outside adds tap * 0.0
+                if (c0 + o < g.W) row[o] = 0.5 * total;
+            }
+        }
+    } else if (LDSF) {
         // the factor of every cell (:285-288): wavefront = rows, lane = a pair of columns, a row's loads issued together; then the border
         // (wavefront 0 joins when its pose and trig are done -- 2.6 us, which its share of the rows would otherwise follow: it takes none)
         if ((g.W & 1) == 0) {
@@ -817,6 +863,67 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
     }
     GMS_STAMP_T(SR_NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 2);
     __syncthreads();
+    if (KHF > 0) {
+        // ---- pass 2: vertical sums and factors in place
+        constexpr int K = KHF > 0 ? KHF : 1, NTAP = 2 * K + 1;
+        double tp[NTAP];
+#pragma unroll
+        for (int i = 0; i < NTAP; i++) tp[i] = taps_g[i];
+        const int32_t nb = max(1, min(SR_NT / g.W, g.H / K));                  // (a band has at least K rows: its ring is primed from its own rows)
+        const int32_t rows_per = (g.H + nb - 1) / nb;
+        const int32_t band = (int32_t)threadIdx.x / g.W, x = (int32_t)threadIdx.x - band * g.W;
+        const int32_t r0 = band * rows_per, r1 = min(g.H, r0 + rows_per);
+        const bool work = band < nb && r0 < g.H;
+        double top[K], bot[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const int32_t yt = r0 - K + i, yb = r1 + i;
+            top[i] = work && yt >= 0 ? s_f[(size_t)yt * fp + x] : 0.0;         // (a row outside the map: + tap * 0.0 below, Util.java:418)
+            bot[i] = work && yb < g.H ? s_f[(size_t)yb * fp + x] : 0.0;
+        }
+        __syncthreads();                               // every band's neighbours are in registers: the rows may be overwritten
+        if (work) {
+            double P[NTAP];                            // the horizontal sums of rows y - K .. y + K: logical entry i of step o is P[(o + i) % NTAP]
+#pragma unroll
+            for (int i = 0; i < K; i++) P[i] = top[i];
+#pragma unroll
+            for (int i = 0; i < K; i++) P[K + i] = r0 + i < r1 ? s_f[(size_t)(r0 + i) * fp + x] : 0.0;    // (short of K rows only at the map's last rows: nothing below)
+            // a chunk of NTAP rows per pass of the loop (the ring's indices are then compile-time), the NEXT chunk's incoming rows
+            // read before this chunk's factors are stored: none of them is a row this chunk writes
+            auto incoming = [&](int32_t y, double (&hin)[NTAP]) {
+#pragma unroll
+                for (int o = 0; o < NTAP; o++) {
+                    const int32_t yin = y + o + K;
+                    double v = 0.0;
+                    if (yin < r1) v = s_f[(size_t)yin * fp + x];
+                    else {
+#pragma unroll
+                        for (int i = 0; i < K; i++) if (yin - r1 == i) v = bot[i];
+                    }
+                    hin[o] = v;
+                }
+            };
+            double hnext[NTAP];
+            incoming(r0, hnext);
+            for (int32_t y = r0; y < r1; y += NTAP) {
+                double hcur[NTAP];
+#pragma unroll
+                for (int o = 0; o < NTAP; o++) hcur[o] = hnext[o];
+                if (y + NTAP < r1) incoming(y + NTAP, hnext);
+#pragma unroll
+                for (int o = 0; o < NTAP; o++) {
+                    const int32_t yy = y + o;
+                    P[(o + 2 * K) % NTAP] = hcur[o];
+                    double total = tp[0] * P[o % NTAP];
+#pragma unroll
+                    for (int i = 1; i < NTAP; i++) total += tp[i] * P[(o + i) % NTAP];    // Util.java:413-422
+                    if (yy < r1) s_f[(size_t)yy * fp + x] = lik_factor(g, total);        // GridMap.java:285-288
+                }
+            }
+        }
+        for (int32_t i = threadIdx.x; i < g.H; i += SR_NT) s_f[i * fp + g.W] = 1.0;
+        for (int32_t i = threadIdx.x; i <= g.W; i += SR_NT) s_f[g.H * fp + i] = 1.0;
+    }
     GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 3);
 #if defined(SR_EXP) && SR_EXP == 1            // experiment: staging only
     if (s_nhit >= 0) return;
@@ -1193,13 +1300,54 @@ void gms_launch_slam_trace(gms_pf *pf, const gms_beam *d_beams, int32_t B, int32
     hipLaunchKernelGGL(k_slam_trace, dim3(1), dim3(256), 0, m->stream, m->gd, d_beams, B, pf->d_pose, pf->d_cs, particle, d_cells, d_cls, cap, d_counts);
 }
 
-// findBestPose for every particle of pf against its own field sb.lik [n][cells] (SLAM.java:96); motion (may be NULL): the motion-model
-// sample of SLAM.java:90 is drawn first.  field_in_lds: -1 the launcher decides (whenever it fits), 0 never (tests of the other form).
-// Returns false (nothing launched) where a theta step's tables do not fit a workgroup's LDS (scans of more than ~2600 beams) or a
-// map side does not fit their 16-bit entries.
-bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, const SlamBufs &sb, const MotionModel *motion, int32_t field_in_lds) {
+struct RefinePlan {
+    bool ok, ldsf;
+    int32_t khf, Bpad, fp, nt_batch;               // khf: 0 the field is read from memory (staged or looked up), 3 / 5 computed in LDS from the class plane
+    size_t smem;
+};
+static RefinePlan slam_refine_plan(const gms_map *m, int32_t B, int32_t field_in_lds, int64_t code_words) {
+    RefinePlan r{};
+    if (m->gd.W > 65535 || m->gd.H > 65535) return r;
+    r.Bpad = B < 8 ? 8 : (B + 7) & ~7;
+    const int32_t nt = slam_lattice_steps(SR_THETA_SPAN, SR_THETA_STEP, nullptr);
+    const int32_t nc = 2 * slam_lattice_steps(SR_XSPAN, SR_TRANS_STEP, nullptr);
+    r.fp = m->gd.W + 1;
+    const size_t beams_b = (size_t)r.Bpad * 16, tab1_b = (size_t)nc * r.Bpad * 2, field_b = (((size_t)(m->gd.H + 1) * r.fp + 1) & ~(size_t)1) * 8;
+    const size_t room = (size_t)m->lds_per_cu - 2048;                            // (static LDS: 0.5 KB; allocation granularity)
+    if (beams_b + tab1_b > room) return r;
+    // the field in LDS: its 16-bit table entries must hold (H + 1) * pitch, and one theta step's tables must fit beside it
+    r.ldsf = field_in_lds != 0 && (size_t)(m->gd.H + 1) * r.fp <= 65535 && field_b + beams_b + tab1_b <= room;
+    // (the field in memory: 48 KB of tables per workgroup, so that three workgroups -- 64 registers, 30 wavefronts -- share a CU and
+    //  hide each other's misses: 4096 x 256^2 x 180 beams 2.33 ms with 96 KB and one workgroup per CU, 1.69 with two, 1.61 with three)
+    static const size_t tab_budget = []() { const char *e = getenv("GMS_SLAM_REFINE_TAB_KB"); return (size_t)(e && atoi(e) > 0 ? atoi(e) : 48) * 1024; }();
+    const size_t left = (r.ldsf ? room - field_b : std::max(tab_budget, beams_b + tab1_b)) - beams_b;
+    r.nt_batch = (int32_t)(left / tab1_b);
+    if (r.nt_batch > nt) r.nt_batch = nt;
+    if (r.nt_batch < 1) r.nt_batch = 1;
+    r.nt_batch = (nt + (nt + r.nt_batch - 1) / r.nt_batch - 1) / ((nt + r.nt_batch - 1) / r.nt_batch);  // batches of equal size (6 + 4 theta steps keep ten wavefronts busy for two rounds each)
+    r.smem = (r.ldsf ? field_b : 0) + beams_b + (size_t)r.nt_batch * tab1_b;
+    // ... computed there from the class plane: the compile-time blur kernels' conditions (gms_map::lik_kh: 7 or 11 plain taps), a thread
+    // per column in the vertical pass and per strip in the horizontal one.  field_in_lds 2: not this form (tests of the staged one)
+    if (r.ldsf && field_in_lds != 2 && code_words > 0 && m->lik_kh != 0 && m->gd.W <= SR_NT && m->gd.H >= m->lik_kh) r.khf = m->lik_kh;
+    r.ok = true;
+    return r;
+}
+// whether the refinement of a scan of B beams computes its field itself (no k_slam_likelihood launch in front of it)
+bool gms_slam_refine_from_planes(const gms_map *m, int32_t B, int32_t field_in_lds, int64_t code_words) {
+    const RefinePlan r = slam_refine_plan(m, B, field_in_lds, code_words);
+    return r.ok && r.khf != 0;
+}
+
+// findBestPose for every particle of pf against its own field (SLAM.java:96): sb.lik [n][cells], or -- code_words != 0 and
+// gms_slam_refine_from_planes -- the field computed from the particle's class plane inside the workgroup.  motion (may be NULL): the
+// motion-model sample of SLAM.java:90 is drawn first.  field_in_lds: -1 the launcher decides (whenever it fits), 0 never, 2 staged
+// from memory wherever it fits (tests of the other forms).  Returns false (nothing launched) where a theta step's tables do not fit
+// a workgroup's LDS (scans of more than ~2600 beams) or a map side does not fit their 16-bit entries.
+bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, const SlamBufs &sb, const MotionModel *motion, int32_t field_in_lds,
+                            int64_t code_words) {
     gms_map *m = pf->map;
-    if (m->gd.W > 65535 || m->gd.H > 65535) return false;
+    const RefinePlan r = slam_refine_plan(m, B, field_in_lds, code_words);
+    if (!r.ok) return false;
     MotionArgs mo;
     mo.on = 0; mo.d_center = mo.d_theta = mo.d_center_sd = mo.d_theta_sd = 0.0; mo.seed = mo.sequence = 0; mo.index0 = pf->offset;
     if (motion) {
@@ -1207,32 +1355,17 @@ bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, cons
         mo.d_center_sd = (0.01 + fabs(motion->d_center) * 0.05) / 2;             // Odometry.java:63
         mo.d_theta_sd = 5 * (3.141592653589793 / 180.0) + 0.1 * fabs(motion->d_theta);   // :64
     }
-    const int32_t Bpad = B < 8 ? 8 : (B + 7) & ~7;
-    const int32_t nt = slam_lattice_steps(SR_THETA_SPAN, SR_THETA_STEP, nullptr);
-    const int32_t nc = 2 * slam_lattice_steps(SR_XSPAN, SR_TRANS_STEP, nullptr);
-    const int32_t fp = m->gd.W + 1;
-    const size_t beams_b = (size_t)Bpad * 16, tab1_b = (size_t)nc * Bpad * 2, field_b = (((size_t)(m->gd.H + 1) * fp + 1) & ~(size_t)1) * 8;
-    const size_t room = (size_t)m->lds_per_cu - 2048;                            // (static LDS: 0.5 KB; allocation granularity)
-    if (beams_b + tab1_b > room) return false;
     ProfScope ps(m, GMS_K_REFINE);
-    // the field in LDS: its 16-bit table entries must hold (H + 1) * pitch, and one theta step's tables must fit beside it
-    const bool ldsf = field_in_lds != 0 && (size_t)(m->gd.H + 1) * fp <= 65535 && field_b + beams_b + tab1_b <= room;
-    // (the field in memory: 48 KB of tables per workgroup, so that three workgroups -- 64 registers, 30 wavefronts -- share a CU and
-    //  hide each other's misses: 4096 x 256^2 x 180 beams 2.33 ms with 96 KB and one workgroup per CU, 1.69 with two, 1.61 with three)
-    static const size_t tab_budget = []() { const char *e = getenv("GMS_SLAM_REFINE_TAB_KB"); return (size_t)(e && atoi(e) > 0 ? atoi(e) : 48) * 1024; }();
-    const size_t left = (ldsf ? room - field_b : std::max(tab_budget, beams_b + tab1_b)) - beams_b;
-    int32_t nt_batch = (int32_t)(left / tab1_b);
-    if (nt_batch > nt) nt_batch = nt;
-    if (nt_batch < 1) nt_batch = 1;
-    nt_batch = (nt + (nt + nt_batch - 1) / nt_batch - 1) / ((nt + nt_batch - 1) / nt_batch);          // batches of equal size (6 + 4 theta steps keep ten wavefronts busy for two rounds each)
-    const size_t smem = (ldsf ? field_b : 0) + beams_b + (size_t)nt_batch * tab1_b;
-#define SR_LAUNCH(LF)                                                                                                                  \
+#define SR_LAUNCH(LF, KF)                                                                                                               \
     do {                                                                                                                                \
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_refine<LF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((k_slam_refine<LF>), dim3((unsigned)pf->n), dim3(SR_NT), smem, m->stream, m->gd, d_beams, B, Bpad, sb,         \
-                           pf->d_pose, pf->d_cs, mo, fp, nt_batch);                                                                    \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_refine<LF, KF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)r.smem); \
+        hipLaunchKernelGGL((k_slam_refine<LF, KF>), dim3((unsigned)pf->n), dim3(SR_NT), r.smem, m->stream, m->gd, d_beams, B, r.Bpad, sb, \
+                           pf->d_pose, pf->d_cs, mo, r.fp, r.nt_batch, (int32_t)code_words, m->d_taps);                                \
     } while (0)
-    if (ldsf) SR_LAUNCH(true); else SR_LAUNCH(false);
+    if (r.khf == 3) SR_LAUNCH(true, 3);
+    else if (r.khf == 5) SR_LAUNCH(true, 5);
+    else if (r.ldsf) SR_LAUNCH(true, 0);
+    else SR_LAUNCH(false, 0);
 #undef SR_LAUNCH
     return true;
 }

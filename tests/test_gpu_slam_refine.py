@@ -1,7 +1,8 @@
 """SLAM.update's pose refinement in the reference's own filter shape (J/slam/SLAM.java:96-97 -> GridMap.findBestPose,
 J/slam/GridMap.java:319-346): every particle's pose is replaced by the best pose of an 11 x 11 x 10 lattice around its motion-model
 sample, searched against THE PARTICLE'S OWN likelihood field, before the particle is weighted and its map updated at that pose.  The
-device (gms_slam_set_refine: k_slam_refine, the particle's field staged in the CU's LDS) against the oracle's literal loop
+device (gms_slam_set_refine: k_slam_refine, the particle's field computed in the CU's LDS from the particle's class plane, or staged
+there from memory, or read from memory: GMS_SLAM_REFINE_LDS) against the oracle's literal loop
 (orc_slam_update(..., refine = 1)): poses EQUAL (the argmax is over products of doubles taken in beam order: any other association
 could pick another pose), weights to 1e-13 (the weight sum is a blocked sum on the device), maps as in
 tests/test_gpu_slam_particle_maps.py.  The motion-model samples are set by hand (Philox variates computed on the host) so that the
@@ -68,21 +69,27 @@ def test_refined_update_at_the_reference_operating_point():
     dev.close()
 
 
-@pytest.mark.parametrize("case", ["field_in_memory_forced", "field_from_class_plane", "256x256_does_not_fit", "2cm_11_taps", "ragged_map", "long_scan", "underflow_700_beams"])
+@pytest.mark.parametrize("case", ["field_in_memory_forced", "field_staged_from_memory", "field_from_class_plane", "short_bands", "one_strip_rows", "256x256_does_not_fit", "2cm_11_taps", "ragged_map", "long_scan", "underflow_700_beams"])
 def test_refined_update_other_shapes(case, monkeypatch):
-    """the form that reads the field from memory (forced on a small map; a 256 x 256 map, 512 KB, which no LDS holds), the field in
+    """the form that reads the field from memory (forced on a small map; a 256 x 256 map, 512 KB, which no LDS holds), the form that
+    stages a field written by k_slam_likelihood in the LDS (the default computes it there from the class plane), maps of 20 x 10 cells
+    (the column march's bands are as short as they may be, the last one shorter than the kernel's half width) and of 7 x 40 (a row
+    is one strip, and that one not full), the field in
     front of the refinement written from the particles' class planes (what a filter does whose logData exceeds the infinity cache:
     gms_slam::refine_field), the 11-tap
     kernel of a 2 cm map, a map whose width is odd (the staging's scalar form), a scan of 300 beams (whose rotation table does not
     fit beside the field: rotated per look-up), and a scan of 700 beams in a map so much larger than the room that no lattice pose
     puts an end point outside it: every product underflows to 0, maxProb stays 0 and the start pose is kept (GridMap.java:320-321,
     334) -- and update() then divides 0 by 0, on both sides."""
-    W, H, res, B, N, T = {"field_in_memory_forced": (4.0, 4.0, 0.05, 72, 24, 4), "field_from_class_plane": (4.0, 4.0, 0.05, 72, 24, 5),
+    W, H, res, B, N, T = {"field_in_memory_forced": (4.0, 4.0, 0.05, 72, 24, 4), "field_staged_from_memory": (4.0, 4.0, 0.05, 72, 24, 4),
+                          "short_bands": (1.0, 0.5, 0.05, 48, 10, 4), "one_strip_rows": (0.35, 2.0, 0.05, 48, 10, 4), "field_from_class_plane": (4.0, 4.0, 0.05, 72, 24, 5),
                           "256x256_does_not_fit": (12.8, 12.8, 0.05, 120, 24, 3),
                           "2cm_11_taps": (2.4, 2.4, 0.02, 72, 12, 3), "ragged_map": (2.55, 3.35, 0.05, 64, 10, 4),
                           "long_scan": (6.0, 6.0, 0.05, 300, 8, 3), "underflow_700_beams": (12.8, 12.8, 0.05, 700, 8, 2)}[case]
     if case == "field_in_memory_forced":
         monkeypatch.setenv("GMS_SLAM_REFINE_LDS", "0")
+    if case == "field_staged_from_memory":
+        monkeypatch.setenv("GMS_SLAM_REFINE_LDS", "2")
     if case == "field_from_class_plane":
         monkeypatch.setenv("GMS_SLAM_REFINE_FIELD", "codes")
     ext = min(W, H)
