@@ -812,25 +812,42 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
         //  threads than nine wavefronts have)
         const int32_t skip = (SR_NT - 64) >> sh > 0 ? 64 : 0;
         const int32_t st = ((int32_t)threadIdx.x - skip) & ((1 << sh) - 1), rows_it = (SR_NT - skip) >> sh;
-        for (int32_t y = ((int32_t)threadIdx.x - skip) >> sh; (int32_t)threadIdx.x >= skip && y < g.H && st < nstrips; y += rows_it) {
-            const int32_t c0 = st * STRIP, cw0 = c0 - K;                       // the strip's first cell, its window's first column
-            const int32_t ci = y * g.W + cw0, d = max(0, -ci), ci2 = ci + d;   // (row 0's window starts left of the plane: shifted in, those columns are masked)
-            const uint32_t w0 = gpl[ci2 >> 4], w1 = gpl[(ci2 >> 4) + 1];       // (a spare word follows the plane)
-            const uint32_t wv = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2 * (ci2 & 15))) << (2 * d);
-            const int32_t tlo = max(0, -cw0), thi = min(NV - 1, g.W - 1 - cw0);        // columns inside the map (:396)
-            const uint32_t inside = (uint32_t)((1ull << (2 * thi + 2)) - 1ull) & ~((1u << (2 * tlo)) - 1u);
-            // class 0 (logData == 0: 0.5) -> 1, class 1 (< 0: 0.0) -> 0, class 2 (> 0: 1.0) -> 2 (GridMap.java:239-244); outside: 0
-            const uint32_t cw = (((~(wv | (wv >> 1))) & 0x55555555u) | (wv & 0xaaaaaaaau)) & inside;
-            double v[NV];
+        const int32_t c0 = st * STRIP, cw0 = c0 - K;                           // the strip's first cell, its window's first column
+        const int32_t tlo = max(0, -cw0), thi = min(NV - 1, g.W - 1 - cw0);    // columns inside the map (:396)
+        const uint32_t inside = (uint32_t)((1ull << (2 * max(thi, 0) + 2)) - 1ull) & ~((1u << (2 * tlo)) - 1u);
+        constexpr int PF = 4;                          // rows whose windows are on their way together (a window per row and round trip left the loop waiting on memory)
+        for (int32_t y0 = ((int32_t)threadIdx.x - skip) >> sh; (int32_t)threadIdx.x >= skip && y0 < g.H && st < nstrips; y0 += PF * rows_it) {
+            uint32_t w0[PF], w1[PF];
 #pragma unroll
-            for (int t = 0; t < NV; t++) v[t] = (double)((cw >> (2 * t)) & 3u);
-            double *row = s_f + (size_t)y * fp + c0;
+            for (int u = 0; u < PF; u++) {
+                const int32_t y = min(y0 + u * rows_it, g.H - 1);
+                const int32_t ci = y * g.W + cw0, ci2 = max(ci, 0);            // (row 0's window starts left of the plane: shifted in below, those columns are masked)
+                w0[u] = gpl[ci2 >> 4]; w1[u] = gpl[(ci2 >> 4) + 1];            // (a spare word follows the plane)
+            }
 #pragma unroll
-            for (int o = 0; o < STRIP; o++) {
-                double total = tp[0] * v[o];                                   // (== 0.0 + the product: no tap is negative)
+            for (int u = 0; u < PF; u++) {
+                const int32_t y = y0 + u * rows_it;
+                if (y < g.H) {
+                    const int32_t ci = y * g.W + cw0, d = max(0, -ci), ci2 = ci + d;
+                    const uint32_t wv = (uint32_t)((((uint64_t)w1[u] << 32) | w0[u]) >> (2 * (ci2 & 15))) << (2 * d);
+                    // class 0 (logData == 0: 0.5) -> 1, class 1 (< 0: 0.0) -> 0, class 2 (> 0: 1.0) -> 2 (GridMap.java:239-244); outside: 0
+                    const uint32_t cw = (((~(wv | (wv >> 1))) & 0x55555555u) | (wv & 0xaaaaaaaau)) & inside;
+                    double v[NV];
 #pragma unroll
-                for (int i = 1; i < NTAP; i++) total += tp[i] * v[o + i];      // Util.java:399, twice over: a column outside adds tap * 0.0
-                if (c0 + o < g.W) row[o] = 0.5 * total;
+                    for (int t = 0; t < NV; t++) v[t] = (double)((cw >> (2 * t)) & 3u);
+                    double *row = s_f + (size_t)y * fp + c0;
+                    double tot[STRIP];                 // (all sums first, in one block: the strip's chains of dependent additions interleave)
+#pragma unroll
+                    for (int o = 0; o < STRIP; o++) {
+                        double total = tp[0] * v[o];                           // (== 0.0 + the product: no tap is negative)
+#pragma unroll
+                        for (int i = 1; i < NTAP; i++) total += tp[i] * v[o + i];      // Util.java:399, twice over: a column outside adds tap * 0.0
+                        tot[o] = 0.5 * total;
+                    }
+#pragma unroll
+                    for (int o = 0; o < STRIP; o++)
+                        if (c0 + o < g.W) row[o] = tot[o];
+                }
             }
         }
     } else if (LDSF) {
@@ -883,16 +900,18 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
         }
         __syncthreads();                               // every band's neighbours are in registers: the rows may be overwritten
         if (work) {
-            double P[NTAP];                            // the horizontal sums of rows y - K .. y + K: logical entry i of step o is P[(o + i) % NTAP]
+            // the horizontal sums of rows y - K .. y + K in a ring of RING = NTAP + 1 registers: logical entry i of step o is P[(o + i) % RING];
+            // a chunk of RING rows per pass of the loop makes those indices compile-time (24 rows per band at 120 x 120: three chunks of 8),
+            // and the NEXT chunk's incoming rows are read before this chunk's factors are stored: none of them is a row this chunk writes
+            constexpr int RING = NTAP + 1;
+            double P[RING];
 #pragma unroll
             for (int i = 0; i < K; i++) P[i] = top[i];
 #pragma unroll
             for (int i = 0; i < K; i++) P[K + i] = r0 + i < r1 ? s_f[(size_t)(r0 + i) * fp + x] : 0.0;    // (short of K rows only at the map's last rows: nothing below)
-            // a chunk of NTAP rows per pass of the loop (the ring's indices are then compile-time), the NEXT chunk's incoming rows
-            // read before this chunk's factors are stored: none of them is a row this chunk writes
-            auto incoming = [&](int32_t y, double (&hin)[NTAP]) {
+            auto incoming = [&](int32_t y, double (&hin)[RING]) {
 #pragma unroll
-                for (int o = 0; o < NTAP; o++) {
+                for (int o = 0; o < RING; o++) {
                     const int32_t yin = y + o + K;
                     double v = 0.0;
                     if (yin < r1) v = s_f[(size_t)yin * fp + x];
@@ -903,22 +922,25 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
                     hin[o] = v;
                 }
             };
-            double hnext[NTAP];
+            double hnext[RING];
             incoming(r0, hnext);
-            for (int32_t y = r0; y < r1; y += NTAP) {
-                double hcur[NTAP];
+            for (int32_t y = r0; y < r1; y += RING) {
+                double hcur[RING];
 #pragma unroll
-                for (int o = 0; o < NTAP; o++) hcur[o] = hnext[o];
-                if (y + NTAP < r1) incoming(y + NTAP, hnext);
+                for (int o = 0; o < RING; o++) hcur[o] = hnext[o];
+                if (y + RING < r1) incoming(y + RING, hnext);
+                double fac[RING];                      // (all sums first: the chunk's chains of dependent additions interleave)
 #pragma unroll
-                for (int o = 0; o < NTAP; o++) {
-                    const int32_t yy = y + o;
-                    P[(o + 2 * K) % NTAP] = hcur[o];
-                    double total = tp[0] * P[o % NTAP];
+                for (int o = 0; o < RING; o++) {
+                    P[(o + 2 * K) % RING] = hcur[o];
+                    double total = tp[0] * P[o % RING];
 #pragma unroll
-                    for (int i = 1; i < NTAP; i++) total += tp[i] * P[(o + i) % NTAP];    // Util.java:413-422
-                    if (yy < r1) s_f[(size_t)yy * fp + x] = lik_factor(g, total);        // GridMap.java:285-288
+                    for (int i = 1; i < NTAP; i++) total += tp[i] * P[(o + i) % RING];    // Util.java:413-422
+                    fac[o] = lik_factor(g, total);                                       // GridMap.java:285-288
                 }
+#pragma unroll
+                for (int o = 0; o < RING; o++)
+                    if (y + o < r1) s_f[(size_t)(y + o) * fp + x] = fac[o];
             }
         }
         for (int32_t i = threadIdx.x; i < g.H; i += SR_NT) s_f[i * fp + g.W] = 1.0;
