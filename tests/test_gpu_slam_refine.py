@@ -69,12 +69,13 @@ def test_refined_update_at_the_reference_operating_point():
     dev.close()
 
 
-@pytest.mark.parametrize("case", ["field_in_memory_forced", "field_staged_from_memory", "field_from_class_plane", "short_bands", "one_strip_rows", "256x256_does_not_fit", "2cm_11_taps", "ragged_map", "long_scan", "underflow_700_beams"])
+@pytest.mark.parametrize("case", ["field_in_memory_forced", "field_staged_from_memory", "field_from_class_plane", "short_bands", "one_strip_rows", "nine_taps", "256x256_does_not_fit", "2cm_11_taps", "ragged_map", "long_scan", "underflow_700_beams"])
 def test_refined_update_other_shapes(case, monkeypatch):
     """the form that reads the field from memory (forced on a small map; a 256 x 256 map, 512 KB, which no LDS holds), the form that
     stages a field written by k_slam_likelihood in the LDS (the default computes it there from the class plane), maps of 20 x 10 cells
     (the column march's bands are as short as they may be, the last one shorter than the kernel's half width) and of 7 x 40 (a row
-    is one strip, and that one not full), the field in
+    is one strip, and that one not full), a blur kernel of nine taps given by the caller (no compile-time kernel: k_slam_likelihood's generic
+    form writes the field, the refinement stages it), the field in
     front of the refinement written from the particles' class planes (what a filter does whose logData exceeds the infinity cache:
     gms_slam::refine_field), the 11-tap
     kernel of a 2 cm map, a map whose width is odd (the staging's scalar form), a scan of 300 beams (whose rotation table does not
@@ -82,7 +83,7 @@ def test_refined_update_other_shapes(case, monkeypatch):
     puts an end point outside it: every product underflows to 0, maxProb stays 0 and the start pose is kept (GridMap.java:320-321,
     334) -- and update() then divides 0 by 0, on both sides."""
     W, H, res, B, N, T = {"field_in_memory_forced": (4.0, 4.0, 0.05, 72, 24, 4), "field_staged_from_memory": (4.0, 4.0, 0.05, 72, 24, 4),
-                          "short_bands": (1.0, 0.5, 0.05, 48, 10, 4), "one_strip_rows": (0.35, 2.0, 0.05, 48, 10, 4), "field_from_class_plane": (4.0, 4.0, 0.05, 72, 24, 5),
+                          "short_bands": (1.0, 0.5, 0.05, 48, 10, 4), "one_strip_rows": (0.35, 2.0, 0.05, 48, 10, 4), "nine_taps": (4.0, 4.0, 0.05, 72, 16, 4), "field_from_class_plane": (4.0, 4.0, 0.05, 72, 24, 5),
                           "256x256_does_not_fit": (12.8, 12.8, 0.05, 120, 24, 3),
                           "2cm_11_taps": (2.4, 2.4, 0.02, 72, 12, 3), "ragged_map": (2.55, 3.35, 0.05, 64, 10, 4),
                           "long_scan": (6.0, 6.0, 0.05, 300, 8, 3), "underflow_700_beams": (12.8, 12.8, 0.05, 700, 8, 2)}[case]
@@ -95,7 +96,10 @@ def test_refined_update_other_shapes(case, monkeypatch):
     ext = min(W, H)
     tr = synth.make_trace(min(ext, 6.4), res, B, T=T + 1, seed=61)
     g = orc.Grid(W, H, res, -W / 2, -H / 2)
-    dev = SLAMParticleMaps(W, H, res, (-W / 2, -H / 2), num_particles=N, max_beams=max(128, B))
+    taps = [0.01, 0.05, 0.12, 0.2, 0.24, 0.2, 0.12, 0.05, 0.01] if case == "nine_taps" else None      # (none of the compile-time kernels: the field is written to memory first)
+    if taps is not None:
+        g.set_kernel(taps)
+    dev = SLAMParticleMaps(W, H, res, (-W / 2, -H / 2), num_particles=N, max_beams=max(128, B), kernel=taps)
     o = orc.Slam(g, N)
     assert (dev.W, dev.H) == (g.W, g.H)
     dev.set_refine(True)
