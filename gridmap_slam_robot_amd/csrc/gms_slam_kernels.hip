@@ -710,7 +710,12 @@ k_slam_trace(GridDev g, const gms_beam *__restrict__ beams, int32_t B, const flo
 // LDSF = false: the field stays in memory (maps too large for the LDS: 256 x 256 cells are 512 KB), factor formed at the look-up.
 // The motion-model sample (SLAM.java:90) is drawn here when refinement is on: it precedes findBestPose (:90 -> :96).
 // ---------------------------------------------------------------------------------------------
-#define SR_NT 640                       // ten wavefronts: the lattice is 10 theta steps x 2 wavefronts of (dx, dy) pairs
+#define SR_NT 640                       // the field in memory: ten wavefronts (the lattice is 10 theta steps x 2 wavefronts of (dx, dy) pairs), three workgroups per CU
+#define SR_NT_LDS 1024                  // the field in LDS, one workgroup per CU: SIXTEEN wavefronts, four on every SIMD.  Ten sat 3 + 3 + 2 + 2 and the SIMDs that
+                                        // held three set every phase's pace (the twenty look-up tasks fell 6 + 6 + 4 + 4: the youngest wavefront left the look-ups
+                                        // 2.9 us after the oldest); with sixteen, wavefront w takes tasks w and w + 16: 5 + 5 + 5 + 5, the field's passes are two
+                                        // rounds instead of four and three, the tables two instead of three -- 25.9 -> 22.2 us per workgroup (twelve: 23.5)
+#define SR_NT_OF(LDSF, KHF) ((LDSF) ? ((KHF) == 5 ? 768 : SR_NT_LDS) : SR_NT)      // (the 11-tap field passes hold 130+ registers: twelve wavefronts, 170 each)
 #define SR_MAXSTEPS 16
 // the reference's float loop `for (float d = -span; d < span; d += step)` (GridMap.java:328-330): the offsets and how many
 __host__ __device__ inline int32_t slam_lattice_steps(float span, float step, float *out) {
@@ -734,14 +739,14 @@ __host__ __device__ inline int32_t slam_lattice_steps(float span, float step, fl
 //           needs of the neighbouring bands are read before anybody overwrites anything), replacing them by the factor of the
 //           vertical sum (:413-422, GridMap.java:285-288): lane = column, so the LDS accesses are contiguous.
 template <bool LDSF, int KHF>
-__global__ void __launch_bounds__(SR_NT) __attribute__((amdgpu_waves_per_eu(LDSF ? 3 : 8)))      // (the field in LDS: one workgroup per CU; in memory: three, 64 registers)
+__global__ void __launch_bounds__(SR_NT_OF(LDSF, KHF)) __attribute__((amdgpu_waves_per_eu(LDSF ? (KHF == 5 ? 3 : 4) : 8)))      // (the field in LDS: one workgroup of sixteen wavefronts per CU; in memory: three of ten, 64 registers)
 k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t Bpad, SlamBufs sb,
               float *__restrict__ pose, float *__restrict__ cs, MotionArgs mo, int32_t fp, int32_t nt_batch, int32_t code_words,
               const double *__restrict__ taps_g) {
     static_assert(KHF == 0 || LDSF, "the field is computed into LDS");
     extern __shared__ __align__(16) unsigned char smem[];
     const double *__restrict__ lik_all = sb_lik(sb, sb.epoch[0] & 1);
-    constexpr int NW = SR_NT / 64;
+    constexpr int NT = SR_NT_OF(LDSF, KHF), NW = NT / 64;
     double *s_f = reinterpret_cast<double *>(smem);                            // [H + 1][fp] factors, column W and row H neutral (LDSF)
     // (every carve offset a multiple of 16: a 16-byte LDS access off its alignment is replayed at 64 cycles -- 121 x 121 doubles are not)
     double2 *s_hb = reinterpret_cast<double2 *>(s_f + (LDSF ? (((size_t)(g.H + 1) * fp + 1) & ~(size_t)1) : 0));    // [Bpad] the hit beams' (localX, localY), in beam order
@@ -807,11 +812,11 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
 #pragma unroll
         for (int i = 0; i < NTAP; i++) tp[i] = taps_g[i];
         const int32_t nstrips = (g.W + STRIP - 1) / STRIP;
-        const int32_t sh = nstrips > 1 ? 32 - __clz(nstrips - 1) : 0;          // (at most SR_NT threads per row: the launcher checks)
+        const int32_t sh = nstrips > 1 ? 32 - __clz(nstrips - 1) : 0;          // (at most NT threads per row: the launcher checks)
         // (wavefront 0 takes none: its pose and trig end 2.6 us in, where the others' rows are nearly done -- unless a row needs more
         //  threads than nine wavefronts have)
-        const int32_t skip = (SR_NT - 64) >> sh > 0 ? 64 : 0;
-        const int32_t st = ((int32_t)threadIdx.x - skip) & ((1 << sh) - 1), rows_it = (SR_NT - skip) >> sh;
+        const int32_t skip = (NT - 64) >> sh > 0 ? 64 : 0;
+        const int32_t st = ((int32_t)threadIdx.x - skip) & ((1 << sh) - 1), rows_it = (NT - skip) >> sh;
         const int32_t c0 = st * STRIP, cw0 = c0 - K;                           // the strip's first cell, its window's first column
         const int32_t tlo = max(0, -cw0), thi = min(NV - 1, g.W - 1 - cw0);    // columns inside the map (:396)
         const uint32_t inside = (uint32_t)((1ull << (2 * max(thi, 0) + 2)) - 1ull) & ~((1u << (2 * tlo)) - 1u);
@@ -870,15 +875,15 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
                 }
             }
         } else {
-            for (int32_t i = threadIdx.x; i < g.W * g.H; i += SR_NT) {
+            for (int32_t i = threadIdx.x; i < g.W * g.H; i += NT) {
                 const int32_t y = i / g.W, x = i - y * g.W;
                 s_f[y * fp + x] = lik_factor(g, lik[i]);
             }
         }
-        for (int32_t i = threadIdx.x; i < g.H; i += SR_NT) s_f[i * fp + g.W] = 1.0;
-        for (int32_t i = threadIdx.x; i <= g.W; i += SR_NT) s_f[g.H * fp + i] = 1.0;
+        for (int32_t i = threadIdx.x; i < g.H; i += NT) s_f[i * fp + g.W] = 1.0;
+        for (int32_t i = threadIdx.x; i <= g.W; i += NT) s_f[g.H * fp + i] = 1.0;
     }
-    GMS_STAMP_T(SR_NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 2);
+    GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 2);
     __syncthreads();
     if (KHF > 0) {
         // ---- pass 2: vertical sums and factors in place
@@ -886,7 +891,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
         double tp[NTAP];
 #pragma unroll
         for (int i = 0; i < NTAP; i++) tp[i] = taps_g[i];
-        const int32_t nb = max(1, min(SR_NT / g.W, g.H / K));                  // (a band has at least K rows: its ring is primed from its own rows)
+        const int32_t nb = max(1, min(NT / g.W, g.H / K));                  // (a band has at least K rows: its ring is primed from its own rows)
         const int32_t rows_per = (g.H + nb - 1) / nb;
         const int32_t band = (int32_t)threadIdx.x / g.W, x = (int32_t)threadIdx.x - band * g.W;
         const int32_t r0 = band * rows_per, r1 = min(g.H, r0 + rows_per);
@@ -943,8 +948,8 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
                     if (y + o < r1) s_f[(size_t)(y + o) * fp + x] = fac[o];
             }
         }
-        for (int32_t i = threadIdx.x; i < g.H; i += SR_NT) s_f[i * fp + g.W] = 1.0;
-        for (int32_t i = threadIdx.x; i <= g.W; i += SR_NT) s_f[g.H * fp + i] = 1.0;
+        for (int32_t i = threadIdx.x; i < g.H; i += NT) s_f[i * fp + g.W] = 1.0;
+        for (int32_t i = threadIdx.x; i <= g.W; i += NT) s_f[g.H * fp + i] = 1.0;
     }
     GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 3);
 #if defined(SR_EXP) && SR_EXP == 1            // experiment: staging only
@@ -962,7 +967,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
         // ---- the tables: entry (theta step, coordinate c, beam j), j fastest.  A work item is one (theta step, x | y, beam): the
         //      rotated beam once, then the nx (ny) lattice offsets along that axis.  One expression for both coordinates:
         //      x s + y c == x s - y (-c) bit for bit (negation is exact), so gy is gx's arithmetic with (s, -c) for (c, s).
-        for (int32_t i = threadIdx.x; i < ntb * 2 * nhit; i += SR_NT) {
+        for (int32_t i = threadIdx.x; i < ntb * 2 * nhit; i += NT) {
             const int32_t j = i % nhit, r2 = i / nhit, itl = r2 >> 1;
             const bool isx = (r2 & 1) == 0;
             const float cf = s_c[it0 + itl], sf = s_s[it0 + itl];
@@ -987,7 +992,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
                     out[(size_t)k * Bpad] = (uint16_t)(min((uint32_t)j_cell_exact(w, g.res), lim) * mul);
                 }
         }
-        GMS_STAMP_T(SR_NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 4);
+        GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 4);
         __syncthreads();
         GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 5);
 #if defined(SR_EXP) && SR_EXP == 2            // experiment: staging and tables
@@ -1045,7 +1050,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
             if (live && (prod > best || (prod == best && prod > 0.0 && q < bestq))) { best = prod; bestq = q; }   // :334
         }
     }
-    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 6); GMS_STAMP_T(SR_NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 7); GMS_STAMP_T(128, GMS_STAMP_ROW(3, blockIdx.x), 8);
+    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 6); GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 7); GMS_STAMP_T(128, GMS_STAMP_ROW(3, blockIdx.x), 8);
     // the first maximum over the lattice: the larger probability wins, of equal ones the earlier pose
 #define GMS_STEP_(O) { const double v2 = wave_xor<O>(best); const int32_t q2 = wave_xor<O>(bestq); \
                        if (v2 > best || (v2 == best && q2 < bestq)) { best = v2; bestq = q2; } }
@@ -1350,7 +1355,7 @@ static RefinePlan slam_refine_plan(const gms_map *m, int32_t B, int32_t field_in
     r.smem = (r.ldsf ? field_b : 0) + beams_b + (size_t)r.nt_batch * tab1_b;
     // ... computed there from the class plane: the compile-time blur kernels' conditions (gms_map::lik_kh: 7 or 11 plain taps), a thread
     // per column in the vertical pass and per strip in the horizontal one.  field_in_lds 2: not this form (tests of the staged one)
-    if (r.ldsf && field_in_lds != 2 && code_words > 0 && m->lik_kh != 0 && m->gd.W <= SR_NT && m->gd.H >= m->lik_kh) r.khf = m->lik_kh;
+    if (r.ldsf && field_in_lds != 2 && code_words > 0 && m->lik_kh != 0 && m->gd.W <= SR_NT_OF(true, m->lik_kh) && m->gd.H >= m->lik_kh) r.khf = m->lik_kh;
     r.ok = true;
     return r;
 }
@@ -1381,7 +1386,7 @@ bool gms_launch_slam_refine(gms_pf *pf, const gms_beam *d_beams, int32_t B, cons
 #define SR_LAUNCH(LF, KF)                                                                                                               \
     do {                                                                                                                                \
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slam_refine<LF, KF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)r.smem); \
-        hipLaunchKernelGGL((k_slam_refine<LF, KF>), dim3((unsigned)pf->n), dim3(SR_NT), r.smem, m->stream, m->gd, d_beams, B, r.Bpad, sb, \
+        hipLaunchKernelGGL((k_slam_refine<LF, KF>), dim3((unsigned)pf->n), dim3(SR_NT_OF(LF, KF)), r.smem, m->stream, m->gd, d_beams, B, r.Bpad, sb, \
                            pf->d_pose, pf->d_cs, mo, r.fp, r.nt_batch, (int32_t)code_words, m->d_taps);                                \
     } while (0)
     if (r.khf == 3) SR_LAUNCH(true, 3);
