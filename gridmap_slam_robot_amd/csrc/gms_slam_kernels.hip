@@ -820,7 +820,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
         const int32_t c0 = st * STRIP, cw0 = c0 - K;                           // the strip's first cell, its window's first column
         const int32_t tlo = max(0, -cw0), thi = min(NV - 1, g.W - 1 - cw0);    // columns inside the map (:396)
         const uint32_t inside = (uint32_t)((1ull << (2 * max(thi, 0) + 2)) - 1ull) & ~((1u << (2 * tlo)) - 1u);
-        constexpr int PF = 4;                          // rows whose windows are on their way together (a window per row and round trip left the loop waiting on memory)
+        constexpr int PF = 2;                          // rows whose windows are on their way together (a window per row and round trip left the loop waiting on memory)
         for (int32_t y0 = ((int32_t)threadIdx.x - skip) >> sh; (int32_t)threadIdx.x >= skip && y0 < g.H && st < nstrips; y0 += PF * rows_it) {
             uint32_t w0[PF], w1[PF];
 #pragma unroll
@@ -885,6 +885,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
     }
     GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 2);
     __syncthreads();
+    GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 10);
     if (KHF > 0) {
         // ---- pass 2: vertical sums and factors in place
         constexpr int K = KHF > 0 ? KHF : 1, NTAP = 2 * K + 1;
@@ -904,6 +905,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
             bot[i] = work && yb < g.H ? s_f[(size_t)yb * fp + x] : 0.0;
         }
         __syncthreads();                               // every band's neighbours are in registers: the rows may be overwritten
+        GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 11);
         if (work) {
             // the horizontal sums of rows y - K .. y + K in a ring of RING = NTAP + 1 registers: logical entry i of step o is P[(o + i) % RING];
             // a chunk of RING rows per pass of the loop makes those indices compile-time (24 rows per band at 120 x 120: three chunks of 8),
@@ -948,6 +950,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
                     if (y + o < r1) s_f[(size_t)(y + o) * fp + x] = fac[o];
             }
         }
+        GMS_STAMP(GMS_STAMP_ROW(3, blockIdx.x), 12);
         for (int32_t i = threadIdx.x; i < g.H; i += NT) s_f[i * fp + g.W] = 1.0;
         for (int32_t i = threadIdx.x; i <= g.W; i += NT) s_f[g.H * fp + i] = 1.0;
     }
@@ -1058,11 +1061,18 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
 #undef GMS_STEP_
     if (lane == 0) { s_best[wave] = best; s_bestq[wave] = bestq; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double b = 0.0; int32_t bq = INT32_MAX;
-        for (int k = 0; k < NW; k++)
-            if (s_best[k] > b || (s_best[k] == b && s_bestq[k] < bq)) { b = s_best[k]; bq = s_bestq[k]; }
-        if (bq != INT32_MAX) {
+    if (wave == 0) {
+        // the wavefronts' maxima by one more butterfly (NW <= 16 of them, a lane each: a loop over them by one thread was sixteen
+        // dependent LDS round trips in front of the kernel's end)
+        double b = lane < NW ? s_best[lane] : 0.0;
+        int32_t bq = lane < NW ? s_bestq[lane] : INT32_MAX;
+#define GMS_STEP16_(O) { const double v2 = wave_xor<O>(b); const int32_t q2 = wave_xor<O>(bq); \
+                         if (v2 > b || (v2 == b && q2 < bq)) { b = v2; bq = q2; } }
+        GMS_STEP16_(1) GMS_STEP16_(2) GMS_STEP16_(4) GMS_STEP16_(8)
+#undef GMS_STEP16_
+        static_assert(NW <= 16, "one lane per wavefront, four butterfly steps");
+        if (lane == 0 && !(b > 0.0)) bq = INT32_MAX;   // maxProb = 0 is never exceeded (:321, :334): the start pose stays
+        if (lane == 0 && bq != INT32_MAX) {
             const int32_t it = bq % nt, iy = (bq / nt) % ny, ix = bq / (nt * ny);
             pose[3 * (size_t)p] = x0 + s_dx[ix]; pose[3 * (size_t)p + 1] = y0 + s_dy[iy]; pose[3 * (size_t)p + 2] = t0 + s_dt[it];
             cs[2 * (size_t)p] = s_c[it]; cs[2 * (size_t)p + 1] = s_s[it];

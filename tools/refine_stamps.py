@@ -30,7 +30,8 @@ st = buf.cpu().numpy().reshape(4, 1024, 16).astype(np.float64)[3]
 st[st == 0] = np.nan
 n = min(N, 1024)
 t0 = np.nanmin(st[:n, 0])
-names = {0: "entered", 1: "pose + trig (wavefront 0)", 2: "field staged (last wavefront)", 3: "past the first barrier", 4: "tables built (last wavefront)",
+names = {0: "entered", 1: "pose + trig (wavefront 0)", 2: "field staged / horizontal sums (last wavefront)", 10: "past the first barrier", 11: "neighbours' rows read, second barrier", 12: "column march done (wavefront 0)",
+         3: "field complete", 4: "tables built (last wavefront)",
          5: "past the tables' barrier", 6: "look-ups done (wavefront 0)", 7: "look-ups done (last wavefront)", 8: "look-ups done (wavefront 2)", 9: "left"}
 print(f"k_slam_refine, {N} particles x {s.W}x{s.H}, {B} beams: microseconds after the first workgroup entered")
 for k, nm in names.items():
@@ -38,5 +39,6 @@ for k, nm in names.items():
     v = v[~np.isnan(v)]
     if v.size: print(f"  {nm:34s} n={v.size:4d} first {v.min():7.2f} median {np.median(v):7.2f} last {v.max():7.2f}")
 d = (st[:n] - st[:n, 0:1]) * 0.01
-print("  per workgroup, microseconds after ITS OWN entry (median):", " | ".join(f"{names[k]} {np.nanmedian(d[:, k]):.2f}" for k in (1, 2, 3, 4, 5, 6, 7, 8, 9)))
-print("  ids < 256:", " | ".join(f"{np.nanmedian(d[:256, k]):.2f}" for k in (1, 2, 3, 4, 5, 6, 7, 8, 9)), " ids >= 256:", " | ".join(f"{np.nanmedian(d[256:n, k]):.2f}" for k in (1, 2, 3, 4, 5, 6, 7, 8, 9)))
+ORDER = (1, 2, 10, 11, 12, 3, 4, 5, 6, 7, 8, 9)
+print("  per workgroup, microseconds after ITS OWN entry (median):", " | ".join(f"{names[k]} {np.nanmedian(d[:, k]):.2f}" for k in ORDER if np.isfinite(d[:, k]).any()))
+print("  ids < 256:", " | ".join(f"{np.nanmedian(d[:256, k]):.2f}" for k in ORDER if np.isfinite(d[:, k]).any()), " ids >= 256:", " | ".join(f"{np.nanmedian(d[256:n, k]):.2f}" for k in ORDER if np.isfinite(d[:, k]).any()))
