@@ -67,6 +67,7 @@ struct RayMeta {
 // keeps the compiler from caching or reordering around them.
 typedef __attribute__((address_space(3))) uint64_t gms_lds_u64;
 typedef __attribute__((address_space(3))) uint32_t gms_lds_u32;
+typedef __attribute__((address_space(3))) double gms_lds_f64;
 __device__ __forceinline__ uint32_t lds_offset(const uint64_t *p) { return (uint32_t)(uintptr_t)(const gms_lds_u64 *)p; }
 __device__ __forceinline__ void lds_publish_u64(uint64_t *p, uint64_t v) {
     asm volatile("ds_write_b64 %0, %1" : : "v"(lds_offset(p)), "v"(v) : "memory");

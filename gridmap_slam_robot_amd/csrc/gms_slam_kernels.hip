@@ -959,6 +959,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
     if (s_nhit >= 0) return;
 #endif
     const int32_t nx = s_n[0], ny = s_n[1], nt = s_n[2], nhit = s_nhit;
+    const uint32_t base8 = (uint32_t)(uintptr_t)(const gms_lds_f64 *)s_f >> 3;                        // the field's LDS offset in doubles (16-byte aligned)
     const float x0 = s_pose[0], y0 = s_pose[1], t0 = s_pose[2];
     const int32_t nc = nx + ny;
     const int32_t nxy = nx * ny, nhalf = (nxy + 63) >> 6;
@@ -979,6 +980,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
             const double rot = bm.x * A - bm.y * Bn;                                       // Transform.java:23,28 before `+ px`
             const double pos = isx ? g.posx : g.posy;
             const uint32_t lim = (uint32_t)(isx ? g.W : g.H), mul = LDSF && !isx ? (uint32_t)fp : 1u;
+            const uint32_t off = LDSF && !isx ? base8 : 0u;                                // (the y entries carry the field's LDS offset / 8: the look-ups)
             const float base = isx ? x0 : y0;
             const float *dd = isx ? s_dx : s_dy;
             const int32_t nk = isx ? nx : ny;
@@ -987,12 +989,12 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
 #pragma unroll 4
             for (int32_t k = 0; k < nk; k++) {
                 const double w = rot + (double)(base + dd[k]) - pos;                       // :332 (a float sum) ... - position (:273-274)
-                out[(size_t)k * Bpad] = (uint16_t)(min((uint32_t)j_cell_fast(w, g.rinv, guard), lim) * mul);
+                out[(size_t)k * Bpad] = (uint16_t)(min((uint32_t)j_cell_fast(w, g.rinv, guard), lim) * mul + off);
             }
             if (__builtin_expect(guard, 0))                // a quotient within 2^-19 of an integer: the reference's division decides
                 for (int32_t k = 0; k < nk; k++) {
                     const double w = rot + (double)(base + dd[k]) - pos;
-                    out[(size_t)k * Bpad] = (uint16_t)(min((uint32_t)j_cell_exact(w, g.res), lim) * mul);
+                    out[(size_t)k * Bpad] = (uint16_t)(min((uint32_t)j_cell_exact(w, g.res), lim) * mul + off);
                 }
         }
         GMS_STAMP_T(NT - 64, GMS_STAMP_ROW(3, blockIdx.x), 4);
@@ -1010,7 +1012,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
             const uint16_t *tx = s_tab + (size_t)(itl * nc + ix) * Bpad, *ty = s_tab + (size_t)(itl * nc + nx + iy) * Bpad;
             auto factor_at = [&](uint32_t ex, uint32_t ey) -> double {
                 if (LDSF) {
-                    return s_f[ex + ey];
+                    return *reinterpret_cast<const gms_lds_f64 *>((uintptr_t)((ex + ey) << 3));        // (ey carries the field's LDS offset: the tables)
                 } else {
                     const bool in = ex < (uint32_t)g.W && ey < (uint32_t)g.H;                      // :276
                     const double v = lik[in ? (size_t)ey * g.W + ex : 0];
@@ -1028,8 +1030,16 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
                 const uint32_t ax[4] = {ta.x, ta.y, ta.z, ta.w}, bx[4] = {tb.x, tb.y, tb.z, tb.w};
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    f[2 * u] = factor_at(ax[u] & 0xffffu, bx[u] & 0xffffu);
-                    f[2 * u + 1] = factor_at(ax[u] >> 16, bx[u] >> 16);
+                    if (LDSF) {
+                        // tx + ty of two beams in ONE addition (the sums stay below 2^16: the launcher checks, no carry crosses), the y entries
+                        // carry the field's LDS offset / 8: a look-up is a word extracted and shifted, and the read
+                        const uint32_t sm = ax[u] + bx[u];
+                        f[2 * u] = *reinterpret_cast<const gms_lds_f64 *>((uintptr_t)((sm & 0xffffu) << 3));
+                        f[2 * u + 1] = *reinterpret_cast<const gms_lds_f64 *>((uintptr_t)((sm >> 16) << 3));
+                    } else {
+                        f[2 * u] = factor_at(ax[u] & 0xffffu, bx[u] & 0xffffu);
+                        f[2 * u + 1] = factor_at(ax[u] >> 16, bx[u] >> 16);
+                    }
                 }
             };
             if (npass > 0) {
@@ -1037,15 +1047,21 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
                 issue(fc);
                 if (npass > 1) { ta = *reinterpret_cast<const uint4 *>(tx + 8); tb = *reinterpret_cast<const uint4 *>(ty + 8); }
             }
-            for (int32_t ps = 0; ps < npass; ps++) {
+            for (int32_t ps = 0; ps < npass; ps += 2) {                                   // (two passes per turn: the two sets of factors swap roles, no copies)
                 if (ps + 1 < npass) {
                     issue(fn);
                     if (ps + 2 < npass) { ta = *reinterpret_cast<const uint4 *>(tx + 8 * (ps + 2)); tb = *reinterpret_cast<const uint4 *>(ty + 8 * (ps + 2)); }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) prod *= fc[u];                                 // beams in order (:267-288)
+                if (ps + 1 < npass) {
+                    if (ps + 2 < npass) {
+                        issue(fc);
+                        if (ps + 3 < npass) { ta = *reinterpret_cast<const uint4 *>(tx + 8 * (ps + 3)); tb = *reinterpret_cast<const uint4 *>(ty + 8 * (ps + 3)); }
+                    }
 #pragma unroll
-                for (int u = 0; u < 8; u++) fc[u] = fn[u];
+                    for (int u = 0; u < 8; u++) prod *= fn[u];
+                }
             }
             int32_t j = npass << 3;
             for (; j < nhit; j++) prod *= factor_at(tx[j], ty[j]);
@@ -1353,7 +1369,7 @@ static RefinePlan slam_refine_plan(const gms_map *m, int32_t B, int32_t field_in
     const size_t room = (size_t)m->lds_per_cu - 2048;                            // (static LDS: 0.5 KB; allocation granularity)
     if (beams_b + tab1_b > room) return r;
     // the field in LDS: its 16-bit table entries must hold (H + 1) * pitch, and one theta step's tables must fit beside it
-    r.ldsf = field_in_lds != 0 && (size_t)(m->gd.H + 1) * r.fp <= 65535 && field_b + beams_b + tab1_b <= room;
+    r.ldsf = field_in_lds != 0 && (size_t)(m->gd.H + 1) * r.fp + 512 <= 65535 && field_b + beams_b + tab1_b <= room;    // (+ the field's own LDS offset / 8, which the y entries carry: the static LDS is below 4 KB)
     // (the field in memory: 48 KB of tables per workgroup, so that three workgroups -- 64 registers, 30 wavefronts -- share a CU and
     //  hide each other's misses: 4096 x 256^2 x 180 beams 2.33 ms with 96 KB and one workgroup per CU, 1.69 with two, 1.61 with three)
     static const size_t tab_budget = []() { const char *e = getenv("GMS_SLAM_REFINE_TAB_KB"); return (size_t)(e && atoi(e) > 0 ? atoi(e) : 48) * 1024; }();
