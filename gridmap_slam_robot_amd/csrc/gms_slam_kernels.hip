@@ -989,7 +989,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
 #pragma unroll 4
             for (int32_t k = 0; k < nk; k++) {
                 const double w = rot + (double)(base + dd[k]) - pos;                       // :332 (a float sum) ... - position (:273-274)
-                out[(size_t)k * Bpad] = (uint16_t)(min((uint32_t)j_cell_fast(w, g.rinv, guard), lim) * mul + off);
+                out[(size_t)k * Bpad] = (uint16_t)(__umul24(min((uint32_t)j_cell_fast(w, g.rinv, guard), lim), mul) + off);      // (both below 2^24: one v_mad_u32_u24)
             }
             if (__builtin_expect(guard, 0))                // a quotient within 2^-19 of an integer: the reference's division decides
                 for (int32_t k = 0; k < nk; k++) {
