@@ -960,6 +960,7 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
 #endif
     const int32_t nx = s_n[0], ny = s_n[1], nt = s_n[2], nhit = s_nhit;
     const uint32_t base8 = (uint32_t)(uintptr_t)(const gms_lds_f64 *)s_f >> 3;                        // the field's LDS offset in doubles (16-byte aligned)
+    if (LDSF && base8 > 512u) __builtin_trap();        // (the launcher's 16-bit bound on the table sums allows for 4 KB of static LDS in front of the field: this kernel has 0.7)
     const float x0 = s_pose[0], y0 = s_pose[1], t0 = s_pose[2];
     const int32_t nc = nx + ny;
     const int32_t nxy = nx * ny, nhalf = (nxy + 63) >> 6;
