@@ -303,8 +303,9 @@ int gms_slam_update_per_particle_dev(gms_slam *s, const gms_beam *dev_beams, int
  * maximum wins) for every particle against ITS OWN likelihood field, between computeLikelihoodMap(p.m) (:93) and the weighting (:99);
  * the particle is then weighted, and its map updated, at the refined pose.  The reference calls findBestPoseOptim (:97: BOBYQA from
  * commons-math on an objective that is 0 / NaN) and keeps this search commented out beside it (:96).  One workgroup per
- * particle; the particle's field is staged into the CU's LDS as probabilityOf's factors when it fits (120 x 120 cells: 115 KB of 160),
- * read from memory otherwise (GMS_SLAM_REFINE_LDS=0 forces that form).  Default off. */
+ * particle; where the particle's field fits the CU's LDS as probabilityOf's factors (120 x 120 cells: 115 KB of 160) it is COMPUTED there
+ * from the particle's class plane (no launch writes it first; blur kernels of 7 or 11 plain taps) or staged there from memory
+ * (GMS_SLAM_REFINE_LDS=2 forces that form), and read from memory otherwise (GMS_SLAM_REFINE_LDS=0 forces that one).  Default off. */
 int gms_slam_set_refine(gms_slam *s, int32_t on);
 /* SLAM.resample() (SLAM.java:133-153) with Math.random() = r01: the systematic draw over the particles' weights, then every slot's
  * deep copy -- pose, weight (:42-43) and both arrays of the map (:44, GridMap.java:118-121): map[m] <- map[idx[m]], double-buffered,
