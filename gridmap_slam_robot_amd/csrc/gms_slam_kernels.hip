@@ -986,8 +986,15 @@ k_slam_refine(GridDev g, const gms_beam *__restrict__ beams, int32_t B, int32_t 
             const float *dd = isx ? s_dx : s_dy;
             const int32_t nk = isx ? nx : ny;
             uint16_t *out = s_tab + ((size_t)(itl * nc + (isx ? 0 : nx)) * Bpad + j);
-            bool guard = false;                            // (one for the work item: the loop below has no branch and is unrolled)
-#pragma unroll 4
+            bool guard = false;                            // (one for the work item)
+            constexpr int NKC = 11;                        // the translation offsets of the reference's lattice (slam_lattice_steps(0.20f, 0.04f): the float counter stops after eleven)
+            if (LDSF && nxy == NKC * NKC) {                // (uniform) the usual count at compile time: no loop, the offsets' LDS reads issued together
+#pragma unroll
+                for (int k = 0; k < NKC; k++) {
+                    const double w = rot + (double)(base + dd[k]) - pos;                   // :332 (a float sum) ... - position (:273-274)
+                    out[(size_t)k * Bpad] = (uint16_t)(__umul24(min((uint32_t)j_cell_fast(w, g.rinv, guard), lim), mul) + off);
+                }
+            } else
             for (int32_t k = 0; k < nk; k++) {
                 const double w = rot + (double)(base + dd[k]) - pos;                       // :332 (a float sum) ... - position (:273-274)
                 out[(size_t)k * Bpad] = (uint16_t)(__umul24(min((uint32_t)j_cell_fast(w, g.rinv, guard), lim), mul) + off);      // (both below 2^24: one v_mad_u32_u24)
