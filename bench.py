@@ -903,7 +903,22 @@ def trace_replay(path: str, steps: int, warmup: int, particles: int, extent: flo
     return out
 
 
-def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res: float, beams: int, steps: int, warm_frames: int = 12,
+def particle_maps_run(*args, **kwargs):
+    """_particle_maps_run with the collector off: a collection inside one of its few-millisecond regions -- the previous runs' handles
+    and tensors going, a hipFree each -- was a third of the region (the default run's first per-particle entry read update_ms 67 us
+    where the same build, alone in its process, reads 46)"""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        return _particle_maps_run(*args, **kwargs)
+    finally:
+        if was:
+            gc.enable()
+
+
+def _particle_maps_run(torch, local_rank: int, particles: int, extent: float, res: float, beams: int, steps: int, warm_frames: int = 12,
                       cpu_seconds: float = 0.0, refine: bool = False):
     """The reference's own filter shape (SLAM.java: one GridMapData per particle; gms_slam_*): `particles` particles with a map of
     extent x extent metres each, scans of `beams` measurements of a synthetic drive through a room that fits the map.  Timed, inputs
@@ -942,48 +957,51 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
             s.resample(float(r01[i % 4096]))
     torch.cuda.synchronize()
     warm_frames += pre                                  # (sequence numbers go on from here)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(warm_frames + i)
-    torch.cuda.synchronize()
-    upd = (time.perf_counter() - t0) / steps
+    # Every figure below is the median of three regions of `steps` steps that start from the SAME poses (a region is a few milliseconds
+    # and one host hiccup inside it -- a collection, a scheduler tick of a busy box -- is a third of it; without the reset the particles,
+    # which diffuse while nothing resamples them, would hand every later region another workload).
+    regions = {}
+    def timed(name, body, reps=3):
+        nonlocal k
+        P0, k0 = s.get_particles()[0].copy(), k
+        out = []
+        for _ in range(reps):
+            s.set_poses(P0)
+            k = k0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                body(i)
+            torch.cuda.synchronize()
+            out.append((time.perf_counter() - t0) / steps)
+        regions[name] = [v * 1e3 for v in out]
+        return sorted(out)[len(out) // 2]
+    upd = timed("update_ms", lambda i: step(warm_frames + i))
     st = s.pf.stats()
     # SLAM.resample as the filter runs it: update, resample, update, ... (the pair's time less the update's).  The library copies
     # logData at once and likelihoodData only if somebody reads it before the next update's computeLikelihoodMap has overwritten every
     # cell of it (gms_slam::lazy_lik; GMS_SLAM_LAZY_LIK_COPY=0: both at once) ...
     lazy = os.environ.get("GMS_SLAM_LAZY_LIK_COPY", "1") != "0"
-    t0 = time.perf_counter()
-    for i in range(steps):
+    def pair_body(i):
         step(warm_frames + steps + i)
         s.resample(float(r01[(17 + i) % 4096]))
-    torch.cuda.synchronize()
-    pair = (time.perf_counter() - t0) / steps
+    pair = timed("update_resample_pair_ms", pair_body)
     rsm = max(pair - upd, 0.0)
     # the reference's loop with its rule decided on the device (gms_slam_resample_maps_if): update + conditional resample, nothing read back
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
+    def rev_body(i):
         step(warm_frames + 3 * steps + i)
         s.resample_if(float(r01[(217 + i) % 4096]), 0.5)
-    torch.cuda.synchronize()
-    rev = (time.perf_counter() - t0) / steps
+    rev = timed("revolution_ms", rev_body)
     # the same revolution while no resampling step is due (fraction 0: Neff < 0 never holds): the rule is evaluated on the device, nothing
     # is drawn, and no map is copied -- which generation of the maps is current is a device-side fact (gms_slam_resample_maps_if)
     copied0 = s.maps_copied()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
+    def idle_body(i):
         step(warm_frames + 4 * steps + i)
         s.resample_if(float(r01[(317 + i) % 4096]), 0.0)
-    torch.cuda.synchronize()
-    rev_idle = (time.perf_counter() - t0) / steps
+    rev_idle = timed("revolution_no_resample_ms", idle_body)
     assert s.maps_copied() == copied0, "a revolution whose rule says no must not copy a map"
     # ... and `steps` draws back to back: every call first brings likelihoodData up to date, so both arrays move per call
-    t0 = time.perf_counter()
-    for i in range(steps):
-        s.resample(float(r01[(517 + i) % 4096]))
-    torch.cuda.synchronize()
-    rsm_both = (time.perf_counter() - t0) / steps
+    rsm_both = timed("resample_both_arrays_ms", lambda i: s.resample(float(r01[(517 + i) % 4096])))
     # per kernel: event brackets (they cost ~2 us each on the stream: these durations are upper bounds of the un-bracketed ones)
     s.grid_map.profile(True)
     s.grid_map.profile_reset()
@@ -1052,7 +1070,7 @@ def particle_maps_run(torch, local_rank: int, particles: int, extent: float, res
                        "probabilityOf, integrateObservation), SLAM.resample with its deep copies of the maps ("
                        + ("logData at once, likelihoodData when it is read: the next update overwrites it first" if lazy else "both arrays at once") + ")",
            "particles": particles, "grid": [s.W, s.H], "beams": beams, "steps": steps, "refine": bool(refine), "mean_hit_beams": float(np.mean(hits)),
-           "update_ms": upd * 1e3, "updates_per_s": 1.0 / upd, "particle_scan_evals_per_s": particles / upd,
+           "update_ms": upd * 1e3, "regions_ms": regions, "updates_per_s": 1.0 / upd, "particle_scan_evals_per_s": particles / upd,
            "likelihood_on_demand": bool(on_demand),
            "update_every_cell_rebuilt_ms": eager_ms,
            "update_every_cell_rebuilt_what": "the same update with computeLikelihoodMap over every cell of every particle's map, as the reference and the CPU port run it "
