@@ -765,7 +765,7 @@ likelihood_body(const GridDev &g, const double *__restrict__ logd, double *__res
     // The staged rectangle of a tile: every load is issued before the first one is consumed (addresses clamped into
     // the map, so no load sits behind a branch: 13 dependent round trips otherwise), and the NEXT tile's loads are
     // issued as soon as this tile's values are in LDS, so they fly during the barriers and the two blur passes.
-    constexpr int32_t CRW = LK_TW + 2 * (KH > 0 ? KH : 1), CRH = LK_TH + 2 * (KH > 0 ? KH : 1);
+    constexpr int32_t CRW = LK_TW + 2 * (KH > 0 ? KH : 1);
     // Which staged cells a thread takes.  Elements 0 .. QM-1: the rectangle's first 64 columns, lane = column, row = wavefront + 4 q:
     // the row is the same for a whole wavefront, so its clamp, its bounds test and its base address are scalar work and a load is
     // `row base (scalar) + column offset (one register for all rows)`: no vector instruction per load.  Elements QM .. P1-1: the
