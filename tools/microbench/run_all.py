@@ -8,10 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 OUT = os.path.join(ROOT, "gpurun_out", "microbench")
 os.makedirs(OUT, exist_ok=True)
 res = {"source": "tools/microbench/*.hip on MI355X (gfx950), hipcc -O3"}
-for name, args in (("gather_coalesce", []), ("gather8", []), ("gather_addr", []), ("dda_chain", []), ("persistent_step", ["-1"])):
+for name, args in (("gather_coalesce", []), ("gather8", []), ("gather_addr", []), ("dda_chain", []), ("persistent_step", ["-1"]), ("fp64_rate", [])):
     src = os.path.join(ROOT, "tools", "microbench", name + ".hip")
     exe = os.path.join("/tmp", "mb_" + name)
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", src, "-o", exe])
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", src, "-o", exe])
     try:
         txt = subprocess.run([exe] + args, capture_output=True, text=True, timeout=180).stdout
     except subprocess.TimeoutExpired as e:
@@ -34,6 +34,9 @@ res["gather_one_line_lanes_per_s"] = (grab(gc, "random lanes in 16x1 cells", r"(
 dd = res["dda_chain_raw"]
 res["dda_clocks_per_step_statement_per_step"] = grab(dd, "(library)", r"([\d.]+) s_memtime")
 res["dda_clocks_per_step_one_statement_per_word"] = grab(dd, "library order, 32 steps", r"([\d.]+) s_memtime")
+fr = res["fp64_rate_raw"]
+for key, tag in (("fp64_mul_ticks_per_instr_one_wavefront", "v_mul_f64           256"), ("fp64_mul_ticks_per_instr_four_wavefronts", "v_mul_f64          1024")):
+    res[key] = grab(fr, tag, r"-> ([\d.]+) ticks")
 ps = res["persistent_step_raw"]
 for key, tag in (("four_launches_us", "L  four launches"), ("one_launch_us", "P  one launch"), ("two_launches_us", "P2 two launches")):
     vals = [float(m.group(1)) for l in ps if tag in l for m in [re.search(r"([\d.]+) us per step", l)] if m]
