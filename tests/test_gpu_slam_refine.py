@@ -69,12 +69,12 @@ def test_refined_update_at_the_reference_operating_point():
     dev.close()
 
 
-@pytest.mark.parametrize("case", ["field_in_memory_forced", "field_staged_from_memory", "field_from_class_plane", "short_bands", "one_strip_rows", "nine_taps", "256x256_does_not_fit", "2cm_11_taps", "ragged_map", "long_scan", "underflow_700_beams"])
+@pytest.mark.parametrize("case", ["field_in_memory_forced", "field_staged_from_memory", "field_from_class_plane", "short_bands", "one_strip_rows", "wide_map", "nine_taps", "256x256_does_not_fit", "2cm_11_taps", "ragged_map", "long_scan", "underflow_700_beams"])
 def test_refined_update_other_shapes(case, monkeypatch):
     """the form that reads the field from memory (forced on a small map; a 256 x 256 map, 512 KB, which no LDS holds), the form that
     stages a field written by k_slam_likelihood in the LDS (the default computes it there from the class plane), maps of 20 x 10 cells
     (the column march's bands are as short as they may be, the last one shorter than the kernel's half width) and of 7 x 40 (a row
-    is one strip, and that one not full), a blur kernel of nine taps given by the caller (no compile-time kernel: k_slam_likelihood's generic
+    is one strip, and that one not full) and of 1100 x 12 (wider than the workgroup has threads: the field fits the LDS but is staged), a blur kernel of nine taps given by the caller (no compile-time kernel: k_slam_likelihood's generic
     form writes the field, the refinement stages it), the field in
     front of the refinement written from the particles' class planes (what a filter does whose logData exceeds the infinity cache:
     gms_slam::refine_field), the 11-tap
@@ -83,7 +83,7 @@ def test_refined_update_other_shapes(case, monkeypatch):
     puts an end point outside it: every product underflows to 0, maxProb stays 0 and the start pose is kept (GridMap.java:320-321,
     334) -- and update() then divides 0 by 0, on both sides."""
     W, H, res, B, N, T = {"field_in_memory_forced": (4.0, 4.0, 0.05, 72, 24, 4), "field_staged_from_memory": (4.0, 4.0, 0.05, 72, 24, 4),
-                          "short_bands": (1.0, 0.5, 0.05, 48, 10, 4), "one_strip_rows": (0.35, 2.0, 0.05, 48, 10, 4), "nine_taps": (4.0, 4.0, 0.05, 72, 16, 4), "field_from_class_plane": (4.0, 4.0, 0.05, 72, 24, 5),
+                          "short_bands": (1.0, 0.5, 0.05, 48, 10, 4), "one_strip_rows": (0.35, 2.0, 0.05, 48, 10, 4), "wide_map": (55.0, 0.6, 0.05, 48, 6, 3), "nine_taps": (4.0, 4.0, 0.05, 72, 16, 4), "field_from_class_plane": (4.0, 4.0, 0.05, 72, 24, 5),
                           "256x256_does_not_fit": (12.8, 12.8, 0.05, 120, 24, 3),
                           "2cm_11_taps": (2.4, 2.4, 0.02, 72, 12, 3), "ragged_map": (2.55, 3.35, 0.05, 64, 10, 4),
                           "long_scan": (6.0, 6.0, 0.05, 300, 8, 3), "underflow_700_beams": (12.8, 12.8, 0.05, 700, 8, 2)}[case]
